@@ -1,0 +1,41 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN
+
+
+@pytest.fixture(scope="session")
+def obj06_tris():
+    import oracle_lib as O
+    return O.ply_load(os.path.join(GOLDEN, "obj_06.ply"))
+
+
+@pytest.fixture(scope="session")
+def scenario(obj06_tris):
+    """test.cpp:22-86 scenario evaluated by the ORACLE: depth of both poses, model cloud, both scenes."""
+    import numpy as np
+    import oracle_lib as O
+    from pose_refine_amd import synth
+    K = synth.K_TEST
+    proj = O.compute_proj(K, synth.WIDTH, synth.HEIGHT)
+    poses = synth.test_cpp_poses()
+    depth = O.render(obj06_tris, poses, synth.WIDTH, synth.HEIGHT, proj)
+    cloud = O.depth2cloud(depth[0], K)
+    return dict(K=K, proj=proj, poses=poses, depth=depth, cloud=cloud, tris=obj06_tris,
+                proj_scene=O.ProjScene(depth[1], K), nn_scene=O.NNScene(depth[1], K))

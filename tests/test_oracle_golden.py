@@ -1,0 +1,125 @@
+"""Pins the CPU oracle (oracle/pose_oracle.c) to the reference's known answers.
+
+CPU only.  If these fail the oracle no longer restates the reference and no parity claim holds.
+"""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from pose_refine_amd import synth
+
+
+@pytest.fixture(scope="module")
+def gold(golden_dir):
+    with open(os.path.join(golden_dir, "survey_8c.json")) as f:
+        return json.load(f)
+
+
+def test_ply_fixture_is_the_reference_file(golden_dir, gold, obj06_tris):
+    with open(os.path.join(golden_dir, "obj_06.ply"), "rb") as f:
+        assert hashlib.md5(f.read()).hexdigest() == gold["scenario"]["ply_md5"]
+    assert len(obj06_tris) == gold["scenario"]["n_triangles"]
+    # python-side loader agrees with the C loader
+    assert np.array_equal(synth.load_ply_triangles(os.path.join(golden_dir, "obj_06.ply")), obj06_tris)
+
+
+def test_render_checksums(scenario, gold):
+    for d, g in zip(scenario["depth"], gold["render"]):
+        ys, xs = np.nonzero(d)
+        assert int((d > 0).sum()) == g["valid"]
+        assert int(d.sum()) == g["sum"]
+        assert int(d[d > 0].min()) == g["min"] and int(d.max()) == g["max"]
+        assert [int(xs.min()), int(xs.max())] == g["bbox_x"]
+        assert [int(ys.min()), int(ys.max())] == g["bbox_y"]
+
+
+def test_cloud_size_and_order(scenario, gold):
+    cloud, d, K = scenario["cloud"], scenario["depth"][0], scenario["K"]
+    assert len(cloud) == gold["cloud_points"]
+    ys, xs = np.nonzero(d)                       # row-major == exclusive-scan order (icp.cpp:85-95)
+    z = d[ys, xs].astype(np.float32) / np.float32(1000.0)
+    assert np.array_equal(cloud[:, 2], z)
+    x = (xs.astype(np.float32) - K[2]) / K[0] * z
+    assert np.array_equal(cloud[:, 0], x.astype(np.float32))
+
+
+def test_kdtree_shape(scenario, gold):
+    nn, g = scenario["nn_scene"], gold["kdtree"]
+    nodes = nn.nodes
+    leaf = (nodes["child1"] < 0) | (nodes["child2"] < 0)
+    assert len(nn.pcd) == g["points"] and len(nodes) == g["nodes"] and int(leaf.sum()) == g["leaves"]
+    assert int((nodes["right"] - nodes["left"])[leaf].max()) == g["max_leaf"]
+    depth = np.zeros(len(nodes), np.int32)
+    for i in range(1, len(nodes)):
+        depth[i] = depth[nodes["parent"][i]] + 1   # level-order: parents precede children
+    assert int(depth.max()) == g["depth"]           # root = depth 0
+    # leaves tile [0, n) exactly once
+    cover = np.zeros(len(nn.pcd), np.int32)
+    for n in nodes[leaf]:
+        cover[n["left"]:n["right"]] += 1
+    assert (cover == 1).all()
+
+
+def test_nn_query_matches_bruteforce(scenario, gold):
+    nn, cloud = scenario["nn_scene"], scenario["cloud"]
+    rng = np.random.default_rng(0)
+    for j in rng.choice(len(cloud), 300, replace=False):
+        ok, win, d2, visits = nn.query(cloud[j])
+        diff = nn.pcd - cloud[j]
+        # same float op order as pcd_scene.h:86-89 (x^2 + y^2) + z^2
+        # NB (src - p)^2 == (p - src)^2 bitwise
+        bf = (diff[:, 0] * diff[:, 0] + diff[:, 1] * diff[:, 1]) + diff[:, 2] * diff[:, 2]
+        assert np.float32(d2) == bf.min()
+        assert ok == 1 and visits > 0
+
+
+@pytest.mark.parametrize("key,scene_key", [("proj_default", "proj_scene"), ("proj_fixed20", "proj_scene"),
+                                           ("nn_default", "nn_scene"), ("nn_fixed20", "nn_scene")])
+def test_icp_known_answers(scenario, gold, key, scene_key):
+    g = gold["icp"][key]
+    res, passes, cl, _ = O.icp(scenario["cloud"], scenario[scene_key], tuple(g["criteria"]), O.SUM_SEQUENTIAL)
+    n = len(scenario["cloud"])
+    assert int(round(float(res["fitness"]) * n)) == g["inliers"]
+    if "fitness" in g:
+        assert float(res["fitness"]) == pytest.approx(g["fitness"], rel=2e-8)
+    assert float(res["inlier_rmse"]) == pytest.approx(g["rmse"], rel=5e-8)
+    T = res["T"].reshape(4, 4)
+    for r, row in enumerate(g["T_rows"]):
+        assert np.allclose(T[r], np.array(row, np.float32), rtol=0, atol=2e-8 + 6e-8 * np.abs(row).max())
+    if g["criteria"][0] == 0.0:
+        assert passes == g["criteria"][2] + 1
+
+
+def test_canonical_tree_close_to_sequential(scenario):
+    """The canonical (GPU) reduction order is the same sum up to float association."""
+    for sk in ("proj_scene", "nn_scene"):
+        a = O.sum29(scenario["cloud"], scenario[sk], O.SUM_SEQUENTIAL)
+        b = O.sum29(scenario["cloud"], scenario[sk], O.SUM_CANONICAL, 2048)
+        assert a[28] == b[28]                                  # inlier count is an exact integer sum
+        assert np.allclose(a, b, rtol=2e-4, atol=1e-6)
+
+
+def test_solver_against_numpy():
+    rng = np.random.default_rng(1)
+    for _ in range(20):
+        J = rng.normal(size=(50, 6)).astype(np.float32)
+        A = (J.T @ J).astype(np.float32); b = (J.T @ rng.normal(size=50) * 0.01).astype(np.float32)
+        T = O.solve666(A, b)
+        x = np.linalg.solve(A.astype(np.float64) + 0.01 * np.eye(6), b.astype(np.float64))
+        cx, sx, cy, sy, cz, sz = np.cos(x[0]), np.sin(x[0]), np.cos(x[1]), np.sin(x[1]), np.cos(x[2]), np.sin(x[2])
+        Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]]); Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+        Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+        ref = np.eye(4); ref[:3, :3] = Rz @ Ry @ Rx; ref[:3, 3] = x[3:]
+        assert np.allclose(T, ref.astype(np.float32), atol=1e-6)
+
+
+def test_roi_render_is_a_crop(scenario):
+    """cuda_renderer/test.cpp:116-157 ROI case: rendering with a ROI == cropping the full render."""
+    roi = (160, 80, 320, 240)
+    full = scenario["depth"][0]
+    part = O.render(scenario["tris"], scenario["poses"][:1], synth.WIDTH, synth.HEIGHT, scenario["proj"], roi)[0]
+    assert np.array_equal(part, full[roi[1]:roi[1] + roi[3], roi[0]:roi[0] + roi[2]])
