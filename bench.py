@@ -1,0 +1,175 @@
+#!/usr/bin/env python
+"""bench.py -- refined poses/s of the fused hot path (render -> cloud -> 21-pass ICP) on N MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch of synthetic hypotheses per GPU:
+BASELINE.json configs[1] -- obj_06.ply, 256-pose batch, 640x480, projective association,
+ICPConvergenceCriteria(0,0,20) => exactly 21 correspondence passes / 20 solves per pose
+(SURVEY.md 8d).  Model triangles and the scene are resident in HBM before the timed region; the
+timed region includes the pose upload (64 B/pose), every kernel, the per-iteration host solve
+round trips (PR_SOLVE_HOST) or the device solve, and the result gather.
+
+Multi-GPU (weak scaling): rank r refines hypotheses [r*P, (r+1)*P) of the seeded stream -- no
+data-path collective -- then ONE RCCL gather of the P x 72-byte RegistrationResult records to
+rank 0 over xGMI (torch.distributed backend "nccl" == RCCL).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) including `roofline` for the
+dominant kernel (the correspondence kernel, HIP-event timed on the library's own stream) and
+`cpu_baseline` (the CPU oracle on a bounded sample, rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12                       # MI355X_MICROARCH.md: 8 TB/s spec
+# SURVEY.md 8d algorithmic bytes of the correspondence kernel: per pass 12 B source read + 24 B
+# destination/normal gather, + 12 B write-back on every pass after the first:
+# N*(21*36 + 20*12) = 996 N bytes per pose over 21 launches.
+BYTES_PER_POINT_PASS0, BYTES_PER_POINT_PASSK = 36.0, 48.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--poses", type=int, default=256, help="hypotheses per GPU per step")
+    ap.add_argument("--scene", choices=["proj", "nn"], default="proj")
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--solve", choices=["host", "device"], default=os.environ.get("PR_BENCH_SOLVE", "device"))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-poses", type=int, default=0, help="CPU baseline sample size (0 = auto)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    # torch first: its bundled HIP runtime must be the one both torch and libpose_refine_hip.so use
+    import torch
+    import torch.distributed as dist
+    import numpy as np
+    from pose_refine_amd import api, synth, _lib
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    api.init(local_rank)
+    api.set_option("solve", api.SOLVE_DEVICE if args.solve == "device" else api.SOLVE_HOST)
+
+    W, H, K = synth.WIDTH, synth.HEIGHT, synth.K_TEST
+    P = args.poses
+    model = api.Model(os.path.join(ROOT, "tests", "golden", "obj_06.ply"))
+    proj = api.compute_proj(K, W, H)
+    scene_depth = api.render_host(model, synth.scene_pose()[None], W, H, proj)[0]
+    scene = (api.Scene_projective().init_Scene_projective_cuda(scene_depth, K) if args.scene == "proj"
+             else api.Scene_nn().init_Scene_nn_cuda(scene_depth, K))
+    poses = synth.hypotheses(P, seed=6, first=rank * P)          # this rank's shard of the global batch
+    crit = api.ICPConvergenceCriteria(0.0, 0.0, args.iters)
+
+    results = torch.zeros(P * 18, dtype=torch.float32, device="cuda")          # P x RegistrationResult (72 B)
+    gathered = [torch.zeros_like(results) for _ in range(world)] if (world > 1 and rank == 0) else None
+
+    def step():
+        _, sizes = api.refine_batch(model, poses, W, H, proj, K, scene, crit, results_dev=results.data_ptr())
+        if world > 1:
+            dist.gather(results, gathered, dst=0)                  # the single RCCL exchange of the job
+        return sizes
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        sizes = step()
+    api.set_option("profile", 1)
+    api.profile_reset()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sizes = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    api.set_option("profile", 0)
+    prof = api.profile_read()
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        total_poses = P * world * args.steps
+        launches = max(1, prof["icp_launches"])
+        pts_per_launch = prof["icp_points"] / launches
+        n_pass = args.iters + 1
+        bytes_per_point = (BYTES_PER_POINT_PASS0 + BYTES_PER_POINT_PASSK * (n_pass - 1)) / n_pass
+        avg_launch_s = prof["icp_kernel_ms"] * 1e-3 / launches
+        achieved = bytes_per_point * pts_per_launch / avg_launch_s if avg_launch_s > 0 else 0.0
+        out = {
+            "metric": "refined poses/sec (640x480, 20 ICP iters)",
+            "value": total_poses / elapsed,
+            "unit": "poses/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"obj_06.ply, {P}-pose batch per GPU, 640x480 synthetic depth, "
+                                   f"{'projective' if args.scene == 'proj' else 'stackless kd-tree NN'} association, "
+                                   f"{args.iters} ICP iterations (21 passes), solve on {args.solve}",
+                       "poses_per_gpu": P, "global_batch": P * world, "points_per_pose_mean": float(np.mean(sizes)),
+                       "parallelism": f"pose-shard x{world}, 1 RCCL gather"},
+            "roofline": {"bound": "hbm", "kernel": "icp_pass_kernel (correspondence + 29-term reduce)",
+                         "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK, "traffic": None,
+                         "avg_launch_us": avg_launch_s * 1e6, "launches": int(launches),
+                         "algorithmic_bytes_per_launch": bytes_per_point * pts_per_launch},
+            "phase_ms_per_step": {"icp_kernel": prof["icp_kernel_ms"] / args.steps, "render": prof["render_ms"] / args.steps,
+                                  "cloud": prof["cloud_ms"] / args.steps},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, model.tris, poses, scene_depth, K, W, H)
+        print(json.dumps(out), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, tris, poses, scene_depth, K, W, H):
+    """The CPU oracle (a port of the reference CPU path, oracle/pose_oracle.c) on a bounded sample of
+    the same workload: per-pose render_cpu -> depth2cloud_cpu -> ICP_Point2Plane_cpu with the same
+    fixed 20 iterations, OpenMP across hypotheses on all host cores."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    cores = os.cpu_count() or 1
+    per_pose_s = 0.06 if args.scene == "proj" else 1.5             # single-thread estimates
+    n = args.cpu_poses or int(max(cores, min(len(poses), round(15.0 * cores / per_pose_s))))
+    n = min(n, len(poses))
+    oscene = O.ProjScene(scene_depth, K) if args.scene == "proj" else O.NNScene(scene_depth, K)
+    proj = O.compute_proj(K, W, H)
+    t0 = time.perf_counter()
+    _, _, threads = O.refine_batch(tris, poses[:n], W, H, proj, K, oscene, (0.0, 0.0, args.iters), O.SUM_SEQUENTIAL)
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "poses/s", "cores": int(threads), "kind": "port",
+            "sample": f"first {n} hypotheses of the same batch, {dt:.1f} s wall, OpenMP over poses"}
+
+
+if __name__ == "__main__":
+    main()

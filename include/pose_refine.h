@@ -1,0 +1,165 @@
+/*
+ * pose_refine.h -- C ABI of the MI355X-native render -> cloud -> point-to-plane ICP hot path.
+ *
+ * This is the drop-in boundary.  The reference (meiqua/pose_refine) has no FFI layer: its boundary
+ * is the C++ header API (cuda_renderer/renderer.h, cuda_icp/icp.h, cuda_icp/scene/...).  The C++
+ * adapter headers in include/cuda_renderer and include/cuda_icp keep that API source-compatible
+ * and forward every device-side entry point to the functions below.  Each function cites the
+ * reference interface it replaces (paths relative to the reference root).
+ *
+ * Conventions: plain pointers and sizes, no C++/torch types.  "dev" pointers are device (HBM)
+ * pointers obtained from pr_malloc (or any hipMalloc'd memory of the current device); everything
+ * else is host memory.  All functions return PR_OK (0) or a negative error code; the message of
+ * the last failure on the calling thread is available from pr_last_error().  There is NO CPU
+ * fallback: every device entry point fails with PR_ERR_NO_DEVICE when no gfx950 device is usable.
+ * Work is issued on one library-owned HIP stream per device context; calls are synchronous with
+ * respect to the host unless stated otherwise.
+ */
+#ifndef POSE_REFINE_H
+#define POSE_REFINE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PR_OK                 0
+#define PR_ERR_NO_DEVICE     -1
+#define PR_ERR_HIP           -2
+#define PR_ERR_INVALID       -3
+#define PR_ERR_IO            -4
+#define PR_ERR_NOMEM         -5
+
+/* ---- POD mirrors of the reference types (layouts verified by static_assert in the adapters) -- */
+typedef struct { float x, y, z; } pr_vec3;                         /* ::Vec3f geometry.h:83-103; Model::float3 renderer.h:50-57 (12 B) */
+typedef struct { pr_vec3 v0, v1, v2; } pr_triangle;                /* Model::Triangle renderer.h:58-68 (36 B)                          */
+typedef struct { float m[16]; } pr_mat4;                           /* Model::mat4x4 renderer.h:69-141 = ::Mat4x4f, row-major (64 B)    */
+typedef struct { int x, y, width, height; } pr_roi;                /* Model::ROI renderer.h:43-48                                      */
+typedef struct {                                                   /* ::Node_kdtree pcd_scene.h:5-25 (52 B)                            */
+    int parent, child1, child2;
+    float split_v;
+    float bbox[6];
+    int split_dim;
+    int left, right;
+} pr_kdnode;
+typedef struct { float T[16]; float inlier_rmse; float fitness; } pr_result;        /* cuda_icp::RegistrationResult icp.h:26-36 (72 B) */
+typedef struct { float relative_fitness, relative_rmse; int max_iteration; } pr_criteria; /* cuda_icp::ICPConvergenceCriteria icp.h:38-50 */
+
+/* Scene_projective (depth_scene.h:7-48): non-owning view, passed by value like the reference does. */
+typedef struct {
+    uint64_t width, height;
+    float max_dist_diff;
+    float K[9];
+    const pr_vec3 *pcd;        /* dev, width*height, (0,0,0) where depth==0 */
+    const pr_vec3 *normal;     /* dev, width*height */
+} pr_scene_proj;
+
+/* Scene_nn (pcd_scene.h:48-137): non-owning view of a KDTree_cuda (pcd_scene.h:38-45). */
+typedef struct {
+    float max_dist_diff;
+    const pr_vec3 *pcd;        /* dev, n_points, in tree order */
+    const pr_vec3 *normal;     /* dev, n_points */
+    const pr_kdnode *nodes;    /* dev, n_nodes, level order, nodes[0] = root */
+    uint32_t n_points, n_nodes;
+} pr_scene_nn;
+
+#define PR_SCENE_PROJ 0
+#define PR_SCENE_NN   1
+
+/* where the 6x6 solve of every ICP iteration runs (icp.cu:207 does it on the host) */
+#define PR_SOLVE_HOST   0
+#define PR_SOLVE_DEVICE 1
+
+/* ---- library / device ------------------------------------------------------------------------ */
+const char *pr_last_error(void);
+const char *pr_version(void);
+int pr_device_count(void);                       /* number of visible HIP devices (0 if none)              */
+int pr_init(int device);                         /* select device, create the stream (test.cpp:12-20 warm-up) */
+int pr_shutdown(void);                           /* release cached workspaces + stream                      */
+int pr_sync(void);                               /* wait for the library stream                              */
+
+/* device_vector_holder<T> storage: common.cu:3-40, renderer.cu:15-50 */
+int pr_malloc(void **dev_ptr, size_t bytes);
+int pr_free(void *dev_ptr);
+int pr_memcpy_h2d(void *dev_dst, const void *host_src, size_t bytes);
+int pr_memcpy_d2h(void *host_dst, const void *dev_src, size_t bytes);
+int pr_memcpy_d2d(void *dev_dst, const void *dev_src, size_t bytes);
+int pr_fill_i32(int32_t *dev_dst, size_t count, int32_t value);   /* holder(size, init) fill ctor */
+
+/* ---- host-side model / scene preparation (CPU in the reference too) --------------------------- */
+/* Model::Model(fileName) renderer.cpp:11-58: ASCII PLY -> triangle list (only tris feed this path). */
+int pr_ply_count(const char *path, size_t *n_triangles, size_t *n_vertices);
+int pr_ply_load(const char *path, pr_triangle *tris_out, size_t cap_triangles, size_t *n_triangles);
+/* compute_proj renderer.cpp:161-185 */
+void pr_compute_proj(const float K[9], int width, int height, float near_, float far_, pr_mat4 *proj_out);
+/* get_normal common.cpp:17-107 (depth already uint16, mm) */
+int pr_get_normal(const uint16_t *depth16, int width, int height, const float K[9], pr_vec3 *normals_out);
+/* init_Scene_projective_cpu depth_scene.cpp:3-35: fills width*height pcd + normal host buffers */
+int pr_scene_proj_prepare(const void *depth, int depth_is_i32, const float K[9], size_t width, size_t height,
+                          pr_vec3 *pcd_out, pr_vec3 *normal_out);
+/* init_Scene_nn_cpu pcd_scene.cpp:4-37 + KDTree_cpu::build_tree pcd_scene.cpp:45-184.
+ * pcd_out/normal_out need width*height entries, nodes_out 2*width*height+1 entries (worst case). */
+int pr_scene_nn_prepare(const void *depth, int depth_is_i32, const float K[9], int width, int height,
+                        int max_leaf, pr_vec3 *pcd_out, pr_vec3 *normal_out, pr_kdnode *nodes_out,
+                        size_t cap_nodes, uint32_t *n_points, uint32_t *n_nodes);
+/* KDTree_cpu::build_tree on caller-provided points (reorders pcd/normal in place) */
+int pr_kdtree_build(pr_vec3 *pcd, pr_vec3 *normal, size_t n_points, int max_leaf,
+                    pr_kdnode *nodes_out, size_t cap_nodes, uint32_t *n_nodes);
+/* eigen_slover_666 icp.cpp:29-45 (public in icp.h:54) */
+void pr_solve_666(const float A[36], const float b[6], pr_mat4 *T_out);
+
+/* ---- renderer (cuda_renderer/renderer.cu) ------------------------------------------------------ */
+/* render_cuda_keep_in_gpu renderer.cu:269-336: depth_dev_out[n_poses*rw*rh] int32 mm, 0 = empty.
+ * tris_dev: device triangles (the device_vector_holder<Triangle> overloads); poses on the host. */
+int pr_render(const pr_triangle *tris_dev, size_t n_tris, const pr_mat4 *poses_host, size_t n_poses,
+              size_t width, size_t height, const pr_mat4 *proj, pr_roi roi, int32_t *depth_dev_out);
+/* render_cuda renderer.cu:189-267: same, result copied to the host */
+int pr_render_to_host(const pr_triangle *tris_dev, size_t n_tris, const pr_mat4 *poses_host, size_t n_poses,
+                      size_t width, size_t height, const pr_mat4 *proj, pr_roi roi, int32_t *depth_host_out);
+
+/* ---- depth -> cloud (cuda_icp/icp.cu:228-291 depth2cloud_cuda<T>) ------------------------------ */
+/* Allocates *cloud_dev_out (release with pr_free); points in row-major pixel order, metres. */
+int pr_depth2cloud_i32(const int32_t *depth_dev, uint32_t width, uint32_t height, const float K[9],
+                       uint32_t stride, uint32_t tl_x, uint32_t tl_y, pr_vec3 **cloud_dev_out, uint32_t *n_points);
+int pr_depth2cloud_u16(const uint16_t *depth_dev, uint32_t width, uint32_t height, const float K[9],
+                       uint32_t stride, uint32_t tl_x, uint32_t tl_y, pr_vec3 **cloud_dev_out, uint32_t *n_points);
+
+/* ---- ICP (cuda_icp/icp.cu:156-223 ICP_Point2Plane_cuda<Scene>) --------------------------------- */
+/* One cloud: mutates cloud_dev in place exactly like the reference. */
+int pr_icp_proj(pr_vec3 *cloud_dev, uint32_t n_points, const pr_scene_proj *scene, pr_criteria crit, pr_result *result_out);
+int pr_icp_nn(pr_vec3 *cloud_dev, uint32_t n_points, const pr_scene_nn *scene, pr_criteria crit, pr_result *result_out);
+/* Many clouds against one scene in one launch per iteration (what the reference needs P host
+ * threads + cudaStreamPerThread for, README.md:15): cloud i = clouds_dev[offsets[i] .. offsets[i+1]). */
+int pr_icp_batch(pr_vec3 *clouds_dev, const uint32_t *offsets_host, uint32_t n_clouds, int scene_kind,
+                 const void *scene, pr_criteria crit, pr_result *results_host);
+
+/* ---- fused hypothesis refinement: render -> cloud -> ICP for n_poses hypotheses --------------- */
+/* test.cpp:143-172 for a whole batch, everything resident on the device; results on the host.
+ * cloud_sizes_host (optional) receives the model-cloud size of every hypothesis. */
+int pr_refine_batch(const pr_triangle *tris_dev, size_t n_tris, const pr_mat4 *poses_host, uint32_t n_poses,
+                    uint32_t width, uint32_t height, const pr_mat4 *proj, const float K[9],
+                    int scene_kind, const void *scene, pr_criteria crit,
+                    pr_result *results_host, uint32_t *cloud_sizes_host);
+/* same, results left on the device (for the RCCL gather of the sharded job): results_dev[n_poses] */
+int pr_refine_batch_dev(const pr_triangle *tris_dev, size_t n_tris, const pr_mat4 *poses_host, uint32_t n_poses,
+                        uint32_t width, uint32_t height, const pr_mat4 *proj, const float K[9],
+                        int scene_kind, const void *scene, pr_criteria crit,
+                        pr_result *results_dev, uint32_t *cloud_sizes_host);
+
+/* ---- sharding of a hypothesis batch over ranks (contiguous blocks) ---------------- */
+void pr_shard_range(uint32_t n_items, uint32_t rank, uint32_t world, uint32_t *first, uint32_t *count);
+
+/* ---- options / instrumentation ----------------------------------------------------------------- */
+int  pr_set_option(const char *name, int value);    /* "solve" = PR_SOLVE_HOST|PR_SOLVE_DEVICE, "points_per_block", "profile" */
+int  pr_get_option(const char *name, int *value);
+/* HIP-event timing of the correspondence kernel on the library stream (option "profile"=1):
+ * accumulated since the last reset. points = model points processed, launches = kernel launches. */
+int  pr_profile_reset(void);
+int  pr_profile_read(double *kernel_ms, uint64_t *launches, uint64_t *points, double *render_ms, double *cloud_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POSE_REFINE_H */

@@ -1,0 +1,336 @@
+"""Host-side mirror of the reference's public API for the hot path, on top of the C ABI.
+
+Names, argument meaning and error behaviour follow the reference headers so that tests read like
+the reference's own drivers (``test.cpp``, ``cuda_renderer/test.cpp``):
+
+  cuda_renderer::Model / compute_proj / render / render_host        cuda_renderer/renderer.h:27-248
+  cuda_icp::depth2cloud / ICP_Point2Plane / RegistrationResult /
+            ICPConvergenceCriteria                                  cuda_icp/icp.h:26-120
+  ::Scene_projective / ::Scene_nn / KDTree_cuda                     cuda_icp/scene/**.h
+  ::device_vector_holder<T>                                         cuda_icp/scene/common.h:16-44
+
+The C++ adapters in include/cuda_renderer and include/cuda_icp are the compiled drop-in; this module
+is the same surface for python callers (tests, bench.py).  Everything that touches the device goes
+through libpose_refine_hip.so -- nothing here computes on the CPU except what the reference also
+computes on the CPU (model import, scene preparation).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import (Criteria, KDNODE, RESULT, Roi, SCENE_NN, SCENE_PROJ, SOLVE_DEVICE, SOLVE_HOST, PoseRefineError,
+                   SceneNNDesc, SceneProjDesc, check, ptr)
+
+
+def _f32(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a if shape is None else a.reshape(shape)
+
+
+# ------------------------------------------------------------------------------------------------
+# library / options
+# ------------------------------------------------------------------------------------------------
+def init(device: int = 0):
+    check(_lib.load().pr_init(device))
+
+
+def device_count() -> int:
+    return _lib.load().pr_device_count()
+
+
+def set_option(name: str, value: int):
+    check(_lib.load().pr_set_option(name.encode(), int(value)))
+
+
+def get_option(name: str) -> int:
+    v = C.c_int()
+    check(_lib.load().pr_get_option(name.encode(), C.byref(v)))
+    return v.value
+
+
+def profile_reset():
+    check(_lib.load().pr_profile_reset())
+
+
+def profile_read():
+    ms, rms, cms = C.c_double(), C.c_double(), C.c_double()
+    n, pts = C.c_uint64(), C.c_uint64()
+    check(_lib.load().pr_profile_read(C.byref(ms), C.byref(n), C.byref(pts), C.byref(rms), C.byref(cms)))
+    return dict(icp_kernel_ms=ms.value, icp_launches=n.value, icp_points=pts.value, render_ms=rms.value, cloud_ms=cms.value)
+
+
+def shard_range(n_items: int, rank: int, world: int):
+    first, count = C.c_uint32(), C.c_uint32()
+    _lib.load().pr_shard_range(n_items, rank, world, C.byref(first), C.byref(count))
+    return first.value, count.value
+
+
+# ------------------------------------------------------------------------------------------------
+# device_vector_holder<T>
+# ------------------------------------------------------------------------------------------------
+class DeviceVector:
+    """RAII device buffer (``device_vector_holder<T>``: common.h:16-44 / renderer.h:161-187)."""
+
+    def __init__(self, count: int = 0, dtype=np.float32, _adopt: Optional[int] = None):
+        self.dtype = np.dtype(dtype)
+        self.count = int(count)
+        self._ptr = None
+        if _adopt is not None:
+            self._ptr = int(_adopt)
+        elif count > 0:
+            p = C.c_void_p()
+            check(_lib.load().pr_malloc(C.byref(p), self.count * self.dtype.itemsize))
+            self._ptr = p.value
+
+    @classmethod
+    def from_host(cls, arr: np.ndarray, dtype=None) -> "DeviceVector":
+        arr = np.ascontiguousarray(arr, dtype=dtype)
+        dv = cls(arr.size if arr.dtype.fields is None else arr.shape[0], arr.dtype)
+        if arr.nbytes:
+            check(_lib.load().pr_memcpy_h2d(dv._ptr, ptr(arr), arr.nbytes))
+        return dv
+
+    def data(self) -> int:
+        return self._ptr or 0
+
+    def size(self) -> int:
+        return self.count
+
+    def to_host(self) -> np.ndarray:
+        out = np.empty(self.count, self.dtype)
+        if self.count:
+            check(_lib.load().pr_memcpy_d2h(ptr(out), self._ptr, out.nbytes))
+        return out
+
+    def free(self):
+        if self._ptr:
+            _lib.load().pr_free(self._ptr)
+            self._ptr = None
+            self.count = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+# ------------------------------------------------------------------------------------------------
+# cuda_renderer
+# ------------------------------------------------------------------------------------------------
+class Model:
+    """``cuda_renderer::Model(fileName)`` -- only ``tris`` feeds this path (renderer.cpp:11-58)."""
+
+    def __init__(self, file_name: Optional[str] = None, tris: Optional[np.ndarray] = None):
+        if tris is not None:
+            self.tris = _f32(tris, (-1, 3, 3))
+        else:
+            lib = _lib.load()
+            nt, nv = C.c_size_t(), C.c_size_t()
+            check(lib.pr_ply_count(file_name.encode(), C.byref(nt), C.byref(nv)))
+            buf = np.zeros((nt.value, 3, 3), np.float32)
+            got = C.c_size_t()
+            check(lib.pr_ply_load(file_name.encode(), ptr(buf), nt.value, C.byref(got)))
+            self.tris = np.ascontiguousarray(buf[:got.value])
+        self._dev: Optional[DeviceVector] = None
+
+    def device_tris(self) -> DeviceVector:
+        """Triangles resident on the device (the ``device_vector_holder<Triangle>`` overloads)."""
+        if self._dev is None:
+            self._dev = DeviceVector.from_host(self.tris.reshape(-1), np.float32)
+        return self._dev
+
+
+def compute_proj(K, width: int, height: int, near: float = 10.0, far: float = 10000.0) -> np.ndarray:
+    out = np.zeros(16, np.float32)
+    k = _f32(K, -1)
+    _lib.load().pr_compute_proj(ptr(k), width, height, near, far, ptr(out))
+    return out
+
+
+def _tris_dev(tris) -> DeviceVector:
+    if isinstance(tris, Model):
+        return tris.device_tris()
+    if isinstance(tris, DeviceVector):
+        return tris
+    return DeviceVector.from_host(_f32(tris, -1))
+
+
+def render(tris, poses, width: int, height: int, proj, roi: Sequence[int] = (0, 0, 0, 0)) -> DeviceVector:
+    """``cuda_renderer::render`` -> ``render_cuda_keep_in_gpu`` (renderer.cu:269-336): int32 depth in mm
+    for every pose, kept on the device, 0 where nothing was drawn."""
+    td = _tris_dev(tris)
+    poses = _f32(poses, (-1, 16))
+    rw, rh = (roi[2], roi[3]) if roi[2] > 0 and roi[3] > 0 else (width, height)
+    out = DeviceVector(len(poses) * rw * rh, np.int32)
+    pj = _f32(proj, -1)
+    check(_lib.load().pr_render(td.data(), td.size() // 9, ptr(poses), len(poses), width, height, ptr(pj), Roi(*roi), out.data()))
+    return out
+
+
+def render_host(tris, poses, width: int, height: int, proj, roi: Sequence[int] = (0, 0, 0, 0)) -> np.ndarray:
+    """``cuda_renderer::render_host`` -> ``render_cuda`` (renderer.cu:189-267): result on the host."""
+    td = _tris_dev(tris)
+    poses = _f32(poses, (-1, 16))
+    rw, rh = (roi[2], roi[3]) if roi[2] > 0 and roi[3] > 0 else (width, height)
+    out = np.empty((len(poses), rh, rw), np.int32)
+    pj = _f32(proj, -1)
+    check(_lib.load().pr_render_to_host(td.data(), td.size() // 9, ptr(poses), len(poses), width, height, ptr(pj), Roi(*roi), ptr(out)))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# cuda_icp
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class ICPConvergenceCriteria:           # icp.h:38-50
+    relative_fitness: float = 1e-5
+    relative_rmse: float = 1e-5
+    max_iteration: int = 30
+
+    def c(self) -> Criteria:
+        return Criteria(self.relative_fitness, self.relative_rmse, self.max_iteration)
+
+
+@dataclass
+class RegistrationResult:               # icp.h:26-36
+    transformation_: np.ndarray
+    inlier_rmse_: float
+    fitness_: float
+
+    @classmethod
+    def from_record(cls, r) -> "RegistrationResult":
+        return cls(np.array(r["T"], np.float32).reshape(4, 4), float(r["inlier_rmse"]), float(r["fitness"]))
+
+
+def depth2cloud(depth_dev, width: int, height: int, K, stride: int = 1, tl_x: int = 0, tl_y: int = 0,
+                dtype=np.int32, offset_elems: int = 0) -> DeviceVector:
+    """``cuda_icp::depth2cloud_cuda<T>`` (icp.cu:256-291): DEVICE depth pointer in, device cloud out.
+    ``depth_dev`` is a DeviceVector (or raw device address); offset_elems selects an image of a stack."""
+    base = depth_dev.data() if isinstance(depth_dev, DeviceVector) else int(depth_dev)
+    dt = np.dtype(dtype)
+    k = _f32(K, -1)
+    out, n = C.c_void_p(), C.c_uint32()
+    fn = _lib.load().pr_depth2cloud_u16 if dt == np.uint16 else _lib.load().pr_depth2cloud_i32
+    check(fn(base + offset_elems * dt.itemsize, width, height, ptr(k), stride, tl_x, tl_y, C.byref(out), C.byref(n)))
+    return DeviceVector(n.value * 3, np.float32, _adopt=out.value)
+
+
+class Scene_projective:
+    """``::Scene_projective`` (depth_scene.h:7-48) initialised like ``init_Scene_projective_cuda``
+    (depth_scene.cu:3-20): CPU preparation (back-projection + normals), then two uploads."""
+
+    def __init__(self):
+        self.width, self.height, self.max_dist_diff = 640, 480, 0.1
+        self.K = np.zeros(9, np.float32)
+        self.pcd_buffer: Optional[DeviceVector] = None
+        self.normal_buffer: Optional[DeviceVector] = None
+        self.pcd_host = self.normal_host = None
+
+    def init_Scene_projective_cuda(self, scene_depth: np.ndarray, scene_K, width: int = 640, height: int = 480,
+                                   max_dist_diff: float = 0.1):
+        if scene_depth.dtype not in (np.uint16, np.int32):          # depth_scene.cpp:11-12 assert
+            raise ValueError("scene depth must be CV_16U or CV_32S")
+        self.width, self.height, self.max_dist_diff = width, height, max_dist_diff
+        self.K = _f32(scene_K, -1)
+        d = np.ascontiguousarray(scene_depth)
+        pcd = np.zeros((width * height, 3), np.float32)
+        nrm = np.zeros((width * height, 3), np.float32)
+        check(_lib.load().pr_scene_proj_prepare(ptr(d), int(d.dtype == np.int32), ptr(self.K), width, height, ptr(pcd), ptr(nrm)))
+        self.pcd_host, self.normal_host = pcd, nrm
+        self.pcd_buffer = DeviceVector.from_host(pcd.reshape(-1))
+        self.normal_buffer = DeviceVector.from_host(nrm.reshape(-1))
+        return self
+
+    kind = SCENE_PROJ
+
+    def desc(self) -> SceneProjDesc:
+        return SceneProjDesc(self.width, self.height, self.max_dist_diff, (C.c_float * 9)(*self.K),
+                             self.pcd_buffer.data(), self.normal_buffer.data())
+
+
+class Scene_nn:
+    """``::Scene_nn`` + ``KDTree_cuda`` (pcd_scene.h:27-137) initialised like ``init_Scene_nn_cuda``
+    (pcd_scene.cu:3-20): CPU normals + kd-tree build, then three uploads."""
+
+    kind = SCENE_NN
+
+    def __init__(self):
+        self.max_dist_diff = 0.1
+        self.pcd_buffer = self.normal_buffer = self.nodes = None
+        self.pcd_host = self.normal_host = self.nodes_host = None
+
+    def init_Scene_nn_cuda(self, scene_depth: np.ndarray, scene_K, max_leaf: int = 10, max_dist_diff: float = 0.1):
+        if scene_depth.dtype not in (np.uint16, np.int32):          # pcd_scene.cpp:6-7 assert
+            raise ValueError("scene depth must be CV_16U or CV_32S")
+        h, w = scene_depth.shape
+        k = _f32(scene_K, -1)
+        d = np.ascontiguousarray(scene_depth)
+        pcd = np.zeros((w * h, 3), np.float32)
+        nrm = np.zeros((w * h, 3), np.float32)
+        nodes = np.zeros(2 * w * h + 1, KDNODE)
+        npts, nnodes = C.c_uint32(), C.c_uint32()
+        check(_lib.load().pr_scene_nn_prepare(ptr(d), int(d.dtype == np.int32), ptr(k), w, h, max_leaf, ptr(pcd), ptr(nrm),
+                                              ptr(nodes), len(nodes), C.byref(npts), C.byref(nnodes)))
+        self.max_dist_diff = max_dist_diff
+        self.pcd_host = np.ascontiguousarray(pcd[:npts.value])
+        self.normal_host = np.ascontiguousarray(nrm[:npts.value])
+        self.nodes_host = np.ascontiguousarray(nodes[:nnodes.value])
+        self.pcd_buffer = DeviceVector.from_host(self.pcd_host.reshape(-1))
+        self.normal_buffer = DeviceVector.from_host(self.normal_host.reshape(-1))
+        self.nodes = DeviceVector.from_host(self.nodes_host)
+        return self
+
+    def desc(self) -> SceneNNDesc:
+        return SceneNNDesc(self.max_dist_diff, self.pcd_buffer.data(), self.normal_buffer.data(), self.nodes.data(),
+                           len(self.pcd_host), len(self.nodes_host))
+
+
+def ICP_Point2Plane(model_pcd: DeviceVector, scene, criteria: ICPConvergenceCriteria = ICPConvergenceCriteria()) -> RegistrationResult:
+    """``cuda_icp::ICP_Point2Plane_cuda<Scene>`` (icp.cu:156-223).  Mutates ``model_pcd`` in place."""
+    res = np.zeros(1, RESULT)
+    d = scene.desc()
+    fn = _lib.load().pr_icp_nn if scene.kind == SCENE_NN else _lib.load().pr_icp_proj
+    check(fn(model_pcd.data(), model_pcd.size() // 3, C.addressof(d), criteria.c(), ptr(res)))
+    return RegistrationResult.from_record(res[0])
+
+
+def ICP_Point2Plane_batch(clouds: DeviceVector, offsets, scene, criteria: ICPConvergenceCriteria = ICPConvergenceCriteria()) -> np.ndarray:
+    """Many clouds against one scene (one launch per iteration).  offsets: P+1 point offsets."""
+    offsets = np.ascontiguousarray(offsets, np.uint32)
+    res = np.zeros(len(offsets) - 1, RESULT)
+    d = scene.desc()
+    check(_lib.load().pr_icp_batch(clouds.data(), ptr(offsets), len(offsets) - 1, scene.kind, C.addressof(d), criteria.c(), ptr(res)))
+    return res
+
+
+def refine_batch(tris, poses, width: int, height: int, proj, K, scene,
+                 criteria: ICPConvergenceCriteria = ICPConvergenceCriteria(), results_dev: Optional[int] = None):
+    """Fused hypothesis refinement (test.cpp:143-172 for a batch): render -> cloud -> ICP on the device.
+    Returns (records[P] of RESULT dtype or None when results_dev is given, cloud sizes[P])."""
+    td = _tris_dev(tris)
+    poses = _f32(poses, (-1, 16))
+    pj, k = _f32(proj, -1), _f32(K, -1)
+    sizes = np.zeros(len(poses), np.uint32)
+    d = scene.desc()
+    if results_dev is None:
+        res = np.zeros(len(poses), RESULT)
+        check(_lib.load().pr_refine_batch(td.data(), td.size() // 9, ptr(poses), len(poses), width, height, ptr(pj), ptr(k),
+                                          scene.kind, C.addressof(d), criteria.c(), ptr(res), ptr(sizes)))
+        return res, sizes
+    check(_lib.load().pr_refine_batch_dev(td.data(), td.size() // 9, ptr(poses), len(poses), width, height, ptr(pj), ptr(k),
+                                          scene.kind, C.addressof(d), criteria.c(), int(results_dev), ptr(sizes)))
+    return None, sizes
+
+
+def eigen_slover_666(A, b) -> np.ndarray:
+    """``cuda_icp::eigen_slover_666`` (icp.cpp:29-45, public in icp.h:54)."""
+    T = np.zeros(16, np.float32)
+    a, bb = _f32(A, -1), _f32(b, -1)
+    _lib.load().pr_solve_666(ptr(a), ptr(bb), ptr(T))
+    return T.reshape(4, 4)

@@ -1,0 +1,628 @@
+// pr_api.cpp -- the C ABI (include/pose_refine.h): device context, workspaces, and the batched
+// ICP driver that replaces the per-pose host loop of cuda_icp/icp.cu:156-217.
+//
+// One library-owned HIP stream; workspaces are grow-only and reused between calls (the reference
+// cudaMallocs per call: common.cu:27, renderer.cu:39).  No CPU fallback: every device entry point
+// returns PR_ERR_NO_DEVICE when no GPU is usable.
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "pr_internal.h"
+
+namespace prh {
+static thread_local std::string g_err;
+void set_error(const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    g_err = buf;
+}
+}  // namespace prh
+
+namespace {
+
+using prh::set_error;
+
+#define HIP_TRY(expr)                                                                           \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess) {                                                                 \
+            set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return PR_ERR_HIP;                                                                  \
+        }                                                                                       \
+    } while (0)
+#define PR_TRY(expr) do { int rc_ = (expr); if (rc_ != PR_OK) return rc_; } while (0)
+
+struct DevBuf {                      // grow-only device workspace
+    void *p = nullptr; size_t cap = 0;
+    int ensure(size_t bytes)
+    {
+        if (bytes <= cap) return PR_OK;
+        if (p) { hipFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) { set_error("hipMalloc(%zu) failed: %s", want, hipGetErrorString(e)); p = nullptr; return PR_ERR_NOMEM; }
+        cap = want;
+        return PR_OK;
+    }
+    void release() { if (p) hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T *as() const { return static_cast<T *>(p); }
+};
+struct PinBuf {                      // grow-only pinned host staging
+    void *p = nullptr; size_t cap = 0;
+    int ensure(size_t bytes)
+    {
+        if (bytes <= cap) return PR_OK;
+        if (p) { hipHostFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        if (e != hipSuccess) { set_error("hipHostMalloc(%zu) failed: %s", want, hipGetErrorString(e)); p = nullptr; return PR_ERR_NOMEM; }
+        cap = want;
+        return PR_OK;
+    }
+    void release() { if (p) hipHostFree(p); p = nullptr; cap = 0; }
+    template <class T> T *as() const { return static_cast<T *>(p); }
+};
+
+struct Ctx {
+    bool ready = false;
+    int device = -1;
+    hipStream_t stream = nullptr;
+    // options
+    int solve_mode = PR_SOLVE_HOST;
+    int steps = 2;                   // 1024-point steps per workgroup -> 2048 points per workgroup
+    int profile = 0;
+    int nn_lds_nodes = 1024;
+    // workspaces
+    DevBuf poses, depth, row_count, row_off, counts, cloud, start, state, xform, partial, sums, rec, topo, bmin, bmax, pts, dstate, dresults;
+    PinBuf h_sums, h_xform, h_state, h_counts, h_start, h_results;
+    // profiling
+    std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
+    struct Span { size_t e0, e1; int kind; };
+    std::vector<Span> spans;
+    double icp_ms = 0, render_ms = 0, cloud_ms = 0; uint64_t icp_launches = 0, icp_points = 0;
+};
+Ctx g;
+std::mutex g_mu;
+
+int require_ctx()
+{
+    if (g.ready) return PR_OK;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        set_error("no usable HIP device (hipGetDeviceCount: %s, count %d) -- this library has no CPU fallback",
+                  hipGetErrorString(e), n);
+        return PR_ERR_NO_DEVICE;
+    }
+    int dev = g.device >= 0 ? g.device : 0;
+    if (dev >= n) { set_error("device %d out of range (%d visible)", dev, n); return PR_ERR_NO_DEVICE; }
+    HIP_TRY(hipSetDevice(dev));
+    HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+    g.device = dev;
+    g.ready = true;
+    return PR_OK;
+}
+
+// ---- profiling spans (HIP events on the library stream) ------------------------------------------
+enum { kSpanIcp = 0, kSpanRender = 1, kSpanCloud = 2 };
+size_t take_event()
+{
+    if (g.ev_used == g.ev_pool.size()) { hipEvent_t e; hipEventCreate(&e); g.ev_pool.push_back(e); }
+    return g.ev_used++;
+}
+struct SpanGuard {
+    bool on; size_t e0 = 0; int kind;
+    explicit SpanGuard(int k) : on(g.profile != 0), kind(k) { if (on) { e0 = take_event(); hipEventRecord(g.ev_pool[e0], g.stream); } }
+    ~SpanGuard() { if (on) { size_t e1 = take_event(); hipEventRecord(g.ev_pool[e1], g.stream); g.spans.push_back({ e0, e1, kind }); } }
+};
+void drain_spans()                   // call after the stream has been synchronised
+{
+    for (const auto &s : g.spans) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, g.ev_pool[s.e0], g.ev_pool[s.e1]) != hipSuccess) continue;
+        if (s.kind == kSpanIcp) { g.icp_ms += ms; g.icp_launches++; }
+        else if (s.kind == kSpanRender) g.render_ms += ms;
+        else g.cloud_ms += ms;
+    }
+    g.spans.clear();
+    g.ev_used = 0;
+}
+
+inline void identity16(float *T) { for (int i = 0; i < 16; ++i) T[i] = (i % 5 == 0) ? 1.0f : 0.0f; }
+
+// ---- scene variants -----------------------------------------------------------------------------
+struct SceneSel {
+    int kind = PR_SCENE_PROJ;
+    bool packed = false;
+    prk::SceneProjAoS aos{};
+    prk::SceneProjPacked pk{};
+    prk::SceneNNDev nn{};
+};
+
+int make_scene(int kind, const void *scene, bool want_packed, SceneSel &out)
+{
+    out.kind = kind;
+    if (kind == PR_SCENE_PROJ) {
+        const pr_scene_proj *s = static_cast<const pr_scene_proj *>(scene);
+        if (!s || !s->pcd || !s->normal || s->width == 0 || s->height == 0) { set_error("invalid pr_scene_proj"); return PR_ERR_INVALID; }
+        out.aos = prk::SceneProjAoS{ (uint32_t)s->width, (uint32_t)s->height, s->max_dist_diff, s->K[0], s->K[4], s->K[2], s->K[5], s->pcd, s->normal };
+        out.packed = want_packed;
+        if (want_packed) {
+            const size_t n = (size_t)s->width * s->height;
+            PR_TRY(g.rec.ensure(n * sizeof(float4)));
+            HIP_TRY(prk::launch_pack_proj_scene(s->pcd, s->normal, g.rec.as<float4>(), n, g.stream));
+            out.pk = prk::SceneProjPacked{ (uint32_t)s->width, (uint32_t)s->height, s->max_dist_diff, s->K[0], s->K[4], s->K[2], s->K[5], g.rec.as<float4>() };
+        }
+        return PR_OK;
+    }
+    if (kind == PR_SCENE_NN) {
+        const pr_scene_nn *s = static_cast<const pr_scene_nn *>(scene);
+        if (!s || !s->pcd || !s->normal || !s->nodes || s->n_nodes == 0 || s->n_points == 0) { set_error("invalid pr_scene_nn"); return PR_ERR_INVALID; }
+        PR_TRY(g.topo.ensure((size_t)s->n_nodes * sizeof(int4)));
+        PR_TRY(g.bmin.ensure((size_t)s->n_nodes * sizeof(float4)));
+        PR_TRY(g.bmax.ensure((size_t)s->n_nodes * sizeof(float4)));
+        PR_TRY(g.pts.ensure((size_t)s->n_points * sizeof(float4)));
+        HIP_TRY(prk::launch_build_nn_accel(s->nodes, s->n_nodes, s->pcd, s->n_points, g.topo.as<int4>(), g.bmin.as<float4>(),
+                                           g.bmax.as<float4>(), g.pts.as<float4>(), g.stream));
+        uint32_t lds = (uint32_t)std::max(0, g.nn_lds_nodes);
+        lds = std::min(lds, s->n_nodes);
+        lds = std::min<uint32_t>(lds, 8192);                      // <= 128 KiB of LDS
+        out.nn = prk::SceneNNDev{ s->max_dist_diff, g.topo.as<int4>(), g.bmin.as<float4>(), g.bmax.as<float4>(), g.pts.as<float4>(),
+                                  s->pcd, s->normal, s->n_nodes, lds };
+        return PR_OK;
+    }
+    set_error("unknown scene kind %d", kind);
+    return PR_ERR_INVALID;
+}
+
+hipError_t launch_pass(const prk::IcpBatch &b, const SceneSel &sc, uint32_t P)
+{
+    if (sc.kind == PR_SCENE_NN) return prk::launch_icp_pass_nn(b, sc.nn, P, g.stream);
+    if (sc.packed) return prk::launch_icp_pass_proj_packed(b, sc.pk, P, g.stream);
+    return prk::launch_icp_pass_proj_aos(b, sc.aos, P, g.stream);
+}
+
+// ---- the batched ICP driver -----------------------------------------------------------------------
+// clouds: cloud i = cloud_base[start_h[i] .. start_h[i]+count_h[i]).  start/count must already be in
+// g.start / g.counts on the device when dev_meta_ready, otherwise they are uploaded here.
+int icp_drive(pr_vec3 *cloud_base, const uint32_t *start_h, const uint32_t *count_h, uint32_t P, const SceneSel &sc,
+              pr_criteria crit, pr_result *results_host, pr_result *results_dev)
+{
+    if (P == 0) return PR_OK;
+    if (crit.max_iteration < 0) { set_error("max_iteration must be >= 0"); return PR_ERR_INVALID; }
+    const uint32_t steps = (uint32_t)std::max(1, g.steps);
+    const uint32_t ppb = steps * prk::kPointsPerStep;
+    uint32_t max_n = 0; uint64_t sum_n = 0;
+    for (uint32_t i = 0; i < P; ++i) { max_n = std::max(max_n, count_h[i]); sum_n += count_h[i]; }
+    const uint32_t nblk = (max_n + ppb - 1) / ppb;
+
+    PR_TRY(g.start.ensure(sizeof(uint32_t) * P));
+    PR_TRY(g.counts.ensure(sizeof(uint32_t) * P));
+    PR_TRY(g.state.ensure(sizeof(int32_t) * P));
+    PR_TRY(g.xform.ensure(sizeof(float) * 12 * P));
+    PR_TRY(g.partial.ensure(sizeof(float) * prk::kAccStride * (size_t)std::max(1u, nblk) * P));
+    PR_TRY(g.sums.ensure(sizeof(float) * prk::kAccStride * P));
+    PR_TRY(g.h_state.ensure(sizeof(int32_t) * P));
+    PR_TRY(g.h_xform.ensure(sizeof(float) * 12 * P));
+    PR_TRY(g.h_sums.ensure(sizeof(float) * prk::kAccStride * P));
+    PR_TRY(g.h_start.ensure(sizeof(uint32_t) * 2 * P));
+    PR_TRY(g.h_results.ensure(sizeof(pr_result) * P));
+
+    uint32_t *hs = g.h_start.as<uint32_t>();
+    std::memcpy(hs, start_h, sizeof(uint32_t) * P);
+    std::memcpy(hs + P, count_h, sizeof(uint32_t) * P);
+    HIP_TRY(hipMemcpyAsync(g.start.p, hs, sizeof(uint32_t) * P, hipMemcpyHostToDevice, g.stream));
+    HIP_TRY(hipMemcpyAsync(g.counts.p, hs + P, sizeof(uint32_t) * P, hipMemcpyHostToDevice, g.stream));
+
+    prk::IcpBatch b{};
+    b.cloud = cloud_base; b.start = g.start.as<uint32_t>(); b.count = g.counts.as<uint32_t>();
+    b.xform = g.xform.as<float>(); b.state = g.state.as<int32_t>(); b.partial = g.partial.as<float>();
+    b.nblk = nblk; b.steps = steps;
+
+    int32_t *h_state = g.h_state.as<int32_t>();
+    float *h_xform = g.h_xform.as<float>();
+    float *h_sums = g.h_sums.as<float>();
+    pr_result *res = g.h_results.as<pr_result>();
+    for (uint32_t i = 0; i < P; ++i) {
+        identity16(res[i].T); res[i].inlier_rmse = 0.0f; res[i].fitness = 0.0f;   // icp.h:29-31
+        h_state[i] = (count_h[i] > 0) ? prk::kRun : prk::kSkip;    // empty cloud: count==0 -> identity result (icp.cu:183)
+    }
+
+    if (g.solve_mode == PR_SOLVE_DEVICE) {
+        PR_TRY(g.dstate.ensure(sizeof(prk::DevIcpState) * P));
+        std::vector<prk::DevIcpState> init(P);
+        for (uint32_t i = 0; i < P; ++i) { identity16(init[i].T); init[i].fitness = 0; init[i].rmse = 0; init[i].done = (h_state[i] == prk::kSkip); init[i].passes = 0; }
+        HIP_TRY(hipMemcpyAsync(g.dstate.p, init.data(), sizeof(prk::DevIcpState) * P, hipMemcpyHostToDevice, g.stream));
+        HIP_TRY(hipMemcpyAsync(g.state.p, h_state, sizeof(int32_t) * P, hipMemcpyHostToDevice, g.stream));
+        HIP_TRY(hipStreamSynchronize(g.stream));                   // `init` is pageable: finish before it goes away
+        const bool may_exit_early = (crit.relative_fitness > 0.0f && crit.relative_rmse > 0.0f);
+        for (uint32_t it = 0; it <= (uint32_t)crit.max_iteration; ++it) {
+            { SpanGuard sp(kSpanIcp); HIP_TRY(launch_pass(b, sc, P)); }
+            if (g.profile) g.icp_points += sum_n;
+            HIP_TRY(prk::launch_icp_finalize_solve(g.partial.as<float>(), g.counts.as<uint32_t>(), g.state.as<int32_t>(), nblk, steps,
+                                                   g.xform.as<float>(), g.dstate.as<prk::DevIcpState>(), crit, it, P, g.stream));
+            if (may_exit_early && (it & 3) == 3 && it < (uint32_t)crit.max_iteration) {
+                HIP_TRY(hipMemcpyAsync(h_state, g.state.p, sizeof(int32_t) * P, hipMemcpyDeviceToHost, g.stream));
+                HIP_TRY(hipStreamSynchronize(g.stream));
+                bool any = false;
+                for (uint32_t i = 0; i < P; ++i) any |= (h_state[i] != prk::kSkip);
+                if (!any) break;
+            }
+        }
+        pr_result *dres = results_dev;
+        if (!dres) { PR_TRY(g.dresults.ensure(sizeof(pr_result) * P)); dres = g.dresults.as<pr_result>(); }
+        HIP_TRY(prk::launch_pack_results(g.dstate.as<prk::DevIcpState>(), dres, P, g.stream));
+        if (results_host) HIP_TRY(hipMemcpyAsync(results_host, dres, sizeof(pr_result) * P, hipMemcpyDeviceToHost, g.stream));
+        HIP_TRY(hipStreamSynchronize(g.stream));
+        drain_spans();
+        return PR_OK;
+    }
+
+    // PR_SOLVE_HOST: one launch + one small D2H per iteration, the per-pose logic of icp.cu:178-212 on the host
+    uint32_t active = 0;
+    for (uint32_t i = 0; i < P; ++i) active += (h_state[i] != prk::kSkip);
+    for (uint32_t it = 0; it <= (uint32_t)crit.max_iteration && active > 0; ++it) {
+        HIP_TRY(hipMemcpyAsync(g.state.p, h_state, sizeof(int32_t) * P, hipMemcpyHostToDevice, g.stream));
+        if (it > 0) HIP_TRY(hipMemcpyAsync(g.xform.p, h_xform, sizeof(float) * 12 * P, hipMemcpyHostToDevice, g.stream));
+        { SpanGuard sp(kSpanIcp); HIP_TRY(launch_pass(b, sc, P)); }
+        if (g.profile) for (uint32_t i = 0; i < P; ++i) if (h_state[i] != prk::kSkip) g.icp_points += count_h[i];
+        HIP_TRY(prk::launch_icp_finalize(g.partial.as<float>(), g.counts.as<uint32_t>(), g.state.as<int32_t>(), nblk, steps,
+                                         g.sums.as<float>(), P, g.stream));
+        HIP_TRY(hipMemcpyAsync(h_sums, g.sums.p, sizeof(float) * prk::kAccStride * P, hipMemcpyDeviceToHost, g.stream));
+        HIP_TRY(hipStreamSynchronize(g.stream));
+        active = 0;
+        for (uint32_t i = 0; i < P; ++i) {
+            if (h_state[i] == prk::kSkip) continue;
+            const float *Ab = h_sums + (size_t)i * prk::kAccStride;
+            pr_result &r = res[i];
+            const float prev_fit = r.fitness, prev_rmse = r.inlier_rmse;
+            const float cnt = Ab[28], err = Ab[27];
+            if (cnt == 0) { h_state[i] = prk::kSkip; continue; }                        // icp.cu:183
+            r.fitness = cnt / (float)count_h[i];                                          // icp.cu:185
+            r.inlier_rmse = std::sqrt(err / cnt);                                         // icp.cu:186
+            if (it == (uint32_t)crit.max_iteration) { h_state[i] = prk::kSkip; continue; }   // icp.cu:189
+            if (std::fabs(r.fitness - prev_fit) < crit.relative_fitness &&
+                std::fabs(r.inlier_rmse - prev_rmse) < crit.relative_rmse) { h_state[i] = prk::kSkip; continue; }   // icp.cu:191-194
+            float A[36], bb[6], E[16];
+            for (int k = 0; k < 6; ++k) bb[k] = Ab[21 + k];
+            int sh = 0;
+            for (int y = 0; y < 6; ++y) for (int x = y; x < 6; ++x) { A[x + y * 6] = Ab[sh]; A[y + x * 6] = Ab[sh]; ++sh; }   // icp.cu:196-205
+            prh::solve_666(A, bb, E);
+            std::memcpy(h_xform + (size_t)i * 12, E, sizeof(float) * 12);
+            prh::mat4_mul(E, r.T, r.T);                                                   // icp.cu:212
+            h_state[i] = prk::kRunWithTransform;
+            ++active;
+        }
+    }
+    if (results_host) std::memcpy(results_host, res, sizeof(pr_result) * P);
+    if (results_dev) {
+        HIP_TRY(hipMemcpyAsync(results_dev, res, sizeof(pr_result) * P, hipMemcpyHostToDevice, g.stream));
+        HIP_TRY(hipStreamSynchronize(g.stream));
+    }
+    drain_spans();
+    return PR_OK;
+}
+
+int render_impl(const pr_triangle *tris_dev, size_t n_tris, const pr_mat4 *poses_host, size_t P, size_t W, size_t H,
+                const pr_mat4 *proj, pr_roi roi, int32_t *depth_dev, bool zero_empty)
+{
+    if (!tris_dev || !poses_host || !proj || !depth_dev || W == 0 || H == 0) { set_error("pr_render: bad arguments"); return PR_ERR_INVALID; }
+    size_t rw = W, rh = H;
+    if (roi.width > 0 && roi.height > 0) {
+        if (roi.x < 0 || roi.y < 0 || (size_t)(roi.x + roi.width) > W || (size_t)(roi.y + roi.height) > H) {
+            set_error("pr_render: roi out of image");        // renderer.cu:202-203 asserts
+            return PR_ERR_INVALID;
+        }
+        rw = (size_t)roi.width; rh = (size_t)roi.height;
+    }
+    if (P == 0) return PR_OK;
+    PR_TRY(g.poses.ensure(sizeof(pr_mat4) * P));
+    SpanGuard sp(kSpanRender);
+    HIP_TRY(hipMemcpyAsync(g.poses.p, poses_host, sizeof(pr_mat4) * P, hipMemcpyHostToDevice, g.stream));
+    HIP_TRY(prk::launch_fill_i32(depth_dev, P * rw * rh, INT32_MAX, g.stream));
+    HIP_TRY(prk::launch_raster(tris_dev, (uint32_t)n_tris, g.poses.as<pr_mat4>(), (uint32_t)P, depth_dev, (uint32_t)W, (uint32_t)H,
+                               *proj, roi, (uint32_t)rw, (uint32_t)rh, g.stream));
+    if (zero_empty) HIP_TRY(prk::launch_max2zero(depth_dev, P * rw * rh, g.stream));
+    return PR_OK;
+}
+
+template <typename T>
+int depth2cloud_impl(const T *depth_dev, uint32_t W, uint32_t H, const float K[9], uint32_t stride, uint32_t tl_x, uint32_t tl_y,
+                     pr_vec3 **cloud_out, uint32_t *n_out)
+{
+    if (!depth_dev || !K || !cloud_out || !n_out || W == 0 || H == 0 || stride == 0) { set_error("pr_depth2cloud: bad arguments"); return PR_ERR_INVALID; }
+    const uint32_t gh = H / stride;
+    PR_TRY(g.row_count.ensure(sizeof(uint32_t) * std::max(1u, gh)));
+    PR_TRY(g.row_off.ensure(sizeof(uint32_t) * std::max(1u, gh)));
+    PR_TRY(g.counts.ensure(sizeof(uint32_t)));
+    HIP_TRY(prk::launch_depth2cloud<T>(depth_dev, 1, 0, W, H, stride, tl_x, tl_y, K[0], K[4], K[2], K[5], false, g.row_count.as<uint32_t>(),
+                                       g.row_off.as<uint32_t>(), g.counts.as<uint32_t>(), nullptr, 0, false, g.stream));
+    uint32_t n = 0;
+    HIP_TRY(hipMemcpyAsync(&n, g.counts.p, sizeof n, hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    pr_vec3 *cloud = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&cloud), sizeof(pr_vec3) * std::max(1u, n)));
+    if (n > 0) {
+        hipError_t e = prk::launch_depth2cloud<T>(depth_dev, 1, 0, W, H, stride, tl_x, tl_y, K[0], K[4], K[2], K[5], false, g.row_count.as<uint32_t>(),
+                                                  g.row_off.as<uint32_t>(), g.counts.as<uint32_t>(), cloud, 0, true, g.stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(g.stream);
+        if (e != hipSuccess) { hipFree(cloud); set_error("depth2cloud emit failed: %s", hipGetErrorString(e)); return PR_ERR_HIP; }
+    }
+    *cloud_out = cloud; *n_out = n;
+    return PR_OK;
+}
+
+int refine_impl(const pr_triangle *tris_dev, size_t n_tris, const pr_mat4 *poses_host, uint32_t P, uint32_t W, uint32_t H,
+                const pr_mat4 *proj, const float K[9], int scene_kind, const void *scene, pr_criteria crit,
+                pr_result *results_host, pr_result *results_dev, uint32_t *sizes_host)
+{
+    if (!K || W == 0 || H == 0) { set_error("pr_refine_batch: bad arguments"); return PR_ERR_INVALID; }
+    if (P == 0) return PR_OK;
+    SceneSel sc;
+    PR_TRY(make_scene(scene_kind, scene, /*want_packed=*/true, sc));
+    // bound the depth workspace to ~4 GiB per chunk (288 GB of HBM would allow far more; this keeps
+    // first-touch cost and the 2^32 element index space comfortable)
+    const size_t img = (size_t)W * H;
+    uint32_t chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(P, ((size_t)4 << 30) / (img * sizeof(int32_t))));
+    std::vector<uint32_t> start(chunk), count(chunk);
+    for (uint32_t p0 = 0; p0 < P; p0 += chunk) {
+        const uint32_t np = std::min(chunk, P - p0);
+        PR_TRY(g.depth.ensure(sizeof(int32_t) * img * np));
+        PR_TRY(g.row_count.ensure(sizeof(uint32_t) * (size_t)H * np));
+        PR_TRY(g.row_off.ensure(sizeof(uint32_t) * (size_t)H * np));
+        PR_TRY(g.counts.ensure(sizeof(uint32_t) * np));
+        PR_TRY(g.h_counts.ensure(sizeof(uint32_t) * np));
+        pr_roi none{ 0, 0, 0, 0 };
+        PR_TRY(render_impl(tris_dev, n_tris, poses_host + p0, np, W, H, proj, none, g.depth.as<int32_t>(), /*zero_empty=*/false));
+        uint32_t *h_counts = g.h_counts.as<uint32_t>();
+        {
+            SpanGuard sp(kSpanCloud);
+            HIP_TRY(prk::launch_depth2cloud<int32_t>(g.depth.as<int32_t>(), np, img, W, H, 1, 0, 0, K[0], K[4], K[2], K[5], true,
+                                                     g.row_count.as<uint32_t>(), g.row_off.as<uint32_t>(), g.counts.as<uint32_t>(),
+                                                     nullptr, 0, false, g.stream));
+        }
+        HIP_TRY(hipMemcpyAsync(h_counts, g.counts.p, sizeof(uint32_t) * np, hipMemcpyDeviceToHost, g.stream));
+        HIP_TRY(hipStreamSynchronize(g.stream));
+        uint32_t max_n = 0;
+        for (uint32_t i = 0; i < np; ++i) max_n = std::max(max_n, h_counts[i]);
+        const size_t cstride = ((size_t)max_n + 3) & ~(size_t)3;           // keeps every cloud 16-byte aligned
+        PR_TRY(g.cloud.ensure(sizeof(pr_vec3) * std::max<size_t>(4, cstride) * np));
+        if (max_n > 0) {
+            SpanGuard sp(kSpanCloud);
+            HIP_TRY(prk::launch_depth2cloud<int32_t>(g.depth.as<int32_t>(), np, img, W, H, 1, 0, 0, K[0], K[4], K[2], K[5], true,
+                                                     g.row_count.as<uint32_t>(), g.row_off.as<uint32_t>(), g.counts.as<uint32_t>(),
+                                                     g.cloud.as<pr_vec3>(), cstride, true, g.stream));
+        }
+        for (uint32_t i = 0; i < np; ++i) { start[i] = (uint32_t)(i * cstride); count[i] = h_counts[i]; }
+        if (sizes_host) std::memcpy(sizes_host + p0, count.data(), sizeof(uint32_t) * np);
+        PR_TRY(icp_drive(g.cloud.as<pr_vec3>(), start.data(), count.data(), np, sc, crit,
+                         results_host ? results_host + p0 : nullptr, results_dev ? results_dev + p0 : nullptr));
+    }
+    return PR_OK;
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+const char *pr_last_error(void) { return prh::g_err.c_str(); }
+const char *pr_version(void) { return "pose_refine_amd 0.1 (gfx950)"; }
+
+int pr_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int pr_init(int device)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g.ready && g.device == device) return PR_OK;
+    if (g.ready) { set_error("pr_init: already initialised on device %d", g.device); return PR_ERR_INVALID; }
+    g.device = device;
+    return require_ctx();
+}
+
+int pr_shutdown(void)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g.ready) return PR_OK;
+    hipStreamSynchronize(g.stream);
+    for (DevBuf *b : { &g.poses, &g.depth, &g.row_count, &g.row_off, &g.counts, &g.cloud, &g.start, &g.state, &g.xform, &g.partial,
+                       &g.sums, &g.rec, &g.topo, &g.bmin, &g.bmax, &g.pts, &g.dstate, &g.dresults }) b->release();
+    for (PinBuf *b : { &g.h_sums, &g.h_xform, &g.h_state, &g.h_counts, &g.h_start, &g.h_results }) b->release();
+    for (hipEvent_t e : g.ev_pool) hipEventDestroy(e);
+    g.ev_pool.clear(); g.ev_used = 0; g.spans.clear();
+    hipStreamDestroy(g.stream);
+    g.stream = nullptr; g.ready = false; g.device = -1;
+    return PR_OK;
+}
+
+int pr_sync(void)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    PR_TRY(require_ctx());
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    return PR_OK;
+}
+
+int pr_malloc(void **dev_ptr, size_t bytes)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    PR_TRY(require_ctx());
+    if (!dev_ptr) { set_error("pr_malloc: null out pointer"); return PR_ERR_INVALID; }
+    HIP_TRY(hipMalloc(dev_ptr, bytes ? bytes : 1));
+    return PR_OK;
+}
+int pr_free(void *dev_ptr)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!dev_ptr) return PR_OK;
+    PR_TRY(require_ctx());
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    HIP_TRY(hipFree(dev_ptr));
+    return PR_OK;
+}
+static int copy_sync(void *dst, const void *src, size_t bytes, hipMemcpyKind kind)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    PR_TRY(require_ctx());
+    if (bytes == 0) return PR_OK;
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, kind, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    return PR_OK;
+}
+int pr_memcpy_h2d(void *d, const void *s, size_t n) { return copy_sync(d, s, n, hipMemcpyHostToDevice); }
+int pr_memcpy_d2h(void *d, const void *s, size_t n) { return copy_sync(d, s, n, hipMemcpyDeviceToHost); }
+int pr_memcpy_d2d(void *d, const void *s, size_t n) { return copy_sync(d, s, n, hipMemcpyDeviceToDevice); }
+
+int pr_fill_i32(int32_t *dev_dst, size_t count, int32_t value)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    PR_TRY(require_ctx());
+    HIP_TRY(prk::launch_fill_i32(dev_dst, count, value, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    return PR_OK;
+}
+
+int pr_render(const pr_triangle *tris_dev, size_t n_tris, const pr_mat4 *poses_host, size_t n_poses, size_t width, size_t height,
+              const pr_mat4 *proj, pr_roi roi, int32_t *depth_dev_out)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    PR_TRY(require_ctx());
+    PR_TRY(render_impl(tris_dev, n_tris, poses_host, n_poses, width, height, proj, roi, depth_dev_out, true));
+    HIP_TRY(hipStreamSynchronize(g.stream));            // renderer.cu:295 cudaDeviceSynchronize
+    drain_spans();
+    return PR_OK;
+}
+
+int pr_render_to_host(const pr_triangle *tris_dev, size_t n_tris, const pr_mat4 *poses_host, size_t n_poses, size_t width, size_t height,
+                      const pr_mat4 *proj, pr_roi roi, int32_t *depth_host_out)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    PR_TRY(require_ctx());
+    size_t rw = width, rh = height;
+    if (roi.width > 0 && roi.height > 0) { rw = (size_t)roi.width; rh = (size_t)roi.height; }
+    PR_TRY(g.depth.ensure(sizeof(int32_t) * std::max<size_t>(1, n_poses * rw * rh)));
+    PR_TRY(render_impl(tris_dev, n_tris, poses_host, n_poses, width, height, proj, roi, g.depth.as<int32_t>(), true));
+    HIP_TRY(hipMemcpyAsync(depth_host_out, g.depth.p, sizeof(int32_t) * n_poses * rw * rh, hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    drain_spans();
+    return PR_OK;
+}
+
+int pr_depth2cloud_i32(const int32_t *depth_dev, uint32_t width, uint32_t height, const float K[9], uint32_t stride, uint32_t tl_x,
+                       uint32_t tl_y, pr_vec3 **cloud_dev_out, uint32_t *n_points)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    PR_TRY(require_ctx());
+    return depth2cloud_impl<int32_t>(depth_dev, width, height, K, stride, tl_x, tl_y, cloud_dev_out, n_points);
+}
+int pr_depth2cloud_u16(const uint16_t *depth_dev, uint32_t width, uint32_t height, const float K[9], uint32_t stride, uint32_t tl_x,
+                       uint32_t tl_y, pr_vec3 **cloud_dev_out, uint32_t *n_points)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    PR_TRY(require_ctx());
+    return depth2cloud_impl<uint16_t>(depth_dev, width, height, K, stride, tl_x, tl_y, cloud_dev_out, n_points);
+}
+
+int pr_icp_batch(pr_vec3 *clouds_dev, const uint32_t *offsets_host, uint32_t n_clouds, int scene_kind, const void *scene,
+                 pr_criteria crit, pr_result *results_host)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    PR_TRY(require_ctx());
+    if (!clouds_dev || !offsets_host || !results_host) { set_error("pr_icp_batch: bad arguments"); return PR_ERR_INVALID; }
+    SceneSel sc;
+    PR_TRY(make_scene(scene_kind, scene, /*want_packed=*/false, sc));
+    std::vector<uint32_t> start(n_clouds), count(n_clouds);
+    for (uint32_t i = 0; i < n_clouds; ++i) {
+        if (offsets_host[i + 1] < offsets_host[i]) { set_error("pr_icp_batch: offsets must be non-decreasing"); return PR_ERR_INVALID; }
+        start[i] = offsets_host[i]; count[i] = offsets_host[i + 1] - offsets_host[i];
+    }
+    return icp_drive(clouds_dev, start.data(), count.data(), n_clouds, sc, crit, results_host, nullptr);
+}
+
+int pr_icp_proj(pr_vec3 *cloud_dev, uint32_t n_points, const pr_scene_proj *scene, pr_criteria crit, pr_result *result_out)
+{
+    const uint32_t off[2] = { 0, n_points };
+    return pr_icp_batch(cloud_dev, off, 1, PR_SCENE_PROJ, scene, crit, result_out);
+}
+int pr_icp_nn(pr_vec3 *cloud_dev, uint32_t n_points, const pr_scene_nn *scene, pr_criteria crit, pr_result *result_out)
+{
+    const uint32_t off[2] = { 0, n_points };
+    return pr_icp_batch(cloud_dev, off, 1, PR_SCENE_NN, scene, crit, result_out);
+}
+
+int pr_refine_batch(const pr_triangle *tris_dev, size_t n_tris, const pr_mat4 *poses_host, uint32_t n_poses, uint32_t width, uint32_t height,
+                    const pr_mat4 *proj, const float K[9], int scene_kind, const void *scene, pr_criteria crit,
+                    pr_result *results_host, uint32_t *cloud_sizes_host)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    PR_TRY(require_ctx());
+    if (!results_host) { set_error("pr_refine_batch: results_host is null"); return PR_ERR_INVALID; }
+    return refine_impl(tris_dev, n_tris, poses_host, n_poses, width, height, proj, K, scene_kind, scene, crit, results_host, nullptr, cloud_sizes_host);
+}
+int pr_refine_batch_dev(const pr_triangle *tris_dev, size_t n_tris, const pr_mat4 *poses_host, uint32_t n_poses, uint32_t width, uint32_t height,
+                        const pr_mat4 *proj, const float K[9], int scene_kind, const void *scene, pr_criteria crit,
+                        pr_result *results_dev, uint32_t *cloud_sizes_host)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    PR_TRY(require_ctx());
+    if (!results_dev) { set_error("pr_refine_batch_dev: results_dev is null"); return PR_ERR_INVALID; }
+    return refine_impl(tris_dev, n_tris, poses_host, n_poses, width, height, proj, K, scene_kind, scene, crit, nullptr, results_dev, cloud_sizes_host);
+}
+
+int pr_set_option(const char *name, int value)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!name) { set_error("pr_set_option: null name"); return PR_ERR_INVALID; }
+    const std::string n(name);
+    if (n == "solve") { if (value != PR_SOLVE_HOST && value != PR_SOLVE_DEVICE) { set_error("solve must be 0 or 1"); return PR_ERR_INVALID; } g.solve_mode = value; }
+    else if (n == "points_per_block") { if (value < 1024 || value % 1024) { set_error("points_per_block must be a multiple of 1024"); return PR_ERR_INVALID; } g.steps = value / 1024; }
+    else if (n == "profile") g.profile = value ? 1 : 0;
+    else if (n == "nn_lds_nodes") g.nn_lds_nodes = std::max(0, value);
+    else { set_error("unknown option %s", name); return PR_ERR_INVALID; }
+    return PR_OK;
+}
+int pr_get_option(const char *name, int *value)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!name || !value) { set_error("pr_get_option: null argument"); return PR_ERR_INVALID; }
+    const std::string n(name);
+    if (n == "solve") *value = g.solve_mode;
+    else if (n == "points_per_block") *value = g.steps * 1024;
+    else if (n == "profile") *value = g.profile;
+    else if (n == "nn_lds_nodes") *value = g.nn_lds_nodes;
+    else { set_error("unknown option %s", name); return PR_ERR_INVALID; }
+    return PR_OK;
+}
+
+int pr_profile_reset(void)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    g.icp_ms = g.render_ms = g.cloud_ms = 0; g.icp_launches = g.icp_points = 0;
+    return PR_OK;
+}
+int pr_profile_read(double *kernel_ms, uint64_t *launches, uint64_t *points, double *render_ms, double *cloud_ms)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (kernel_ms) *kernel_ms = g.icp_ms;
+    if (launches) *launches = g.icp_launches;
+    if (points) *points = g.icp_points;
+    if (render_ms) *render_ms = g.render_ms;
+    if (cloud_ms) *cloud_ms = g.cloud_ms;
+    return PR_OK;
+}
+
+}  // extern "C"

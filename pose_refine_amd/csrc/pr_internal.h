@@ -1,0 +1,102 @@
+// pr_internal.h -- declarations shared by the HIP kernels TU and the C-ABI/host TUs.
+// Not part of the public boundary (that is include/pose_refine.h).
+#pragma once
+
+#include <hip/hip_runtime_api.h>
+#include <hip/hip_vector_types.h>
+#include <stdint.h>
+
+#include "pose_refine.h"
+
+namespace prk {
+
+// ---- canonical reduction geometry (DESIGN.md "canonical tree"; oracle: sum29_canonical) -----------
+constexpr uint32_t kBlockThreads   = 256;                       // 4 wavefronts
+constexpr uint32_t kPointsPerLane  = 4;                         // consecutive points per lane per step
+constexpr uint32_t kPointsPerStep  = kBlockThreads * kPointsPerLane;   // 1024
+constexpr uint32_t kAccStride      = 32;                        // 29 sums padded to 32 floats
+
+// per-hypothesis run state consumed by the correspondence kernel
+enum : int32_t { kSkip = 0, kRun = 1, kRunWithTransform = 2 };
+
+// batch of model clouds handed to one correspondence pass
+struct IcpBatch {
+    pr_vec3        *cloud;      // base of all clouds (dev)
+    const uint32_t *start;      // [P] first point of cloud i (dev)
+    const uint32_t *count;      // [P] points in cloud i (dev)
+    const float    *xform;      // [P][12] pending rigid update rows 0..2 (dev)
+    const int32_t  *state;      // [P] kSkip / kRun / kRunWithTransform (dev)
+    float          *partial;    // [P][nblk][kAccStride] workgroup sums (dev)
+    uint32_t        nblk;       // workgroups per hypothesis (grid.x)
+    uint32_t        steps;      // steps of 1024 points per workgroup
+};
+
+// projective scene exactly as the reference API hands it over (two Vec3f arrays)
+struct SceneProjAoS {
+    uint32_t width, height;
+    float max_dist_diff, fx, fy, cx, cy;
+    const pr_vec3 *pcd, *normal;
+};
+// projective scene repacked by the fused pipeline: one 16-byte record {nx,ny,nz,z} per pixel
+struct SceneProjPacked {
+    uint32_t width, height;
+    float max_dist_diff, fx, fy, cx, cy;
+    const float4 *rec;
+};
+// kd-tree scene: reference arrays + the traversal structure derived from them (build_nn_accel)
+struct SceneNNDev {
+    float max_dist_diff;
+    const int4   *topo;         // per node: {split_v|left, child1|right, child2|-1, (parent+1)|dim<<30}
+    const float4 *bmin, *bmax;  // per node tight bbox (leaves included)
+    const float4 *pts;          // per point {x,y,z,0}
+    const pr_vec3 *pcd, *normal;
+    uint32_t n_nodes;
+    uint32_t lds_nodes;         // how many leading (top-level) nodes the kernel stages in LDS
+};
+
+// device-side solver state for PR_SOLVE_DEVICE (one record per hypothesis)
+struct DevIcpState {
+    float T[16];
+    float fitness, rmse;
+    int32_t done;               // 0 running, 1 finished
+    int32_t passes;
+};
+
+// ---- launchers (all asynchronous on `s`) ----------------------------------------------------------
+hipError_t launch_fill_i32(int32_t *dst, size_t n, int32_t v, hipStream_t s);
+hipError_t launch_raster(const pr_triangle *tris, uint32_t n_tris, const pr_mat4 *poses_dev, uint32_t n_poses,
+                         int32_t *depth, uint32_t width, uint32_t height, const pr_mat4 &proj, pr_roi roi,
+                         uint32_t rw, uint32_t rh, hipStream_t s);
+hipError_t launch_max2zero(int32_t *depth, size_t n, hipStream_t s);
+
+// depth -> cloud: rows are counted, scanned per image, then emitted in row-major order.
+// images: n_img images of width*height pixels each `img_stride` elements apart; cloud i is written
+// at cloud + i*cloud_stride; counts[i] receives its size.  empty_intmax: INT_MAX also means "no depth".
+template <typename T>
+hipError_t launch_depth2cloud(const T *depth, uint32_t n_img, size_t img_stride, uint32_t width, uint32_t height,
+                              uint32_t stride, uint32_t tl_x, uint32_t tl_y, float fx, float fy, float cx, float cy,
+                              bool empty_intmax, uint32_t *row_count, uint32_t *row_off, uint32_t *counts,
+                              pr_vec3 *cloud, size_t cloud_stride, bool emit, hipStream_t s);
+
+hipError_t launch_icp_pass_proj_aos(const IcpBatch &b, const SceneProjAoS &sc, uint32_t n_poses, hipStream_t s);
+hipError_t launch_icp_pass_proj_packed(const IcpBatch &b, const SceneProjPacked &sc, uint32_t n_poses, hipStream_t s);
+hipError_t launch_icp_pass_nn(const IcpBatch &b, const SceneNNDev &sc, uint32_t n_poses, hipStream_t s);
+hipError_t launch_icp_finalize(const float *partial, const uint32_t *count, const int32_t *state, uint32_t nblk,
+                               uint32_t steps, float *sums, uint32_t n_poses, hipStream_t s);
+// PR_SOLVE_DEVICE: finalize + convergence test + 6x6 solve + state update in one kernel
+hipError_t launch_icp_finalize_solve(const float *partial, const uint32_t *count, int32_t *state, uint32_t nblk,
+                                     uint32_t steps, float *xform, DevIcpState *st, pr_criteria crit, uint32_t iter,
+                                     uint32_t n_poses, hipStream_t s);
+hipError_t launch_pack_results(const DevIcpState *st, pr_result *out, uint32_t n_poses, hipStream_t s);
+
+hipError_t launch_pack_proj_scene(const pr_vec3 *pcd, const pr_vec3 *normal, float4 *rec, size_t n, hipStream_t s);
+hipError_t launch_build_nn_accel(const pr_kdnode *nodes, uint32_t n_nodes, const pr_vec3 *pcd, uint32_t n_points,
+                                 int4 *topo, float4 *bmin, float4 *bmax, float4 *pts, hipStream_t s);
+
+}  // namespace prk
+
+// ---- host-side math shared by the C ABI (pr_host.cpp) ------------------------------------------
+namespace prh {
+void solve_666(const float A[36], const float b[6], float T[16]);
+void mat4_mul(const float A[16], const float B[16], float C[16]);
+}

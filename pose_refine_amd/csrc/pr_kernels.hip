@@ -1,0 +1,706 @@
+// pr_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the hot path.
+//
+//   raster_kernel          <- render_triangle + rasterization        cuda_renderer/renderer.cu:83-187
+//   depth2cloud kernels    <- depth2mask / exclusive_scan / depth2cloud   cuda_icp/icp.cu:228-291
+//   icp_pass_kernel<Scene> <- thrust::transform_reduce(thrust__pcd2Ab<Scene>) fused with
+//                             transform_pcd_cuda of the previous iteration   icp.cu:142-153,170-172, icp.h:128-209
+//   icp_finalize*          <- second reduction stage (+ optional device-side solve, icp.cu:181-212)
+//
+// All float arithmetic follows the operand order of the reference expression by expression and
+// the TU is compiled with -ffp-contract=off, so every per-element value is bit-identical to the
+// CPU restatement; sums are bit-identical because the reduction tree is fixed ("canonical tree").
+// No MFMA, no Thrust/rocPRIM, wave64 DPP reductions, 16-byte vector memory operations.
+#include <hip/hip_runtime.h>
+#include <limits.h>
+#include <float.h>
+
+#include "pr_internal.h"
+
+#define PR_HD __host__ __device__
+#include "pr_solver.inl"
+
+namespace prk {
+
+// ------------------------------------------------------------------------------------------------
+// conversions with the semantics the reference CPU build has on x86-64 (cvttss2si): out-of-range
+// and NaN inputs give INT_MIN.  v_cvt_i32_f32 saturates instead, so the range test is explicit.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int f2i_x86(float v)
+{
+    return (v > -2147483904.0f && v < 2147483648.0f) ? (int)v : INT_MIN;
+}
+// size_t(float) for loop starts that are later compared against a bound < 2^24: anything
+// outside (-1, 2^24) can never satisfy "(float)p <= bound", so it maps to "no iterations".
+__device__ __forceinline__ int loop_start(float v)
+{
+    return (v > -1.0f && v < 16777216.0f) ? (int)v : INT_MAX;
+}
+
+__device__ __forceinline__ float sel_max(float a, float b) { return (a > b) ? a : b; }
+__device__ __forceinline__ float sel_min(float a, float b) { return (a < b) ? a : b; }
+
+// ================================================================================================
+//  fill / max2zero
+// ================================================================================================
+__global__ __launch_bounds__(256) void fill_i32_kernel(int32_t *dst, size_t n, int32_t v)
+{
+    size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    const size_t stride = (size_t)gridDim.x * 256 * 4;
+    for (; i + 3 < n; i += stride) *reinterpret_cast<int4 *>(dst + i) = make_int4(v, v, v, v);
+    if (i < n) for (size_t k = i; k < n && k < i + 4; ++k) dst[k] = v;
+}
+
+// renderer.cu:71-80 max2zero_functor over the whole stack of images
+__global__ __launch_bounds__(256) void max2zero_kernel(int32_t *d, size_t n)
+{
+    size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    const size_t stride = (size_t)gridDim.x * 256 * 4;
+    for (; i + 3 < n; i += stride) {
+        int4 v = *reinterpret_cast<int4 *>(d + i);
+        v.x = (v.x == INT_MAX) ? 0 : v.x; v.y = (v.y == INT_MAX) ? 0 : v.y;
+        v.z = (v.z == INT_MAX) ? 0 : v.z; v.w = (v.w == INT_MAX) ? 0 : v.w;
+        *reinterpret_cast<int4 *>(d + i) = v;
+    }
+    if (i < n) for (size_t k = i; k < n && k < i + 4; ++k) if (d[k] == INT_MAX) d[k] = 0;
+}
+
+// ================================================================================================
+//  triangle raster: one lane = one (triangle, hypothesis); int32 atomicMin resolves depth
+// ================================================================================================
+__device__ __forceinline__ float area2(float ax, float ay, float bx, float by, float cx, float cy)
+{   // renderer.h:315-318 calculateSignedArea
+    return 0.5f * ((cx - ax) * (by - ay) - (bx - ax) * (cy - ay));
+}
+
+__global__ __launch_bounds__(256) void raster_kernel(const pr_triangle *__restrict__ tris, uint32_t n_tris,
+                                                     const pr_mat4 *__restrict__ poses, int32_t *__restrict__ depth,
+                                                     uint32_t width, uint32_t height, pr_mat4 proj, pr_roi roi,
+                                                     uint32_t rw, uint32_t rh)
+{
+    const uint32_t ti = blockIdx.x * 256 + threadIdx.x;
+    if (ti >= n_tris) return;
+    const float *M = poses[blockIdx.y].m;                       // wave-uniform -> scalar loads
+    int32_t *img = depth + (size_t)blockIdx.y * rw * rh;
+
+    const float *tv = reinterpret_cast<const float *>(tris + ti);
+    float px[3], py[3], w3[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float x = tv[3 * k], y = tv[3 * k + 1], z = tv[3 * k + 2];
+        // model transform (renderer.h:296-303 mat_mul_v, rows a,b,c)
+        const float lx = M[0] * x + M[1] * y + M[2] * z + M[3];
+        const float ly = M[4] * x + M[5] * y + M[6] * z + M[7];
+        const float lz = M[8] * x + M[9] * y + M[10] * z + M[11];
+        w3[k] = lz;                                              // renderer.cu:177-183 last_row
+        // projection transform: only x and y of the result are used downstream
+        const float cxp = proj.m[0] * lx + proj.m[1] * ly + proj.m[2] * lz + proj.m[3];
+        const float cyp = proj.m[4] * lx + proj.m[5] * ly + proj.m[6] * lz + proj.m[7];
+        // viewport (renderer.cu:90-98)
+        px[k] = cxp / lz * (float)width / 2.0f + (float)width / 2.0f;
+        py[k] = cyp / lz * (float)height / 2.0f + (float)height / 2.0f;
+    }
+
+    float lo0 = FLT_MAX, lo1 = FLT_MAX, hi0 = -FLT_MAX, hi1 = -FLT_MAX;
+    float cmin0 = 0.0f, cmin1 = 0.0f, cmax0 = (float)(width - 1), cmax1 = (float)(height - 1);
+    if (roi.width > 0 && roi.height > 0) {                       // renderer.cu:106-113 (image is flipped in y)
+        cmin0 = (float)roi.x;
+        cmin1 = (float)((unsigned long long)(height - 1) - (unsigned long long)(long long)(roi.y + roi.height - 1));
+        cmax0 = (float)((roi.x + roi.width) - 1);
+        cmax1 = (float)((unsigned long long)(height - 1) - (unsigned long long)(long long)roi.y);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        lo0 = sel_max(cmin0, sel_min(lo0, px[k]));  hi0 = sel_min(cmax0, sel_max(hi0, px[k]));
+        lo1 = sel_max(cmin1, sel_min(lo1, py[k]));  hi1 = sel_min(cmax1, sel_max(hi1, py[k]));
+    }
+
+    const float area = area2(px[0], py[0], px[1], py[1], px[2], py[2]);
+    if (!(area != 0.0f)) return;                                 // documented: zero-area triangles are skipped
+    const float base_inv = 1 / area;
+
+    const int x0 = loop_start(lo0 + 0.5f);
+    for (int y = loop_start(lo1 + 0.5f); (float)y <= hi1; ++y) {
+        const float fy = (float)y;
+        for (int x = x0; (float)x <= hi0; ++x) {
+            const float fx = (float)x;
+            // renderer.h:320-333 barycentric
+            const float beta  = area2(px[0], py[0], fx, fy, px[2], py[2]) * base_inv;
+            const float gamma = area2(px[0], py[0], px[1], py[1], fx, fy) * base_inv;
+            const float alpha = 1.0f - beta - gamma;
+            if (alpha < -0.0f || beta < -0.0f || gamma < -0.0f || alpha > 1.0f || beta > 1.0f || gamma > 1.0f) continue;
+            const float az = alpha / w3[0], bz = beta / w3[1], gz = gamma / w3[2];
+            const float frag = (alpha + beta + gamma) / (az + bz + gz);
+            const int d = f2i_x86(frag + 0.5f);
+            const uint32_t xw = (uint32_t)(x - roi.x);
+            const uint32_t yw = (uint32_t)((int)height - 1 - y - roi.y);
+            atomicMin(&img[xw + (size_t)yw * rw], d);
+        }
+    }
+}
+
+// ================================================================================================
+//  depth -> cloud: count per row, scan rows per image, emit in row-major order
+// ================================================================================================
+template <typename T> __device__ __forceinline__ bool depth_valid(T d, bool empty_intmax)
+{
+    return d > 0 && !(empty_intmax && (long long)d == (long long)INT_MAX);
+}
+
+// one wavefront per grid row; lanes sweep the row 64 pixels at a time
+template <typename T>
+__global__ __launch_bounds__(256) void d2c_count_kernel(const T *__restrict__ depth, size_t img_stride, uint32_t width,
+                                                        uint32_t gw, uint32_t gh, uint32_t stride, bool empty_intmax,
+                                                        uint32_t *__restrict__ row_count)
+{
+    const uint32_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63;
+    if (row >= gh) return;
+    const T *line = depth + (size_t)blockIdx.y * img_stride + (size_t)row * stride * width;
+    uint32_t cnt = 0;
+    for (uint32_t x0 = 0; x0 < gw; x0 += 64) {
+        const uint32_t x = x0 + lane;
+        const bool v = (x < gw) && depth_valid(line[(size_t)x * stride], empty_intmax);
+        cnt += (uint32_t)__popcll(__ballot(v));
+    }
+    if (lane == 0) row_count[(size_t)blockIdx.y * gh + row] = cnt;
+}
+
+// one workgroup per image: exclusive scan of the row counts (serial carry over chunks of 256 rows)
+__global__ __launch_bounds__(256) void d2c_scan_kernel(const uint32_t *__restrict__ row_count, uint32_t gh,
+                                                       uint32_t *__restrict__ row_off, uint32_t *__restrict__ counts)
+{
+    __shared__ uint32_t buf[256];
+    __shared__ uint32_t carry;
+    const uint32_t *rc = row_count + (size_t)blockIdx.x * gh;
+    uint32_t *ro = row_off + (size_t)blockIdx.x * gh;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < gh; base += 256) {
+        const uint32_t r = base + threadIdx.x;
+        const uint32_t v = (r < gh) ? rc[r] : 0;
+        buf[threadIdx.x] = v;
+        __syncthreads();
+        for (uint32_t off = 1; off < 256; off <<= 1) {           // Hillis-Steele inclusive scan
+            uint32_t t = (threadIdx.x >= off) ? buf[threadIdx.x - off] : 0;
+            __syncthreads();
+            buf[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (r < gh) ro[r] = carry + buf[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 255) carry += buf[255];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) counts[blockIdx.x] = carry;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void d2c_emit_kernel(const T *__restrict__ depth, size_t img_stride, uint32_t width,
+                                                       uint32_t gw, uint32_t gh, uint32_t stride, uint32_t tl_x, uint32_t tl_y,
+                                                       float fx, float fy, float cx, float cy, bool empty_intmax,
+                                                       const uint32_t *__restrict__ row_count,
+                                                       const uint32_t *__restrict__ row_off,
+                                                       pr_vec3 *__restrict__ cloud, size_t cloud_stride)
+{
+    const uint32_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63;
+    if (row >= gh) return;
+    if (row_count[(size_t)blockIdx.y * gh + row] == 0) return;    // wave-uniform: empty rows cost one load
+    const T *line = depth + (size_t)blockIdx.y * img_stride + (size_t)row * stride * width;
+    pr_vec3 *out = cloud + (size_t)blockIdx.y * cloud_stride + row_off[(size_t)blockIdx.y * gh + row];
+    uint32_t done = 0;
+    for (uint32_t x0 = 0; x0 < gw; x0 += 64) {
+        const uint32_t x = x0 + lane;
+        T d = 0;
+        if (x < gw) d = line[(size_t)x * stride];
+        const bool v = (x < gw) && depth_valid(d, empty_intmax);
+        const unsigned long long m = __ballot(v);
+        if (v) {
+            const uint32_t k = done + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            // icp.cu:249-253: z = d/1000.f; x = (u + tl_x - cx)/fx*z; y = (v + tl_y - cy)/fy*z
+            const float z = d / 1000.0f;
+            pr_vec3 p;
+            p.x = ((float)(x + tl_x) - cx) / fx * z;
+            p.y = ((float)(row + tl_y) - cy) / fy * z;
+            p.z = z;
+            out[k] = p;
+        }
+        done += (uint32_t)__popcll(m);
+    }
+}
+
+// ================================================================================================
+//  scene queries
+// ================================================================================================
+struct Corr { float dx, dy, dz, nx, ny, nz; };   // destination point and its normal
+
+// Scene_projective::query depth_scene.h:29-48 + pcd2dep common.h:63-73
+__device__ __forceinline__ bool proj_pixel(float sx, float sy, float sz, float fx, float fy, float cx, float cy,
+                                           uint32_t width, uint32_t height, uint32_t &idx, int &px, int &py)
+{
+    px = f2i_x86(sx / sz * fx + cx - 0.0f + 0.5f);
+    py = f2i_x86(sy / sz * fy + cy - 0.0f + 0.5f);
+    if (px < 0 || py < 0 || (uint32_t)px >= width || (uint32_t)py >= height) return false;
+    idx = (uint32_t)px + (uint32_t)py * width;
+    return true;
+}
+
+__device__ __forceinline__ bool query(const SceneProjAoS &s, float sx, float sy, float sz, Corr &c)
+{
+    uint32_t idx; int px, py;
+    if (!proj_pixel(sx, sy, sz, s.fx, s.fy, s.cx, s.cy, s.width, s.height, idx, px, py)) return false;
+    const float *d = reinterpret_cast<const float *>(s.pcd + idx);
+    const float dz = d[2];
+    const float diff = sz - dz;
+    const float adiff = (diff > 0) ? diff : -diff;
+    if (dz <= 0 || adiff > s.max_dist_diff) return false;
+    const float *n = reinterpret_cast<const float *>(s.normal + idx);
+    c.dx = d[0]; c.dy = d[1]; c.dz = dz; c.nx = n[0]; c.ny = n[1]; c.nz = n[2];
+    return true;
+}
+
+__device__ __forceinline__ bool query(const SceneProjPacked &s, float sx, float sy, float sz, Corr &c)
+{
+    uint32_t idx; int px, py;
+    if (!proj_pixel(sx, sy, sz, s.fx, s.fy, s.cx, s.cy, s.width, s.height, idx, px, py)) return false;
+    const float4 r = s.rec[idx];                                 // one 16-byte gather: {nx, ny, nz, z}
+    const float dz = r.w;
+    const float diff = sz - dz;
+    const float adiff = (diff > 0) ? diff : -diff;
+    if (dz <= 0 || adiff > s.max_dist_diff) return false;
+    // the scene point is re-derived from its depth exactly as dep2pcd (common.h:47-61) built it
+    c.dx = ((float)px - s.cx) / s.fx * dz;
+    c.dy = ((float)py - s.cy) / s.fy * dz;
+    c.dz = dz; c.nx = r.x; c.ny = r.y; c.nz = r.z;
+    return true;
+}
+
+// Scene_nn::query pcd_scene.h:60-136 -- same stackless near-first traversal, same strict '<' on
+// leaf points and '<=' on the bound, but the bound is the FAR CHILD's own tight box instead of
+// the current node's box.  That prunes a superset of what the reference prunes and can only skip
+// subtrees whose every point is farther than the current best, so winner and distance are
+// identical (DESIGN.md "kd-tree bound").
+__device__ __forceinline__ float box_dist_sq(float sx, float sy, float sz, const float4 lo, const float4 hi)
+{
+    float lb = 0;
+    if (sx < lo.x) lb += (lo.x - sx) * (lo.x - sx); else if (sx > hi.x) lb += (hi.x - sx) * (hi.x - sx);
+    if (sy < lo.y) lb += (lo.y - sy) * (lo.y - sy); else if (sy > hi.y) lb += (hi.y - sy) * (hi.y - sy);
+    if (sz < lo.z) lb += (lo.z - sz) * (lo.z - sz); else if (sz > hi.z) lb += (hi.z - sz) * (hi.z - sz);
+    return lb;
+}
+
+template <bool kUseLds>
+__device__ __forceinline__ bool query_nn(const SceneNNDev &s, const int4 *lds_topo, float sx, float sy, float sz, Corr &c)
+{
+    int cur = 0, prev = -1, best_i = 0;
+    bool climbing = false;
+    float best = FLT_MAX;
+    while (cur >= 0) {
+        const int4 t = (kUseLds && (uint32_t)cur < s.lds_nodes) ? lds_topo[cur] : s.topo[cur];
+        const int parent = (t.w & 0x3fffffff) - 1;
+        const bool leaf = t.z < 0;
+        if (!climbing && leaf) {
+            for (int i = t.x; i < t.y; ++i) {
+                const float4 p = s.pts[i];
+                const float d2 = (sx - p.x) * (sx - p.x) + (sy - p.y) * (sy - p.y) + (sz - p.z) * (sz - p.z);
+                if (d2 < best) { best = d2; best_i = i; }
+            }
+            climbing = true; prev = cur; cur = parent;
+            continue;
+        }
+        const int dim = (int)((uint32_t)t.w >> 30);
+        const float q = (dim == 0) ? sx : ((dim == 1) ? sy : sz);
+        const float diff = q - __int_as_float(t.x);
+        const int near_c = (diff < 0) ? t.y : t.z;
+        const int far_c  = (diff < 0) ? t.z : t.y;
+        if (!climbing) { prev = cur; cur = near_c; continue; }
+        if (prev == near_c) {
+            const float lb = box_dist_sq(sx, sy, sz, s.bmin[far_c], s.bmax[far_c]);
+            if (lb <= best) { prev = cur; cur = far_c; climbing = false; continue; }
+        }
+        prev = cur; cur = parent;
+    }
+    if (!(best < s.max_dist_diff * s.max_dist_diff)) return false;
+    const float *d = reinterpret_cast<const float *>(s.pcd + best_i);
+    const float *n = reinterpret_cast<const float *>(s.normal + best_i);
+    c.dx = d[0]; c.dy = d[1]; c.dz = d[2]; c.nx = n[0]; c.ny = n[1]; c.nz = n[2];
+    return true;
+}
+
+// ================================================================================================
+//  29-term contribution (icp.h:138-206) accumulated straight into the lane's registers
+// ================================================================================================
+__device__ __forceinline__ void accumulate(float (&acc)[29], float sx, float sy, float sz, const Corr &c)
+{
+    const float ex = c.dx - sx, ey = c.dy - sy, ez = c.dz - sz;
+    const float r = ex * c.nx + ey * c.ny + ez * c.nz;
+    float J[6];
+    J[0] = c.nz * sy - c.ny * sz;
+    J[1] = c.nx * sz - c.nz * sx;
+    J[2] = c.ny * sx - c.nx * sy;
+    J[3] = c.nx; J[4] = c.ny; J[5] = c.nz;
+    int k = 0;
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int b = a; b < 6; ++b) { acc[k] += J[a] * J[b]; ++k; }
+#pragma unroll
+    for (int a = 0; a < 6; ++a) acc[21 + a] += J[a] * r;
+    acc[27] += ex * ex + ey * ey + ez * ez;
+    acc[28] += 1.0f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// wave64 sum with a fixed balanced pairwise tree in lane order, result in lane 63:
+//   row_shr:1,2,4,8 inside each 16-lane row, row_bcast15 into rows 1 and 3, row_bcast31 into rows 2,3.
+// ------------------------------------------------------------------------------------------------
+template <int kCtrl, int kRowMask>
+__device__ __forceinline__ float dpp_get(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), kCtrl, kRowMask, 0xf, true));
+}
+__device__ __forceinline__ float wave_tree_sum(float v)
+{
+    v += dpp_get<0x111, 0xf>(v);     // row_shr:1
+    v += dpp_get<0x112, 0xf>(v);     // row_shr:2
+    v += dpp_get<0x114, 0xf>(v);     // row_shr:4
+    v += dpp_get<0x118, 0xf>(v);     // row_shr:8
+    v += dpp_get<0x142, 0xa>(v);     // row_bcast15 -> rows 1,3
+    v += dpp_get<0x143, 0xc>(v);     // row_bcast31 -> rows 2,3
+    return v;
+}
+
+// ================================================================================================
+//  THE hot kernel: pending transform + correspondence + 29-term transform-reduce, all hypotheses
+//  of a batch in one launch.  grid = (workgroups per hypothesis, hypotheses), 256 lanes.
+// ================================================================================================
+template <class Scene, bool kNN>
+__global__ __launch_bounds__(256) void icp_pass_kernel(IcpBatch b, Scene scene)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    __shared__ float wsum[4][kAccStride];
+
+    const uint32_t pose = blockIdx.y;
+    const int32_t st = b.state[pose];
+    if (st == kSkip) return;
+    const uint32_t n = b.count[pose];
+    const uint32_t ppb = b.steps * kPointsPerStep;
+    const uint32_t first = blockIdx.x * ppb;
+    if (first >= n) return;
+
+    const int4 *lds_topo = nullptr;
+    if constexpr (kNN) {
+        int4 *dst = reinterpret_cast<int4 *>(lds_raw);
+        for (uint32_t i = threadIdx.x; i < scene.lds_nodes; i += kBlockThreads) dst[i] = scene.topo[i];
+        __syncthreads();
+        lds_topo = dst;
+    }
+
+    float *cl = reinterpret_cast<float *>(b.cloud + b.start[pose]);
+    const bool vec_ok = ((reinterpret_cast<uintptr_t>(cl) & 15u) == 0);
+    const bool xf = (st == kRunWithTransform);
+    float M[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) M[i] = xf ? b.xform[(size_t)pose * 12 + i] : 0.0f;
+
+    float acc[29];
+#pragma unroll
+    for (int i = 0; i < 29; ++i) acc[i] = 0.0f;
+
+    for (uint32_t s = 0; s < b.steps; ++s) {
+        const uint32_t j0 = first + s * kPointsPerStep + threadIdx.x * kPointsPerLane;
+        if (j0 >= n) break;
+        const uint32_t cnt = (n - j0 < kPointsPerLane) ? (n - j0) : kPointsPerLane;
+        float p[12];
+        const bool full = vec_ok && cnt == kPointsPerLane;
+        if (full) {
+            const float4 *src = reinterpret_cast<const float4 *>(cl + (size_t)j0 * 3);
+            const float4 a0 = src[0], a1 = src[1], a2 = src[2];
+            p[0] = a0.x; p[1] = a0.y; p[2] = a0.z; p[3] = a0.w; p[4] = a1.x; p[5] = a1.y;
+            p[6] = a1.z; p[7] = a1.w; p[8] = a2.x; p[9] = a2.y; p[10] = a2.z; p[11] = a2.w;
+        } else {
+#pragma unroll
+            for (uint32_t i = 0; i < 12; ++i) p[i] = (i < cnt * 3) ? cl[(size_t)j0 * 3 + i] : 0.0f;
+        }
+        if (xf) {                                                // icp.cu:142-153 transform_pcd_cuda, fused
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float x = p[3 * i], y = p[3 * i + 1], z = p[3 * i + 2];
+                p[3 * i]     = M[0] * x + M[1] * y + M[2]  * z + M[3];
+                p[3 * i + 1] = M[4] * x + M[5] * y + M[6]  * z + M[7];
+                p[3 * i + 2] = M[8] * x + M[9] * y + M[10] * z + M[11];
+            }
+            if (full) {
+                float4 *dst = reinterpret_cast<float4 *>(cl + (size_t)j0 * 3);
+                dst[0] = make_float4(p[0], p[1], p[2], p[3]);
+                dst[1] = make_float4(p[4], p[5], p[6], p[7]);
+                dst[2] = make_float4(p[8], p[9], p[10], p[11]);
+            } else {
+#pragma unroll
+                for (uint32_t i = 0; i < 12; ++i) if (i < cnt * 3) cl[(size_t)j0 * 3 + i] = p[i];
+            }
+        }
+#pragma unroll
+        for (uint32_t i = 0; i < 4; ++i) {
+            if (i < cnt) {
+                Corr c;
+                bool ok;
+                if constexpr (kNN) ok = query_nn<true>(scene, lds_topo, p[3 * i], p[3 * i + 1], p[3 * i + 2], c);
+                else               ok = query(scene, p[3 * i], p[3 * i + 1], p[3 * i + 2], c);
+                if (ok) accumulate(acc, p[3 * i], p[3 * i + 1], p[3 * i + 2], c);
+            }
+        }
+    }
+
+    // canonical tree: wave (balanced pairwise over lanes) -> ((w0+w1)+w2)+w3
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 29; ++i) {
+        const float t = wave_tree_sum(acc[i]);
+        if (lane == 63) wsum[wave][i] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < 29) {
+        const float t = ((wsum[0][threadIdx.x] + wsum[1][threadIdx.x]) + wsum[2][threadIdx.x]) + wsum[3][threadIdx.x];
+        b.partial[((size_t)pose * b.nblk + blockIdx.x) * kAccStride + threadIdx.x] = t;
+    }
+}
+
+// second stage: workgroup sums added sequentially in workgroup order, starting from 0
+__device__ __forceinline__ float sum_partials(const float *partial, uint32_t pose, uint32_t nblk, uint32_t used, uint32_t comp)
+{
+    float total = 0.0f;
+    const float *p = partial + (size_t)pose * nblk * kAccStride + comp;
+    for (uint32_t g = 0; g < used; ++g) total += p[(size_t)g * kAccStride];
+    return total;
+}
+
+__global__ __launch_bounds__(64) void icp_finalize_kernel(const float *__restrict__ partial, const uint32_t *__restrict__ count,
+                                                          const int32_t *__restrict__ state, uint32_t nblk, uint32_t ppb,
+                                                          float *__restrict__ sums)
+{
+    const uint32_t pose = blockIdx.x;
+    if (state[pose] == kSkip) return;
+    const uint32_t n = count[pose];
+    const uint32_t used = (n + ppb - 1) / ppb;
+    if (threadIdx.x < kAccStride)
+        sums[(size_t)pose * kAccStride + threadIdx.x] = (threadIdx.x < 29) ? sum_partials(partial, pose, nblk, used, threadIdx.x) : 0.0f;
+}
+
+// PR_SOLVE_DEVICE: the per-iteration host logic of icp.cu:178-212 for one hypothesis per wavefront
+__global__ __launch_bounds__(64) void icp_finalize_solve_kernel(const float *__restrict__ partial, const uint32_t *__restrict__ count,
+                                                                int32_t *__restrict__ state, uint32_t nblk, uint32_t ppb,
+                                                                float *__restrict__ xform, DevIcpState *__restrict__ st,
+                                                                pr_criteria crit, uint32_t iter)
+{
+    __shared__ float Ab[kAccStride];
+    const uint32_t pose = blockIdx.x;
+    if (state[pose] == kSkip) return;
+    const uint32_t n = count[pose];
+    const uint32_t used = (n + ppb - 1) / ppb;
+    if (threadIdx.x < 29) Ab[threadIdx.x] = sum_partials(partial, pose, nblk, used, threadIdx.x);
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+
+    DevIcpState s = st[pose];
+    s.passes += 1;
+    const float cnt = Ab[28], err = Ab[27];
+    bool finished = false;
+    if (cnt == 0) finished = true;                                           // icp.cu:183
+    else {
+        const float prev_fit = s.fitness, prev_rmse = s.rmse;
+        s.fitness = cnt / (float)n;                                          // icp.cu:185
+        s.rmse = sqrtf(err / cnt);                                           // icp.cu:186
+        if (iter == (uint32_t)crit.max_iteration) finished = true;           // icp.cu:189
+        else {
+            const float df = s.fitness - prev_fit, dr = s.rmse - prev_rmse;
+            if (((df < 0) ? -df : df) < crit.relative_fitness && ((dr < 0) ? -dr : dr) < crit.relative_rmse) finished = true;
+        }
+    }
+    if (finished) { s.done = 1; state[pose] = kSkip; }
+    else {
+        float A[36], bb[6], E[16];
+        for (int i = 0; i < 6; ++i) bb[i] = Ab[21 + i];
+        int k = 0;
+        for (int y = 0; y < 6; ++y) for (int x = y; x < 6; ++x) { A[x + y * 6] = Ab[k]; A[y + x * 6] = Ab[k]; ++k; }
+        prs::solve_666_impl(A, bb, E);
+        for (int i = 0; i < 12; ++i) xform[(size_t)pose * 12 + i] = E[i];
+        prs::mat4_mul_impl(E, s.T, s.T);
+        state[pose] = kRunWithTransform;
+    }
+    st[pose] = s;
+}
+
+__global__ void pack_results_kernel(const DevIcpState *__restrict__ st, pr_result *__restrict__ out, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    pr_result r;
+    for (int k = 0; k < 16; ++k) r.T[k] = st[i].T[k];
+    r.inlier_rmse = st[i].rmse; r.fitness = st[i].fitness;
+    out[i] = r;
+}
+
+// ================================================================================================
+//  scene repacking
+// ================================================================================================
+__global__ __launch_bounds__(256) void pack_proj_scene_kernel(const pr_vec3 *__restrict__ pcd, const pr_vec3 *__restrict__ normal,
+                                                              float4 *__restrict__ rec, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    rec[i] = make_float4(normal[i].x, normal[i].y, normal[i].z, pcd[i].z);
+}
+
+__global__ __launch_bounds__(256) void nn_accel_kernel(const pr_kdnode *__restrict__ nodes, uint32_t n_nodes,
+                                                       const pr_vec3 *__restrict__ pcd, uint32_t n_points,
+                                                       int4 *__restrict__ topo, float4 *__restrict__ bmin,
+                                                       float4 *__restrict__ bmax, float4 *__restrict__ pts)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n_points) pts[i] = make_float4(pcd[i].x, pcd[i].y, pcd[i].z, 0.0f);
+    if (i >= n_nodes) return;
+    const pr_kdnode nd = nodes[i];
+    const bool leaf = (nd.child1 < 0 || nd.child2 < 0);              // pcd_scene.h:21-24
+    const int pw = ((nd.parent + 1) & 0x3fffffff) | (int)((uint32_t)(nd.split_dim & 3) << 30);
+    if (leaf) {
+        float lo[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, hi[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
+        for (int k = nd.left; k < nd.right; ++k) {
+            const float c3[3] = { pcd[k].x, pcd[k].y, pcd[k].z };
+            for (int d = 0; d < 3; ++d) { lo[d] = fminf(lo[d], c3[d]); hi[d] = fmaxf(hi[d], c3[d]); }
+        }
+        topo[i] = make_int4(nd.left, nd.right, -1, pw);
+        bmin[i] = make_float4(lo[0], lo[1], lo[2], 0.0f);
+        bmax[i] = make_float4(hi[0], hi[1], hi[2], 0.0f);
+    } else {
+        topo[i] = make_int4(__float_as_int(nd.split_v), nd.child1, nd.child2, pw);
+        bmin[i] = make_float4(nd.bbox[0], nd.bbox[2], nd.bbox[4], 0.0f);
+        bmax[i] = make_float4(nd.bbox[1], nd.bbox[3], nd.bbox[5], 0.0f);
+    }
+}
+
+// ================================================================================================
+//  launchers
+// ================================================================================================
+static inline uint32_t cap_grid(size_t want) { return (uint32_t)(want < 1 ? 1 : (want > 8192 ? 8192 : want)); }
+
+hipError_t launch_fill_i32(int32_t *dst, size_t n, int32_t v, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(fill_i32_kernel, dim3(cap_grid((n + 1023) / 1024)), dim3(256), 0, s, dst, n, v);
+    return hipGetLastError();
+}
+
+hipError_t launch_max2zero(int32_t *depth, size_t n, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(max2zero_kernel, dim3(cap_grid((n + 1023) / 1024)), dim3(256), 0, s, depth, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_raster(const pr_triangle *tris, uint32_t n_tris, const pr_mat4 *poses_dev, uint32_t n_poses,
+                         int32_t *depth, uint32_t width, uint32_t height, const pr_mat4 &proj, pr_roi roi,
+                         uint32_t rw, uint32_t rh, hipStream_t s)
+{
+    if (n_tris == 0 || n_poses == 0) return hipSuccess;
+    // grid.y is limited to 65535: split very large batches
+    for (uint32_t p0 = 0; p0 < n_poses; p0 += 32768) {
+        const uint32_t np = (n_poses - p0 < 32768) ? (n_poses - p0) : 32768;
+        hipLaunchKernelGGL(raster_kernel, dim3((n_tris + 255) / 256, np), dim3(256), 0, s, tris, n_tris, poses_dev + p0,
+                           depth + (size_t)p0 * rw * rh, width, height, proj, roi, rw, rh);
+    }
+    return hipGetLastError();
+}
+
+template <typename T>
+hipError_t launch_depth2cloud(const T *depth, uint32_t n_img, size_t img_stride, uint32_t width, uint32_t height,
+                              uint32_t stride, uint32_t tl_x, uint32_t tl_y, float fx, float fy, float cx, float cy,
+                              bool empty_intmax, uint32_t *row_count, uint32_t *row_off, uint32_t *counts,
+                              pr_vec3 *cloud, size_t cloud_stride, bool emit, hipStream_t s)
+{
+    const uint32_t gw = width / stride, gh = height / stride;
+    if (n_img == 0) return hipSuccess;
+    if (gw == 0 || gh == 0) return hipMemsetAsync(counts, 0, sizeof(uint32_t) * n_img, s);
+    for (uint32_t i0 = 0; i0 < n_img; i0 += 32768) {
+        const uint32_t ni = (n_img - i0 < 32768) ? (n_img - i0) : 32768;
+        const dim3 grid((gh + 3) / 4, ni);
+        if (!emit) {
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(d2c_count_kernel<T>), grid, dim3(256), 0, s, depth + (size_t)i0 * img_stride,
+                               img_stride, width, gw, gh, stride, empty_intmax, row_count + (size_t)i0 * gh);
+            hipLaunchKernelGGL(d2c_scan_kernel, dim3(ni), dim3(256), 0, s, row_count + (size_t)i0 * gh, gh,
+                               row_off + (size_t)i0 * gh, counts + i0);
+        } else {
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(d2c_emit_kernel<T>), grid, dim3(256), 0, s, depth + (size_t)i0 * img_stride,
+                               img_stride, width, gw, gh, stride, tl_x, tl_y, fx, fy, cx, cy, empty_intmax,
+                               row_count + (size_t)i0 * gh, row_off + (size_t)i0 * gh,
+                               cloud + (size_t)i0 * cloud_stride, cloud_stride);
+        }
+    }
+    return hipGetLastError();
+}
+template hipError_t launch_depth2cloud<int32_t>(const int32_t *, uint32_t, size_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t,
+                                                float, float, float, float, bool, uint32_t *, uint32_t *, uint32_t *, pr_vec3 *,
+                                                size_t, bool, hipStream_t);
+template hipError_t launch_depth2cloud<uint16_t>(const uint16_t *, uint32_t, size_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t,
+                                                 float, float, float, float, bool, uint32_t *, uint32_t *, uint32_t *, pr_vec3 *,
+                                                 size_t, bool, hipStream_t);
+
+template <class Scene, bool kNN>
+static hipError_t launch_pass(const IcpBatch &b, const Scene &sc, uint32_t n_poses, size_t lds_bytes, hipStream_t s)
+{
+    if (n_poses == 0 || b.nblk == 0) return hipSuccess;
+    for (uint32_t p0 = 0; p0 < n_poses; p0 += 32768) {
+        const uint32_t np = (n_poses - p0 < 32768) ? (n_poses - p0) : 32768;
+        IcpBatch bb = b;
+        bb.start += p0; bb.count += p0; bb.state += p0; bb.xform += (size_t)p0 * 12;
+        bb.partial += (size_t)p0 * b.nblk * kAccStride;
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(icp_pass_kernel<Scene, kNN>), dim3(b.nblk, np), dim3(kBlockThreads), lds_bytes, s, bb, sc);
+    }
+    return hipGetLastError();
+}
+hipError_t launch_icp_pass_proj_aos(const IcpBatch &b, const SceneProjAoS &sc, uint32_t n_poses, hipStream_t s)
+{ return launch_pass<SceneProjAoS, false>(b, sc, n_poses, 0, s); }
+hipError_t launch_icp_pass_proj_packed(const IcpBatch &b, const SceneProjPacked &sc, uint32_t n_poses, hipStream_t s)
+{ return launch_pass<SceneProjPacked, false>(b, sc, n_poses, 0, s); }
+hipError_t launch_icp_pass_nn(const IcpBatch &b, const SceneNNDev &sc, uint32_t n_poses, hipStream_t s)
+{ return launch_pass<SceneNNDev, true>(b, sc, n_poses, (size_t)sc.lds_nodes * sizeof(int4), s); }
+
+hipError_t launch_icp_finalize(const float *partial, const uint32_t *count, const int32_t *state, uint32_t nblk,
+                               uint32_t steps, float *sums, uint32_t n_poses, hipStream_t s)
+{
+    if (n_poses == 0) return hipSuccess;
+    hipLaunchKernelGGL(icp_finalize_kernel, dim3(n_poses), dim3(64), 0, s, partial, count, state, nblk, steps * kPointsPerStep, sums);
+    return hipGetLastError();
+}
+hipError_t launch_icp_finalize_solve(const float *partial, const uint32_t *count, int32_t *state, uint32_t nblk,
+                                     uint32_t steps, float *xform, DevIcpState *st, pr_criteria crit, uint32_t iter,
+                                     uint32_t n_poses, hipStream_t s)
+{
+    if (n_poses == 0) return hipSuccess;
+    hipLaunchKernelGGL(icp_finalize_solve_kernel, dim3(n_poses), dim3(64), 0, s, partial, count, state, nblk,
+                       steps * kPointsPerStep, xform, st, crit, iter);
+    return hipGetLastError();
+}
+hipError_t launch_pack_results(const DevIcpState *st, pr_result *out, uint32_t n_poses, hipStream_t s)
+{
+    if (n_poses == 0) return hipSuccess;
+    hipLaunchKernelGGL(pack_results_kernel, dim3((n_poses + 255) / 256), dim3(256), 0, s, st, out, n_poses);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_proj_scene(const pr_vec3 *pcd, const pr_vec3 *normal, float4 *rec, size_t n, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(pack_proj_scene_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, pcd, normal, rec, n);
+    return hipGetLastError();
+}
+hipError_t launch_build_nn_accel(const pr_kdnode *nodes, uint32_t n_nodes, const pr_vec3 *pcd, uint32_t n_points,
+                                 int4 *topo, float4 *bmin, float4 *bmax, float4 *pts, hipStream_t s)
+{
+    const uint32_t m = (n_nodes > n_points) ? n_nodes : n_points;
+    if (m == 0) return hipSuccess;
+    hipLaunchKernelGGL(nn_accel_kernel, dim3((m + 255) / 256), dim3(256), 0, s, nodes, n_nodes, pcd, n_points, topo, bmin, bmax, pts);
+    return hipGetLastError();
+}
+
+}  // namespace prk

@@ -1,0 +1,164 @@
+// pr_solver.inl -- the per-iteration rigid update: (A + 0.01 I) x = b in double, x -> 4x4.
+//
+// Replaces cuda_icp::eigen_slover_666 / TransformVector6dToMatrix4d / eigen_to_custom
+// (cuda_icp/icp.cpp:7-45).  The reference calls Eigen (absent from its tree, version unpinned);
+// this file restates Eigen's published algorithms:
+//   * LDLT<Matrix6d>::compute/solve -- unblocked lower LDL^T with symmetric pivoting on the largest
+//     |diagonal| entry, pseudo-inverse of D with tolerance 1/DBL_MAX;
+//   * AngleAxisd(z)*AngleAxisd(y)*AngleAxisd(x) -- composed as unit quaternions, then
+//     Quaterniond::toRotationMatrix.
+// The same source is compiled for the host (PR_SOLVE_HOST, pr_solve_666) and for the device
+// (PR_SOLVE_DEVICE finalize kernel).  sin/cos come from the fixed polynomial below rather than
+// libm/ocml so that both builds produce bit-identical updates (all operations are IEEE double
+// add/mul/div with contraction disabled); it is accurate to < 1 ulp on |x| <= pi/4 and uses a
+// two-term Cody-Waite reduction beyond.
+#pragma once
+
+#ifndef PR_HD
+#define PR_HD
+#endif
+
+namespace prs {
+
+PR_HD inline double dabs(double v) { return v < 0 ? -v : v; }
+
+// minimax kernels on [-pi/4, pi/4] (the classic fdlibm coefficient set)
+PR_HD inline double ksin(double x)
+{
+    const double z = x * x;
+    double p = 1.58969099521155010221e-10;
+    p = p * z + -2.50507602534068634195e-08;
+    p = p * z + 2.75573137070700676789e-06;
+    p = p * z + -1.98412698298579493134e-04;
+    p = p * z + 8.33333333332248946124e-03;
+    p = p * z + -1.66666666666666324348e-01;
+    return x + (x * z) * p;
+}
+PR_HD inline double kcos(double x)
+{
+    const double z = x * x;
+    double p = -1.13596475577881948265e-11;
+    p = p * z + 2.08757232129817482790e-09;
+    p = p * z + -2.75573143513906633035e-07;
+    p = p * z + 2.48015872894767294178e-05;
+    p = p * z + -1.38888888888741095749e-03;
+    p = p * z + 4.16666666666666019037e-02;
+    return (1.0 - 0.5 * z) + (z * z) * p;
+}
+PR_HD inline void sincos_d(double x, double *s, double *c)
+{
+    const double quarter_pi = 0.78539816339744830962;
+    if (dabs(x) <= quarter_pi) { *s = ksin(x); *c = kcos(x); return; }
+    if (!(dabs(x) < 1.0e9)) { *s = 0.0; *c = 1.0; return; }            // non-finite / absurd update
+    const double two_over_pi = 0.63661977236758134308;
+    const double pio2_hi = 1.57079632673412561417e+00;                 // first 33 bits of pi/2
+    const double pio2_lo = 6.07710050650619224932e-11;                 // pi/2 - pio2_hi
+    double t = x * two_over_pi;
+    long long n = (long long)(t < 0 ? t - 0.5 : t + 0.5);
+    double fn = (double)n;
+    double r = (x - fn * pio2_hi) - fn * pio2_lo;
+    double sr = ksin(r), cr = kcos(r);
+    switch ((int)(n & 3)) {
+        case 0:  *s = sr;  *c = cr;  break;
+        case 1:  *s = cr;  *c = -sr; break;
+        case 2:  *s = -sr; *c = -cr; break;
+        default: *s = -cr; *c = sr;  break;
+    }
+}
+
+// lower-triangular LDL^T with diagonal pivoting, in place on the 6x6 (row-major, lower part used)
+PR_HD inline void ldlt6(double *m /*36*/, const double *rhs, double *x)
+{
+#define MM(r, c) m[(r) * 6 + (c)]
+    int swp[6];
+    for (int k = 0; k < 6; ++k) {
+        int p = k;
+        double top = dabs(MM(k, k));
+        for (int i = k + 1; i < 6; ++i) {
+            double a = dabs(MM(i, i));
+            if (a > top) { top = a; p = i; }
+        }
+        swp[k] = p;
+        if (p != k) {
+            for (int j = 0; j < k; ++j)       { double t = MM(k, j); MM(k, j) = MM(p, j); MM(p, j) = t; }
+            for (int i = p + 1; i < 6; ++i)   { double t = MM(i, k); MM(i, k) = MM(i, p); MM(i, p) = t; }
+            for (int i = k + 1; i < p; ++i)   { double t = MM(i, k); MM(i, k) = MM(p, i); MM(p, i) = t; }
+            double t = MM(k, k); MM(k, k) = MM(p, p); MM(p, p) = t;
+        }
+        double w[6];
+        double dot = 0.0;
+        for (int j = 0; j < k; ++j) { w[j] = MM(j, j) * MM(k, j); dot += MM(k, j) * w[j]; }
+        MM(k, k) -= dot;
+        const double dk = MM(k, k);
+        for (int i = k + 1; i < 6; ++i) {
+            double acc = 0.0;
+            for (int j = 0; j < k; ++j) acc += MM(i, j) * w[j];
+            double v = MM(i, k) - acc;
+            MM(i, k) = (dabs(dk) > 0.0) ? v / dk : v;
+        }
+    }
+    double y[6];
+    for (int i = 0; i < 6; ++i) y[i] = rhs[i];
+    for (int k = 0; k < 6; ++k) if (swp[k] != k) { double t = y[k]; y[k] = y[swp[k]]; y[swp[k]] = t; }
+    for (int i = 1; i < 6; ++i) for (int j = 0; j < i; ++j) y[i] -= MM(i, j) * y[j];
+    const double tiny = 1.0 / 1.7976931348623157e308;
+    for (int i = 0; i < 6; ++i) y[i] = (dabs(MM(i, i)) > tiny) ? y[i] / MM(i, i) : 0.0;
+    for (int i = 4; i >= 0; --i) for (int j = i + 1; j < 6; ++j) y[i] -= MM(j, i) * y[j];
+    for (int k = 5; k >= 0; --k) if (swp[k] != k) { double t = y[k]; y[k] = y[swp[k]]; y[swp[k]] = t; }
+    for (int i = 0; i < 6; ++i) x[i] = y[i];
+#undef MM
+}
+
+// A: 36 floats (symmetric, any major), b: 6 floats -> T: row-major 4x4 float
+PR_HD inline void solve_666_impl(const float *A, const float *b, float *T)
+{
+    double m[36], rhs[6], u[6];
+    for (int r = 0; r < 6; ++r)
+        for (int c = 0; c < 6; ++c) m[r * 6 + c] = (double)A[c * 6 + r] + (r == c ? 0.01 : 0.0);
+    for (int i = 0; i < 6; ++i) rhs[i] = (double)b[i];
+    ldlt6(m, rhs, u);
+
+    double sx, cx, sy, cy, sz, cz;
+    sincos_d(0.5 * u[0], &sx, &cx);
+    sincos_d(0.5 * u[1], &sy, &cy);
+    sincos_d(0.5 * u[2], &sz, &cz);
+    // q = qz * qy * qx with qz=(cz;0,0,sz), qy=(cy;0,sy,0), qx=(cx;sx,0,0), general Hamilton products
+    // first qzy = qz*qy
+    double aw = cz * cy - 0.0 * 0.0 - 0.0 * sy - sz * 0.0;
+    double ax = cz * 0.0 + 0.0 * cy + 0.0 * 0.0 - sz * sy;
+    double ay = cz * sy + 0.0 * cy + sz * 0.0 - 0.0 * 0.0;
+    double az = cz * 0.0 + sz * cy + 0.0 * sy - 0.0 * 0.0;
+    // then q = qzy*qx
+    double qw = aw * cx - ax * sx - ay * 0.0 - az * 0.0;
+    double qx = aw * sx + ax * cx + ay * 0.0 - az * 0.0;
+    double qy = aw * 0.0 + ay * cx + az * sx - ax * 0.0;
+    double qz = aw * 0.0 + az * cx + ax * 0.0 - ay * sx;
+
+    const double tx = 2.0 * qx, ty = 2.0 * qy, tz = 2.0 * qz;
+    const double twx = tx * qw, twy = ty * qw, twz = tz * qw;
+    const double txx = tx * qx, txy = ty * qx, txz = tz * qx;
+    const double tyy = ty * qy, tyz = tz * qy, tzz = tz * qz;
+    T[0] = (float)(1.0 - (tyy + tzz)); T[1] = (float)(txy - twz);         T[2]  = (float)(txz + twy);         T[3]  = (float)u[3];
+    T[4] = (float)(txy + twz);         T[5] = (float)(1.0 - (txx + tzz)); T[6]  = (float)(tyz - twx);         T[7]  = (float)u[4];
+    T[8] = (float)(txz - twy);         T[9] = (float)(tyz + twx);         T[10] = (float)(1.0 - (txx + tyy)); T[11] = (float)u[5];
+    T[12] = 0.0f; T[13] = 0.0f; T[14] = 0.0f; T[15] = 1.0f;
+}
+
+// result.T = E * result.T with the reference's summation order: index 3,2,1,0 from 0
+// (cuda_icp/geometry.h:106-111 dot product, :292-298 mat*mat)
+PR_HD inline void mat4_mul_impl(const float *A, const float *B, float *C)
+{
+    float tmp[16];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            float acc = 0.0f;
+            acc += A[i * 4 + 3] * B[12 + j];
+            acc += A[i * 4 + 2] * B[8 + j];
+            acc += A[i * 4 + 1] * B[4 + j];
+            acc += A[i * 4 + 0] * B[j];
+            tmp[i * 4 + j] = acc;
+        }
+    for (int i = 0; i < 16; ++i) C[i] = tmp[i];
+}
+
+}  // namespace prs

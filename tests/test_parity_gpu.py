@@ -1,0 +1,239 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against the CPU oracle on the
+same seeded inputs.  Integer outputs (depth images, cloud sizes, inlier counts) must be bit-exact;
+per-pass 29-float sums are bit-exact against the oracle's canonical tree; transforms within 1e-4
+(BASELINE.json north_star tolerance) -- in practice they are bit-identical too.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from pose_refine_amd import api, synth
+
+pytestmark = pytest.mark.gpu
+
+W, H = synth.WIDTH, synth.HEIGHT
+TOL_T = 1e-4          # north_star: "transforms within 1e-4"
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    api.init(0)
+    return True
+
+
+@pytest.fixture(scope="module")
+def model(gpu, golden_dir):
+    return api.Model(os.path.join(golden_dir, "obj_06.ply"))
+
+
+@pytest.fixture(scope="module")
+def gscenes(gpu, scenario):
+    d = scenario["depth"][1]
+    return dict(proj=api.Scene_projective().init_Scene_projective_cuda(d, scenario["K"]),
+                nn=api.Scene_nn().init_Scene_nn_cuda(d, scenario["K"]))
+
+
+def inliers(fitness, n):
+    return np.rint(np.asarray(fitness, np.float64) * np.asarray(n, np.float64)).astype(np.int64)
+
+
+# ---- renderer: cuda_renderer/test.cpp:79-106 (full frame) and :122-149 (ROI) ------------------------
+def test_render_matches_cpu_bit_exact(model, scenario):
+    poses = np.concatenate([scenario["poses"], synth.hypotheses(6)[1:]])
+    ref = O.render(scenario["tris"], poses, W, H, scenario["proj"])
+    got_host = api.render_host(model, poses, W, H, scenario["proj"])
+    assert np.array_equal(got_host, ref)
+    keep = api.render(model, poses, W, H, scenario["proj"])           # render_cuda_keep_in_gpu
+    assert np.array_equal(keep.to_host().reshape(ref.shape), ref)
+
+
+def test_render_100_identical_poses_like_reference_test(model, scenario):
+    poses = np.repeat(scenario["poses"][:1], 100, axis=0)              # cuda_renderer/test.cpp:63
+    got = api.render_host(model, poses, W, H, scenario["proj"])
+    assert np.abs(got.astype(np.int64) - scenario["depth"][0][None].astype(np.int64)).sum() == 0
+
+
+def test_render_roi(model, scenario):
+    roi = (160, 80, 320, 240)                                          # cuda_renderer/test.cpp:122
+    poses = scenario["poses"]
+    ref = O.render(scenario["tris"], poses, W, H, scenario["proj"], roi)
+    got = api.render_host(model, poses, W, H, scenario["proj"], roi)
+    assert got.shape == ref.shape and np.array_equal(got, ref)
+    with pytest.raises(api.PoseRefineError):
+        api.render_host(model, poses, W, H, scenario["proj"], (600, 0, 100, 100))   # roi out of image
+
+
+def test_render_offscreen_and_empty(model, scenario):
+    far = scenario["poses"][:1].copy()
+    far[0, 0, 3] = 5000.0                                              # pushed out of the frustum sideways
+    assert api.render_host(model, far, W, H, scenario["proj"]).sum() == 0
+    assert api.render_host(model, np.zeros((0, 16), np.float32), W, H, scenario["proj"]).size == 0
+
+
+# ---- depth -> cloud -------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [np.int32, np.uint16])
+def test_depth2cloud_bit_exact(gpu, scenario, dtype):
+    d = scenario["depth"][0].astype(dtype)
+    dev = api.DeviceVector.from_host(d.reshape(-1))
+    got = api.depth2cloud(dev, W, H, scenario["K"], dtype=dtype).to_host().reshape(-1, 3)
+    ref = O.depth2cloud(d, scenario["K"])
+    assert got.shape == ref.shape and np.array_equal(got, ref)
+
+
+def test_depth2cloud_crop_offsets_and_empty(gpu, scenario):
+    d = np.ascontiguousarray(scenario["depth"][0][80:320, 160:480])    # cropped render, tl = (160, 80)
+    dev = api.DeviceVector.from_host(d.reshape(-1))
+    got = api.depth2cloud(dev, 320, 240, scenario["K"], 1, 160, 80).to_host().reshape(-1, 3)
+    assert np.array_equal(got, O.depth2cloud(d, scenario["K"], 1, 160, 80))
+    z = api.DeviceVector.from_host(np.zeros(64 * 48, np.int32))
+    assert api.depth2cloud(z, 64, 48, scenario["K"]).size() == 0
+
+
+def test_depth2cloud_stride2(gpu, scenario):
+    d = scenario["depth"][0]
+    dev = api.DeviceVector.from_host(d.reshape(-1))
+    got = api.depth2cloud(dev, W, H, scenario["K"], 2).to_host().reshape(-1, 3)
+    assert np.array_equal(got, O.depth2cloud(d, scenario["K"], 2))
+
+
+# ---- single-cloud ICP: test.cpp:153-172 -----------------------------------------------------------
+@pytest.mark.parametrize("kind", ["proj", "nn"])
+@pytest.mark.parametrize("crit", [(1e-5, 1e-5, 30), (0.0, 0.0, 20)])
+@pytest.mark.parametrize("solve", [api.SOLVE_HOST, api.SOLVE_DEVICE])
+def test_icp_single_cloud(gpu, scenario, gscenes, kind, crit, solve):
+    api.set_option("solve", solve)
+    try:
+        cloud = scenario["cloud"]
+        dev = api.DeviceVector.from_host(cloud.reshape(-1))
+        res = api.ICP_Point2Plane(dev, gscenes[kind], api.ICPConvergenceCriteria(*crit))
+        oscene = scenario["proj_scene" if kind == "proj" else "nn_scene"]
+        ores, passes, ocloud, _ = O.icp(cloud, oscene, crit, O.SUM_CANONICAL, api.get_option("points_per_block"))
+        n = len(cloud)
+        assert inliers(res.fitness_, n) == inliers(ores["fitness"], n)          # bit-exact inlier count
+        assert res.fitness_ == float(ores["fitness"])
+        assert res.inlier_rmse_ == pytest.approx(float(ores["inlier_rmse"]), rel=1e-6)
+        assert np.allclose(res.transformation_, ores["T"].reshape(4, 4), rtol=0, atol=TOL_T)
+        # the reference mutates the caller's cloud (test.cpp:129 comment)
+        assert np.allclose(dev.to_host().reshape(-1, 3), ocloud, rtol=0, atol=1e-5)
+        if solve == api.SOLVE_HOST:
+            assert np.array_equal(res.transformation_, ores["T"].reshape(4, 4)) or \
+                np.allclose(res.transformation_, ores["T"].reshape(4, 4), rtol=0, atol=1e-6)
+    finally:
+        api.set_option("solve", api.SOLVE_HOST)
+
+
+@pytest.mark.parametrize("kind", ["proj", "nn"])
+def test_first_pass_sums_bit_exact(gpu, scenario, gscenes, kind):
+    """max_iteration=0 -> exactly one correspondence pass: fitness and rmse are functions of the
+    canonical-tree sums [28] and [27], so equality here pins the reduction order bit for bit."""
+    cloud = scenario["cloud"]
+    dev = api.DeviceVector.from_host(cloud.reshape(-1))
+    res = api.ICP_Point2Plane(dev, gscenes[kind], api.ICPConvergenceCriteria(0.0, 0.0, 0))
+    oscene = scenario["proj_scene" if kind == "proj" else "nn_scene"]
+    s = O.sum29(cloud, oscene, O.SUM_CANONICAL, api.get_option("points_per_block"))
+    assert res.fitness_ == np.float32(s[28] / np.float32(len(cloud)))
+    assert res.inlier_rmse_ == np.float32(np.sqrt(np.float32(s[27] / s[28])))
+    assert np.array_equal(res.transformation_, np.eye(4, dtype=np.float32))
+
+
+def test_host_and_device_solve_agree_bitwise(gpu, scenario, gscenes):
+    out = []
+    for solve in (api.SOLVE_HOST, api.SOLVE_DEVICE):
+        api.set_option("solve", solve)
+        dev = api.DeviceVector.from_host(scenario["cloud"].reshape(-1))
+        r = api.ICP_Point2Plane(dev, gscenes["proj"], api.ICPConvergenceCriteria(0.0, 0.0, 20))
+        out.append((r.transformation_.copy(), r.fitness_, r.inlier_rmse_, dev.to_host()))
+    api.set_option("solve", api.SOLVE_HOST)
+    assert np.array_equal(out[0][0], out[1][0]) and out[0][1] == out[1][1] and out[0][2] == out[1][2]
+    assert np.array_equal(out[0][3], out[1][3])
+
+
+# ---- edge cases -----------------------------------------------------------------------------------
+def test_icp_degenerate_clouds(gpu, scenario, gscenes):
+    # no correspondences at all: count==0 -> identity, fitness 0 (icp.cu:183)
+    far = scenario["cloud"] + np.array([0, 0, 5.0], np.float32)
+    dev = api.DeviceVector.from_host(far.reshape(-1))
+    for kind in ("proj", "nn"):
+        r = api.ICP_Point2Plane(dev, gscenes[kind])
+        assert r.fitness_ == 0.0 and r.inlier_rmse_ == 0.0 and np.array_equal(r.transformation_, np.eye(4, dtype=np.float32))
+    # ragged batch incl. an empty cloud and sizes that are not multiples of 4 (scalar tail path,
+    # unaligned cloud starts)
+    cl = scenario["cloud"]
+    parts = [cl[:1], cl[:0], cl[:4099], cl[5:2054], cl]
+    offs = np.cumsum([0] + [len(p) for p in parts]).astype(np.uint32)
+    dev = api.DeviceVector.from_host(np.concatenate(parts).reshape(-1))
+    crit = (0.0, 0.0, 5)
+    res = api.ICP_Point2Plane_batch(dev, offs, gscenes["proj"], api.ICPConvergenceCriteria(*crit))
+    ppb = api.get_option("points_per_block")
+    for i, p in enumerate(parts):
+        o, _, _, _ = O.icp(p, scenario["proj_scene"], crit, O.SUM_CANONICAL, ppb)
+        assert res[i]["fitness"] == o["fitness"], i
+        assert np.allclose(res[i]["T"], o["T"], rtol=0, atol=TOL_T), i
+
+
+# ---- fused batch: BASELINE.json configs[1]/[2] at parity-test size -----------------------------------
+@pytest.mark.parametrize("kind,P", [("proj", 24), ("nn", 6)])
+@pytest.mark.parametrize("solve", [api.SOLVE_HOST, api.SOLVE_DEVICE])
+def test_refine_batch_against_oracle(gpu, model, scenario, gscenes, kind, P, solve):
+    api.set_option("solve", solve)
+    try:
+        poses = synth.hypotheses(P)
+        crit = (0.0, 0.0, 20)
+        res, sizes = api.refine_batch(model, poses, W, H, scenario["proj"], scenario["K"], gscenes[kind],
+                                      api.ICPConvergenceCriteria(*crit))
+        oscene = scenario["proj_scene" if kind == "proj" else "nn_scene"]
+        ores, osizes, _ = O.refine_batch(scenario["tris"], poses, W, H, scenario["proj"], scenario["K"], oscene, crit,
+                                         O.SUM_CANONICAL, api.get_option("points_per_block"))
+        assert np.array_equal(sizes, osizes)
+        assert np.array_equal(inliers(res["fitness"], sizes), inliers(ores["fitness"], osizes))
+        assert np.array_equal(res["fitness"], ores["fitness"])
+        assert np.allclose(res["inlier_rmse"], ores["inlier_rmse"], rtol=1e-6, atol=0)
+        assert np.allclose(res["T"], ores["T"], rtol=0, atol=TOL_T)
+    finally:
+        api.set_option("solve", api.SOLVE_HOST)
+
+
+def test_refine_batch_default_criteria_early_exit(gpu, model, scenario, gscenes):
+    poses = synth.hypotheses(8)
+    crit = (1e-5, 1e-5, 30)
+    res, sizes = api.refine_batch(model, poses, W, H, scenario["proj"], scenario["K"], gscenes["proj"],
+                                  api.ICPConvergenceCriteria(*crit))
+    ores, osizes, _ = O.refine_batch(scenario["tris"], poses, W, H, scenario["proj"], scenario["K"], scenario["proj_scene"],
+                                     crit, O.SUM_CANONICAL, api.get_option("points_per_block"))
+    assert np.array_equal(sizes, osizes) and np.array_equal(res["fitness"], ores["fitness"])
+    assert np.allclose(res["T"], ores["T"], rtol=0, atol=TOL_T)
+
+
+# ---- full-size properties (configs[1]: 256 hypotheses) --------------------------------------------
+def test_full_batch_properties(gpu, model, scenario, gscenes):
+    """At BASELINE size the oracle is too slow for every pose; check size-independent properties:
+    batch results are independent of batch composition (each pose equals its single-pose run),
+    the batch is permutation-equivariant, and pose 0 equals the oracle run of pose 0."""
+    P = 256
+    poses = synth.hypotheses(P)
+    crit = api.ICPConvergenceCriteria(0.0, 0.0, 20)
+    res, sizes = api.refine_batch(model, poses, W, H, scenario["proj"], scenario["K"], gscenes["proj"], crit)
+    perm = np.random.default_rng(3).permutation(P)
+    res_p, sizes_p = api.refine_batch(model, poses[perm], W, H, scenario["proj"], scenario["K"], gscenes["proj"], crit)
+    assert np.array_equal(sizes[perm], sizes_p)
+    assert np.array_equal(res["T"][perm], res_p["T"]) and np.array_equal(res["fitness"][perm], res_p["fitness"])
+    for i in (0, 17, 255):
+        one, s1 = api.refine_batch(model, poses[i:i + 1], W, H, scenario["proj"], scenario["K"], gscenes["proj"], crit)
+        assert s1[0] == sizes[i] and np.array_equal(one["T"][0], res["T"][i]) and one["fitness"][0] == res["fitness"][i]
+    ores, osizes, _ = O.refine_batch(scenario["tris"], poses[:1], W, H, scenario["proj"], scenario["K"], scenario["proj_scene"],
+                                     (0.0, 0.0, 20), O.SUM_CANONICAL, api.get_option("points_per_block"))
+    assert sizes[0] == osizes[0] and res["fitness"][0] == ores["fitness"][0]
+    assert np.allclose(res["T"][0], ores["T"][0], rtol=0, atol=TOL_T)
+    # every hypothesis is a rigid transform: R^T R = I, det = +1
+    R = res["T"].reshape(P, 4, 4)[:, :3, :3].astype(np.float64)
+    assert np.allclose(np.einsum("pij,pik->pjk", R, R), np.eye(3), atol=1e-5)
+    assert np.allclose(np.linalg.det(R), 1.0, atol=1e-5)
+
+
+def test_no_device_option_errors(gpu):
+    with pytest.raises(api.PoseRefineError):
+        api.set_option("no_such_option", 1)
+    with pytest.raises(api.PoseRefineError):
+        api.set_option("points_per_block", 1000)
