@@ -56,7 +56,8 @@ def main():
     import torch
     import torch.distributed as dist
     import numpy as np
-    from pose_refine_amd import api, synth, _lib
+    from pose_refine_amd import api, synth
+    from pose_refine_amd import dist as prd
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
@@ -78,12 +79,11 @@ def main():
     crit = api.ICPConvergenceCriteria(0.0, 0.0, args.iters)
 
     results = torch.zeros(P * 18, dtype=torch.float32, device="cuda")          # P x RegistrationResult (72 B)
-    gathered = [torch.zeros_like(results) for _ in range(world)] if (world > 1 and rank == 0) else None
 
     def step():
         _, sizes = api.refine_batch(model, poses, W, H, proj, K, scene, crit, results_dev=results.data_ptr())
         if world > 1:
-            dist.gather(results, gathered, dst=0)                  # the single RCCL exchange of the job
+            prd.gather_results(results, world, rank, dst=0)        # the single RCCL exchange of the job
         return sizes
 
     def fence():
@@ -160,15 +160,16 @@ def cpu_baseline(args, tris, poses, scene_depth, K, W, H):
     import oracle_lib as O
     cores = os.cpu_count() or 1
     per_pose_s = 0.06 if args.scene == "proj" else 1.5             # single-thread estimates
-    n = args.cpu_poses or int(max(cores, min(len(poses), round(15.0 * cores / per_pose_s))))
-    n = min(n, len(poses))
+    n = args.cpu_poses or int(max(cores, min(20000, round(12.0 * cores / per_pose_s))))
+    from pose_refine_amd import synth
+    poses = synth.hypotheses(n)                                     # same seeded stream, longer prefix
     oscene = O.ProjScene(scene_depth, K) if args.scene == "proj" else O.NNScene(scene_depth, K)
     proj = O.compute_proj(K, W, H)
     t0 = time.perf_counter()
     _, _, threads = O.refine_batch(tris, poses[:n], W, H, proj, K, oscene, (0.0, 0.0, args.iters), O.SUM_SEQUENTIAL)
     dt = time.perf_counter() - t0
     return {"value": n / dt, "unit": "poses/s", "cores": int(threads), "kind": "port",
-            "sample": f"first {n} hypotheses of the same batch, {dt:.1f} s wall, OpenMP over poses"}
+            "sample": f"first {n} hypotheses of the same seeded stream, {dt:.1f} s wall, OpenMP over poses"}
 
 
 if __name__ == "__main__":
