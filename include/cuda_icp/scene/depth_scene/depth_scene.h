@@ -1,0 +1,48 @@
+// depth_scene.h -- ::Scene_projective (cuda_icp/scene/depth_scene/depth_scene.h:7-48): a non-owning view
+// {width, height, max_dist_diff, K, pcd_ptr, normal_ptr} over user-owned buffers.  72 bytes, same
+// field order as the reference, bit-compatible with pr_scene_proj of the C ABI.
+#pragma once
+#include "../common.h"
+
+struct Scene_projective {
+    size_t width = 640, height = 480;
+    float max_dist_diff = 0.1f;
+    Mat3x3f K;
+    Vec3f *pcd_ptr = nullptr;
+    Vec3f *normal_ptr = nullptr;
+
+    void init_Scene_projective_cpu(cv::Mat &scene_depth, Mat3x3f &scene_K, std::vector<Vec3f> &pcd_buffer, std::vector<Vec3f> &normal_buffer,
+                                   size_t width_ = 640, size_t height_ = 480, float max_dist_diff_ = 0.1f)
+    {
+        assert(scene_depth.type() == CV_16U || scene_depth.type() == CV_32S);
+        K = scene_K; width = width_; height = height_; max_dist_diff = max_dist_diff_;
+        pcd_buffer.assign(width * height, Vec3f()); normal_buffer.assign(width * height, Vec3f());
+        pose_refine_detail::must(pr_scene_proj_prepare(scene_depth.data, scene_depth.type() == CV_32S, K.data(), width, height,
+                                                       reinterpret_cast<pr_vec3 *>(pcd_buffer.data()), reinterpret_cast<pr_vec3 *>(normal_buffer.data())),
+                                 "pr_scene_proj_prepare");
+        pcd_ptr = pcd_buffer.data(); normal_ptr = normal_buffer.data();
+    }
+    // depth_scene.cu:3-20: CPU preparation + two uploads
+    void init_Scene_projective_cuda(cv::Mat &scene_depth, Mat3x3f &scene_K, device_vector_holder<Vec3f> &pcd_buffer,
+                                    device_vector_holder<Vec3f> &normal_buffer, size_t width_ = 640, size_t height_ = 480, float max_dist_diff_ = 0.1f)
+    {
+        std::vector<Vec3f> p, n;
+        init_Scene_projective_cpu(scene_depth, scene_K, p, n, width_, height_, max_dist_diff_);
+        pcd_buffer.upload(p); normal_buffer.upload(n);
+        pcd_ptr = pcd_buffer.data(); normal_ptr = normal_buffer.data();
+    }
+    // depth_scene.h:29-48 (host evaluation; only meaningful when the pointers are host pointers)
+    void query(const Vec3f &src, Vec3f &dst, Vec3f &nrm, bool &valid) const
+    {
+        Vec3i q = pcd2dep(src, K);
+        valid = false;
+        if (q.x < 0 || q.y < 0 || (size_t)q.x >= width || (size_t)q.y >= height) return;
+        size_t idx = q.x + q.y * width;
+        dst = pcd_ptr[idx];
+        if (dst.z <= 0 || std__abs(src.z - dst.z) > max_dist_diff) return;
+        valid = true; nrm = normal_ptr[idx];
+    }
+    pr_scene_proj c_view() const { pr_scene_proj s; s.width = width; s.height = height; s.max_dist_diff = max_dist_diff;
+        for (int i = 0; i < 9; ++i) s.K[i] = K.data()[i]; s.pcd = reinterpret_cast<const pr_vec3 *>(pcd_ptr); s.normal = reinterpret_cast<const pr_vec3 *>(normal_ptr); return s; }
+};
+static_assert(sizeof(Scene_projective) == 72, "Scene_projective is passed by value; keep the reference's size");

@@ -1,0 +1,109 @@
+// renderer.h -- cuda_renderer:: API of cuda_renderer/renderer.h:25-248 over the C ABI.
+// Model keeps the public members the path uses (tris, vertices, faces, nested PODs); the assimp
+// scene graph members are gone (own ASCII-PLY reader behind pr_ply_load).
+#pragma once
+#include <cassert>
+#include <iostream>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "pose_refine.h"
+#include "pose_refine/cv_compat.h"
+
+namespace cuda_renderer {
+
+class Model {
+public:
+    struct int3 { int v0, v1, v2; };
+    struct ROI { int x, y, width, height; };
+    struct float3 { float x, y, z; };
+    struct Triangle { float3 v0, v1, v2; };
+    struct mat4x4 {                               // row-major a0..d3, identity by default (renderer.h:69-141)
+        float a0 = 1, a1 = 0, a2 = 0, a3 = 0, b0 = 0, b1 = 1, b2 = 0, b3 = 0, c0 = 0, c1 = 0, c2 = 1, c3 = 0, d0 = 0, d1 = 0, d2 = 0, d3 = 1;
+        void t() { std::swap(a1, b0); std::swap(a2, c0); std::swap(a3, d0); std::swap(b2, c1); std::swap(b3, d1); std::swap(c3, d2); }
+        void init_from_ptr(const float *d) { float *m = &a0; for (int i = 0; i < 16; ++i) m[i] = d[i]; }
+        void init_from_ptr(const float *R, const float *tr) { a0 = R[0]; a1 = R[1]; a2 = R[2]; a3 = tr[0]; b0 = R[3]; b1 = R[4]; b2 = R[5]; b3 = tr[1]; c0 = R[6]; c1 = R[7]; c2 = R[8]; c3 = tr[2]; }
+        void init_from_cv(const cv::Mat &pose) { assert(pose.type() == CV_32F); init_from_ptr(pose.ptr<float>()); }
+        void init_from_cv(const cv::Mat &R, const cv::Mat &tr) { assert(R.type() == CV_32F && tr.type() == CV_32F); init_from_ptr(R.ptr<float>(), tr.ptr<float>()); d0 = d1 = d2 = 0; d3 = 1; }
+    };
+    Model() {}
+    ~Model() {}
+    explicit Model(const std::string &fileName) { LoadModel(fileName); }
+    void LoadModel(const std::string &fileName)
+    {
+        size_t nt = 0, nv = 0;
+        if (pr_ply_count(fileName.c_str(), &nt, &nv) != PR_OK) { std::cerr << pr_last_error() << std::endl; std::exit(1); }
+        tris.resize(nt);
+        if (pr_ply_load(fileName.c_str(), reinterpret_cast<pr_triangle *>(tris.data()), nt, &nt) != PR_OK) { std::cerr << pr_last_error() << std::endl; std::exit(1); }
+        tris.resize(nt);
+        std::cout << "load model success\nface(triangles) nums: " << tris.size() << std::endl;
+    }
+    std::vector<Triangle> tris;
+    std::vector<float3> vertices;
+    std::vector<int3> faces;
+};
+static_assert(sizeof(Model::Triangle) == sizeof(pr_triangle) && sizeof(Model::mat4x4) == sizeof(pr_mat4) && sizeof(Model::ROI) == sizeof(pr_roi), "POD layouts");
+
+template <typename T> class device_vector_holder {           // renderer.h:161-187, move-only
+public:
+    T *__gpu_memory = nullptr; size_t __size = 0; bool valid = false;
+    device_vector_holder() {}
+    explicit device_vector_holder(size_t n) { __malloc(n); }
+    device_vector_holder(const device_vector_holder &) = delete;
+    device_vector_holder(device_vector_holder &&o) noexcept : __gpu_memory(o.__gpu_memory), __size(o.__size), valid(o.valid) { o.__gpu_memory = nullptr; o.valid = false; o.__size = 0; }
+    ~device_vector_holder() { __free(); }
+    T *data() { return __gpu_memory; }
+    T *begin() { return __gpu_memory; }
+    T *end() { return __gpu_memory + __size; }
+    size_t size() const { return __size; }
+    void __malloc(size_t n) { if (valid) __free(); void *p = nullptr; if (pr_malloc(&p, n * sizeof(T)) != PR_OK) { std::cerr << pr_last_error() << std::endl; std::exit(1); } __gpu_memory = static_cast<T *>(p); __size = n; valid = true; }
+    void __free() { if (valid) { pr_free(__gpu_memory); valid = false; __size = 0; __gpu_memory = nullptr; } }
+    void upload(const std::vector<T> &h) { if (__size != h.size()) __malloc(h.size()); if (!h.empty()) pr_memcpy_h2d(__gpu_memory, h.data(), h.size() * sizeof(T)); }
+    std::vector<T> download() const { std::vector<T> h(__size); if (__size) pr_memcpy_d2h(h.data(), __gpu_memory, __size * sizeof(T)); return h; }
+};
+using Int_holder = device_vector_holder<int>;
+
+inline std::vector<Model::mat4x4> mat_to_compact_4x4(const std::vector<cv::Mat> &poses)
+{ std::vector<Model::mat4x4> out(poses.size()); for (size_t i = 0; i < poses.size(); ++i) out[i].init_from_cv(poses[i]); return out; }
+
+inline Model::mat4x4 compute_proj(const cv::Mat &K, int width, int height, float near = 10, float far = 10000)   // renderer.cpp:161-185
+{ assert(K.type() == CV_32F); Model::mat4x4 p; pr_compute_proj(K.ptr<float>(), width, height, near, far, reinterpret_cast<pr_mat4 *>(&p)); return p; }
+
+namespace detail {
+inline void must(int rc) { if (rc != PR_OK) { std::cerr << "pose_refine: " << pr_last_error() << std::endl; std::exit(rc); } }   // renderer.cu:4-12
+inline size_t out_pixels(size_t w, size_t h, const Model::ROI &r) { return (r.width > 0 && r.height > 0) ? (size_t)r.width * r.height : w * h; }
+inline pr_roi roi(const Model::ROI &r) { return pr_roi{ r.x, r.y, r.width, r.height }; }
+}  // namespace detail
+
+// renderer.cu:306-336 (device-resident triangles)
+inline device_vector_holder<int> render_cuda_keep_in_gpu(device_vector_holder<Model::Triangle> &tris, const std::vector<Model::mat4x4> &poses,
+                                                         size_t width, size_t height, const Model::mat4x4 &proj_mat, const Model::ROI roi = { 0, 0, 0, 0 })
+{
+    device_vector_holder<int> out(poses.size() * detail::out_pixels(width, height, roi));
+    detail::must(pr_render(reinterpret_cast<const pr_triangle *>(tris.data()), tris.size(), reinterpret_cast<const pr_mat4 *>(poses.data()), poses.size(),
+                           width, height, reinterpret_cast<const pr_mat4 *>(&proj_mat), detail::roi(roi), out.data()));
+    return out;
+}
+// renderer.cu:269-303 (host triangles: uploaded on every call like the reference)
+inline device_vector_holder<int> render_cuda_keep_in_gpu(const std::vector<Model::Triangle> &tris, const std::vector<Model::mat4x4> &poses,
+                                                         size_t width, size_t height, const Model::mat4x4 &proj_mat, const Model::ROI roi = { 0, 0, 0, 0 })
+{ device_vector_holder<Model::Triangle> d; d.upload(tris); return render_cuda_keep_in_gpu(d, poses, width, height, proj_mat, roi); }
+
+// renderer.cu:189-267
+inline std::vector<int32_t> render_cuda(device_vector_holder<Model::Triangle> &tris, const std::vector<Model::mat4x4> &poses,
+                                        size_t width, size_t height, const Model::mat4x4 &proj_mat, const Model::ROI roi = { 0, 0, 0, 0 })
+{
+    std::vector<int32_t> out(poses.size() * detail::out_pixels(width, height, roi));
+    detail::must(pr_render_to_host(reinterpret_cast<const pr_triangle *>(tris.data()), tris.size(), reinterpret_cast<const pr_mat4 *>(poses.data()), poses.size(),
+                                   width, height, reinterpret_cast<const pr_mat4 *>(&proj_mat), detail::roi(roi), out.data()));
+    return out;
+}
+inline std::vector<int32_t> render_cuda(const std::vector<Model::Triangle> &tris, const std::vector<Model::mat4x4> &poses,
+                                        size_t width, size_t height, const Model::mat4x4 &proj_mat, const Model::ROI roi = { 0, 0, 0, 0 })
+{ device_vector_holder<Model::Triangle> d; d.upload(tris); return render_cuda(d, poses, width, height, proj_mat, roi); }
+
+template <typename... Params> Int_holder render(Params &&...p) { return render_cuda_keep_in_gpu(std::forward<Params>(p)...); }          // renderer.h:230-238
+template <typename... Params> std::vector<int32_t> render_host(Params &&...p) { return render_cuda(std::forward<Params>(p)...); }      // renderer.h:240-248
+
+}  // namespace cuda_renderer
