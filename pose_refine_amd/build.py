@@ -41,7 +41,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not is_stale():
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    cmd = [hipcc()] + FLAGS + ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC] + \
+    extra = os.environ.get("PR_EXTRA_FLAGS", "").split()
+    cmd = [hipcc()] + FLAGS + extra + ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC] + \
           [os.path.join(CSRC, s) for s in SOURCES] + ["-o", OUT]
     if verbose:
         print(" ".join(cmd))

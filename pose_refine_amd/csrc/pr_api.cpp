@@ -158,9 +158,13 @@ int make_scene(int kind, const void *scene, bool want_packed, SceneSel &out)
         out.packed = want_packed;
         if (want_packed) {
             const size_t n = (size_t)s->width * s->height;
-            PR_TRY(g.rec.ensure(n * sizeof(float4)));
-            HIP_TRY(prk::launch_pack_proj_scene(s->pcd, s->normal, g.rec.as<float4>(), n, g.stream));
-            out.pk = prk::SceneProjPacked{ (uint32_t)s->width, (uint32_t)s->height, s->max_dist_diff, s->K[0], s->K[4], s->K[2], s->K[5], g.rec.as<float4>() };
+            PR_TRY(g.rec.ensure(n * sizeof(float4) + (s->width + s->height) * sizeof(float)));
+            float *colf = reinterpret_cast<float *>(g.rec.as<float4>() + n);
+            float *rowf = colf + s->width;
+            HIP_TRY(prk::launch_pack_proj_scene(s->pcd, s->normal, g.rec.as<float4>(), n, colf, rowf, (uint32_t)s->width, (uint32_t)s->height,
+                                                s->K[0], s->K[4], s->K[2], s->K[5], g.stream));
+            out.pk = prk::SceneProjPacked{ (uint32_t)s->width, (uint32_t)s->height, s->max_dist_diff, s->K[0], s->K[4], s->K[2], s->K[5],
+                                           g.rec.as<float4>(), colf, rowf };
         }
         return PR_OK;
     }

@@ -42,6 +42,7 @@ struct SceneProjPacked {
     uint32_t width, height;
     float max_dist_diff, fx, fy, cx, cy;
     const float4 *rec;
+    const float *colf, *rowf;   // colf[x] = ((float)x - cx)/fx, rowf[y] = ((float)y - cy)/fy
 };
 // kd-tree scene: reference arrays + the traversal structure derived from them (build_nn_accel)
 struct SceneNNDev {
@@ -89,7 +90,8 @@ hipError_t launch_icp_finalize_solve(const float *partial, const uint32_t *count
                                      uint32_t n_poses, hipStream_t s);
 hipError_t launch_pack_results(const DevIcpState *st, pr_result *out, uint32_t n_poses, hipStream_t s);
 
-hipError_t launch_pack_proj_scene(const pr_vec3 *pcd, const pr_vec3 *normal, float4 *rec, size_t n, hipStream_t s);
+hipError_t launch_pack_proj_scene(const pr_vec3 *pcd, const pr_vec3 *normal, float4 *rec, size_t n, float *colf, float *rowf,
+                                  uint32_t width, uint32_t height, float fx, float fy, float cx, float cy, hipStream_t s);
 hipError_t launch_build_nn_accel(const pr_kdnode *nodes, uint32_t n_nodes, const pr_vec3 *pcd, uint32_t n_points,
                                  int4 *topo, float4 *bmin, float4 *bmax, float4 *pts, hipStream_t s);
 

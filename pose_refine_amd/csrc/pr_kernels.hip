@@ -263,17 +263,70 @@ __device__ __forceinline__ bool query(const SceneProjPacked &s, float sx, float 
 {
     uint32_t idx; int px, py;
     if (!proj_pixel(sx, sy, sz, s.fx, s.fy, s.cx, s.cy, s.width, s.height, idx, px, py)) return false;
+#ifdef PR_ABL_NOGATHER
+    const float4 r = make_float4(0.f, 0.f, 1.f, sz + 1e-3f * (float)(idx & 7));
+#else
     const float4 r = s.rec[idx];                                 // one 16-byte gather: {nx, ny, nz, z}
+#endif
     const float dz = r.w;
     const float diff = sz - dz;
     const float adiff = (diff > 0) ? diff : -diff;
     if (dz <= 0 || adiff > s.max_dist_diff) return false;
-    // the scene point is re-derived from its depth exactly as dep2pcd (common.h:47-61) built it
-    c.dx = ((float)px - s.cx) / s.fx * dz;
-    c.dy = ((float)py - s.cy) / s.fy * dz;
+    // the scene point is re-derived from its depth exactly as dep2pcd (common.h:47-61) built it:
+    // colf[x] = ((float)x - cx)/fx and rowf[y] = ((float)y - cy)/fy are tabulated per scene
+    // (same float operations, evaluated once per column/row instead of once per point)
+    c.dx = s.colf[px] * dz;
+    c.dy = s.rowf[py] * dz;
     c.dz = dz; c.nx = r.x; c.ny = r.y; c.nz = r.z;
     return true;
 }
+
+// Split form of the two projective queries above for the hot kernel: gather_issue() computes the
+// pixel and starts the loads for it without looking at the data, gather_finish() applies the
+// validity rules of depth_scene.h:38-45.  Same arithmetic as query(); only the order of memory
+// operations differs.
+struct Gathered { float a0, a1, a2, a3, b0, b1, b2; };
+
+__device__ __forceinline__ bool gather_issue(const SceneProjAoS &s, float sx, float sy, float sz, bool live, Gathered &g)
+{
+    uint32_t idx; int px, py;
+    const bool in_img = live && proj_pixel(sx, sy, sz, s.fx, s.fy, s.cx, s.cy, s.width, s.height, idx, px, py);
+    const uint32_t at = in_img ? idx : 0u;
+    const float *d = reinterpret_cast<const float *>(s.pcd + at);
+    const float *n = reinterpret_cast<const float *>(s.normal + at);
+    g.a0 = d[0]; g.a1 = d[1]; g.a2 = d[2]; g.a3 = 0.0f; g.b0 = n[0]; g.b1 = n[1]; g.b2 = n[2];
+    return in_img;
+}
+__device__ __forceinline__ bool gather_finish(const SceneProjAoS &s, bool in_img, float sz, const Gathered &g, Corr &c)
+{
+    const float dz = g.a2;
+    const float diff = sz - dz;
+    const float adiff = (diff > 0) ? diff : -diff;
+    if (!in_img || dz <= 0 || adiff > s.max_dist_diff) return false;
+    c.dx = g.a0; c.dy = g.a1; c.dz = dz; c.nx = g.b0; c.ny = g.b1; c.nz = g.b2;
+    return true;
+}
+__device__ __forceinline__ bool gather_issue(const SceneProjPacked &s, float sx, float sy, float sz, bool live, Gathered &g)
+{
+    uint32_t idx; int px, py;
+    const bool in_img = live && proj_pixel(sx, sy, sz, s.fx, s.fy, s.cx, s.cy, s.width, s.height, idx, px, py);
+    const float4 r = s.rec[in_img ? idx : 0u];                    // {nx, ny, nz, z}
+    g.a0 = r.x; g.a1 = r.y; g.a2 = r.z; g.a3 = r.w;
+    g.b0 = s.colf[in_img ? px : 0]; g.b1 = s.rowf[in_img ? py : 0]; g.b2 = 0.0f;
+    return in_img;
+}
+__device__ __forceinline__ bool gather_finish(const SceneProjPacked &s, bool in_img, float sz, const Gathered &g, Corr &c)
+{
+    const float dz = g.a3;
+    const float diff = sz - dz;
+    const float adiff = (diff > 0) ? diff : -diff;
+    if (!in_img || dz <= 0 || adiff > s.max_dist_diff) return false;
+    c.dx = g.b0 * dz; c.dy = g.b1 * dz; c.dz = dz; c.nx = g.a0; c.ny = g.a1; c.nz = g.a2;
+    return true;
+}
+// never instantiated for the kd-tree scene (it has its own query loop)
+__device__ __forceinline__ bool gather_issue(const SceneNNDev &, float, float, float, bool, Gathered &) { return false; }
+__device__ __forceinline__ bool gather_finish(const SceneNNDev &, bool, float, const Gathered &, Corr &) { return false; }
 
 // Scene_nn::query pcd_scene.h:60-136 -- same stackless near-first traversal, same strict '<' on
 // leaf points and '<=' on the bound, but the bound is the FAR CHILD's own tight box instead of
@@ -374,8 +427,11 @@ __device__ __forceinline__ float wave_tree_sum(float v)
 //  THE hot kernel: pending transform + correspondence + 29-term transform-reduce, all hypotheses
 //  of a batch in one launch.  grid = (workgroups per hypothesis, hypotheses), 256 lanes.
 // ================================================================================================
+#ifndef PR_PASS_WAVES
+#define PR_PASS_WAVES 1
+#endif
 template <class Scene, bool kNN>
-__global__ __launch_bounds__(256) void icp_pass_kernel(IcpBatch b, Scene scene)
+__global__ __launch_bounds__(256, PR_PASS_WAVES) void icp_pass_kernel(IcpBatch b, Scene scene)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     __shared__ float wsum[4][kAccStride];
@@ -430,6 +486,7 @@ __global__ __launch_bounds__(256) void icp_pass_kernel(IcpBatch b, Scene scene)
                 p[3 * i + 1] = M[4] * x + M[5] * y + M[6]  * z + M[7];
                 p[3 * i + 2] = M[8] * x + M[9] * y + M[10] * z + M[11];
             }
+#ifndef PR_ABL_NOSTORE
             if (full) {
                 float4 *dst = reinterpret_cast<float4 *>(cl + (size_t)j0 * 3);
                 dst[0] = make_float4(p[0], p[1], p[2], p[3]);
@@ -439,26 +496,44 @@ __global__ __launch_bounds__(256) void icp_pass_kernel(IcpBatch b, Scene scene)
 #pragma unroll
                 for (uint32_t i = 0; i < 12; ++i) if (i < cnt * 3) cl[(size_t)j0 * 3 + i] = p[i];
             }
+#endif
         }
+        if constexpr (kNN) {
 #pragma unroll
-        for (uint32_t i = 0; i < 4; ++i) {
-            if (i < cnt) {
+            for (uint32_t i = 0; i < 4; ++i) {
+                if (i < cnt) {
+                    Corr c;
+                    if (query_nn<true>(scene, lds_topo, p[3 * i], p[3 * i + 1], p[3 * i + 2], c))
+                        accumulate(acc, p[3 * i], p[3 * i + 1], p[3 * i + 2], c);
+                }
+            }
+        } else {
+            // projective: all four gathers of the lane are issued back to back, unconditionally
+            // (pixel 0 stands in for out-of-image points), and only then tested -- one memory round
+            // trip per step instead of eight dependent ones.
+            Gathered gth[4];
+            bool in_img[4];
+#pragma unroll
+            for (uint32_t i = 0; i < 4; ++i) in_img[i] = gather_issue(scene, p[3 * i], p[3 * i + 1], p[3 * i + 2], i < cnt, gth[i]);
+#pragma unroll
+            for (uint32_t i = 0; i < 4; ++i) {
                 Corr c;
-                bool ok;
-                if constexpr (kNN) ok = query_nn<true>(scene, lds_topo, p[3 * i], p[3 * i + 1], p[3 * i + 2], c);
-                else               ok = query(scene, p[3 * i], p[3 * i + 1], p[3 * i + 2], c);
-                if (ok) accumulate(acc, p[3 * i], p[3 * i + 1], p[3 * i + 2], c);
+                if (gather_finish(scene, in_img[i], p[3 * i + 2], gth[i], c)) accumulate(acc, p[3 * i], p[3 * i + 1], p[3 * i + 2], c);
             }
         }
     }
 
     // canonical tree: wave (balanced pairwise over lanes) -> ((w0+w1)+w2)+w3
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#ifdef PR_ABL_NOREDUCE
+    { float t = 0; for (int i = 0; i < 29; ++i) t += acc[i]; if (lane == 63) wsum[wave][0] = t; }
+#else
 #pragma unroll
     for (int i = 0; i < 29; ++i) {
         const float t = wave_tree_sum(acc[i]);
         if (lane == 63) wsum[wave][i] = t;
     }
+#endif
     __syncthreads();
     if (threadIdx.x < 29) {
         const float t = ((wsum[0][threadIdx.x] + wsum[1][threadIdx.x]) + wsum[2][threadIdx.x]) + wsum[3][threadIdx.x];
@@ -545,9 +620,13 @@ __global__ void pack_results_kernel(const DevIcpState *__restrict__ st, pr_resul
 //  scene repacking
 // ================================================================================================
 __global__ __launch_bounds__(256) void pack_proj_scene_kernel(const pr_vec3 *__restrict__ pcd, const pr_vec3 *__restrict__ normal,
-                                                              float4 *__restrict__ rec, size_t n)
+                                                              float4 *__restrict__ rec, size_t n, float *__restrict__ colf,
+                                                              float *__restrict__ rowf, uint32_t width, uint32_t height,
+                                                              float fx, float fy, float cx, float cy)
 {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < width) colf[i] = ((float)i - cx) / fx;
+    if (i < height) rowf[i] = ((float)i - cy) / fy;
     if (i >= n) return;
     rec[i] = make_float4(normal[i].x, normal[i].y, normal[i].z, pcd[i].z);
 }
@@ -688,10 +767,12 @@ hipError_t launch_pack_results(const DevIcpState *st, pr_result *out, uint32_t n
     return hipGetLastError();
 }
 
-hipError_t launch_pack_proj_scene(const pr_vec3 *pcd, const pr_vec3 *normal, float4 *rec, size_t n, hipStream_t s)
+hipError_t launch_pack_proj_scene(const pr_vec3 *pcd, const pr_vec3 *normal, float4 *rec, size_t n, float *colf, float *rowf,
+                                  uint32_t width, uint32_t height, float fx, float fy, float cx, float cy, hipStream_t s)
 {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(pack_proj_scene_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, pcd, normal, rec, n);
+    hipLaunchKernelGGL(pack_proj_scene_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, pcd, normal, rec, n, colf, rowf,
+                       width, height, fx, fy, cx, cy);
     return hipGetLastError();
 }
 hipError_t launch_build_nn_accel(const pr_kdnode *nodes, uint32_t n_nodes, const pr_vec3 *pcd, uint32_t n_points,
