@@ -81,8 +81,11 @@ struct Ctx {
     int steps = 2;                   // 1024-point steps per workgroup -> 2048 points per workgroup
     int profile = 0;
     int nn_lds_nodes = 1024;
+    int raster_mode = 1;             // fused path: 1 = LDS depth bands over the per-pose pixel box, 0 = global atomicMin (reference scheme)
+    int n_cus = 256;
+    const void *aabb_key = nullptr; size_t aabb_n = 0;
     // workspaces
-    DevBuf poses, depth, row_count, row_off, counts, cloud, start, state, xform, partial, sums, rec, topo, bmin, bmax, pts, dstate, dresults;
+    DevBuf aabb, bbox, poses, depth, row_count, row_off, counts, cloud, start, state, xform, partial, sums, rec, topo, bmin, bmax, pts, dstate, dresults;
     PinBuf h_sums, h_xform, h_state, h_counts, h_start, h_results;
     // profiling
     std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
@@ -107,6 +110,8 @@ int require_ctx()
     if (dev >= n) { set_error("device %d out of range (%d visible)", dev, n); return PR_ERR_NO_DEVICE; }
     HIP_TRY(hipSetDevice(dev));
     HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) g.n_cus = prop.multiProcessorCount;
     g.device = dev;
     g.ready = true;
     return PR_OK;
@@ -385,10 +390,25 @@ int refine_impl(const pr_triangle *tris_dev, size_t n_tris, const pr_mat4 *poses
         PR_TRY(g.row_off.ensure(sizeof(uint32_t) * (size_t)H * np));
         PR_TRY(g.counts.ensure(sizeof(uint32_t) * np));
         PR_TRY(g.h_counts.ensure(sizeof(uint32_t) * np));
-        pr_roi none{ 0, 0, 0, 0 };
-        PR_TRY(render_impl(tris_dev, n_tris, poses_host + p0, np, W, H, proj, none, g.depth.as<int32_t>(), /*zero_empty=*/false));
         uint32_t *h_counts = g.h_counts.as<uint32_t>();
-        {
+        const bool bands = (g.raster_mode == 1);
+        if (bands) {
+            // model box once per (triangle buffer, size); boxes + LDS-band raster + row counts + row scan
+            PR_TRY(g.aabb.ensure(6 * sizeof(float)));
+            PR_TRY(g.bbox.ensure(sizeof(int4) * np));
+            PR_TRY(g.poses.ensure(sizeof(pr_mat4) * np));
+            if (g.aabb_key != tris_dev || g.aabb_n != n_tris) {
+                HIP_TRY(prk::launch_model_aabb(tris_dev, (uint32_t)n_tris, g.aabb.as<float>(), g.stream));
+                g.aabb_key = tris_dev; g.aabb_n = n_tris;
+            }
+            SpanGuard sp(kSpanRender);
+            HIP_TRY(hipMemcpyAsync(g.poses.p, poses_host + p0, sizeof(pr_mat4) * np, hipMemcpyHostToDevice, g.stream));
+            HIP_TRY(prk::launch_render_bands(tris_dev, (uint32_t)n_tris, g.poses.as<pr_mat4>(), np, g.aabb.as<float>(), g.bbox.as<int4>(),
+                                             g.depth.as<int32_t>(), g.row_count.as<uint32_t>(), g.row_off.as<uint32_t>(),
+                                             g.counts.as<uint32_t>(), W, H, *proj, (uint32_t)g.n_cus, g.stream));
+        } else {
+            pr_roi none{ 0, 0, 0, 0 };
+            PR_TRY(render_impl(tris_dev, n_tris, poses_host + p0, np, W, H, proj, none, g.depth.as<int32_t>(), /*zero_empty=*/false));
             SpanGuard sp(kSpanCloud);
             HIP_TRY(prk::launch_depth2cloud<int32_t>(g.depth.as<int32_t>(), np, img, W, H, 1, 0, 0, K[0], K[4], K[2], K[5], true,
                                                      g.row_count.as<uint32_t>(), g.row_off.as<uint32_t>(), g.counts.as<uint32_t>(),
@@ -402,9 +422,13 @@ int refine_impl(const pr_triangle *tris_dev, size_t n_tris, const pr_mat4 *poses
         PR_TRY(g.cloud.ensure(sizeof(pr_vec3) * std::max<size_t>(4, cstride) * np));
         if (max_n > 0) {
             SpanGuard sp(kSpanCloud);
-            HIP_TRY(prk::launch_depth2cloud<int32_t>(g.depth.as<int32_t>(), np, img, W, H, 1, 0, 0, K[0], K[4], K[2], K[5], true,
-                                                     g.row_count.as<uint32_t>(), g.row_off.as<uint32_t>(), g.counts.as<uint32_t>(),
-                                                     g.cloud.as<pr_vec3>(), cstride, true, g.stream));
+            if (bands)
+                HIP_TRY(prk::launch_emit_box(g.depth.as<int32_t>(), np, W, H, g.bbox.as<int4>(), K[0], K[4], K[2], K[5],
+                                             g.row_count.as<uint32_t>(), g.row_off.as<uint32_t>(), g.cloud.as<pr_vec3>(), cstride, g.stream));
+            else
+                HIP_TRY(prk::launch_depth2cloud<int32_t>(g.depth.as<int32_t>(), np, img, W, H, 1, 0, 0, K[0], K[4], K[2], K[5], true,
+                                                         g.row_count.as<uint32_t>(), g.row_off.as<uint32_t>(), g.counts.as<uint32_t>(),
+                                                         g.cloud.as<pr_vec3>(), cstride, true, g.stream));
         }
         for (uint32_t i = 0; i < np; ++i) { start[i] = (uint32_t)(i * cstride); count[i] = h_counts[i]; }
         if (sizes_host) std::memcpy(sizes_host + p0, count.data(), sizeof(uint32_t) * np);
@@ -443,13 +467,13 @@ int pr_shutdown(void)
     std::lock_guard<std::mutex> lk(g_mu);
     if (!g.ready) return PR_OK;
     hipStreamSynchronize(g.stream);
-    for (DevBuf *b : { &g.poses, &g.depth, &g.row_count, &g.row_off, &g.counts, &g.cloud, &g.start, &g.state, &g.xform, &g.partial,
+    for (DevBuf *b : { &g.aabb, &g.bbox, &g.poses, &g.depth, &g.row_count, &g.row_off, &g.counts, &g.cloud, &g.start, &g.state, &g.xform, &g.partial,
                        &g.sums, &g.rec, &g.topo, &g.bmin, &g.bmax, &g.pts, &g.dstate, &g.dresults }) b->release();
     for (PinBuf *b : { &g.h_sums, &g.h_xform, &g.h_state, &g.h_counts, &g.h_start, &g.h_results }) b->release();
     for (hipEvent_t e : g.ev_pool) hipEventDestroy(e);
     g.ev_pool.clear(); g.ev_used = 0; g.spans.clear();
     hipStreamDestroy(g.stream);
-    g.stream = nullptr; g.ready = false; g.device = -1;
+    g.stream = nullptr; g.ready = false; g.device = -1; g.aabb_key = nullptr; g.aabb_n = 0;
     return PR_OK;
 }
 
@@ -596,6 +620,7 @@ int pr_set_option(const char *name, int value)
     else if (n == "points_per_block") { if (value < 1024 || value % 1024) { set_error("points_per_block must be a multiple of 1024"); return PR_ERR_INVALID; } g.steps = value / 1024; }
     else if (n == "profile") g.profile = value ? 1 : 0;
     else if (n == "nn_lds_nodes") g.nn_lds_nodes = std::max(0, value);
+    else if (n == "raster_mode") { if (value != 0 && value != 1) { set_error("raster_mode must be 0 or 1"); return PR_ERR_INVALID; } g.raster_mode = value; }
     else { set_error("unknown option %s", name); return PR_ERR_INVALID; }
     return PR_OK;
 }
@@ -608,6 +633,7 @@ int pr_get_option(const char *name, int *value)
     else if (n == "points_per_block") *value = g.steps * 1024;
     else if (n == "profile") *value = g.profile;
     else if (n == "nn_lds_nodes") *value = g.nn_lds_nodes;
+    else if (n == "raster_mode") *value = g.raster_mode;
     else { set_error("unknown option %s", name); return PR_ERR_INVALID; }
     return PR_OK;
 }

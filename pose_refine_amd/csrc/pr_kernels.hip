@@ -139,6 +139,189 @@ __global__ __launch_bounds__(256) void raster_kernel(const pr_triangle *__restri
 }
 
 // ================================================================================================
+//  fused-path raster: per-hypothesis screen bounding box + LDS depth bands (no global atomics, no
+//  full-frame clear).  The depth values are produced by exactly the arithmetic of raster_kernel;
+//  only where the min is taken (LDS ds_min instead of L2/memory atomics) and which pixels are
+//  touched (the conservative box of the object instead of the whole frame) differ.
+// ================================================================================================
+
+// axis-aligned box of the mesh: {minx,miny,minz,maxx,maxy,maxz}.  One workgroup.
+__global__ __launch_bounds__(1024) void model_aabb_kernel(const pr_triangle *__restrict__ tris, uint32_t n_tris, float *__restrict__ aabb)
+{
+    __shared__ float red[16][6];
+    float lo[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, hi[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
+    const float *v = reinterpret_cast<const float *>(tris);
+    for (uint32_t i = threadIdx.x; i < n_tris * 3u; i += 1024) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { const float c = v[(size_t)i * 3 + a]; lo[a] = fminf(lo[a], c); hi[a] = fmaxf(hi[a], c); }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+        for (int off = 32; off > 0; off >>= 1) { lo[a] = fminf(lo[a], __shfl_xor(lo[a], off)); hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], off)); }
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) for (int a = 0; a < 3; ++a) { red[wave][a] = lo[a]; red[wave][3 + a] = hi[a]; }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        float r = red[0][threadIdx.x];
+        for (int w = 1; w < 16; ++w) r = (threadIdx.x < 3) ? fminf(r, red[w][threadIdx.x]) : fmaxf(r, red[w][threadIdx.x]);
+        aabb[threadIdx.x] = r;
+    }
+}
+
+// Conservative pixel box {x0,y0,x1,y1} (raster coordinates, y not yet flipped) of the mesh under
+// every pose: the 8 box corners go through the same model / projection / viewport arithmetic as
+// the vertices; the projection of any point of the box lies in the hull of the projected corners
+// as long as all of them are in front of the camera, and 2 pixels of padding cover float rounding.
+// Any corner at or behind the camera plane -> the whole frame.
+__global__ __launch_bounds__(256) void pose_bbox_kernel(const float *__restrict__ aabb, const pr_mat4 *__restrict__ poses, uint32_t n_poses,
+                                                        pr_mat4 proj, uint32_t width, uint32_t height, int4 *__restrict__ bbox)
+{
+    const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= n_poses) return;
+    const float *M = poses[p].m;
+    float mnx = FLT_MAX, mny = FLT_MAX, mxx = -FLT_MAX, mxy = -FLT_MAX;
+    bool all_front = true;
+    for (int c = 0; c < 8; ++c) {
+        const float x = aabb[(c & 1) ? 3 : 0], y = aabb[(c & 2) ? 4 : 1], z = aabb[(c & 4) ? 5 : 2];
+        const float lx = M[0] * x + M[1] * y + M[2] * z + M[3];
+        const float ly = M[4] * x + M[5] * y + M[6] * z + M[7];
+        const float lz = M[8] * x + M[9] * y + M[10] * z + M[11];
+        if (!(lz > 1e-3f)) all_front = false;
+        const float cxp = proj.m[0] * lx + proj.m[1] * ly + proj.m[2] * lz + proj.m[3];
+        const float cyp = proj.m[4] * lx + proj.m[5] * ly + proj.m[6] * lz + proj.m[7];
+        const float sx = cxp / lz * (float)width / 2.0f + (float)width / 2.0f;
+        const float sy = cyp / lz * (float)height / 2.0f + (float)height / 2.0f;
+        mnx = fminf(mnx, sx); mxx = fmaxf(mxx, sx); mny = fminf(mny, sy); mxy = fmaxf(mxy, sy);
+    }
+    int x0 = 0, y0 = 0, x1 = (int)width - 1, y1 = (int)height - 1;
+    const bool finite = (mnx > -1e8f) && (mxx < 1e8f) && (mny > -1e8f) && (mxy < 1e8f);
+    if (all_front && finite) {
+        x0 = max(0, (int)floorf(mnx) - 2);  x1 = min((int)width - 1, (int)ceilf(mxx) + 2);
+        y0 = max(0, (int)floorf(mny) - 2);  y1 = min((int)height - 1, (int)ceilf(mxy) + 2);
+    }
+    bbox[p] = make_int4(x0, y0, x1, y1);
+}
+
+// Persistent workgroups walk the (hypothesis, band) items; a band is a run of raster rows of the
+// hypothesis' box that fits the LDS tile.  Each workgroup rasterises ALL triangles against its band
+// with ds_min, then writes the band (INT_MAX = empty) and its per-row valid counts.
+__global__ __launch_bounds__(1024) void raster_band_kernel(const pr_triangle *__restrict__ tris, uint32_t n_tris,
+                                                           const pr_mat4 *__restrict__ poses, uint32_t n_poses,
+                                                           const int4 *__restrict__ bbox, int32_t *__restrict__ depth,
+                                                           uint32_t *__restrict__ row_count, uint32_t width, uint32_t height,
+                                                           pr_mat4 proj, uint32_t cap_px, uint32_t max_bands)
+{
+    extern __shared__ __attribute__((aligned(16))) int32_t tile[];
+    const uint32_t n_items = n_poses * max_bands;
+    for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const uint32_t pose = item / max_bands, band = item - pose * max_bands;
+        const int4 bb = bbox[pose];
+        const int bw = bb.z - bb.x + 1, bh = bb.w - bb.y + 1;
+        if (bw <= 0 || bh <= 0) continue;
+        const int rows_per_band = max(1, (int)(cap_px / (uint32_t)bw));
+        const int n_bands = (bh + rows_per_band - 1) / rows_per_band;
+        if ((int)band >= n_bands) continue;
+        const int by0 = bb.y + (int)band * rows_per_band;
+        const int by1 = min(bb.w, by0 + rows_per_band - 1);
+        const int n_px = (by1 - by0 + 1) * bw;
+        for (int i = threadIdx.x; i < n_px; i += 1024) tile[i] = INT_MAX;
+        __syncthreads();
+
+        const float *M = poses[pose].m;
+        const float cmin0 = (float)bb.x, cmax0 = (float)bb.z, cmin1 = (float)by0, cmax1 = (float)by1;
+        for (uint32_t ti = threadIdx.x; ti < n_tris; ti += 1024) {
+            const float *tv = reinterpret_cast<const float *>(tris + ti);
+            float px[3], py[3], w3[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float x = tv[3 * k], y = tv[3 * k + 1], z = tv[3 * k + 2];
+                const float lx = M[0] * x + M[1] * y + M[2] * z + M[3];
+                const float ly = M[4] * x + M[5] * y + M[6] * z + M[7];
+                const float lz = M[8] * x + M[9] * y + M[10] * z + M[11];
+                w3[k] = lz;
+                const float cxp = proj.m[0] * lx + proj.m[1] * ly + proj.m[2] * lz + proj.m[3];
+                const float cyp = proj.m[4] * lx + proj.m[5] * ly + proj.m[6] * lz + proj.m[7];
+                px[k] = cxp / lz * (float)width / 2.0f + (float)width / 2.0f;
+                py[k] = cyp / lz * (float)height / 2.0f + (float)height / 2.0f;
+            }
+            float lo0 = FLT_MAX, lo1 = FLT_MAX, hi0 = -FLT_MAX, hi1 = -FLT_MAX;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                lo0 = sel_max(cmin0, sel_min(lo0, px[k]));  hi0 = sel_min(cmax0, sel_max(hi0, px[k]));
+                lo1 = sel_max(cmin1, sel_min(lo1, py[k]));  hi1 = sel_min(cmax1, sel_max(hi1, py[k]));
+            }
+            const float area = area2(px[0], py[0], px[1], py[1], px[2], py[2]);
+            if (!(area != 0.0f)) continue;
+            const float base_inv = 1 / area;
+            const int x0 = loop_start(lo0 + 0.5f);
+            for (int y = loop_start(lo1 + 0.5f); (float)y <= hi1; ++y) {
+                const float fy = (float)y;
+                for (int x = x0; (float)x <= hi0; ++x) {
+                    const float fx = (float)x;
+                    const float beta  = area2(px[0], py[0], fx, fy, px[2], py[2]) * base_inv;
+                    const float gamma = area2(px[0], py[0], px[1], py[1], fx, fy) * base_inv;
+                    const float alpha = 1.0f - beta - gamma;
+                    if (alpha < -0.0f || beta < -0.0f || gamma < -0.0f || alpha > 1.0f || beta > 1.0f || gamma > 1.0f) continue;
+                    const float az = alpha / w3[0], bz = beta / w3[1], gz = gamma / w3[2];
+                    const float frag = (alpha + beta + gamma) / (az + bz + gz);
+                    atomicMin(&tile[(y - by0) * bw + (x - bb.x)], f2i_x86(frag + 0.5f));
+                }
+            }
+        }
+        __syncthreads();
+
+        // write the band: raster row y lands on image row height-1-y (renderer.cu:142)
+        int32_t *img = depth + (size_t)pose * width * height;
+        const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        for (int r = (int)wave; r <= by1 - by0; r += 16) {
+            const int yw = (int)height - 1 - (by0 + r);
+            uint32_t cnt = 0;
+            for (int c0 = 0; c0 < bw; c0 += 64) {
+                const int c = c0 + (int)lane;
+                int32_t v = INT_MAX;
+                if (c < bw) { v = tile[r * bw + c]; img[(size_t)yw * width + bb.x + c] = v; }
+                cnt += (uint32_t)__popcll(__ballot(c < bw && v > 0 && v != INT_MAX));
+            }
+            if (lane == 0) row_count[(size_t)pose * height + yw] = cnt;
+        }
+        __syncthreads();
+    }
+}
+
+// depth2cloud emit restricted to the hypothesis' pixel box (the fused path never reads outside it)
+__global__ __launch_bounds__(256) void d2c_emit_box_kernel(const int32_t *__restrict__ depth, uint32_t width, uint32_t height,
+                                                           const int4 *__restrict__ bbox, float fx, float fy, float cx, float cy,
+                                                           const uint32_t *__restrict__ row_count, const uint32_t *__restrict__ row_off,
+                                                           pr_vec3 *__restrict__ cloud, size_t cloud_stride)
+{
+    const uint32_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63;
+    if (row >= height) return;
+    if (row_count[(size_t)blockIdx.y * height + row] == 0) return;
+    const int4 bb = bbox[blockIdx.y];
+    const int32_t *line = depth + ((size_t)blockIdx.y * height + row) * width;
+    pr_vec3 *out = cloud + (size_t)blockIdx.y * cloud_stride + row_off[(size_t)blockIdx.y * height + row];
+    uint32_t done = 0;
+    for (int x0 = bb.x; x0 <= bb.z; x0 += 64) {
+        const int x = x0 + (int)lane;
+        int32_t d = 0;
+        if (x <= bb.z) d = line[x];
+        const bool v = (x <= bb.z) && d > 0 && d != INT_MAX;
+        const unsigned long long m = __ballot(v);
+        if (v) {
+            const uint32_t k = done + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            const float z = d / 1000.0f;
+            pr_vec3 p;
+            p.x = ((float)(uint32_t)x - cx) / fx * z;
+            p.y = ((float)row - cy) / fy * z;
+            p.z = z;
+            out[k] = p;
+        }
+        done += (uint32_t)__popcll(m);
+    }
+}
+
+// ================================================================================================
 //  depth -> cloud: count per row, scan rows per image, emit in row-major order
 // ================================================================================================
 template <typename T> __device__ __forceinline__ bool depth_valid(T d, bool empty_intmax)
@@ -595,10 +778,18 @@ __global__ __launch_bounds__(64) void icp_finalize_solve_kernel(const float *__r
     if (finished) { s.done = 1; state[pose] = kSkip; }
     else {
         float A[36], bb[6], E[16];
+#pragma unroll
         for (int i = 0; i < 6; ++i) bb[i] = Ab[21 + i];
-        int k = 0;
-        for (int y = 0; y < 6; ++y) for (int x = y; x < 6; ++x) { A[x + y * 6] = Ab[k]; A[y + x * 6] = Ab[k]; ++k; }
+        {
+            int k = 0;
+#pragma unroll
+            for (int y = 0; y < 6; ++y) {
+#pragma unroll
+                for (int x = y; x < 6; ++x) { A[x + y * 6] = Ab[k]; A[y + x * 6] = Ab[k]; ++k; }
+            }
+        }
         prs::solve_666_impl(A, bb, E);
+#pragma unroll
         for (int i = 0; i < 12; ++i) xform[(size_t)pose * 12 + i] = E[i];
         prs::mat4_mul_impl(E, s.T, s.T);
         state[pose] = kRunWithTransform;
@@ -687,6 +878,54 @@ hipError_t launch_raster(const pr_triangle *tris, uint32_t n_tris, const pr_mat4
         const uint32_t np = (n_poses - p0 < 32768) ? (n_poses - p0) : 32768;
         hipLaunchKernelGGL(raster_kernel, dim3((n_tris + 255) / 256, np), dim3(256), 0, s, tris, n_tris, poses_dev + p0,
                            depth + (size_t)p0 * rw * rh, width, height, proj, roi, rw, rh);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_model_aabb(const pr_triangle *tris, uint32_t n_tris, float *aabb, hipStream_t s)
+{
+    hipLaunchKernelGGL(model_aabb_kernel, dim3(1), dim3(1024), 0, s, tris, n_tris, aabb);
+    return hipGetLastError();
+}
+
+// fused-path render: boxes, LDS-band raster (depth + row counts), row scan.  Leaves depth valid only
+// inside each hypothesis' box; row_count/row_off/counts as launch_depth2cloud(emit=false) would.
+hipError_t launch_render_bands(const pr_triangle *tris, uint32_t n_tris, const pr_mat4 *poses_dev, uint32_t n_poses, const float *aabb,
+                               int4 *bbox, int32_t *depth, uint32_t *row_count, uint32_t *row_off, uint32_t *counts,
+                               uint32_t width, uint32_t height, const pr_mat4 &proj, uint32_t n_cus, hipStream_t s)
+{
+    if (n_poses == 0) return hipSuccess;
+    static bool attr_set = false;
+    const uint32_t cap_px = 36864;                                  // 144 KiB of the 160 KiB LDS
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(raster_band_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)(cap_px * sizeof(int32_t)));
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(pose_bbox_kernel, dim3((n_poses + 255) / 256), dim3(256), 0, s, aabb, poses_dev, n_poses, proj, width, height, bbox);
+    hipError_t e = hipMemsetAsync(row_count, 0, sizeof(uint32_t) * (size_t)n_poses * height, s);
+    if (e != hipSuccess) return e;
+    const uint32_t rows_min = cap_px / width > 0 ? cap_px / width : 1;
+    const uint32_t max_bands = (height + rows_min - 1) / rows_min;
+    const uint32_t items = n_poses * max_bands;
+    const uint32_t grid = items < n_cus ? items : n_cus;
+    hipLaunchKernelGGL(raster_band_kernel, dim3(grid), dim3(1024), cap_px * sizeof(int32_t), s, tris, n_tris, poses_dev, n_poses, bbox, depth,
+                       row_count, width, height, proj, cap_px, max_bands);
+    hipLaunchKernelGGL(d2c_scan_kernel, dim3(n_poses), dim3(256), 0, s, row_count, height, row_off, counts);
+    return hipGetLastError();
+}
+
+hipError_t launch_emit_box(const int32_t *depth, uint32_t n_poses, uint32_t width, uint32_t height, const int4 *bbox, float fx, float fy,
+                           float cx, float cy, const uint32_t *row_count, const uint32_t *row_off, pr_vec3 *cloud, size_t cloud_stride,
+                           hipStream_t s)
+{
+    if (n_poses == 0) return hipSuccess;
+    for (uint32_t i0 = 0; i0 < n_poses; i0 += 32768) {
+        const uint32_t ni = (n_poses - i0 < 32768) ? (n_poses - i0) : 32768;
+        hipLaunchKernelGGL(d2c_emit_box_kernel, dim3((height + 3) / 4, ni), dim3(256), 0, s, depth + (size_t)i0 * width * height, width, height,
+                           bbox + i0, fx, fy, cx, cy, row_count + (size_t)i0 * height, row_off + (size_t)i0 * height,
+                           cloud + (size_t)i0 * cloud_stride, cloud_stride);
     }
     return hipGetLastError();
 }

@@ -66,45 +66,87 @@ PR_HD inline void sincos_d(double x, double *s, double *c)
     }
 }
 
-// lower-triangular LDL^T with diagonal pivoting, in place on the 6x6 (row-major, lower part used)
+// lower-triangular LDL^T with diagonal pivoting, in place on the 6x6 (row-major, lower part used).
+// Every array index below is a compile-time constant after unrolling (the data-dependent pivot is
+// applied through a chain of constant-index conditional swaps), so on the device the whole 6x6
+// lives in registers instead of scratch memory.
+template <int K, int P> PR_HD inline void sym_swap(double *m)
+{
+#define MM(r, c) m[(r) * 6 + (c)]
+#pragma unroll
+    for (int j = 0; j < K; ++j)       { double t = MM(K, j); MM(K, j) = MM(P, j); MM(P, j) = t; }
+#pragma unroll
+    for (int i = P + 1; i < 6; ++i)   { double t = MM(i, K); MM(i, K) = MM(i, P); MM(i, P) = t; }
+#pragma unroll
+    for (int i = K + 1; i < P; ++i)   { double t = MM(i, K); MM(i, K) = MM(P, i); MM(P, i) = t; }
+    double t = MM(K, K); MM(K, K) = MM(P, P); MM(P, P) = t;
+#undef MM
+}
+template <int K> PR_HD inline int ldlt6_step(double *m)
+{
+#define MM(r, c) m[(r) * 6 + (c)]
+    int p = K;
+    double top = dabs(MM(K, K));
+#pragma unroll
+    for (int i = K + 1; i < 6; ++i) {
+        double a = dabs(MM(i, i));
+        if (a > top) { top = a; p = i; }
+    }
+    if (K + 1 < 6 && p == K + 1) sym_swap<K, (K + 1 < 6 ? K + 1 : 5)>(m);
+    if (K + 2 < 6 && p == K + 2) sym_swap<K, (K + 2 < 6 ? K + 2 : 5)>(m);
+    if (K + 3 < 6 && p == K + 3) sym_swap<K, (K + 3 < 6 ? K + 3 : 5)>(m);
+    if (K + 4 < 6 && p == K + 4) sym_swap<K, (K + 4 < 6 ? K + 4 : 5)>(m);
+    if (K + 5 < 6 && p == K + 5) sym_swap<K, (K + 5 < 6 ? K + 5 : 5)>(m);
+    double w[6];
+    double dot = 0.0;
+#pragma unroll
+    for (int j = 0; j < K; ++j) { w[j] = MM(j, j) * MM(K, j); dot += MM(K, j) * w[j]; }
+    MM(K, K) -= dot;
+    const double dk = MM(K, K);
+#pragma unroll
+    for (int i = K + 1; i < 6; ++i) {
+        double acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < K; ++j) acc += MM(i, j) * w[j];
+        double v = MM(i, K) - acc;
+        MM(i, K) = (dabs(dk) > 0.0) ? v / dk : v;
+    }
+    return p;
+#undef MM
+}
+template <int K> PR_HD inline void perm_apply(double *y, int p)
+{
+    if (K + 1 < 6 && p == K + 1) { double t = y[K]; y[K] = y[K + 1 < 6 ? K + 1 : 5]; y[K + 1 < 6 ? K + 1 : 5] = t; }
+    if (K + 2 < 6 && p == K + 2) { double t = y[K]; y[K] = y[K + 2 < 6 ? K + 2 : 5]; y[K + 2 < 6 ? K + 2 : 5] = t; }
+    if (K + 3 < 6 && p == K + 3) { double t = y[K]; y[K] = y[K + 3 < 6 ? K + 3 : 5]; y[K + 3 < 6 ? K + 3 : 5] = t; }
+    if (K + 4 < 6 && p == K + 4) { double t = y[K]; y[K] = y[K + 4 < 6 ? K + 4 : 5]; y[K + 4 < 6 ? K + 4 : 5] = t; }
+    if (K + 5 < 6 && p == K + 5) { double t = y[K]; y[K] = y[K + 5 < 6 ? K + 5 : 5]; y[K + 5 < 6 ? K + 5 : 5] = t; }
+}
 PR_HD inline void ldlt6(double *m /*36*/, const double *rhs, double *x)
 {
 #define MM(r, c) m[(r) * 6 + (c)]
-    int swp[6];
-    for (int k = 0; k < 6; ++k) {
-        int p = k;
-        double top = dabs(MM(k, k));
-        for (int i = k + 1; i < 6; ++i) {
-            double a = dabs(MM(i, i));
-            if (a > top) { top = a; p = i; }
-        }
-        swp[k] = p;
-        if (p != k) {
-            for (int j = 0; j < k; ++j)       { double t = MM(k, j); MM(k, j) = MM(p, j); MM(p, j) = t; }
-            for (int i = p + 1; i < 6; ++i)   { double t = MM(i, k); MM(i, k) = MM(i, p); MM(i, p) = t; }
-            for (int i = k + 1; i < p; ++i)   { double t = MM(i, k); MM(i, k) = MM(p, i); MM(p, i) = t; }
-            double t = MM(k, k); MM(k, k) = MM(p, p); MM(p, p) = t;
-        }
-        double w[6];
-        double dot = 0.0;
-        for (int j = 0; j < k; ++j) { w[j] = MM(j, j) * MM(k, j); dot += MM(k, j) * w[j]; }
-        MM(k, k) -= dot;
-        const double dk = MM(k, k);
-        for (int i = k + 1; i < 6; ++i) {
-            double acc = 0.0;
-            for (int j = 0; j < k; ++j) acc += MM(i, j) * w[j];
-            double v = MM(i, k) - acc;
-            MM(i, k) = (dabs(dk) > 0.0) ? v / dk : v;
-        }
-    }
+    const int s0 = ldlt6_step<0>(m), s1 = ldlt6_step<1>(m), s2 = ldlt6_step<2>(m);
+    const int s3 = ldlt6_step<3>(m), s4 = ldlt6_step<4>(m);
+    (void)ldlt6_step<5>(m);
     double y[6];
+#pragma unroll
     for (int i = 0; i < 6; ++i) y[i] = rhs[i];
-    for (int k = 0; k < 6; ++k) if (swp[k] != k) { double t = y[k]; y[k] = y[swp[k]]; y[swp[k]] = t; }
-    for (int i = 1; i < 6; ++i) for (int j = 0; j < i; ++j) y[i] -= MM(i, j) * y[j];
+    perm_apply<0>(y, s0); perm_apply<1>(y, s1); perm_apply<2>(y, s2); perm_apply<3>(y, s3); perm_apply<4>(y, s4);
+#pragma unroll
+    for (int i = 1; i < 6; ++i) {
+#pragma unroll
+        for (int j = 0; j < i; ++j) y[i] -= MM(i, j) * y[j];
+    }
     const double tiny = 1.0 / 1.7976931348623157e308;
+#pragma unroll
     for (int i = 0; i < 6; ++i) y[i] = (dabs(MM(i, i)) > tiny) ? y[i] / MM(i, i) : 0.0;
-    for (int i = 4; i >= 0; --i) for (int j = i + 1; j < 6; ++j) y[i] -= MM(j, i) * y[j];
-    for (int k = 5; k >= 0; --k) if (swp[k] != k) { double t = y[k]; y[k] = y[swp[k]]; y[swp[k]] = t; }
+#pragma unroll
+    for (int i = 4; i >= 0; --i) {
+#pragma unroll
+        for (int j = i + 1; j < 6; ++j) y[i] -= MM(j, i) * y[j];
+    }
+    perm_apply<4>(y, s4); perm_apply<3>(y, s3); perm_apply<2>(y, s2); perm_apply<1>(y, s1); perm_apply<0>(y, s0);
+#pragma unroll
     for (int i = 0; i < 6; ++i) x[i] = y[i];
 #undef MM
 }
@@ -113,8 +155,12 @@ PR_HD inline void ldlt6(double *m /*36*/, const double *rhs, double *x)
 PR_HD inline void solve_666_impl(const float *A, const float *b, float *T)
 {
     double m[36], rhs[6], u[6];
-    for (int r = 0; r < 6; ++r)
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+#pragma unroll
         for (int c = 0; c < 6; ++c) m[r * 6 + c] = (double)A[c * 6 + r] + (r == c ? 0.01 : 0.0);
+    }
+#pragma unroll
     for (int i = 0; i < 6; ++i) rhs[i] = (double)b[i];
     ldlt6(m, rhs, u);
 
@@ -149,7 +195,9 @@ PR_HD inline void solve_666_impl(const float *A, const float *b, float *T)
 PR_HD inline void mat4_mul_impl(const float *A, const float *B, float *C)
 {
     float tmp[16];
+#pragma unroll
     for (int i = 0; i < 4; ++i)
+#pragma unroll
         for (int j = 0; j < 4; ++j) {
             float acc = 0.0f;
             acc += A[i * 4 + 3] * B[12 + j];
@@ -158,6 +206,7 @@ PR_HD inline void mat4_mul_impl(const float *A, const float *B, float *C)
             acc += A[i * 4 + 0] * B[j];
             tmp[i * 4 + j] = acc;
         }
+#pragma unroll
     for (int i = 0; i < 16; ++i) C[i] = tmp[i];
 }
 

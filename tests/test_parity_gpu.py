@@ -237,3 +237,24 @@ def test_no_device_option_errors(gpu):
         api.set_option("no_such_option", 1)
     with pytest.raises(api.PoseRefineError):
         api.set_option("points_per_block", 1000)
+
+
+def test_fused_raster_modes_agree(gpu, model, scenario, gscenes):
+    """LDS-band raster (default) vs the reference-style global atomicMin raster inside the fused path:
+    identical cloud sizes and bit-identical results; includes a close-up pose whose pixel box needs
+    several LDS bands and a pose partly outside the image."""
+    poses = synth.hypotheses(12)
+    close = scenario["poses"][0].copy(); close[2, 3] = 110.0            # object fills most of the frame -> many bands
+    off = scenario["poses"][0].copy(); off[0, 3] = 120.0                # partly outside the image
+    behind = scenario["poses"][0].copy(); behind[2, 3] = 20.0           # camera inside the object's box -> full-frame fallback
+    poses = np.concatenate([poses, close[None], off[None], behind[None]])
+    crit = api.ICPConvergenceCriteria(0.0, 0.0, 4)
+    out = []
+    for mode in (1, 0):
+        api.set_option("raster_mode", mode)
+        out.append(api.refine_batch(model, poses, W, H, scenario["proj"], scenario["K"], gscenes["proj"], crit))
+    api.set_option("raster_mode", 1)
+    assert np.array_equal(out[0][1], out[1][1])
+    assert out[0][0].tobytes() == out[1][0].tobytes()
+    ref = O.render(scenario["tris"], poses[-3:], W, H, scenario["proj"])
+    assert np.array_equal(out[0][1][-3:], (ref > 0).reshape(3, -1).sum(1))
