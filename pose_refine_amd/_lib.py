@@ -85,7 +85,7 @@ SIGNATURES = {
     "pr_set_option": (_i32, [C.c_char_p, _i32]),
     "pr_get_option": (_i32, [C.c_char_p, C.POINTER(_i32)]),
     "pr_profile_reset": (_i32, []),
-    "pr_profile_read": (_i32, [C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+    "pr_profile_read": (_i32, [C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
                                 C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
 

@@ -59,9 +59,10 @@ def profile_reset():
 
 def profile_read():
     ms, rms, cms = C.c_double(), C.c_double(), C.c_double()
-    n, pts = C.c_uint64(), C.c_uint64()
-    check(_lib.load().pr_profile_read(C.byref(ms), C.byref(n), C.byref(pts), C.byref(rms), C.byref(cms)))
-    return dict(icp_kernel_ms=ms.value, icp_launches=n.value, icp_points=pts.value, render_ms=rms.value, cloud_ms=cms.value)
+    n, pts, nbytes = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    check(_lib.load().pr_profile_read(C.byref(ms), C.byref(n), C.byref(pts), C.byref(nbytes), C.byref(rms), C.byref(cms)))
+    return dict(icp_kernel_ms=ms.value, icp_launches=n.value, icp_points=pts.value, icp_bytes=nbytes.value,
+                render_ms=rms.value, cloud_ms=cms.value)
 
 
 def shard_range(n_items: int, rank: int, world: int):

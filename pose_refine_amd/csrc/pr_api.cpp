@@ -81,21 +81,46 @@ struct Ctx {
     int steps = 2;                   // 1024-point steps per workgroup -> 2048 points per workgroup
     int profile = 0;
     int nn_lds_nodes = 1024;
+    int use_graph = 1;               // PR_SOLVE_DEVICE: capture the whole iteration loop in a hipGraph and replay it
     int raster_mode = 1;             // fused path: 1 = LDS depth bands over the per-pose pixel box, 0 = global atomicMin (reference scheme)
     int n_cus = 256;
     const void *aabb_key = nullptr; size_t aabb_n = 0;
     // workspaces
-    DevBuf aabb, bbox, poses, depth, row_count, row_off, counts, cloud, start, state, xform, partial, sums, rec, topo, bmin, bmax, pts, dstate, dresults;
-    PinBuf h_sums, h_xform, h_state, h_counts, h_start, h_results;
+    DevBuf aabb, bbox, poses, depth, row_count, row_off, counts, cloud, meta, partial, sums, rec, topo, bmin, bmax, pts, dstate, dresults;
+    PinBuf h_sums, h_meta, h_counts, h_results, h_dstate;
     // profiling
     std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
     struct Span { size_t e0, e1; int kind; };
     std::vector<Span> spans;
-    double icp_ms = 0, render_ms = 0, cloud_ms = 0; uint64_t icp_launches = 0, icp_points = 0;
+    double icp_ms = 0, render_ms = 0, cloud_ms = 0; uint64_t icp_launches = 0, icp_points = 0, icp_bytes = 0, sample_clock = 0;
 };
 Ctx g;
 std::mutex g_mu;
 
+// ---- hipGraph cache for the device-solve iteration loop ------------------------------------------
+struct GraphKey {
+    unsigned char bytes[256];
+    size_t len = 0;
+    template <class T> void add(const T &v) { if (len + sizeof(T) <= sizeof bytes) { std::memcpy(bytes + len, &v, sizeof(T)); len += sizeof(T); } }
+    bool operator==(const GraphKey &o) const { return len == o.len && std::memcmp(bytes, o.bytes, len) == 0; }
+};
+struct CachedGraph {
+    GraphKey key; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
+    std::vector<hipEvent_t> events;      // pairs around every correspondence launch when captured with profiling on
+    uint64_t stamp = 0;
+};
+std::vector<CachedGraph> g_graphs;
+uint64_t g_graph_clock = 0;
+void destroy_graph(CachedGraph &c)
+{
+    if (c.exec) (void)hipGraphExecDestroy(c.exec);
+    if (c.graph) (void)hipGraphDestroy(c.graph);
+    for (hipEvent_t e : c.events) (void)hipEventDestroy(e);
+    c = CachedGraph();
+}
+void drop_graphs() { for (auto &c : g_graphs) destroy_graph(c); g_graphs.clear(); }
+
+void drop_graphs();
 int require_ctx()
 {
     if (g.ready) return PR_OK;
@@ -214,101 +239,138 @@ int icp_drive(pr_vec3 *cloud_base, const uint32_t *start_h, const uint32_t *coun
     for (uint32_t i = 0; i < P; ++i) { max_n = std::max(max_n, count_h[i]); sum_n += count_h[i]; }
     const uint32_t nblk = (max_n + ppb - 1) / ppb;
 
-    PR_TRY(g.start.ensure(sizeof(uint32_t) * P));
-    PR_TRY(g.counts.ensure(sizeof(uint32_t) * P));
-    PR_TRY(g.state.ensure(sizeof(int32_t) * P));
-    PR_TRY(g.xform.ensure(sizeof(float) * 12 * P));
+    PR_TRY(g.meta.ensure(sizeof(prk::PoseMeta) * P));
     PR_TRY(g.partial.ensure(sizeof(float) * prk::kAccStride * (size_t)std::max(1u, nblk) * P));
     PR_TRY(g.sums.ensure(sizeof(float) * prk::kAccStride * P));
-    PR_TRY(g.h_state.ensure(sizeof(int32_t) * P));
-    PR_TRY(g.h_xform.ensure(sizeof(float) * 12 * P));
+    PR_TRY(g.h_meta.ensure(sizeof(prk::PoseMeta) * P));
     PR_TRY(g.h_sums.ensure(sizeof(float) * prk::kAccStride * P));
-    PR_TRY(g.h_start.ensure(sizeof(uint32_t) * 2 * P));
     PR_TRY(g.h_results.ensure(sizeof(pr_result) * P));
 
-    uint32_t *hs = g.h_start.as<uint32_t>();
-    std::memcpy(hs, start_h, sizeof(uint32_t) * P);
-    std::memcpy(hs + P, count_h, sizeof(uint32_t) * P);
-    HIP_TRY(hipMemcpyAsync(g.start.p, hs, sizeof(uint32_t) * P, hipMemcpyHostToDevice, g.stream));
-    HIP_TRY(hipMemcpyAsync(g.counts.p, hs + P, sizeof(uint32_t) * P, hipMemcpyHostToDevice, g.stream));
-
     prk::IcpBatch b{};
-    b.cloud = cloud_base; b.start = g.start.as<uint32_t>(); b.count = g.counts.as<uint32_t>();
-    b.xform = g.xform.as<float>(); b.state = g.state.as<int32_t>(); b.partial = g.partial.as<float>();
+    b.cloud = cloud_base; b.meta = g.meta.as<prk::PoseMeta>(); b.partial = g.partial.as<float>();
     b.nblk = nblk; b.steps = steps;
 
-    int32_t *h_state = g.h_state.as<int32_t>();
-    float *h_xform = g.h_xform.as<float>();
+    prk::PoseMeta *h_meta = g.h_meta.as<prk::PoseMeta>();
     float *h_sums = g.h_sums.as<float>();
     pr_result *res = g.h_results.as<pr_result>();
     for (uint32_t i = 0; i < P; ++i) {
         identity16(res[i].T); res[i].inlier_rmse = 0.0f; res[i].fitness = 0.0f;   // icp.h:29-31
-        h_state[i] = (count_h[i] > 0) ? prk::kRun : prk::kSkip;    // empty cloud: count==0 -> identity result (icp.cu:183)
+        std::memset(&h_meta[i], 0, sizeof(prk::PoseMeta));
+        h_meta[i].start = start_h[i]; h_meta[i].count = count_h[i];
+        h_meta[i].state = (count_h[i] > 0) ? prk::kRun : prk::kSkip;    // empty cloud: count==0 -> identity result (icp.cu:183)
     }
 
     if (g.solve_mode == PR_SOLVE_DEVICE) {
         PR_TRY(g.dstate.ensure(sizeof(prk::DevIcpState) * P));
-        std::vector<prk::DevIcpState> init(P);
-        for (uint32_t i = 0; i < P; ++i) { identity16(init[i].T); init[i].fitness = 0; init[i].rmse = 0; init[i].done = (h_state[i] == prk::kSkip); init[i].passes = 0; }
-        HIP_TRY(hipMemcpyAsync(g.dstate.p, init.data(), sizeof(prk::DevIcpState) * P, hipMemcpyHostToDevice, g.stream));
-        HIP_TRY(hipMemcpyAsync(g.state.p, h_state, sizeof(int32_t) * P, hipMemcpyHostToDevice, g.stream));
-        HIP_TRY(hipStreamSynchronize(g.stream));                   // `init` is pageable: finish before it goes away
-        const bool may_exit_early = (crit.relative_fitness > 0.0f && crit.relative_rmse > 0.0f);
-        for (uint32_t it = 0; it <= (uint32_t)crit.max_iteration; ++it) {
-            { SpanGuard sp(kSpanIcp); HIP_TRY(launch_pass(b, sc, P)); }
-            if (g.profile) g.icp_points += sum_n;
-            HIP_TRY(prk::launch_icp_finalize_solve(g.partial.as<float>(), g.counts.as<uint32_t>(), g.state.as<int32_t>(), nblk, steps,
-                                                   g.xform.as<float>(), g.dstate.as<prk::DevIcpState>(), crit, it, P, g.stream));
-            if (may_exit_early && (it & 3) == 3 && it < (uint32_t)crit.max_iteration) {
-                HIP_TRY(hipMemcpyAsync(h_state, g.state.p, sizeof(int32_t) * P, hipMemcpyDeviceToHost, g.stream));
-                HIP_TRY(hipStreamSynchronize(g.stream));
-                bool any = false;
-                for (uint32_t i = 0; i < P; ++i) any |= (h_state[i] != prk::kSkip);
-                if (!any) break;
-            }
-        }
+        PR_TRY(g.h_dstate.ensure(sizeof(prk::DevIcpState) * P));
+        prk::DevIcpState *init = g.h_dstate.as<prk::DevIcpState>();
+        for (uint32_t i = 0; i < P; ++i) { identity16(init[i].T); init[i].fitness = 0; init[i].rmse = 0; init[i].done = (h_meta[i].state == prk::kSkip); init[i].passes = 0; }
         pr_result *dres = results_dev;
         if (!dres) { PR_TRY(g.dresults.ensure(sizeof(pr_result) * P)); dres = g.dresults.as<pr_result>(); }
-        HIP_TRY(prk::launch_pack_results(g.dstate.as<prk::DevIcpState>(), dres, P, g.stream));
-        if (results_host) HIP_TRY(hipMemcpyAsync(results_host, dres, sizeof(pr_result) * P, hipMemcpyDeviceToHost, g.stream));
+        const bool may_exit_early = (crit.relative_fitness > 0.0f && crit.relative_rmse > 0.0f);
+
+        // profile==2: time ONE correspondence launch per call, at an iteration index that rotates from call to call
+        const uint32_t sample_it = (uint32_t)((g.sample_clock++ * 5 + 1) % (uint64_t)(crit.max_iteration + 1));
+        // the fixed sequence: state upload, (max_iteration+1) x [correspondence pass, finalize+solve], result pack
+        auto enqueue_all = [&](std::vector<hipEvent_t> *evs, bool host_checks) -> int {
+            HIP_TRY(hipMemcpyAsync(g.dstate.p, init, sizeof(prk::DevIcpState) * P, hipMemcpyHostToDevice, g.stream));
+            HIP_TRY(hipMemcpyAsync(g.meta.p, h_meta, sizeof(prk::PoseMeta) * P, hipMemcpyHostToDevice, g.stream));
+            for (uint32_t it = 0; it <= (uint32_t)crit.max_iteration; ++it) {
+                if (evs) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); evs->push_back(e); HIP_TRY(hipEventRecord(e, g.stream)); }
+                if (!evs && (g.profile == 1 || (g.profile == 2 && it == sample_it))) {
+                    SpanGuard sp(kSpanIcp); HIP_TRY(launch_pass(b, sc, P));
+                    g.icp_points += sum_n; g.icp_bytes += sum_n * (it == 0 ? 36u : 48u);
+                } else HIP_TRY(launch_pass(b, sc, P));
+                if (evs) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); evs->push_back(e); HIP_TRY(hipEventRecord(e, g.stream)); }
+                HIP_TRY(prk::launch_icp_finalize_solve(g.partial.as<float>(), g.meta.as<prk::PoseMeta>(), nblk, steps,
+                                                       g.dstate.as<prk::DevIcpState>(), crit, it, P, g.stream));
+                if (host_checks && may_exit_early && (it & 3) == 3 && it < (uint32_t)crit.max_iteration) {
+                    HIP_TRY(hipMemcpyAsync(h_meta, g.meta.p, sizeof(prk::PoseMeta) * P, hipMemcpyDeviceToHost, g.stream));
+                    HIP_TRY(hipStreamSynchronize(g.stream));
+                    bool any = false;
+                    for (uint32_t i = 0; i < P; ++i) any |= (h_meta[i].state != prk::kSkip);
+                    if (!any) break;
+                }
+            }
+            HIP_TRY(prk::launch_pack_results(g.dstate.as<prk::DevIcpState>(), dres, P, g.stream));
+            // results go to the pinned staging buffer (a pageable destination is not capturable)
+            if (results_host) HIP_TRY(hipMemcpyAsync(res, dres, sizeof(pr_result) * P, hipMemcpyDeviceToHost, g.stream));
+            return PR_OK;
+        };
+
+        if (g.use_graph && g.profile == 0) {                    // HIP events recorded inside a captured graph cannot be timed: profile => direct launches
+            GraphKey key;
+            key.add(P); key.add(nblk); key.add(steps); key.add(crit); key.add(sc); key.add(cloud_base); key.add(g.meta.p); key.add(g.partial.p);
+            key.add(g.dstate.p); key.add(dres); key.add(results_host != nullptr); key.add(res); key.add(h_meta); key.add(init); key.add(g.profile);
+            CachedGraph *hit = nullptr;
+            for (auto &c : g_graphs) if (c.exec && c.key == key) { hit = &c; break; }
+            if (!hit) {
+                if (g_graphs.size() >= 8) {                         // evict the least recently used entry
+                    size_t lru = 0;
+                    for (size_t i = 1; i < g_graphs.size(); ++i) if (g_graphs[i].stamp < g_graphs[lru].stamp) lru = i;
+                    destroy_graph(g_graphs[lru]);
+                    g_graphs.erase(g_graphs.begin() + lru);
+                }
+                CachedGraph c; c.key = key;
+                HIP_TRY(hipStreamSynchronize(g.stream));
+                HIP_TRY(hipStreamBeginCapture(g.stream, hipStreamCaptureModeThreadLocal));
+                int rc = enqueue_all(nullptr, /*host_checks=*/false);
+                hipError_t ce = hipStreamEndCapture(g.stream, &c.graph);
+                if (rc != PR_OK || ce != hipSuccess) { destroy_graph(c); if (rc == PR_OK) { set_error("hipStreamEndCapture failed: %s", hipGetErrorString(ce)); rc = PR_ERR_HIP; } return rc; }
+                HIP_TRY(hipGraphInstantiate(&c.exec, c.graph, nullptr, nullptr, 0));
+                g_graphs.push_back(std::move(c));
+                hit = &g_graphs.back();
+            }
+            hit->stamp = ++g_graph_clock;
+            HIP_TRY(hipGraphLaunch(hit->exec, g.stream));
+            HIP_TRY(hipStreamSynchronize(g.stream));
+            if (results_host) std::memcpy(results_host, res, sizeof(pr_result) * P);
+            drain_spans();
+            return PR_OK;
+        }
+
+        PR_TRY(enqueue_all(nullptr, /*host_checks=*/true));
         HIP_TRY(hipStreamSynchronize(g.stream));
+        if (results_host) std::memcpy(results_host, res, sizeof(pr_result) * P);
         drain_spans();
         return PR_OK;
     }
 
     // PR_SOLVE_HOST: one launch + one small D2H per iteration, the per-pose logic of icp.cu:178-212 on the host
+    const uint32_t host_sample_it = (uint32_t)((g.sample_clock++ * 5 + 1) % (uint64_t)(crit.max_iteration + 1));
     uint32_t active = 0;
-    for (uint32_t i = 0; i < P; ++i) active += (h_state[i] != prk::kSkip);
+    for (uint32_t i = 0; i < P; ++i) active += (h_meta[i].state != prk::kSkip);
     for (uint32_t it = 0; it <= (uint32_t)crit.max_iteration && active > 0; ++it) {
-        HIP_TRY(hipMemcpyAsync(g.state.p, h_state, sizeof(int32_t) * P, hipMemcpyHostToDevice, g.stream));
-        if (it > 0) HIP_TRY(hipMemcpyAsync(g.xform.p, h_xform, sizeof(float) * 12 * P, hipMemcpyHostToDevice, g.stream));
-        { SpanGuard sp(kSpanIcp); HIP_TRY(launch_pass(b, sc, P)); }
-        if (g.profile) for (uint32_t i = 0; i < P; ++i) if (h_state[i] != prk::kSkip) g.icp_points += count_h[i];
-        HIP_TRY(prk::launch_icp_finalize(g.partial.as<float>(), g.counts.as<uint32_t>(), g.state.as<int32_t>(), nblk, steps,
+        HIP_TRY(hipMemcpyAsync(g.meta.p, h_meta, sizeof(prk::PoseMeta) * P, hipMemcpyHostToDevice, g.stream));
+        if (g.profile == 1 || (g.profile == 2 && it == host_sample_it)) {
+            SpanGuard sp(kSpanIcp); HIP_TRY(launch_pass(b, sc, P));
+            for (uint32_t i = 0; i < P; ++i) if (h_meta[i].state != prk::kSkip) { g.icp_points += count_h[i]; g.icp_bytes += (uint64_t)count_h[i] * (it == 0 ? 36u : 48u); }
+        } else HIP_TRY(launch_pass(b, sc, P));
+        HIP_TRY(prk::launch_icp_finalize(g.partial.as<float>(), g.meta.as<prk::PoseMeta>(), nblk, steps,
                                          g.sums.as<float>(), P, g.stream));
         HIP_TRY(hipMemcpyAsync(h_sums, g.sums.p, sizeof(float) * prk::kAccStride * P, hipMemcpyDeviceToHost, g.stream));
         HIP_TRY(hipStreamSynchronize(g.stream));
         active = 0;
         for (uint32_t i = 0; i < P; ++i) {
-            if (h_state[i] == prk::kSkip) continue;
+            if (h_meta[i].state == prk::kSkip) continue;
             const float *Ab = h_sums + (size_t)i * prk::kAccStride;
             pr_result &r = res[i];
             const float prev_fit = r.fitness, prev_rmse = r.inlier_rmse;
             const float cnt = Ab[28], err = Ab[27];
-            if (cnt == 0) { h_state[i] = prk::kSkip; continue; }                        // icp.cu:183
+            if (cnt == 0) { h_meta[i].state = prk::kSkip; continue; }                        // icp.cu:183
             r.fitness = cnt / (float)count_h[i];                                          // icp.cu:185
             r.inlier_rmse = std::sqrt(err / cnt);                                         // icp.cu:186
-            if (it == (uint32_t)crit.max_iteration) { h_state[i] = prk::kSkip; continue; }   // icp.cu:189
+            if (it == (uint32_t)crit.max_iteration) { h_meta[i].state = prk::kSkip; continue; }   // icp.cu:189
             if (std::fabs(r.fitness - prev_fit) < crit.relative_fitness &&
-                std::fabs(r.inlier_rmse - prev_rmse) < crit.relative_rmse) { h_state[i] = prk::kSkip; continue; }   // icp.cu:191-194
+                std::fabs(r.inlier_rmse - prev_rmse) < crit.relative_rmse) { h_meta[i].state = prk::kSkip; continue; }   // icp.cu:191-194
             float A[36], bb[6], E[16];
             for (int k = 0; k < 6; ++k) bb[k] = Ab[21 + k];
             int sh = 0;
             for (int y = 0; y < 6; ++y) for (int x = y; x < 6; ++x) { A[x + y * 6] = Ab[sh]; A[y + x * 6] = Ab[sh]; ++sh; }   // icp.cu:196-205
             prh::solve_666(A, bb, E);
-            std::memcpy(h_xform + (size_t)i * 12, E, sizeof(float) * 12);
+            std::memcpy(h_meta[i].xform, E, sizeof(float) * 12);
             prh::mat4_mul(E, r.T, r.T);                                                   // icp.cu:212
-            h_state[i] = prk::kRunWithTransform;
+            h_meta[i].state = prk::kRunWithTransform;
             ++active;
         }
     }
@@ -377,6 +439,7 @@ int refine_impl(const pr_triangle *tris_dev, size_t n_tris, const pr_mat4 *poses
     if (!K || W == 0 || H == 0) { set_error("pr_refine_batch: bad arguments"); return PR_ERR_INVALID; }
     if (P == 0) return PR_OK;
     SceneSel sc;
+    std::memset(static_cast<void *>(&sc), 0, sizeof sc);           // also zeroes padding: sc is part of the graph-cache key
     PR_TRY(make_scene(scene_kind, scene, /*want_packed=*/true, sc));
     // bound the depth workspace to ~4 GiB per chunk (288 GB of HBM would allow far more; this keeps
     // first-touch cost and the 2^32 element index space comfortable)
@@ -467,9 +530,10 @@ int pr_shutdown(void)
     std::lock_guard<std::mutex> lk(g_mu);
     if (!g.ready) return PR_OK;
     hipStreamSynchronize(g.stream);
-    for (DevBuf *b : { &g.aabb, &g.bbox, &g.poses, &g.depth, &g.row_count, &g.row_off, &g.counts, &g.cloud, &g.start, &g.state, &g.xform, &g.partial,
+    for (DevBuf *b : { &g.aabb, &g.bbox, &g.poses, &g.depth, &g.row_count, &g.row_off, &g.counts, &g.cloud, &g.meta, &g.partial,
                        &g.sums, &g.rec, &g.topo, &g.bmin, &g.bmax, &g.pts, &g.dstate, &g.dresults }) b->release();
-    for (PinBuf *b : { &g.h_sums, &g.h_xform, &g.h_state, &g.h_counts, &g.h_start, &g.h_results }) b->release();
+    for (PinBuf *b : { &g.h_sums, &g.h_meta, &g.h_counts, &g.h_results, &g.h_dstate }) b->release();
+    drop_graphs();
     for (hipEvent_t e : g.ev_pool) hipEventDestroy(e);
     g.ev_pool.clear(); g.ev_used = 0; g.spans.clear();
     hipStreamDestroy(g.stream);
@@ -572,6 +636,7 @@ int pr_icp_batch(pr_vec3 *clouds_dev, const uint32_t *offsets_host, uint32_t n_c
     PR_TRY(require_ctx());
     if (!clouds_dev || !offsets_host || !results_host) { set_error("pr_icp_batch: bad arguments"); return PR_ERR_INVALID; }
     SceneSel sc;
+    std::memset(static_cast<void *>(&sc), 0, sizeof sc);
     PR_TRY(make_scene(scene_kind, scene, /*want_packed=*/false, sc));
     std::vector<uint32_t> start(n_clouds), count(n_clouds);
     for (uint32_t i = 0; i < n_clouds; ++i) {
@@ -618,8 +683,9 @@ int pr_set_option(const char *name, int value)
     const std::string n(name);
     if (n == "solve") { if (value != PR_SOLVE_HOST && value != PR_SOLVE_DEVICE) { set_error("solve must be 0 or 1"); return PR_ERR_INVALID; } g.solve_mode = value; }
     else if (n == "points_per_block") { if (value < 1024 || value % 1024) { set_error("points_per_block must be a multiple of 1024"); return PR_ERR_INVALID; } g.steps = value / 1024; }
-    else if (n == "profile") g.profile = value ? 1 : 0;
+    else if (n == "profile") { if (value < 0 || value > 2) { set_error("profile must be 0, 1 (every launch) or 2 (one sampled launch per call)"); return PR_ERR_INVALID; } g.profile = value; }
     else if (n == "nn_lds_nodes") g.nn_lds_nodes = std::max(0, value);
+    else if (n == "graph") g.use_graph = value ? 1 : 0;
     else if (n == "raster_mode") { if (value != 0 && value != 1) { set_error("raster_mode must be 0 or 1"); return PR_ERR_INVALID; } g.raster_mode = value; }
     else { set_error("unknown option %s", name); return PR_ERR_INVALID; }
     return PR_OK;
@@ -634,6 +700,7 @@ int pr_get_option(const char *name, int *value)
     else if (n == "profile") *value = g.profile;
     else if (n == "nn_lds_nodes") *value = g.nn_lds_nodes;
     else if (n == "raster_mode") *value = g.raster_mode;
+    else if (n == "graph") *value = g.use_graph;
     else { set_error("unknown option %s", name); return PR_ERR_INVALID; }
     return PR_OK;
 }
@@ -641,15 +708,16 @@ int pr_get_option(const char *name, int *value)
 int pr_profile_reset(void)
 {
     std::lock_guard<std::mutex> lk(g_mu);
-    g.icp_ms = g.render_ms = g.cloud_ms = 0; g.icp_launches = g.icp_points = 0;
+    g.icp_ms = g.render_ms = g.cloud_ms = 0; g.icp_launches = g.icp_points = g.icp_bytes = 0;
     return PR_OK;
 }
-int pr_profile_read(double *kernel_ms, uint64_t *launches, uint64_t *points, double *render_ms, double *cloud_ms)
+int pr_profile_read(double *kernel_ms, uint64_t *launches, uint64_t *points, uint64_t *algorithmic_bytes, double *render_ms, double *cloud_ms)
 {
     std::lock_guard<std::mutex> lk(g_mu);
     if (kernel_ms) *kernel_ms = g.icp_ms;
     if (launches) *launches = g.icp_launches;
     if (points) *points = g.icp_points;
+    if (algorithmic_bytes) *algorithmic_bytes = g.icp_bytes;
     if (render_ms) *render_ms = g.render_ms;
     if (cloud_ms) *cloud_ms = g.cloud_ms;
     return PR_OK;

@@ -19,13 +19,21 @@ constexpr uint32_t kAccStride      = 32;                        // 29 sums padde
 // per-hypothesis run state consumed by the correspondence kernel
 enum : int32_t { kSkip = 0, kRun = 1, kRunWithTransform = 2 };
 
+// everything a workgroup needs to know about its hypothesis, in ONE 64-byte record so that the
+// wavefront fetches it with a single scalar load instead of a chain of dependent ones
+struct alignas(64) PoseMeta {
+    uint32_t start;             // first point of the cloud (in points, relative to IcpBatch::cloud)
+    uint32_t count;             // points in the cloud
+    int32_t  state;             // kSkip / kRun / kRunWithTransform
+    uint32_t pad;
+    float    xform[12];         // pending rigid update, rows 0..2 of the 4x4
+};
+static_assert(sizeof(PoseMeta) == 64, "PoseMeta must stay one 64-byte record");
+
 // batch of model clouds handed to one correspondence pass
 struct IcpBatch {
     pr_vec3        *cloud;      // base of all clouds (dev)
-    const uint32_t *start;      // [P] first point of cloud i (dev)
-    const uint32_t *count;      // [P] points in cloud i (dev)
-    const float    *xform;      // [P][12] pending rigid update rows 0..2 (dev)
-    const int32_t  *state;      // [P] kSkip / kRun / kRunWithTransform (dev)
+    const PoseMeta *meta;       // [P] (dev)
     float          *partial;    // [P][nblk][kAccStride] workgroup sums (dev)
     uint32_t        nblk;       // workgroups per hypothesis (grid.x)
     uint32_t        steps;      // steps of 1024 points per workgroup
@@ -90,11 +98,11 @@ hipError_t launch_emit_box(const int32_t *depth, uint32_t n_poses, uint32_t widt
 hipError_t launch_icp_pass_proj_aos(const IcpBatch &b, const SceneProjAoS &sc, uint32_t n_poses, hipStream_t s);
 hipError_t launch_icp_pass_proj_packed(const IcpBatch &b, const SceneProjPacked &sc, uint32_t n_poses, hipStream_t s);
 hipError_t launch_icp_pass_nn(const IcpBatch &b, const SceneNNDev &sc, uint32_t n_poses, hipStream_t s);
-hipError_t launch_icp_finalize(const float *partial, const uint32_t *count, const int32_t *state, uint32_t nblk,
+hipError_t launch_icp_finalize(const float *partial, const PoseMeta *meta, uint32_t nblk,
                                uint32_t steps, float *sums, uint32_t n_poses, hipStream_t s);
 // PR_SOLVE_DEVICE: finalize + convergence test + 6x6 solve + state update in one kernel
-hipError_t launch_icp_finalize_solve(const float *partial, const uint32_t *count, int32_t *state, uint32_t nblk,
-                                     uint32_t steps, float *xform, DevIcpState *st, pr_criteria crit, uint32_t iter,
+hipError_t launch_icp_finalize_solve(const float *partial, PoseMeta *meta, uint32_t nblk,
+                                     uint32_t steps, DevIcpState *st, pr_criteria crit, uint32_t iter,
                                      uint32_t n_poses, hipStream_t s);
 hipError_t launch_pack_results(const DevIcpState *st, pr_result *out, uint32_t n_poses, hipStream_t s);
 

@@ -72,18 +72,22 @@ __device__ __forceinline__ float area2(float ax, float ay, float bx, float by, f
     return 0.5f * ((cx - ax) * (by - ay) - (bx - ax) * (cy - ay));
 }
 
-__global__ __launch_bounds__(256) void raster_kernel(const pr_triangle *__restrict__ tris, uint32_t n_tris,
-                                                     const pr_mat4 *__restrict__ poses, int32_t *__restrict__ depth,
-                                                     uint32_t width, uint32_t height, pr_mat4 proj, pr_roi roi,
-                                                     uint32_t rw, uint32_t rh)
-{
-    const uint32_t ti = blockIdx.x * 256 + threadIdx.x;
-    if (ti >= n_tris) return;
-    const float *M = poses[blockIdx.y].m;                       // wave-uniform -> scalar loads
-    int32_t *img = depth + (size_t)blockIdx.y * rw * rh;
-
-    const float *tv = reinterpret_cast<const float *>(tris + ti);
+// Per-triangle screen-space setup shared by the raster kernels: model + projection + viewport
+// transform (renderer.cu:159-186, :90-98), clamped pixel box (:100-122), signed area (renderer.h:315-333).
+struct TriSetup {
     float px[3], py[3], w3[3];
+    float base_inv;
+    int x0, y0, nx, ny;          // first pixel column/row of the loops of renderer.cu:124-125 and their trip counts
+};
+__device__ __forceinline__ int trip_count(int first, float hi)
+{   // number of iterations of  for (p = first; (float)p <= hi; ++p)  with first in [0, 2^24) or INT_MAX
+    if (first == INT_MAX || !(hi >= (float)first)) return 0;
+    return (int)floorf(hi) - first + 1;
+}
+__device__ __forceinline__ void tri_setup(const float *__restrict__ tv, const float *__restrict__ M, const pr_mat4 &proj,
+                                          uint32_t width, uint32_t height, float cmin0, float cmin1, float cmax0, float cmax1,
+                                          TriSetup &t)
+{
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const float x = tv[3 * k], y = tv[3 * k + 1], z = tv[3 * k + 2];
@@ -91,16 +95,63 @@ __global__ __launch_bounds__(256) void raster_kernel(const pr_triangle *__restri
         const float lx = M[0] * x + M[1] * y + M[2] * z + M[3];
         const float ly = M[4] * x + M[5] * y + M[6] * z + M[7];
         const float lz = M[8] * x + M[9] * y + M[10] * z + M[11];
-        w3[k] = lz;                                              // renderer.cu:177-183 last_row
+        t.w3[k] = lz;                                            // renderer.cu:177-183 last_row
         // projection transform: only x and y of the result are used downstream
         const float cxp = proj.m[0] * lx + proj.m[1] * ly + proj.m[2] * lz + proj.m[3];
         const float cyp = proj.m[4] * lx + proj.m[5] * ly + proj.m[6] * lz + proj.m[7];
         // viewport (renderer.cu:90-98)
-        px[k] = cxp / lz * (float)width / 2.0f + (float)width / 2.0f;
-        py[k] = cyp / lz * (float)height / 2.0f + (float)height / 2.0f;
+        t.px[k] = cxp / lz * (float)width / 2.0f + (float)width / 2.0f;
+        t.py[k] = cyp / lz * (float)height / 2.0f + (float)height / 2.0f;
     }
-
     float lo0 = FLT_MAX, lo1 = FLT_MAX, hi0 = -FLT_MAX, hi1 = -FLT_MAX;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        lo0 = sel_max(cmin0, sel_min(lo0, t.px[k]));  hi0 = sel_min(cmax0, sel_max(hi0, t.px[k]));
+        lo1 = sel_max(cmin1, sel_min(lo1, t.py[k]));  hi1 = sel_min(cmax1, sel_max(hi1, t.py[k]));
+    }
+    const float area = area2(t.px[0], t.py[0], t.px[1], t.py[1], t.px[2], t.py[2]);
+    t.x0 = loop_start(lo0 + 0.5f);
+    t.y0 = loop_start(lo1 + 0.5f);
+    t.nx = trip_count(t.x0, hi0);
+    t.ny = trip_count(t.y0, hi1);
+    if (!(area != 0.0f)) { t.nx = 0; t.ny = 0; }                 // documented: zero-area triangles are skipped
+    t.base_inv = 1 / area;
+}
+// one candidate pixel of one triangle: barycentric test + perspective depth (renderer.cu:126-140)
+__device__ __forceinline__ bool tri_fragment(const float px[3], const float py[3], float base_inv, int x, int y,
+                                             float &alpha, float &beta, float &gamma)
+{
+    const float fx = (float)x, fy = (float)y;
+    beta  = area2(px[0], py[0], fx, fy, px[2], py[2]) * base_inv;
+    gamma = area2(px[0], py[0], px[1], py[1], fx, fy) * base_inv;
+    alpha = 1.0f - beta - gamma;
+    return !(alpha < -0.0f || beta < -0.0f || gamma < -0.0f || alpha > 1.0f || beta > 1.0f || gamma > 1.0f);
+}
+__device__ __forceinline__ int fragment_depth(float alpha, float beta, float gamma, float w0, float w1, float w2)
+{
+    const float az = alpha / w0, bz = beta / w1, gz = gamma / w2;
+    const float frag = (alpha + beta + gamma) / (az + bz + gz);
+    return f2i_x86(frag + 0.5f);
+}
+
+// Wave-cooperative raster.  Thread-per-triangle pixel loops waste most lanes (the average triangle
+// of obj_06 tests 7 pixel centres, the largest 36), so each wavefront first sets up its 64
+// (triangle, hypothesis) pairs -- one per lane -- then expands them into one dense list of candidate
+// pixels (exclusive scan of the per-triangle trip counts) and walks that list 64 candidates at a
+// time: every lane finds the owner of its candidate by a 6-step search over the scanned offsets and
+// reads the owner's setup back from LDS.  Same arithmetic per candidate, same int32 atomicMin.
+constexpr int kSetupWords = 14;
+__global__ __launch_bounds__(256) void raster_kernel(const pr_triangle *__restrict__ tris, uint32_t n_tris,
+                                                     const pr_mat4 *__restrict__ poses, int32_t *__restrict__ depth,
+                                                     uint32_t width, uint32_t height, pr_mat4 proj, pr_roi roi,
+                                                     uint32_t rw, uint32_t rh, const int4 *__restrict__ boxes)
+{
+    __shared__ float sh[4][kSetupWords][64];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t ti = blockIdx.x * 256 + threadIdx.x;
+    const float *M = poses[blockIdx.y].m;                        // wave-uniform -> scalar loads
+    int32_t *img = depth + (size_t)blockIdx.y * rw * rh;
+
     float cmin0 = 0.0f, cmin1 = 0.0f, cmax0 = (float)(width - 1), cmax1 = (float)(height - 1);
     if (roi.width > 0 && roi.height > 0) {                       // renderer.cu:106-113 (image is flipped in y)
         cmin0 = (float)roi.x;
@@ -108,34 +159,60 @@ __global__ __launch_bounds__(256) void raster_kernel(const pr_triangle *__restri
         cmax0 = (float)((roi.x + roi.width) - 1);
         cmax1 = (float)((unsigned long long)(height - 1) - (unsigned long long)(long long)roi.y);
     }
+    (void)boxes;
+
+    TriSetup t;
+    int n = 0;
+    if (ti < n_tris) {
+        tri_setup(reinterpret_cast<const float *>(tris + ti), M, proj, width, height, cmin0, cmin1, cmax0, cmax1, t);
+        n = t.nx * t.ny;
+    } else { t.nx = t.ny = 0; t.x0 = t.y0 = 0; t.base_inv = 0; for (int k = 0; k < 3; ++k) t.px[k] = t.py[k] = t.w3[k] = 0; }
+
+    // exclusive scan of n over the wavefront
+    int incl = n;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        lo0 = sel_max(cmin0, sel_min(lo0, px[k]));  hi0 = sel_min(cmax0, sel_max(hi0, px[k]));
-        lo1 = sel_max(cmin1, sel_min(lo1, py[k]));  hi1 = sel_min(cmax1, sel_max(hi1, py[k]));
-    }
+    for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off); if ((int)lane >= off) incl += v; }
+    const int excl = incl - n;
+    const int total = __shfl(incl, 63);
 
-    const float area = area2(px[0], py[0], px[1], py[1], px[2], py[2]);
-    if (!(area != 0.0f)) return;                                 // documented: zero-area triangles are skipped
-    const float base_inv = 1 / area;
+    float (*w)[64] = sh[wave];
+    w[0][lane] = t.px[0]; w[1][lane] = t.py[0]; w[2][lane] = t.px[1]; w[3][lane] = t.py[1]; w[4][lane] = t.px[2]; w[5][lane] = t.py[2];
+    w[6][lane] = t.w3[0]; w[7][lane] = t.w3[1]; w[8][lane] = t.w3[2]; w[9][lane] = t.base_inv;
+    w[10][lane] = __int_as_float(t.x0); w[11][lane] = __int_as_float(t.y0); w[12][lane] = __int_as_float(t.nx > 0 ? t.nx : 1);
+    w[13][lane] = __int_as_float(excl);
+    // the four wavefronts only touch their own slice; a wave-level fence is enough for LDS ordering
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 
-    const int x0 = loop_start(lo0 + 0.5f);
-    for (int y = loop_start(lo1 + 0.5f); (float)y <= hi1; ++y) {
-        const float fy = (float)y;
-        for (int x = x0; (float)x <= hi0; ++x) {
-            const float fx = (float)x;
-            // renderer.h:320-333 barycentric
-            const float beta  = area2(px[0], py[0], fx, fy, px[2], py[2]) * base_inv;
-            const float gamma = area2(px[0], py[0], px[1], py[1], fx, fy) * base_inv;
-            const float alpha = 1.0f - beta - gamma;
-            if (alpha < -0.0f || beta < -0.0f || gamma < -0.0f || alpha > 1.0f || beta > 1.0f || gamma > 1.0f) continue;
-            const float az = alpha / w3[0], bz = beta / w3[1], gz = gamma / w3[2];
-            const float frag = (alpha + beta + gamma) / (az + bz + gz);
-            const int d = f2i_x86(frag + 0.5f);
-            const uint32_t xw = (uint32_t)(x - roi.x);
-            const uint32_t yw = (uint32_t)((int)height - 1 - y - roi.y);
-            atomicMin(&img[xw + (size_t)yw * rw], d);
-        }
+#ifdef PR_ABL_NOATOMIC
+    int sink = INT_MAX;
+#endif
+    for (int c = (int)lane; c < total; c += 64) {
+        int o = 0;
+#pragma unroll
+        for (int s = 32; s > 0; s >>= 1) { if (__float_as_int(w[13][o + s]) <= c) o += s; }
+        const int k = c - __float_as_int(w[13][o]);
+        const int nx = __float_as_int(w[12][o]);
+        int q = (int)((float)k * __builtin_amdgcn_rcpf((float)nx));          // k / nx with a one-step correction
+        if (q * nx > k) --q;
+        if ((q + 1) * nx <= k) ++q;
+        const int x = __float_as_int(w[10][o]) + (k - q * nx);
+        const int y = __float_as_int(w[11][o]) + q;
+        const float px[3] = { w[0][o], w[2][o], w[4][o] }, py[3] = { w[1][o], w[3][o], w[5][o] };
+        float alpha, beta, gamma;
+        if (!tri_fragment(px, py, w[9][o], x, y, alpha, beta, gamma)) continue;
+        const int d = fragment_depth(alpha, beta, gamma, w[6][o], w[7][o], w[8][o]);
+        const uint32_t xw = (uint32_t)(x - roi.x);
+        const uint32_t yw = (uint32_t)((int)height - 1 - y - roi.y);
+#ifdef PR_ABL_NOATOMIC
+        sink = min(sink, d + (int)(xw + yw));
+#else
+        atomicMin(&img[xw + (size_t)yw * rw], d);
+#endif
     }
+#ifdef PR_ABL_NOATOMIC
+    if (sink == 12345) img[0] = sink;
+#endif
 }
 
 // ================================================================================================
@@ -620,9 +697,10 @@ __global__ __launch_bounds__(256, PR_PASS_WAVES) void icp_pass_kernel(IcpBatch b
     __shared__ float wsum[4][kAccStride];
 
     const uint32_t pose = blockIdx.y;
-    const int32_t st = b.state[pose];
+    const PoseMeta &pm = b.meta[pose];                           // uniform address: one 64-byte scalar load
+    const int32_t st = pm.state;
     if (st == kSkip) return;
-    const uint32_t n = b.count[pose];
+    const uint32_t n = pm.count;
     const uint32_t ppb = b.steps * kPointsPerStep;
     const uint32_t first = blockIdx.x * ppb;
     if (first >= n) return;
@@ -635,12 +713,12 @@ __global__ __launch_bounds__(256, PR_PASS_WAVES) void icp_pass_kernel(IcpBatch b
         lds_topo = dst;
     }
 
-    float *cl = reinterpret_cast<float *>(b.cloud + b.start[pose]);
+    float *cl = reinterpret_cast<float *>(b.cloud + pm.start);
     const bool vec_ok = ((reinterpret_cast<uintptr_t>(cl) & 15u) == 0);
     const bool xf = (st == kRunWithTransform);
     float M[12];
 #pragma unroll
-    for (int i = 0; i < 12; ++i) M[i] = xf ? b.xform[(size_t)pose * 12 + i] : 0.0f;
+    for (int i = 0; i < 12; ++i) M[i] = xf ? pm.xform[i] : 0.0f;
 
     float acc[29];
 #pragma unroll
@@ -733,28 +811,26 @@ __device__ __forceinline__ float sum_partials(const float *partial, uint32_t pos
     return total;
 }
 
-__global__ __launch_bounds__(64) void icp_finalize_kernel(const float *__restrict__ partial, const uint32_t *__restrict__ count,
-                                                          const int32_t *__restrict__ state, uint32_t nblk, uint32_t ppb,
-                                                          float *__restrict__ sums)
+__global__ __launch_bounds__(64) void icp_finalize_kernel(const float *__restrict__ partial, const PoseMeta *__restrict__ meta,
+                                                          uint32_t nblk, uint32_t ppb, float *__restrict__ sums)
 {
     const uint32_t pose = blockIdx.x;
-    if (state[pose] == kSkip) return;
-    const uint32_t n = count[pose];
+    if (meta[pose].state == kSkip) return;
+    const uint32_t n = meta[pose].count;
     const uint32_t used = (n + ppb - 1) / ppb;
     if (threadIdx.x < kAccStride)
         sums[(size_t)pose * kAccStride + threadIdx.x] = (threadIdx.x < 29) ? sum_partials(partial, pose, nblk, used, threadIdx.x) : 0.0f;
 }
 
 // PR_SOLVE_DEVICE: the per-iteration host logic of icp.cu:178-212 for one hypothesis per wavefront
-__global__ __launch_bounds__(64) void icp_finalize_solve_kernel(const float *__restrict__ partial, const uint32_t *__restrict__ count,
-                                                                int32_t *__restrict__ state, uint32_t nblk, uint32_t ppb,
-                                                                float *__restrict__ xform, DevIcpState *__restrict__ st,
+__global__ __launch_bounds__(64) void icp_finalize_solve_kernel(const float *__restrict__ partial, PoseMeta *__restrict__ meta,
+                                                                uint32_t nblk, uint32_t ppb, DevIcpState *__restrict__ st,
                                                                 pr_criteria crit, uint32_t iter)
 {
     __shared__ float Ab[kAccStride];
     const uint32_t pose = blockIdx.x;
-    if (state[pose] == kSkip) return;
-    const uint32_t n = count[pose];
+    if (meta[pose].state == kSkip) return;
+    const uint32_t n = meta[pose].count;
     const uint32_t used = (n + ppb - 1) / ppb;
     if (threadIdx.x < 29) Ab[threadIdx.x] = sum_partials(partial, pose, nblk, used, threadIdx.x);
     __syncthreads();
@@ -775,7 +851,7 @@ __global__ __launch_bounds__(64) void icp_finalize_solve_kernel(const float *__r
             if (((df < 0) ? -df : df) < crit.relative_fitness && ((dr < 0) ? -dr : dr) < crit.relative_rmse) finished = true;
         }
     }
-    if (finished) { s.done = 1; state[pose] = kSkip; }
+    if (finished) { s.done = 1; meta[pose].state = kSkip; }
     else {
         float A[36], bb[6], E[16];
 #pragma unroll
@@ -790,9 +866,9 @@ __global__ __launch_bounds__(64) void icp_finalize_solve_kernel(const float *__r
         }
         prs::solve_666_impl(A, bb, E);
 #pragma unroll
-        for (int i = 0; i < 12; ++i) xform[(size_t)pose * 12 + i] = E[i];
+        for (int i = 0; i < 12; ++i) meta[pose].xform[i] = E[i];
         prs::mat4_mul_impl(E, s.T, s.T);
-        state[pose] = kRunWithTransform;
+        meta[pose].state = kRunWithTransform;
     }
     st[pose] = s;
 }
@@ -877,7 +953,7 @@ hipError_t launch_raster(const pr_triangle *tris, uint32_t n_tris, const pr_mat4
     for (uint32_t p0 = 0; p0 < n_poses; p0 += 32768) {
         const uint32_t np = (n_poses - p0 < 32768) ? (n_poses - p0) : 32768;
         hipLaunchKernelGGL(raster_kernel, dim3((n_tris + 255) / 256, np), dim3(256), 0, s, tris, n_tris, poses_dev + p0,
-                           depth + (size_t)p0 * rw * rh, width, height, proj, roi, rw, rh);
+                           depth + (size_t)p0 * rw * rh, width, height, proj, roi, rw, rh, (const int4 *)nullptr);
     }
     return hipGetLastError();
 }
@@ -970,7 +1046,7 @@ static hipError_t launch_pass(const IcpBatch &b, const Scene &sc, uint32_t n_pos
     for (uint32_t p0 = 0; p0 < n_poses; p0 += 32768) {
         const uint32_t np = (n_poses - p0 < 32768) ? (n_poses - p0) : 32768;
         IcpBatch bb = b;
-        bb.start += p0; bb.count += p0; bb.state += p0; bb.xform += (size_t)p0 * 12;
+        bb.meta += p0;
         bb.partial += (size_t)p0 * b.nblk * kAccStride;
         hipLaunchKernelGGL(HIP_KERNEL_NAME(icp_pass_kernel<Scene, kNN>), dim3(b.nblk, np), dim3(kBlockThreads), lds_bytes, s, bb, sc);
     }
@@ -983,20 +1059,20 @@ hipError_t launch_icp_pass_proj_packed(const IcpBatch &b, const SceneProjPacked 
 hipError_t launch_icp_pass_nn(const IcpBatch &b, const SceneNNDev &sc, uint32_t n_poses, hipStream_t s)
 { return launch_pass<SceneNNDev, true>(b, sc, n_poses, (size_t)sc.lds_nodes * sizeof(int4), s); }
 
-hipError_t launch_icp_finalize(const float *partial, const uint32_t *count, const int32_t *state, uint32_t nblk,
+hipError_t launch_icp_finalize(const float *partial, const PoseMeta *meta, uint32_t nblk,
                                uint32_t steps, float *sums, uint32_t n_poses, hipStream_t s)
 {
     if (n_poses == 0) return hipSuccess;
-    hipLaunchKernelGGL(icp_finalize_kernel, dim3(n_poses), dim3(64), 0, s, partial, count, state, nblk, steps * kPointsPerStep, sums);
+    hipLaunchKernelGGL(icp_finalize_kernel, dim3(n_poses), dim3(64), 0, s, partial, meta, nblk, steps * kPointsPerStep, sums);
     return hipGetLastError();
 }
-hipError_t launch_icp_finalize_solve(const float *partial, const uint32_t *count, int32_t *state, uint32_t nblk,
-                                     uint32_t steps, float *xform, DevIcpState *st, pr_criteria crit, uint32_t iter,
+hipError_t launch_icp_finalize_solve(const float *partial, PoseMeta *meta, uint32_t nblk,
+                                     uint32_t steps, DevIcpState *st, pr_criteria crit, uint32_t iter,
                                      uint32_t n_poses, hipStream_t s)
 {
     if (n_poses == 0) return hipSuccess;
-    hipLaunchKernelGGL(icp_finalize_solve_kernel, dim3(n_poses), dim3(64), 0, s, partial, count, state, nblk,
-                       steps * kPointsPerStep, xform, st, crit, iter);
+    hipLaunchKernelGGL(icp_finalize_solve_kernel, dim3(n_poses), dim3(64), 0, s, partial, meta, nblk,
+                       steps * kPointsPerStep, st, crit, iter);
     return hipGetLastError();
 }
 hipError_t launch_pack_results(const DevIcpState *st, pr_result *out, uint32_t n_poses, hipStream_t s)

@@ -6,9 +6,10 @@ sys.path.insert(0, ROOT)
 import numpy as np
 from pose_refine_amd import api, synth
 
+PROFILE = 1
 def run(model, poses, proj, K, scene, crit, steps=8, warm=2):
     for _ in range(warm): api.refine_batch(model, poses, 640, 480, proj, K, scene, crit)
-    api.set_option("profile", 1); api.profile_reset()
+    api.set_option("profile", PROFILE); api.profile_reset()
     t0 = time.perf_counter()
     for _ in range(steps): res, sizes = api.refine_batch(model, poses, 640, 480, proj, K, scene, crit)
     dt = (time.perf_counter() - t0) / steps
@@ -16,7 +17,7 @@ def run(model, poses, proj, K, scene, crit, steps=8, warm=2):
     p = api.profile_read()
     n = max(1, p["icp_launches"])
     return dict(ms_step=dt * 1e3, poses_s=len(poses) / dt, icp_us=p["icp_kernel_ms"] * 1e3 / n, render_ms=p["render_ms"] / steps,
-                cloud_ms=p["cloud_ms"] / steps, gbs=47.43 * p["icp_points"] / n / (p["icp_kernel_ms"] * 1e-3 / n) / 1e9 if p["icp_kernel_ms"] else 0,
+                cloud_ms=p["cloud_ms"] / steps, gbs=p["icp_bytes"] / (p["icp_kernel_ms"] * 1e-3) / 1e9 if p["icp_kernel_ms"] else 0,
                 chk=float(np.sum(res["fitness"])))
 
 def main():
@@ -26,7 +27,11 @@ def main():
     ap.add_argument("--opt", action="append", default=[], help="name=v1,v2,... sweep")
     ap.add_argument("--solve", default="device")
     ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--profile", type=int, default=1)
     a = ap.parse_args()
+    global PROFILE
+    PROFILE = 0 if a.no_profile else a.profile
     api.init(0)
     api.set_option("solve", 1 if a.solve == "device" else 0)
     model = api.Model(os.path.join(ROOT, "tests/golden/obj_06.ply"))
