@@ -454,28 +454,25 @@ int refine_impl(const pr_triangle *tris_dev, size_t n_tris, const pr_mat4 *poses
         PR_TRY(g.counts.ensure(sizeof(uint32_t) * np));
         PR_TRY(g.h_counts.ensure(sizeof(uint32_t) * np));
         uint32_t *h_counts = g.h_counts.as<uint32_t>();
-        const bool bands = (g.raster_mode == 1);
-        if (bands) {
-            // model box once per (triangle buffer, size); boxes + LDS-band raster + row counts + row scan
-            PR_TRY(g.aabb.ensure(6 * sizeof(float)));
-            PR_TRY(g.bbox.ensure(sizeof(int4) * np));
-            PR_TRY(g.poses.ensure(sizeof(pr_mat4) * np));
-            if (g.aabb_key != tris_dev || g.aabb_n != n_tris) {
-                HIP_TRY(prk::launch_model_aabb(tris_dev, (uint32_t)n_tris, g.aabb.as<float>(), g.stream));
-                g.aabb_key = tris_dev; g.aabb_n = n_tris;
-            }
+        // model box once per (triangle buffer, size); per-pose pixel boxes; raster + row counts + row scan
+        PR_TRY(g.aabb.ensure(6 * sizeof(float)));
+        PR_TRY(g.bbox.ensure(sizeof(int4) * np));
+        PR_TRY(g.poses.ensure(sizeof(pr_mat4) * np));
+        if (g.aabb_key != tris_dev || g.aabb_n != n_tris) {
+            HIP_TRY(prk::launch_model_aabb(tris_dev, (uint32_t)n_tris, g.aabb.as<float>(), g.stream));
+            g.aabb_key = tris_dev; g.aabb_n = n_tris;
+        }
+        {
             SpanGuard sp(kSpanRender);
             HIP_TRY(hipMemcpyAsync(g.poses.p, poses_host + p0, sizeof(pr_mat4) * np, hipMemcpyHostToDevice, g.stream));
-            HIP_TRY(prk::launch_render_bands(tris_dev, (uint32_t)n_tris, g.poses.as<pr_mat4>(), np, g.aabb.as<float>(), g.bbox.as<int4>(),
-                                             g.depth.as<int32_t>(), g.row_count.as<uint32_t>(), g.row_off.as<uint32_t>(),
-                                             g.counts.as<uint32_t>(), W, H, *proj, (uint32_t)g.n_cus, g.stream));
-        } else {
-            pr_roi none{ 0, 0, 0, 0 };
-            PR_TRY(render_impl(tris_dev, n_tris, poses_host + p0, np, W, H, proj, none, g.depth.as<int32_t>(), /*zero_empty=*/false));
-            SpanGuard sp(kSpanCloud);
-            HIP_TRY(prk::launch_depth2cloud<int32_t>(g.depth.as<int32_t>(), np, img, W, H, 1, 0, 0, K[0], K[4], K[2], K[5], true,
-                                                     g.row_count.as<uint32_t>(), g.row_off.as<uint32_t>(), g.counts.as<uint32_t>(),
-                                                     nullptr, 0, false, g.stream));
+            if (g.raster_mode == 1)
+                HIP_TRY(prk::launch_render_bands(tris_dev, (uint32_t)n_tris, g.poses.as<pr_mat4>(), np, g.aabb.as<float>(), g.bbox.as<int4>(),
+                                                 g.depth.as<int32_t>(), g.row_count.as<uint32_t>(), g.row_off.as<uint32_t>(),
+                                                 g.counts.as<uint32_t>(), W, H, *proj, (uint32_t)g.n_cus, g.stream));
+            else
+                HIP_TRY(prk::launch_render_boxes(tris_dev, (uint32_t)n_tris, g.poses.as<pr_mat4>(), np, g.aabb.as<float>(), g.bbox.as<int4>(),
+                                                 g.depth.as<int32_t>(), g.row_count.as<uint32_t>(), g.row_off.as<uint32_t>(),
+                                                 g.counts.as<uint32_t>(), W, H, *proj, g.stream));
         }
         HIP_TRY(hipMemcpyAsync(h_counts, g.counts.p, sizeof(uint32_t) * np, hipMemcpyDeviceToHost, g.stream));
         HIP_TRY(hipStreamSynchronize(g.stream));
@@ -485,13 +482,8 @@ int refine_impl(const pr_triangle *tris_dev, size_t n_tris, const pr_mat4 *poses
         PR_TRY(g.cloud.ensure(sizeof(pr_vec3) * std::max<size_t>(4, cstride) * np));
         if (max_n > 0) {
             SpanGuard sp(kSpanCloud);
-            if (bands)
-                HIP_TRY(prk::launch_emit_box(g.depth.as<int32_t>(), np, W, H, g.bbox.as<int4>(), K[0], K[4], K[2], K[5],
-                                             g.row_count.as<uint32_t>(), g.row_off.as<uint32_t>(), g.cloud.as<pr_vec3>(), cstride, g.stream));
-            else
-                HIP_TRY(prk::launch_depth2cloud<int32_t>(g.depth.as<int32_t>(), np, img, W, H, 1, 0, 0, K[0], K[4], K[2], K[5], true,
-                                                         g.row_count.as<uint32_t>(), g.row_off.as<uint32_t>(), g.counts.as<uint32_t>(),
-                                                         g.cloud.as<pr_vec3>(), cstride, true, g.stream));
+            HIP_TRY(prk::launch_emit_box(g.depth.as<int32_t>(), np, W, H, g.bbox.as<int4>(), K[0], K[4], K[2], K[5],
+                                         g.row_count.as<uint32_t>(), g.row_off.as<uint32_t>(), g.cloud.as<pr_vec3>(), cstride, g.stream));
         }
         for (uint32_t i = 0; i < np; ++i) { start[i] = (uint32_t)(i * cstride); count[i] = h_counts[i]; }
         if (sizes_host) std::memcpy(sizes_host + p0, count.data(), sizeof(uint32_t) * np);

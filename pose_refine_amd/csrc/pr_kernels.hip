@@ -279,6 +279,37 @@ __global__ __launch_bounds__(256) void pose_bbox_kernel(const float *__restrict_
     bbox[p] = make_int4(x0, y0, x1, y1);
 }
 
+// INT_MAX-fill and per-row valid counts restricted to each hypothesis' pixel box (image rows are
+// the flipped raster rows).  One wavefront per image row; rows outside the box only write count 0.
+__global__ __launch_bounds__(256) void fill_box_kernel(int32_t *__restrict__ depth, const int4 *__restrict__ bbox, uint32_t width, uint32_t height)
+{
+    const uint32_t row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= height) return;
+    const int4 bb = bbox[blockIdx.y];
+    const int ry = (int)height - 1 - (int)row;                      // raster row of this image row
+    if (ry < bb.y || ry > bb.w) return;
+    int32_t *line = depth + ((size_t)blockIdx.y * height + row) * width;
+    for (int x = bb.x + (int)lane; x <= bb.z; x += 64) line[x] = INT_MAX;
+}
+__global__ __launch_bounds__(256) void count_box_kernel(const int32_t *__restrict__ depth, const int4 *__restrict__ bbox, uint32_t width,
+                                                        uint32_t height, uint32_t *__restrict__ row_count)
+{
+    const uint32_t row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= height) return;
+    const int4 bb = bbox[blockIdx.y];
+    const int ry = (int)height - 1 - (int)row;
+    uint32_t cnt = 0;
+    if (ry >= bb.y && ry <= bb.w) {
+        const int32_t *line = depth + ((size_t)blockIdx.y * height + row) * width;
+        for (int x0 = bb.x; x0 <= bb.z; x0 += 64) {
+            const int x = x0 + (int)lane;
+            const bool v = (x <= bb.z) && line[x] > 0 && line[x] != INT_MAX;
+            cnt += (uint32_t)__popcll(__ballot(v));
+        }
+    }
+    if (lane == 0) row_count[(size_t)blockIdx.y * height + row] = cnt;
+}
+
 // Persistent workgroups walk the (hypothesis, band) items; a band is a run of raster rows of the
 // hypothesis' box that fits the LDS tile.  Each workgroup rasterises ALL triangles against its band
 // with ds_min, then writes the band (INT_MAX = empty) and its per-row valid counts.
@@ -988,6 +1019,27 @@ hipError_t launch_render_bands(const pr_triangle *tris, uint32_t n_tris, const p
     const uint32_t grid = items < n_cus ? items : n_cus;
     hipLaunchKernelGGL(raster_band_kernel, dim3(grid), dim3(1024), cap_px * sizeof(int32_t), s, tris, n_tris, poses_dev, n_poses, bbox, depth,
                        row_count, width, height, proj, cap_px, max_bands);
+    hipLaunchKernelGGL(d2c_scan_kernel, dim3(n_poses), dim3(256), 0, s, row_count, height, row_off, counts);
+    return hipGetLastError();
+}
+
+// fused-path render, reference scheme (global int32 atomicMin) but only inside each hypothesis' box
+hipError_t launch_render_boxes(const pr_triangle *tris, uint32_t n_tris, const pr_mat4 *poses_dev, uint32_t n_poses, const float *aabb,
+                               int4 *bbox, int32_t *depth, uint32_t *row_count, uint32_t *row_off, uint32_t *counts,
+                               uint32_t width, uint32_t height, const pr_mat4 &proj, hipStream_t s)
+{
+    if (n_poses == 0) return hipSuccess;
+    hipLaunchKernelGGL(pose_bbox_kernel, dim3((n_poses + 255) / 256), dim3(256), 0, s, aabb, poses_dev, n_poses, proj, width, height, bbox);
+    const pr_roi none{ 0, 0, 0, 0 };
+    for (uint32_t p0 = 0; p0 < n_poses; p0 += 32768) {
+        const uint32_t np = (n_poses - p0 < 32768) ? (n_poses - p0) : 32768;
+        const size_t off = (size_t)p0 * width * height;
+        hipLaunchKernelGGL(fill_box_kernel, dim3((height + 3) / 4, np), dim3(256), 0, s, depth + off, bbox + p0, width, height);
+        hipLaunchKernelGGL(raster_kernel, dim3((n_tris + 255) / 256, np), dim3(256), 0, s, tris, n_tris, poses_dev + p0, depth + off,
+                           width, height, proj, none, width, height, (const int4 *)(bbox + p0));
+        hipLaunchKernelGGL(count_box_kernel, dim3((height + 3) / 4, np), dim3(256), 0, s, depth + off, bbox + p0, width, height,
+                           row_count + (size_t)p0 * height);
+    }
     hipLaunchKernelGGL(d2c_scan_kernel, dim3(n_poses), dim3(256), 0, s, row_count, height, row_off, counts);
     return hipGetLastError();
 }
