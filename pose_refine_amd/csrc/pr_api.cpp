@@ -76,13 +76,18 @@ struct Ctx {
     bool ready = false;
     int device = -1;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;   // second lane of the device-solve loop (pose groups overlap pass and solve)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int pose_groups = 1;             // 2: split the batch over two streams so one group's solve overlaps the other's pass (+5 % poses/s,
+                                     // but launches then overlap and can no longer be timed one by one) -- opt-in
     // options
     int solve_mode = PR_SOLVE_HOST;
     int steps = 2;                   // 1024-point steps per workgroup -> 2048 points per workgroup
     int profile = 0;
     int nn_lds_nodes = 1024;
-    int use_graph = 1;               // PR_SOLVE_DEVICE: capture the whole iteration loop in a hipGraph and replay it
-    int raster_mode = 1;             // fused path: 1 = LDS depth bands over the per-pose pixel box, 0 = global atomicMin (reference scheme)
+    int use_graph = 0;               // PR_SOLVE_DEVICE: capture the whole iteration loop in a hipGraph and replay it (measured: no gain over
+                                     // direct launches, and the two pose-group branches do not overlap inside a graph) -- opt-in
+    int raster_mode = 0;             // fused path: 0 = global atomicMin inside the per-pose pixel box (reference scheme), 1 = LDS depth bands
     int n_cus = 256;
     const void *aabb_key = nullptr; size_t aabb_n = 0;
     // workspaces
@@ -135,6 +140,9 @@ int require_ctx()
     if (dev >= n) { set_error("device %d out of range (%d visible)", dev, n); return PR_ERR_NO_DEVICE; }
     HIP_TRY(hipSetDevice(dev));
     HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&g.stream2, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&g.ev_fork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&g.ev_join, hipEventDisableTiming));
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) g.n_cus = prop.multiProcessorCount;
     g.device = dev;
@@ -218,11 +226,12 @@ int make_scene(int kind, const void *scene, bool want_packed, SceneSel &out)
     return PR_ERR_INVALID;
 }
 
-hipError_t launch_pass(const prk::IcpBatch &b, const SceneSel &sc, uint32_t P)
+hipError_t launch_pass(const prk::IcpBatch &b, const SceneSel &sc, uint32_t P, hipStream_t st = nullptr)
 {
-    if (sc.kind == PR_SCENE_NN) return prk::launch_icp_pass_nn(b, sc.nn, P, g.stream);
-    if (sc.packed) return prk::launch_icp_pass_proj_packed(b, sc.pk, P, g.stream);
-    return prk::launch_icp_pass_proj_aos(b, sc.aos, P, g.stream);
+    if (!st) st = g.stream;
+    if (sc.kind == PR_SCENE_NN) return prk::launch_icp_pass_nn(b, sc.nn, P, st);
+    if (sc.packed) return prk::launch_icp_pass_proj_packed(b, sc.pk, P, st);
+    return prk::launch_icp_pass_proj_aos(b, sc.aos, P, st);
 }
 
 // ---- the batched ICP driver -----------------------------------------------------------------------
@@ -272,19 +281,30 @@ int icp_drive(pr_vec3 *cloud_base, const uint32_t *start_h, const uint32_t *coun
         // profile==2: time ONE correspondence launch per call, at an iteration index that rotates from call to call
         const uint32_t sample_it = (uint32_t)((g.sample_clock++ * 5 + 1) % (uint64_t)(crit.max_iteration + 1));
         // the fixed sequence: state upload, (max_iteration+1) x [correspondence pass, finalize+solve], result pack
-        auto enqueue_all = [&](std::vector<hipEvent_t> *evs, bool host_checks) -> int {
+        auto enqueue_all = [&](std::vector<hipEvent_t> *, bool host_checks) -> int {
             HIP_TRY(hipMemcpyAsync(g.dstate.p, init, sizeof(prk::DevIcpState) * P, hipMemcpyHostToDevice, g.stream));
             HIP_TRY(hipMemcpyAsync(g.meta.p, h_meta, sizeof(prk::PoseMeta) * P, hipMemcpyHostToDevice, g.stream));
+            // Two pose groups on two streams: while the (latency-bound, one wavefront per pose) finalize+solve
+            // of one group runs, the correspondence pass of the other group keeps the chip busy.
+            const uint32_t n_groups = (g.pose_groups >= 2 && P >= 64) ? 2u : 1u;
+            const uint32_t split = (n_groups == 2) ? (P + 1) / 2 : P;
+            if (n_groups == 2) { HIP_TRY(hipEventRecord(g.ev_fork, g.stream)); HIP_TRY(hipStreamWaitEvent(g.stream2, g.ev_fork, 0)); }
             for (uint32_t it = 0; it <= (uint32_t)crit.max_iteration; ++it) {
-                if (evs) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); evs->push_back(e); HIP_TRY(hipEventRecord(e, g.stream)); }
-                if (!evs && (g.profile == 1 || (g.profile == 2 && it == sample_it))) {
-                    SpanGuard sp(kSpanIcp); HIP_TRY(launch_pass(b, sc, P));
-                    g.icp_points += sum_n; g.icp_bytes += sum_n * (it == 0 ? 36u : 48u);
-                } else HIP_TRY(launch_pass(b, sc, P));
-                if (evs) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); evs->push_back(e); HIP_TRY(hipEventRecord(e, g.stream)); }
-                HIP_TRY(prk::launch_icp_finalize_solve(g.partial.as<float>(), g.meta.as<prk::PoseMeta>(), nblk, steps,
-                                                       g.dstate.as<prk::DevIcpState>(), crit, it, P, g.stream));
+                for (uint32_t grp = 0; grp < n_groups; ++grp) {
+                    const uint32_t p0 = grp ? split : 0, np = grp ? P - split : split;
+                    hipStream_t st = grp ? g.stream2 : g.stream;
+                    prk::IcpBatch bb = b;
+                    bb.meta += p0; bb.partial += (size_t)p0 * nblk * prk::kAccStride;
+                    if (grp == 0 && (g.profile == 1 || (g.profile == 2 && it == sample_it))) {
+                        SpanGuard sp(kSpanIcp); HIP_TRY(launch_pass(bb, sc, np, st));
+                        uint64_t pts = 0; for (uint32_t i = p0; i < p0 + np; ++i) pts += count_h[i];
+                        g.icp_points += pts; g.icp_bytes += pts * (it == 0 ? 36u : 48u);
+                    } else HIP_TRY(launch_pass(bb, sc, np, st));
+                    HIP_TRY(prk::launch_icp_finalize_solve(bb.partial, g.meta.as<prk::PoseMeta>() + p0, nblk, steps,
+                                                           g.dstate.as<prk::DevIcpState>() + p0, crit, it, np, st));
+                }
                 if (host_checks && may_exit_early && (it & 3) == 3 && it < (uint32_t)crit.max_iteration) {
+                    if (n_groups == 2) HIP_TRY(hipStreamSynchronize(g.stream2));
                     HIP_TRY(hipMemcpyAsync(h_meta, g.meta.p, sizeof(prk::PoseMeta) * P, hipMemcpyDeviceToHost, g.stream));
                     HIP_TRY(hipStreamSynchronize(g.stream));
                     bool any = false;
@@ -292,6 +312,7 @@ int icp_drive(pr_vec3 *cloud_base, const uint32_t *start_h, const uint32_t *coun
                     if (!any) break;
                 }
             }
+            if (n_groups == 2) { HIP_TRY(hipEventRecord(g.ev_join, g.stream2)); HIP_TRY(hipStreamWaitEvent(g.stream, g.ev_join, 0)); }
             HIP_TRY(prk::launch_pack_results(g.dstate.as<prk::DevIcpState>(), dres, P, g.stream));
             // results go to the pinned staging buffer (a pageable destination is not capturable)
             if (results_host) HIP_TRY(hipMemcpyAsync(res, dres, sizeof(pr_result) * P, hipMemcpyDeviceToHost, g.stream));
@@ -301,7 +322,7 @@ int icp_drive(pr_vec3 *cloud_base, const uint32_t *start_h, const uint32_t *coun
         if (g.use_graph && g.profile == 0) {                    // HIP events recorded inside a captured graph cannot be timed: profile => direct launches
             GraphKey key;
             key.add(P); key.add(nblk); key.add(steps); key.add(crit); key.add(sc); key.add(cloud_base); key.add(g.meta.p); key.add(g.partial.p);
-            key.add(g.dstate.p); key.add(dres); key.add(results_host != nullptr); key.add(res); key.add(h_meta); key.add(init); key.add(g.profile);
+            key.add(g.dstate.p); key.add(dres); key.add(results_host != nullptr); key.add(res); key.add(h_meta); key.add(init); key.add(g.profile); key.add(g.pose_groups);
             CachedGraph *hit = nullptr;
             for (auto &c : g_graphs) if (c.exec && c.key == key) { hit = &c; break; }
             if (!hit) {
@@ -529,6 +550,10 @@ int pr_shutdown(void)
     for (hipEvent_t e : g.ev_pool) hipEventDestroy(e);
     g.ev_pool.clear(); g.ev_used = 0; g.spans.clear();
     hipStreamDestroy(g.stream);
+    if (g.stream2) hipStreamDestroy(g.stream2);
+    if (g.ev_fork) hipEventDestroy(g.ev_fork);
+    if (g.ev_join) hipEventDestroy(g.ev_join);
+    g.stream2 = nullptr; g.ev_fork = g.ev_join = nullptr;
     g.stream = nullptr; g.ready = false; g.device = -1; g.aabb_key = nullptr; g.aabb_n = 0;
     return PR_OK;
 }
@@ -678,6 +703,7 @@ int pr_set_option(const char *name, int value)
     else if (n == "profile") { if (value < 0 || value > 2) { set_error("profile must be 0, 1 (every launch) or 2 (one sampled launch per call)"); return PR_ERR_INVALID; } g.profile = value; }
     else if (n == "nn_lds_nodes") g.nn_lds_nodes = std::max(0, value);
     else if (n == "graph") g.use_graph = value ? 1 : 0;
+    else if (n == "pose_groups") g.pose_groups = (value >= 2) ? 2 : 1;
     else if (n == "raster_mode") { if (value != 0 && value != 1) { set_error("raster_mode must be 0 or 1"); return PR_ERR_INVALID; } g.raster_mode = value; }
     else { set_error("unknown option %s", name); return PR_ERR_INVALID; }
     return PR_OK;
@@ -693,6 +719,7 @@ int pr_get_option(const char *name, int *value)
     else if (n == "nn_lds_nodes") *value = g.nn_lds_nodes;
     else if (n == "raster_mode") *value = g.raster_mode;
     else if (n == "graph") *value = g.use_graph;
+    else if (n == "pose_groups") *value = g.pose_groups;
     else { set_error("unknown option %s", name); return PR_ERR_INVALID; }
     return PR_OK;
 }

@@ -755,12 +755,11 @@ __global__ __launch_bounds__(256, PR_PASS_WAVES) void icp_pass_kernel(IcpBatch b
 #pragma unroll
     for (int i = 0; i < 29; ++i) acc[i] = 0.0f;
 
-    for (uint32_t s = 0; s < b.steps; ++s) {
-        const uint32_t j0 = first + s * kPointsPerStep + threadIdx.x * kPointsPerLane;
-        if (j0 >= n) break;
-        const uint32_t cnt = (n - j0 < kPointsPerLane) ? (n - j0) : kPointsPerLane;
-        float p[12];
-        const bool full = vec_ok && cnt == kPointsPerLane;
+    // one 1024-point step of this lane: 4 consecutive points = 48 contiguous bytes
+    auto load_step = [&](uint32_t s, float (&p)[12], uint32_t &j0, uint32_t &cnt, bool &full) {
+        j0 = first + s * kPointsPerStep + threadIdx.x * kPointsPerLane;
+        cnt = (j0 >= n) ? 0u : ((n - j0 < kPointsPerLane) ? (n - j0) : kPointsPerLane);
+        full = vec_ok && cnt == kPointsPerLane;
         if (full) {
             const float4 *src = reinterpret_cast<const float4 *>(cl + (size_t)j0 * 3);
             const float4 a0 = src[0], a1 = src[1], a2 = src[2];
@@ -770,6 +769,9 @@ __global__ __launch_bounds__(256, PR_PASS_WAVES) void icp_pass_kernel(IcpBatch b
 #pragma unroll
             for (uint32_t i = 0; i < 12; ++i) p[i] = (i < cnt * 3) ? cl[(size_t)j0 * 3 + i] : 0.0f;
         }
+    };
+    auto process_step = [&](float (&p)[12], uint32_t j0, uint32_t cnt, bool full) {
+        if (cnt == 0) return;
         if (xf) {                                                // icp.cu:142-153 transform_pcd_cuda, fused
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -813,6 +815,24 @@ __global__ __launch_bounds__(256, PR_PASS_WAVES) void icp_pass_kernel(IcpBatch b
                 if (gather_finish(scene, in_img[i], p[3 * i + 2], gth[i], c)) accumulate(acc, p[3 * i], p[3 * i + 1], p[3 * i + 2], c);
             }
         }
+    };
+
+#if defined(PR_PASS_PREFETCH)
+    if (!kNN && b.steps == 2) {                                  // both steps' point loads in flight before any use
+        float pa[12], pb[12];
+        uint32_t ja, jb, ca, cb; bool fa, fb;
+        load_step(0, pa, ja, ca, fa);
+        load_step(1, pb, jb, cb, fb);
+        process_step(pa, ja, ca, fa);
+        process_step(pb, jb, cb, fb);
+    } else
+#endif
+    for (uint32_t s = 0; s < b.steps; ++s) {
+        float p[12];
+        uint32_t j0, cnt; bool full;
+        load_step(s, p, j0, cnt, full);
+        if (cnt == 0) break;
+        process_step(p, j0, cnt, full);
     }
 
     // canonical tree: wave (balanced pairwise over lanes) -> ((w0+w1)+w2)+w3
