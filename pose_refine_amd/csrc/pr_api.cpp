@@ -85,13 +85,14 @@ struct Ctx {
     int steps = 2;                   // 1024-point steps per workgroup -> 2048 points per workgroup
     int profile = 0;
     int nn_lds_nodes = 1024;
+    int nn_stack = 1;                // kd-tree query: per-lane LDS stack (1) or the reference's stackless walk (0)
     int use_graph = 0;               // PR_SOLVE_DEVICE: capture the whole iteration loop in a hipGraph and replay it (measured: no gain over
                                      // direct launches, and the two pose-group branches do not overlap inside a graph) -- opt-in
     int raster_mode = 0;             // fused path: 0 = global atomicMin inside the per-pose pixel box (reference scheme), 1 = LDS depth bands
     int n_cus = 256;
     const void *aabb_key = nullptr; size_t aabb_n = 0;
     // workspaces
-    DevBuf aabb, bbox, poses, depth, row_count, row_off, counts, cloud, meta, partial, sums, rec, topo, bmin, bmax, pts, dstate, dresults;
+    DevBuf aabb, bbox, poses, depth, row_count, row_off, counts, cloud, meta, partial, sums, rec, topo, bmin, bmax, pts, nnrec, nndepth, dstate, dresults;
     PinBuf h_sums, h_meta, h_counts, h_results, h_dstate;
     // profiling
     std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
@@ -213,13 +214,21 @@ int make_scene(int kind, const void *scene, bool want_packed, SceneSel &out)
         PR_TRY(g.bmin.ensure((size_t)s->n_nodes * sizeof(float4)));
         PR_TRY(g.bmax.ensure((size_t)s->n_nodes * sizeof(float4)));
         PR_TRY(g.pts.ensure((size_t)s->n_points * sizeof(float4)));
+        PR_TRY(g.nnrec.ensure((size_t)s->n_nodes * 4 * sizeof(float4)));
+        PR_TRY(g.nndepth.ensure(sizeof(uint32_t)));
         HIP_TRY(prk::launch_build_nn_accel(s->nodes, s->n_nodes, s->pcd, s->n_points, g.topo.as<int4>(), g.bmin.as<float4>(),
-                                           g.bmax.as<float4>(), g.pts.as<float4>(), g.stream));
+                                           g.bmax.as<float4>(), g.pts.as<float4>(), g.nnrec.as<float4>(), g.nndepth.as<uint32_t>(), g.stream));
+        uint32_t depth = 0;
+        HIP_TRY(hipMemcpyAsync(&depth, g.nndepth.p, sizeof depth, hipMemcpyDeviceToHost, g.stream));
+        HIP_TRY(hipStreamSynchronize(g.stream));
         uint32_t lds = (uint32_t)std::max(0, g.nn_lds_nodes);
         lds = std::min(lds, s->n_nodes);
         lds = std::min<uint32_t>(lds, 8192);                      // <= 128 KiB of LDS
+        // pending far children on the stack never exceed the tree depth; deeper trees use the stackless walk
+        uint32_t stack = 0;
+        if (g.nn_stack) stack = (depth <= 16) ? 16u : ((depth <= 24) ? 24u : 0u);
         out.nn = prk::SceneNNDev{ s->max_dist_diff, g.topo.as<int4>(), g.bmin.as<float4>(), g.bmax.as<float4>(), g.pts.as<float4>(),
-                                  s->pcd, s->normal, s->n_nodes, lds };
+                                  s->pcd, s->normal, s->n_nodes, lds, g.nnrec.as<float4>(), stack };
         return PR_OK;
     }
     set_error("unknown scene kind %d", kind);
@@ -544,7 +553,7 @@ int pr_shutdown(void)
     if (!g.ready) return PR_OK;
     hipStreamSynchronize(g.stream);
     for (DevBuf *b : { &g.aabb, &g.bbox, &g.poses, &g.depth, &g.row_count, &g.row_off, &g.counts, &g.cloud, &g.meta, &g.partial,
-                       &g.sums, &g.rec, &g.topo, &g.bmin, &g.bmax, &g.pts, &g.dstate, &g.dresults }) b->release();
+                       &g.sums, &g.rec, &g.topo, &g.bmin, &g.bmax, &g.pts, &g.nnrec, &g.nndepth, &g.dstate, &g.dresults }) b->release();
     for (PinBuf *b : { &g.h_sums, &g.h_meta, &g.h_counts, &g.h_results, &g.h_dstate }) b->release();
     drop_graphs();
     for (hipEvent_t e : g.ev_pool) hipEventDestroy(e);
@@ -702,6 +711,7 @@ int pr_set_option(const char *name, int value)
     else if (n == "points_per_block") { if (value < 1024 || value % 1024) { set_error("points_per_block must be a multiple of 1024"); return PR_ERR_INVALID; } g.steps = value / 1024; }
     else if (n == "profile") { if (value < 0 || value > 2) { set_error("profile must be 0, 1 (every launch) or 2 (one sampled launch per call)"); return PR_ERR_INVALID; } g.profile = value; }
     else if (n == "nn_lds_nodes") g.nn_lds_nodes = std::max(0, value);
+    else if (n == "nn_stack") g.nn_stack = value ? 1 : 0;
     else if (n == "graph") g.use_graph = value ? 1 : 0;
     else if (n == "pose_groups") g.pose_groups = (value >= 2) ? 2 : 1;
     else if (n == "raster_mode") { if (value != 0 && value != 1) { set_error("raster_mode must be 0 or 1"); return PR_ERR_INVALID; } g.raster_mode = value; }
@@ -717,6 +727,7 @@ int pr_get_option(const char *name, int *value)
     else if (n == "points_per_block") *value = g.steps * 1024;
     else if (n == "profile") *value = g.profile;
     else if (n == "nn_lds_nodes") *value = g.nn_lds_nodes;
+    else if (n == "nn_stack") *value = g.nn_stack;
     else if (n == "raster_mode") *value = g.raster_mode;
     else if (n == "graph") *value = g.use_graph;
     else if (n == "pose_groups") *value = g.pose_groups;

@@ -60,7 +60,9 @@ struct SceneNNDev {
     const float4 *pts;          // per point {x,y,z,0}
     const pr_vec3 *pcd, *normal;
     uint32_t n_nodes;
-    uint32_t lds_nodes;         // how many leading (top-level) nodes the kernel stages in LDS
+    uint32_t lds_nodes;         // stackless variant: how many leading (top-level) nodes the kernel stages in LDS
+    const float4 *rec;          // stack variant: 64-byte record per node (4 x float4), see nn_records_kernel
+    uint32_t stack_depth;       // 0 = stackless traversal, else per-lane LDS stack entries (>= tree depth)
 };
 
 // device-side solver state for PR_SOLVE_DEVICE (one record per hypothesis)
@@ -112,7 +114,7 @@ hipError_t launch_pack_results(const DevIcpState *st, pr_result *out, uint32_t n
 hipError_t launch_pack_proj_scene(const pr_vec3 *pcd, const pr_vec3 *normal, float4 *rec, size_t n, float *colf, float *rowf,
                                   uint32_t width, uint32_t height, float fx, float fy, float cx, float cy, hipStream_t s);
 hipError_t launch_build_nn_accel(const pr_kdnode *nodes, uint32_t n_nodes, const pr_vec3 *pcd, uint32_t n_points,
-                                 int4 *topo, float4 *bmin, float4 *bmax, float4 *pts, hipStream_t s);
+                                 int4 *topo, float4 *bmin, float4 *bmax, float4 *pts, float4 *rec, uint32_t *max_depth, hipStream_t s);
 
 }  // namespace prk
 

@@ -671,6 +671,56 @@ __device__ __forceinline__ bool query_nn(const SceneNNDev &s, const int4 *lds_to
     return true;
 }
 
+// Stack variant of the same search.  The order in which leaves are visited is the reference's
+// near-first depth-first order: a far child is parked on a per-lane stack (LDS, [entry][lane] so the
+// 64 lanes of a wavefront hit 64 different banks) together with the distance of the query to its
+// box, and re-tested against the current best when it is popped -- exactly the test the stackless
+// walk makes when it climbs back to the parent (pcd_scene.h:115).  Each internal node is fetched
+// once, as one 64-byte record that already contains both children's boxes.
+//   record = { split_v | left, child1 | right, child2 | -1, dim,  c1.min.xyz c1.max.xyz  c2.min.xyz c2.max.xyz }
+template <int kDepth>
+__device__ __forceinline__ bool query_nn_stack(const SceneNNDev &s, int *stk_node, float *stk_lb, float sx, float sy, float sz, Corr &c)
+{
+    int cur = 0, sp = 0, best_i = 0;
+    float best = FLT_MAX;
+    for (;;) {
+        const float4 h = s.rec[(size_t)cur * 4];
+        const int hz = __float_as_int(h.z);
+        if (hz < 0) {                                            // leaf: points [left, right)
+            const int lo = __float_as_int(h.x), hi = __float_as_int(h.y);
+            for (int i = lo; i < hi; ++i) {
+                const float4 p = s.pts[i];
+                const float d2 = (sx - p.x) * (sx - p.x) + (sy - p.y) * (sy - p.y) + (sz - p.z) * (sz - p.z);
+                if (d2 < best) { best = d2; best_i = i; }
+            }
+            bool found = false;
+            while (sp > 0) {
+                --sp;
+                if (stk_lb[sp * kBlockThreads] <= best) { cur = stk_node[sp * kBlockThreads]; found = true; break; }
+            }
+            if (!found) break;
+        } else {
+            const float4 b0 = s.rec[(size_t)cur * 4 + 1], b1 = s.rec[(size_t)cur * 4 + 2], b2 = s.rec[(size_t)cur * 4 + 3];
+            const int dim = __float_as_int(h.w);
+            const float q = (dim == 0) ? sx : ((dim == 1) ? sy : sz);
+            const float diff = q - h.x;
+            const bool left_near = diff < 0;
+            const int near_c = left_near ? __float_as_int(h.y) : hz;
+            const int far_c  = left_near ? hz : __float_as_int(h.y);
+            const float4 lo = left_near ? make_float4(b1.z, b1.w, b2.x, 0.f) : make_float4(b0.x, b0.y, b0.z, 0.f);
+            const float4 hi = left_near ? make_float4(b2.y, b2.z, b2.w, 0.f) : make_float4(b0.w, b1.x, b1.y, 0.f);
+            const float lb = box_dist_sq(sx, sy, sz, lo, hi);
+            if (lb <= best && sp < kDepth) { stk_node[sp * kBlockThreads] = far_c; stk_lb[sp * kBlockThreads] = lb; ++sp; }
+            cur = near_c;
+        }
+    }
+    if (!(best < s.max_dist_diff * s.max_dist_diff)) return false;
+    const float *d = reinterpret_cast<const float *>(s.pcd + best_i);
+    const float *n = reinterpret_cast<const float *>(s.normal + best_i);
+    c.dx = d[0]; c.dy = d[1]; c.dz = d[2]; c.nx = n[0]; c.ny = n[1]; c.nz = n[2];
+    return true;
+}
+
 // ================================================================================================
 //  29-term contribution (icp.h:138-206) accumulated straight into the lane's registers
 // ================================================================================================
@@ -721,7 +771,7 @@ __device__ __forceinline__ float wave_tree_sum(float v)
 #ifndef PR_PASS_WAVES
 #define PR_PASS_WAVES 1
 #endif
-template <class Scene, bool kNN>
+template <class Scene, bool kNN, int kStack = 0>
 __global__ __launch_bounds__(256, PR_PASS_WAVES) void icp_pass_kernel(IcpBatch b, Scene scene)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -737,12 +787,18 @@ __global__ __launch_bounds__(256, PR_PASS_WAVES) void icp_pass_kernel(IcpBatch b
     if (first >= n) return;
 
     const int4 *lds_topo = nullptr;
-    if constexpr (kNN) {
+    int *stk_node = nullptr; float *stk_lb = nullptr;
+    if constexpr (kNN && kStack == 0) {
         int4 *dst = reinterpret_cast<int4 *>(lds_raw);
         for (uint32_t i = threadIdx.x; i < scene.lds_nodes; i += kBlockThreads) dst[i] = scene.topo[i];
         __syncthreads();
         lds_topo = dst;
     }
+    if constexpr (kNN && kStack > 0) {                           // per-lane stacks: [entry][lane]
+        stk_node = reinterpret_cast<int *>(lds_raw) + threadIdx.x;
+        stk_lb = reinterpret_cast<float *>(lds_raw) + (size_t)kStack * kBlockThreads + threadIdx.x;
+    }
+    (void)lds_topo; (void)stk_node; (void)stk_lb;
 
     float *cl = reinterpret_cast<float *>(b.cloud + pm.start);
     const bool vec_ok = ((reinterpret_cast<uintptr_t>(cl) & 15u) == 0);
@@ -797,8 +853,10 @@ __global__ __launch_bounds__(256, PR_PASS_WAVES) void icp_pass_kernel(IcpBatch b
             for (uint32_t i = 0; i < 4; ++i) {
                 if (i < cnt) {
                     Corr c;
-                    if (query_nn<true>(scene, lds_topo, p[3 * i], p[3 * i + 1], p[3 * i + 2], c))
-                        accumulate(acc, p[3 * i], p[3 * i + 1], p[3 * i + 2], c);
+                    bool ok;
+                    if constexpr (kStack > 0) ok = query_nn_stack<kStack>(scene, stk_node, stk_lb, p[3 * i], p[3 * i + 1], p[3 * i + 2], c);
+                    else ok = query_nn<true>(scene, lds_topo, p[3 * i], p[3 * i + 1], p[3 * i + 2], c);
+                    if (ok) accumulate(acc, p[3 * i], p[3 * i + 1], p[3 * i + 2], c);
                 }
             }
         } else {
@@ -976,6 +1034,30 @@ __global__ __launch_bounds__(256) void nn_accel_kernel(const pr_kdnode *__restri
     }
 }
 
+// 64-byte traversal records for the stack variant + the depth of the tree (longest root-to-node path)
+__global__ __launch_bounds__(256) void nn_records_kernel(const int4 *__restrict__ topo, const float4 *__restrict__ bmin,
+                                                         const float4 *__restrict__ bmax, uint32_t n_nodes,
+                                                         float4 *__restrict__ rec, uint32_t *__restrict__ max_depth)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_nodes) return;
+    const int4 t = topo[i];
+    float4 r0, r1 = make_float4(0, 0, 0, 0), r2 = r1, r3 = r1;
+    if (t.z < 0) r0 = make_float4(__int_as_float(t.x), __int_as_float(t.y), __int_as_float(-1), 0.0f);
+    else {
+        const int dim = (int)((uint32_t)t.w >> 30);
+        r0 = make_float4(__int_as_float(t.x), __int_as_float(t.y), __int_as_float(t.z), __int_as_float(dim));
+        const float4 a0 = bmin[t.y], a1 = bmax[t.y], c0 = bmin[t.z], c1 = bmax[t.z];
+        r1 = make_float4(a0.x, a0.y, a0.z, a1.x);
+        r2 = make_float4(a1.y, a1.z, c0.x, c0.y);
+        r3 = make_float4(c0.z, c1.x, c1.y, c1.z);
+    }
+    rec[(size_t)i * 4] = r0; rec[(size_t)i * 4 + 1] = r1; rec[(size_t)i * 4 + 2] = r2; rec[(size_t)i * 4 + 3] = r3;
+    uint32_t depth = 0;
+    for (int p = (t.w & 0x3fffffff) - 1; p >= 0 && depth < 4096; p = (topo[p].w & 0x3fffffff) - 1) ++depth;
+    atomicMax(max_depth, depth);
+}
+
 // ================================================================================================
 //  launchers
 // ================================================================================================
@@ -1111,7 +1193,7 @@ template hipError_t launch_depth2cloud<uint16_t>(const uint16_t *, uint32_t, siz
                                                  float, float, float, float, bool, uint32_t *, uint32_t *, uint32_t *, pr_vec3 *,
                                                  size_t, bool, hipStream_t);
 
-template <class Scene, bool kNN>
+template <class Scene, bool kNN, int kStack = 0>
 static hipError_t launch_pass(const IcpBatch &b, const Scene &sc, uint32_t n_poses, size_t lds_bytes, hipStream_t s)
 {
     if (n_poses == 0 || b.nblk == 0) return hipSuccess;
@@ -1120,7 +1202,7 @@ static hipError_t launch_pass(const IcpBatch &b, const Scene &sc, uint32_t n_pos
         IcpBatch bb = b;
         bb.meta += p0;
         bb.partial += (size_t)p0 * b.nblk * kAccStride;
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(icp_pass_kernel<Scene, kNN>), dim3(b.nblk, np), dim3(kBlockThreads), lds_bytes, s, bb, sc);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(icp_pass_kernel<Scene, kNN, kStack>), dim3(b.nblk, np), dim3(kBlockThreads), lds_bytes, s, bb, sc);
     }
     return hipGetLastError();
 }
@@ -1129,7 +1211,11 @@ hipError_t launch_icp_pass_proj_aos(const IcpBatch &b, const SceneProjAoS &sc, u
 hipError_t launch_icp_pass_proj_packed(const IcpBatch &b, const SceneProjPacked &sc, uint32_t n_poses, hipStream_t s)
 { return launch_pass<SceneProjPacked, false>(b, sc, n_poses, 0, s); }
 hipError_t launch_icp_pass_nn(const IcpBatch &b, const SceneNNDev &sc, uint32_t n_poses, hipStream_t s)
-{ return launch_pass<SceneNNDev, true>(b, sc, n_poses, (size_t)sc.lds_nodes * sizeof(int4), s); }
+{
+    if (sc.stack_depth == 16) return launch_pass<SceneNNDev, true, 16>(b, sc, n_poses, (size_t)16 * kBlockThreads * 8, s);
+    if (sc.stack_depth == 24) return launch_pass<SceneNNDev, true, 24>(b, sc, n_poses, (size_t)24 * kBlockThreads * 8, s);
+    return launch_pass<SceneNNDev, true, 0>(b, sc, n_poses, (size_t)sc.lds_nodes * sizeof(int4), s);
+}
 
 hipError_t launch_icp_finalize(const float *partial, const PoseMeta *meta, uint32_t nblk,
                                uint32_t steps, float *sums, uint32_t n_poses, hipStream_t s)
@@ -1163,11 +1249,14 @@ hipError_t launch_pack_proj_scene(const pr_vec3 *pcd, const pr_vec3 *normal, flo
     return hipGetLastError();
 }
 hipError_t launch_build_nn_accel(const pr_kdnode *nodes, uint32_t n_nodes, const pr_vec3 *pcd, uint32_t n_points,
-                                 int4 *topo, float4 *bmin, float4 *bmax, float4 *pts, hipStream_t s)
+                                 int4 *topo, float4 *bmin, float4 *bmax, float4 *pts, float4 *rec, uint32_t *max_depth, hipStream_t s)
 {
     const uint32_t m = (n_nodes > n_points) ? n_nodes : n_points;
     if (m == 0) return hipSuccess;
     hipLaunchKernelGGL(nn_accel_kernel, dim3((m + 255) / 256), dim3(256), 0, s, nodes, n_nodes, pcd, n_points, topo, bmin, bmax, pts);
+    hipError_t e = hipMemsetAsync(max_depth, 0, sizeof(uint32_t), s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(nn_records_kernel, dim3((n_nodes + 255) / 256), dim3(256), 0, s, topo, bmin, bmax, n_nodes, rec, max_depth);
     return hipGetLastError();
 }
 

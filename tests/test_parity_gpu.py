@@ -258,3 +258,17 @@ def test_fused_raster_modes_agree(gpu, model, scenario, gscenes):
     assert out[0][0].tobytes() == out[1][0].tobytes()
     ref = O.render(scenario["tris"], poses[-3:], W, H, scenario["proj"])
     assert np.array_equal(out[0][1][-3:], (ref > 0).reshape(3, -1).sum(1))
+
+
+def test_nn_stack_and_stackless_traversals_agree(gpu, scenario, gscenes):
+    """The per-lane-stack kd query (default) and the reference-style stackless walk give bit-identical ICP
+    results (same winners, same tie-breaks) -- 21 passes on the test.cpp cloud."""
+    out = []
+    for mode in (1, 0):
+        api.set_option("nn_stack", mode)
+        dev = api.DeviceVector.from_host(scenario["cloud"].reshape(-1))
+        r = api.ICP_Point2Plane(dev, gscenes["nn"], api.ICPConvergenceCriteria(0.0, 0.0, 20))
+        out.append((r.transformation_.copy(), r.fitness_, r.inlier_rmse_, dev.to_host()))
+    api.set_option("nn_stack", 1)
+    assert np.array_equal(out[0][0], out[1][0]) and out[0][1] == out[1][1] and out[0][2] == out[1][2]
+    assert np.array_equal(out[0][3], out[1][3])
