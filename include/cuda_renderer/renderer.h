@@ -103,6 +103,67 @@ inline std::vector<int32_t> render_cuda(const std::vector<Model::Triangle> &tris
                                         size_t width, size_t height, const Model::mat4x4 &proj_mat, const Model::ROI roi = { 0, 0, 0, 0 })
 { device_vector_holder<Model::Triangle> d; d.upload(tris); return render_cuda(d, poses, width, height, proj_mat, roi); }
 
+// ---- CPU twin of the renderer (cuda_renderer/renderer.cpp:190-298): part of the reference API (test.cpp:50 renders the
+// scene with it).  Plain host code, same arithmetic as the device raster; never used as a fallback by the device path.
+namespace detail {
+inline Model::float3 mul3(const Model::mat4x4 &m, const Model::float3 &v)          // renderer.h:296-303 mat_mul_v
+{ return { m.a0 * v.x + m.a1 * v.y + m.a2 * v.z + m.a3, m.b0 * v.x + m.b1 * v.y + m.b2 * v.z + m.b3, m.c0 * v.x + m.c1 * v.y + m.c2 * v.z + m.c3 }; }
+inline float pick_max(float a, float b) { return (a > b) ? a : b; }
+inline float pick_min(float a, float b) { return (a < b) ? a : b; }
+inline float half_cross(const float *A, const float *B, const float *C) { return 0.5f * ((C[0] - A[0]) * (B[1] - A[1]) - (B[0] - A[0]) * (C[1] - A[1])); }
+inline void raster_triangle_cpu(const Model::float3 clip[3], const float zc[3], int32_t *img, size_t width, size_t height, const Model::ROI &roi)
+{
+    float s[3][2];
+    for (int i = 0; i < 3; ++i) {
+        s[i][0] = clip[i].x / zc[i] * width / 2.0f + width / 2.0f;
+        s[i][1] = clip[i].y / zc[i] * height / 2.0f + height / 2.0f;
+    }
+    float lo[2] = { 3.402823466e+38f, 3.402823466e+38f }, hi[2] = { -3.402823466e+38f, -3.402823466e+38f };
+    float cmin[2] = { 0, 0 }, cmax[2] = { float(width - 1), float(height - 1) };
+    size_t out_w = width;
+    if (roi.width > 0 && roi.height > 0) {
+        cmin[0] = roi.x; cmin[1] = height - 1 - (roi.y + roi.height - 1);
+        cmax[0] = (roi.x + roi.width) - 1; cmax[1] = height - 1 - roi.y;
+        out_w = roi.width;
+    }
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 2; ++j) {
+        lo[j] = pick_max(cmin[j], pick_min(lo[j], s[i][j]));
+        hi[j] = pick_min(cmax[j], pick_max(hi[j], s[i][j]));
+    }
+    const float area = half_cross(s[0], s[1], s[2]);
+    if (!(area != 0.0f)) return;                                   // zero-area triangles are skipped (DESIGN.md deviations)
+    const float inv = 1 / area;
+    if (!(lo[0] + 0.5f >= 0.0f) || !(lo[1] + 0.5f >= 0.0f)) return; // NaN boxes draw nothing
+    for (size_t y = size_t(lo[1] + 0.5f); y <= hi[1]; ++y)
+        for (size_t x = size_t(lo[0] + 0.5f); x <= hi[0]; ++x) {
+            float P[2] = { float(x), float(y) };
+            const float beta = half_cross(s[0], P, s[2]) * inv, gamma = half_cross(s[0], s[1], P) * inv, alpha = 1.0f - beta - gamma;
+            if (alpha < -0.0f || beta < -0.0f || gamma < -0.0f || alpha > 1.0f || beta > 1.0f || gamma > 1.0f) continue;
+            const float frag = (alpha + beta + gamma) / (alpha / zc[0] + beta / zc[1] + gamma / zc[2]);
+            const int32_t d = int32_t(frag + 0.5f);
+            int32_t &cell = img[(x - roi.x) + (height - 1 - y - roi.y) * out_w];
+            if (d < cell) cell = d;
+        }
+}
+}  // namespace detail
+
+inline std::vector<int32_t> render_cpu(const std::vector<Model::Triangle> &tris, const std::vector<Model::mat4x4> &poses, size_t width,
+                                       size_t height, const Model::mat4x4 &proj_mat, const Model::ROI roi = { 0, 0, 0, 0 })
+{
+    const size_t px = detail::out_pixels(width, height, roi);
+    std::vector<int32_t> depth(poses.size() * px, 2147483647);
+#pragma omp parallel for
+    for (long i = 0; i < (long)poses.size(); ++i)
+        for (const auto &t : tris) {
+            const Model::float3 cam[3] = { detail::mul3(poses[i], t.v0), detail::mul3(poses[i], t.v1), detail::mul3(poses[i], t.v2) };
+            const float zc[3] = { cam[0].z, cam[1].z, cam[2].z };
+            const Model::float3 clip[3] = { detail::mul3(proj_mat, cam[0]), detail::mul3(proj_mat, cam[1]), detail::mul3(proj_mat, cam[2]) };
+            detail::raster_triangle_cpu(clip, zc, depth.data() + (size_t)i * px, width, height, roi);
+        }
+    for (auto &d : depth) if (d == 2147483647) d = 0;
+    return depth;
+}
+
 template <typename... Params> Int_holder render(Params &&...p) { return render_cuda_keep_in_gpu(std::forward<Params>(p)...); }          // renderer.h:230-238
 template <typename... Params> std::vector<int32_t> render_host(Params &&...p) { return render_cuda(std::forward<Params>(p)...); }      // renderer.h:240-248
 

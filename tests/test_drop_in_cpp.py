@@ -41,3 +41,28 @@ def test_drop_in_driver_matches_oracle(scenario):
         assert np.float32(got[key]["fitness"]) == ref["fitness"]
         assert np.allclose(np.array(got[key]["T"], np.float32), ref["T"], rtol=0, atol=1e-4)
         assert got[key]["rmse"] == pytest.approx(float(ref["inlier_rmse"]), rel=1e-6)
+
+
+def test_cpu_twins_match_survey_known_answers(golden_dir):
+    """render_cpu / depth2cloud_cpu / init_Scene_*_cpu / ICP_Point2Plane_cpu of the adapter headers (the CPU half of
+    test.cpp:48-129) reproduce the reference's known answers -- no GPU involved."""
+    from pose_refine_amd import build
+    build.build()
+    lib_dir = os.path.join(ROOT, "pose_refine_amd", "lib")
+    exe = os.path.join(ROOT, "tests", "cpp", "cpu_twins_test")
+    subprocess.run(["g++", "-std=c++14", "-O2", "-Wall", "-I" + os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "cpp", "cpu_twins_test.cpp"), "-o", exe,
+                    "-L" + lib_dir, "-lpose_refine_hip", "-Wl,-rpath," + lib_dir], check=True)
+    out = subprocess.run([exe, golden_dir + "/"], check=True, capture_output=True, text=True).stdout
+    got = json.loads(out[out.index("{"):])
+    with open(os.path.join(golden_dir, "survey_8c.json")) as f:
+        gold = json.load(f)
+    assert got["depth_sum"] == [gold["render"][0]["sum"], gold["render"][1]["sum"]]
+    assert got["cloud_points"] == gold["cloud_points"] and got["kd_nodes"] == gold["kdtree"]["nodes"]
+    for key in ("proj_default", "nn_default"):
+        g = gold["icp"][key]
+        assert int(round(got[key]["fitness"] * gold["cloud_points"])) == g["inliers"]
+        assert got[key]["rmse"] == pytest.approx(g["rmse"], rel=1e-6)
+        T = np.array(got[key]["T"], np.float32).reshape(4, 4)
+        for r, row in enumerate(g["T_rows"]):
+            assert np.allclose(T[r], np.array(row, np.float32), rtol=0, atol=1e-6)
