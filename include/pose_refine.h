@@ -152,7 +152,7 @@ int pr_refine_batch_dev(const pr_triangle *tris_dev, size_t n_tris, const pr_mat
 void pr_shard_range(uint32_t n_items, uint32_t rank, uint32_t world, uint32_t *first, uint32_t *count);
 
 /* ---- options / instrumentation ----------------------------------------------------------------- */
-int  pr_set_option(const char *name, int value);    /* "solve" = PR_SOLVE_HOST|PR_SOLVE_DEVICE, "points_per_block", "profile", "nn_lds_nodes", "raster_mode" (fused path: 0 = global atomicMin inside the pose box, 1 = LDS depth bands), "pose_groups" (1|2 streams in the device-solve loop), "graph" (device solve: replay the iteration loop as a hipGraph) */
+int  pr_set_option(const char *name, int value);    /* "solve" = PR_SOLVE_HOST|PR_SOLVE_DEVICE, "points_per_block", "profile", "nn_lds_nodes", "raster_mode" (fused path: 0 = global atomicMin inside the pose box, 1 = LDS depth bands), "pose_groups" (1|2 streams in the device-solve loop), "graph" (device solve: replay the iteration loop as a hipGraph), "icp_flow" (device solve: 1 = one persistent dataflow launch, 0 = launch per pass), "nn_stack" */
 int  pr_get_option(const char *name, int *value);
 /* HIP-event timing of the correspondence kernel on the library stream: option "profile" = 1 times
  * every launch, 2 times one launch per call at a rotating iteration index (negligible overhead).

@@ -86,14 +86,16 @@ struct Ctx {
     int profile = 0;
     int nn_lds_nodes = 1024;
     int nn_stack = 1;                // kd-tree query: per-lane LDS stack (1) or the reference's stackless walk (0)
-    int use_graph = 0;               // PR_SOLVE_DEVICE: capture the whole iteration loop in a hipGraph and replay it (measured: no gain over
-                                     // direct launches, and the two pose-group branches do not overlap inside a graph) -- opt-in
+    int icp_flow = 0;                // PR_SOLVE_DEVICE: 1 = one persistent dataflow launch for all iterations (bit-identical; measured equal at
+                                     // 256 poses and 35 % slower at 1024), 0 = one launch per pass + per solve
+    int use_graph = 1;               // PR_SOLVE_DEVICE: capture the whole iteration loop in a hipGraph and replay it: 2 % on a fast host, up to
+                                     // 25 % on a slow one (44 launches/step); calls that time a launch with HIP events use direct launches
     int raster_mode = 0;             // fused path: 0 = global atomicMin inside the per-pose pixel box (reference scheme), 1 = LDS depth bands
     int n_cus = 256;
     const void *aabb_key = nullptr; size_t aabb_n = 0;
     // workspaces
-    DevBuf aabb, bbox, poses, depth, row_count, row_off, counts, cloud, meta, partial, sums, rec, topo, bmin, bmax, pts, nnrec, nndepth, dstate, dresults;
-    PinBuf h_sums, h_meta, h_counts, h_results, h_dstate;
+    DevBuf aabb, bbox, poses, depth, row_count, row_off, counts, cloud, meta, partial, sums, rec, topo, bmin, bmax, pts, nnrec, nndepth, dstate, dresults, vbdesc, flowsync;
+    PinBuf h_sums, h_meta, h_counts, h_results, h_dstate, h_flow;
     // profiling
     std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
     struct Span { size_t e0, e1; int kind; };
@@ -287,8 +289,59 @@ int icp_drive(pr_vec3 *cloud_base, const uint32_t *start_h, const uint32_t *coun
         if (!dres) { PR_TRY(g.dresults.ensure(sizeof(pr_result) * P)); dres = g.dresults.as<pr_result>(); }
         const bool may_exit_early = (crit.relative_fitness > 0.0f && crit.relative_rmse > 0.0f);
 
+        if (g.icp_flow) {
+            // ---- dataflow path: one persistent launch runs every iteration of every hypothesis ------------------
+            std::vector<uint2> desc;
+            desc.reserve((size_t)P * std::max(1u, nblk));
+            for (uint32_t i = 0; i < P; ++i) {
+                const uint32_t nb = (count_h[i] + ppb - 1) / ppb;
+                for (uint32_t gi = 0; gi < nb; ++gi) desc.push_back(make_uint2(i, gi));
+            }
+            const uint32_t n_vbs = (uint32_t)desc.size();
+            const size_t sync_words = (size_t)2 * P + 1;
+            PR_TRY(g.vbdesc.ensure(sizeof(uint2) * std::max<size_t>(1, n_vbs)));
+            PR_TRY(g.flowsync.ensure(sizeof(uint32_t) * sync_words));
+            PR_TRY(g.h_flow.ensure(sizeof(uint2) * std::max<size_t>(1, n_vbs) + sizeof(uint32_t) * (sync_words + 1)));
+            uint32_t *h_sync = g.h_flow.as<uint32_t>();
+            uint2 *h_desc = reinterpret_cast<uint2 *>(h_sync + ((sync_words + 2) & ~(size_t)1));
+            for (uint32_t i = 0; i < P; ++i) { h_sync[i] = 0; h_sync[P + i] = (h_meta[i].state == prk::kSkip) ? 0xffffffffu : 0u; }
+            h_sync[2 * P] = 0;
+            if (n_vbs) std::memcpy(h_desc, desc.data(), sizeof(uint2) * n_vbs);
+            HIP_TRY(hipMemcpyAsync(g.dstate.p, init, sizeof(prk::DevIcpState) * P, hipMemcpyHostToDevice, g.stream));
+            HIP_TRY(hipMemcpyAsync(g.meta.p, h_meta, sizeof(prk::PoseMeta) * P, hipMemcpyHostToDevice, g.stream));
+            HIP_TRY(hipMemcpyAsync(g.flowsync.p, h_sync, sizeof(uint32_t) * sync_words, hipMemcpyHostToDevice, g.stream));
+            if (n_vbs) {
+                HIP_TRY(hipMemcpyAsync(g.vbdesc.p, h_desc, sizeof(uint2) * n_vbs, hipMemcpyHostToDevice, g.stream));
+                prk::FlowArgs fa{};
+                fa.cloud = cloud_base; fa.meta = g.meta.as<prk::PoseMeta>(); fa.partial = g.partial.as<float>();
+                fa.st = g.dstate.as<prk::DevIcpState>(); fa.vb_desc = g.vbdesc.as<uint2>();
+                fa.arrive = g.flowsync.as<uint32_t>(); fa.ready = fa.arrive + P; fa.abort_flag = fa.arrive + 2 * P;
+                fa.n_vbs = n_vbs; fa.nblk = nblk; fa.steps = steps; fa.crit = crit;
+                uint32_t grid = 0;
+                SpanGuard sp(kSpanIcp);
+                if (sc.kind == PR_SCENE_NN) HIP_TRY(prk::launch_icp_flow_nn(fa, sc.nn, (uint32_t)g.n_cus, g.stream, &grid));
+                else if (sc.packed) HIP_TRY(prk::launch_icp_flow_proj_packed(fa, sc.pk, (uint32_t)g.n_cus, g.stream, &grid));
+                else HIP_TRY(prk::launch_icp_flow_proj_aos(fa, sc.aos, (uint32_t)g.n_cus, g.stream, &grid));
+                if (g.profile) {                                  // one launch = all passes: 36 B/point on pass 0, 48 B/point afterwards
+                    g.icp_points += sum_n * (uint64_t)(crit.max_iteration + 1);
+                    g.icp_bytes += sum_n * (36ull + 48ull * (uint64_t)crit.max_iteration);
+                }
+            }
+            HIP_TRY(prk::launch_pack_results(g.dstate.as<prk::DevIcpState>(), dres, P, g.stream));
+            if (results_host) HIP_TRY(hipMemcpyAsync(res, dres, sizeof(pr_result) * P, hipMemcpyDeviceToHost, g.stream));
+            HIP_TRY(hipMemcpyAsync(h_sync + 2 * P, g.flowsync.as<uint32_t>() + 2 * P, sizeof(uint32_t), hipMemcpyDeviceToHost, g.stream));
+            HIP_TRY(hipStreamSynchronize(g.stream));
+            drain_spans();
+            if (h_sync[2 * P] != 0) { set_error("dataflow ICP kernel timed out waiting on a hypothesis (workgroups not co-resident?)"); return PR_ERR_HIP; }
+            if (results_host) std::memcpy(results_host, res, sizeof(pr_result) * P);
+            return PR_OK;
+        }
+
         // profile==2: time ONE correspondence launch per call, at an iteration index that rotates from call to call
-        const uint32_t sample_it = (uint32_t)((g.sample_clock++ * 5 + 1) % (uint64_t)(crit.max_iteration + 1));
+        // (and only every 8th call, so that the other calls can replay the captured graph)
+        const uint64_t tick = g.sample_clock++;
+        const bool sample_call = (g.profile == 2) && (tick % 8 == 0);
+        const uint32_t sample_it = (uint32_t)(((tick / 8) * 5 + 1) % (uint64_t)(crit.max_iteration + 1));
         // the fixed sequence: state upload, (max_iteration+1) x [correspondence pass, finalize+solve], result pack
         auto enqueue_all = [&](std::vector<hipEvent_t> *, bool host_checks) -> int {
             HIP_TRY(hipMemcpyAsync(g.dstate.p, init, sizeof(prk::DevIcpState) * P, hipMemcpyHostToDevice, g.stream));
@@ -304,7 +357,7 @@ int icp_drive(pr_vec3 *cloud_base, const uint32_t *start_h, const uint32_t *coun
                     hipStream_t st = grp ? g.stream2 : g.stream;
                     prk::IcpBatch bb = b;
                     bb.meta += p0; bb.partial += (size_t)p0 * nblk * prk::kAccStride;
-                    if (grp == 0 && (g.profile == 1 || (g.profile == 2 && it == sample_it))) {
+                    if (grp == 0 && (g.profile == 1 || (sample_call && it == sample_it))) {
                         SpanGuard sp(kSpanIcp); HIP_TRY(launch_pass(bb, sc, np, st));
                         uint64_t pts = 0; for (uint32_t i = p0; i < p0 + np; ++i) pts += count_h[i];
                         g.icp_points += pts; g.icp_bytes += pts * (it == 0 ? 36u : 48u);
@@ -328,7 +381,7 @@ int icp_drive(pr_vec3 *cloud_base, const uint32_t *start_h, const uint32_t *coun
             return PR_OK;
         };
 
-        if (g.use_graph && g.profile == 0) {                    // HIP events recorded inside a captured graph cannot be timed: profile => direct launches
+        if (g.use_graph && g.pose_groups < 2 && (g.profile == 0 || (g.profile == 2 && !sample_call))) {   // HIP events recorded inside a captured graph cannot be timed
             GraphKey key;
             key.add(P); key.add(nblk); key.add(steps); key.add(crit); key.add(sc); key.add(cloud_base); key.add(g.meta.p); key.add(g.partial.p);
             key.add(g.dstate.p); key.add(dres); key.add(results_host != nullptr); key.add(res); key.add(h_meta); key.add(init); key.add(g.profile); key.add(g.pose_groups);
@@ -553,8 +606,8 @@ int pr_shutdown(void)
     if (!g.ready) return PR_OK;
     hipStreamSynchronize(g.stream);
     for (DevBuf *b : { &g.aabb, &g.bbox, &g.poses, &g.depth, &g.row_count, &g.row_off, &g.counts, &g.cloud, &g.meta, &g.partial,
-                       &g.sums, &g.rec, &g.topo, &g.bmin, &g.bmax, &g.pts, &g.nnrec, &g.nndepth, &g.dstate, &g.dresults }) b->release();
-    for (PinBuf *b : { &g.h_sums, &g.h_meta, &g.h_counts, &g.h_results, &g.h_dstate }) b->release();
+                       &g.sums, &g.rec, &g.topo, &g.bmin, &g.bmax, &g.pts, &g.nnrec, &g.nndepth, &g.dstate, &g.dresults, &g.vbdesc, &g.flowsync }) b->release();
+    for (PinBuf *b : { &g.h_sums, &g.h_meta, &g.h_counts, &g.h_results, &g.h_dstate, &g.h_flow }) b->release();
     drop_graphs();
     for (hipEvent_t e : g.ev_pool) hipEventDestroy(e);
     g.ev_pool.clear(); g.ev_used = 0; g.spans.clear();
@@ -713,6 +766,7 @@ int pr_set_option(const char *name, int value)
     else if (n == "nn_lds_nodes") g.nn_lds_nodes = std::max(0, value);
     else if (n == "nn_stack") g.nn_stack = value ? 1 : 0;
     else if (n == "graph") g.use_graph = value ? 1 : 0;
+    else if (n == "icp_flow") g.icp_flow = value ? 1 : 0;
     else if (n == "pose_groups") g.pose_groups = (value >= 2) ? 2 : 1;
     else if (n == "raster_mode") { if (value != 0 && value != 1) { set_error("raster_mode must be 0 or 1"); return PR_ERR_INVALID; } g.raster_mode = value; }
     else { set_error("unknown option %s", name); return PR_ERR_INVALID; }
@@ -730,6 +784,7 @@ int pr_get_option(const char *name, int *value)
     else if (n == "nn_stack") *value = g.nn_stack;
     else if (n == "raster_mode") *value = g.raster_mode;
     else if (n == "graph") *value = g.use_graph;
+    else if (n == "icp_flow") *value = g.icp_flow;
     else if (n == "pose_groups") *value = g.pose_groups;
     else { set_error("unknown option %s", name); return PR_ERR_INVALID; }
     return PR_OK;
@@ -738,7 +793,7 @@ int pr_get_option(const char *name, int *value)
 int pr_profile_reset(void)
 {
     std::lock_guard<std::mutex> lk(g_mu);
-    g.icp_ms = g.render_ms = g.cloud_ms = 0; g.icp_launches = g.icp_points = g.icp_bytes = 0;
+    g.icp_ms = g.render_ms = g.cloud_ms = 0; g.icp_launches = g.icp_points = g.icp_bytes = 0; g.sample_clock = 0;
     return PR_OK;
 }
 int pr_profile_read(double *kernel_ms, uint64_t *launches, uint64_t *points, uint64_t *algorithmic_bytes, double *render_ms, double *cloud_ms)

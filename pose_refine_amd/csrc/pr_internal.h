@@ -73,6 +73,20 @@ struct DevIcpState {
     int32_t passes;
 };
 
+// arguments of the persistent dataflow ICP kernel (icp_flow_kernel)
+struct FlowArgs {
+    pr_vec3       *cloud;
+    PoseMeta      *meta;        // [P]   read/written through system-scope accesses inside the kernel
+    float         *partial;     // [P][nblk][kAccStride]
+    DevIcpState   *st;          // [P]
+    const uint2   *vb_desc;     // [n_vbs] {pose, g}: the virtual workgroups of the canonical tree, pose-major
+    uint32_t      *arrive;      // [P] zeroed before launch: partial sums delivered so far (monotonic over iterations)
+    uint32_t      *ready;       // [P] zeroed (0xffffffff for empty clouds): iterations whose update is published
+    uint32_t      *abort_flag;  // [1] zeroed; set when a bounded spin times out
+    uint32_t       n_vbs, nblk, steps;
+    pr_criteria    crit;
+};
+
 // ---- launchers (all asynchronous on `s`) ----------------------------------------------------------
 hipError_t launch_fill_i32(int32_t *dst, size_t n, int32_t v, hipStream_t s);
 hipError_t launch_raster(const pr_triangle *tris, uint32_t n_tris, const pr_mat4 *poses_dev, uint32_t n_poses,
@@ -103,6 +117,9 @@ hipError_t launch_emit_box(const int32_t *depth, uint32_t n_poses, uint32_t widt
 hipError_t launch_icp_pass_proj_aos(const IcpBatch &b, const SceneProjAoS &sc, uint32_t n_poses, hipStream_t s);
 hipError_t launch_icp_pass_proj_packed(const IcpBatch &b, const SceneProjPacked &sc, uint32_t n_poses, hipStream_t s);
 hipError_t launch_icp_pass_nn(const IcpBatch &b, const SceneNNDev &sc, uint32_t n_poses, hipStream_t s);
+hipError_t launch_icp_flow_proj_aos(const FlowArgs &a, const SceneProjAoS &sc, uint32_t n_cus, hipStream_t s, uint32_t *grid_out);
+hipError_t launch_icp_flow_proj_packed(const FlowArgs &a, const SceneProjPacked &sc, uint32_t n_cus, hipStream_t s, uint32_t *grid_out);
+hipError_t launch_icp_flow_nn(const FlowArgs &a, const SceneNNDev &sc, uint32_t n_cus, hipStream_t s, uint32_t *grid_out);
 hipError_t launch_icp_finalize(const float *partial, const PoseMeta *meta, uint32_t nblk,
                                uint32_t steps, float *sums, uint32_t n_poses, hipStream_t s);
 // PR_SOLVE_DEVICE: finalize + convergence test + 6x6 solve + state update in one kernel

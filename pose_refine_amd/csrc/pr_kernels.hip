@@ -771,46 +771,16 @@ __device__ __forceinline__ float wave_tree_sum(float v)
 #ifndef PR_PASS_WAVES
 #define PR_PASS_WAVES 1
 #endif
-template <class Scene, bool kNN, int kStack = 0>
-__global__ __launch_bounds__(256, PR_PASS_WAVES) void icp_pass_kernel(IcpBatch b, Scene scene)
+
+// One virtual workgroup of the canonical tree: accumulate the 29 sums of points [first, first + steps*1024) of one
+// cloud into the lane's registers (pending transform applied and written back first when xf).
+template <class Scene, bool kNN, int kStack>
+__device__ __forceinline__ void vb_accumulate(float (&acc)[29], float *cl, uint32_t n, uint32_t first, uint32_t steps, bool xf,
+                                              const float (&M)[12], const Scene &scene, const int4 *lds_topo, int *stk_node, float *stk_lb)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    __shared__ float wsum[4][kAccStride];
-
-    const uint32_t pose = blockIdx.y;
-    const PoseMeta &pm = b.meta[pose];                           // uniform address: one 64-byte scalar load
-    const int32_t st = pm.state;
-    if (st == kSkip) return;
-    const uint32_t n = pm.count;
-    const uint32_t ppb = b.steps * kPointsPerStep;
-    const uint32_t first = blockIdx.x * ppb;
-    if (first >= n) return;
-
-    const int4 *lds_topo = nullptr;
-    int *stk_node = nullptr; float *stk_lb = nullptr;
-    if constexpr (kNN && kStack == 0) {
-        int4 *dst = reinterpret_cast<int4 *>(lds_raw);
-        for (uint32_t i = threadIdx.x; i < scene.lds_nodes; i += kBlockThreads) dst[i] = scene.topo[i];
-        __syncthreads();
-        lds_topo = dst;
-    }
-    if constexpr (kNN && kStack > 0) {                           // per-lane stacks: [entry][lane]
-        stk_node = reinterpret_cast<int *>(lds_raw) + threadIdx.x;
-        stk_lb = reinterpret_cast<float *>(lds_raw) + (size_t)kStack * kBlockThreads + threadIdx.x;
-    }
-    (void)lds_topo; (void)stk_node; (void)stk_lb;
-
-    float *cl = reinterpret_cast<float *>(b.cloud + pm.start);
     const bool vec_ok = ((reinterpret_cast<uintptr_t>(cl) & 15u) == 0);
-    const bool xf = (st == kRunWithTransform);
-    float M[12];
-#pragma unroll
-    for (int i = 0; i < 12; ++i) M[i] = xf ? pm.xform[i] : 0.0f;
-
-    float acc[29];
-#pragma unroll
-    for (int i = 0; i < 29; ++i) acc[i] = 0.0f;
-
+    struct { uint32_t steps; } b{ steps };
+    (void)lds_topo; (void)stk_node; (void)stk_lb;
     // one 1024-point step of this lane: 4 consecutive points = 48 contiguous bytes
     auto load_step = [&](uint32_t s, float (&p)[12], uint32_t &j0, uint32_t &cnt, bool &full) {
         j0 = first + s * kPointsPerStep + threadIdx.x * kPointsPerLane;
@@ -893,7 +863,12 @@ __global__ __launch_bounds__(256, PR_PASS_WAVES) void icp_pass_kernel(IcpBatch b
         process_step(p, j0, cnt, full);
     }
 
-    // canonical tree: wave (balanced pairwise over lanes) -> ((w0+w1)+w2)+w3
+}
+
+// canonical tree, second half: wave (balanced pairwise over lanes) -> ((w0+w1)+w2)+w3.  Returns, in threads 0..28, the
+// workgroup sum of component threadIdx.x.  Contains one __syncthreads().
+__device__ __forceinline__ float vb_reduce(float (&acc)[29], float (*wsum)[kAccStride])
+{
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #ifdef PR_ABL_NOREDUCE
     { float t = 0; for (int i = 0; i < 29; ++i) t += acc[i]; if (lane == 63) wsum[wave][0] = t; }
@@ -905,10 +880,55 @@ __global__ __launch_bounds__(256, PR_PASS_WAVES) void icp_pass_kernel(IcpBatch b
     }
 #endif
     __syncthreads();
-    if (threadIdx.x < 29) {
-        const float t = ((wsum[0][threadIdx.x] + wsum[1][threadIdx.x]) + wsum[2][threadIdx.x]) + wsum[3][threadIdx.x];
-        b.partial[((size_t)pose * b.nblk + blockIdx.x) * kAccStride + threadIdx.x] = t;
+    float t = 0.0f;
+    if (threadIdx.x < 29) t = ((wsum[0][threadIdx.x] + wsum[1][threadIdx.x]) + wsum[2][threadIdx.x]) + wsum[3][threadIdx.x];
+    return t;
+}
+
+// ================================================================================================
+//  THE hot kernel: pending transform + correspondence + 29-term transform-reduce, all hypotheses
+//  of a batch in one launch.  grid = (workgroups per hypothesis, hypotheses), 256 lanes.
+// ================================================================================================
+template <class Scene, bool kNN, int kStack = 0>
+__global__ __launch_bounds__(256, PR_PASS_WAVES) void icp_pass_kernel(IcpBatch b, Scene scene)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    __shared__ float wsum[4][kAccStride];
+
+    const uint32_t pose = blockIdx.y;
+    const PoseMeta &pm = b.meta[pose];                           // uniform address: one 64-byte scalar load
+    const int32_t st = pm.state;
+    if (st == kSkip) return;
+    const uint32_t n = pm.count;
+    const uint32_t ppb = b.steps * kPointsPerStep;
+    const uint32_t first = blockIdx.x * ppb;
+    if (first >= n) return;
+
+    const int4 *lds_topo = nullptr;
+    int *stk_node = nullptr; float *stk_lb = nullptr;
+    if constexpr (kNN && kStack == 0) {
+        int4 *dst = reinterpret_cast<int4 *>(lds_raw);
+        for (uint32_t i = threadIdx.x; i < scene.lds_nodes; i += kBlockThreads) dst[i] = scene.topo[i];
+        __syncthreads();
+        lds_topo = dst;
     }
+    if constexpr (kNN && kStack > 0) {                           // per-lane stacks: [entry][lane]
+        stk_node = reinterpret_cast<int *>(lds_raw) + threadIdx.x;
+        stk_lb = reinterpret_cast<float *>(lds_raw) + (size_t)kStack * kBlockThreads + threadIdx.x;
+    }
+
+    float *cl = reinterpret_cast<float *>(b.cloud + pm.start);
+    const bool xf = (st == kRunWithTransform);
+    float M[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) M[i] = xf ? pm.xform[i] : 0.0f;
+
+    float acc[29];
+#pragma unroll
+    for (int i = 0; i < 29; ++i) acc[i] = 0.0f;
+    vb_accumulate<Scene, kNN, kStack>(acc, cl, n, first, b.steps, xf, M, scene, lds_topo, stk_node, stk_lb);
+    const float t = vb_reduce(acc, wsum);
+    if (threadIdx.x < 29) b.partial[((size_t)pose * b.nblk + blockIdx.x) * kAccStride + threadIdx.x] = t;
 }
 
 // second stage: workgroup sums added sequentially in workgroup order, starting from 0
@@ -931,6 +951,35 @@ __global__ __launch_bounds__(64) void icp_finalize_kernel(const float *__restric
         sums[(size_t)pose * kAccStride + threadIdx.x] = (threadIdx.x < 29) ? sum_partials(partial, pose, nblk, used, threadIdx.x) : 0.0f;
 }
 
+// The per-iteration host logic of icp.cu:178-212 for one hypothesis, on the 29 reduced sums: scores, convergence test,
+// 6x6 solve, accumulation of the transform.  Returns true when the hypothesis is finished; otherwise E holds the update.
+__device__ __forceinline__ bool pose_iteration(const float *Ab, uint32_t n, DevIcpState &s, const pr_criteria &crit, uint32_t iter, float (&E)[16])
+{
+    s.passes += 1;
+    const float cnt = Ab[28], err = Ab[27];
+    if (cnt == 0) return true;                                               // icp.cu:183
+    const float prev_fit = s.fitness, prev_rmse = s.rmse;
+    s.fitness = cnt / (float)n;                                              // icp.cu:185
+    s.rmse = sqrtf(err / cnt);                                               // icp.cu:186
+    if (iter == (uint32_t)crit.max_iteration) return true;                   // icp.cu:189
+    const float df = s.fitness - prev_fit, dr = s.rmse - prev_rmse;
+    if (((df < 0) ? -df : df) < crit.relative_fitness && ((dr < 0) ? -dr : dr) < crit.relative_rmse) return true;   // icp.cu:191-194
+    float A[36], bb[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) bb[i] = Ab[21 + i];
+    {
+        int k = 0;
+#pragma unroll
+        for (int y = 0; y < 6; ++y) {
+#pragma unroll
+            for (int x = y; x < 6; ++x) { A[x + y * 6] = Ab[k]; A[y + x * 6] = Ab[k]; ++k; }
+        }
+    }
+    prs::solve_666_impl(A, bb, E);
+    prs::mat4_mul_impl(E, s.T, s.T);                                         // icp.cu:212
+    return false;
+}
+
 // PR_SOLVE_DEVICE: the per-iteration host logic of icp.cu:178-212 for one hypothesis per wavefront
 __global__ __launch_bounds__(64) void icp_finalize_solve_kernel(const float *__restrict__ partial, PoseMeta *__restrict__ meta,
                                                                 uint32_t nblk, uint32_t ppb, DevIcpState *__restrict__ st,
@@ -946,37 +995,11 @@ __global__ __launch_bounds__(64) void icp_finalize_solve_kernel(const float *__r
     if (threadIdx.x != 0) return;
 
     DevIcpState s = st[pose];
-    s.passes += 1;
-    const float cnt = Ab[28], err = Ab[27];
-    bool finished = false;
-    if (cnt == 0) finished = true;                                           // icp.cu:183
+    float E[16];
+    if (pose_iteration(Ab, n, s, crit, iter, E)) { s.done = 1; meta[pose].state = kSkip; }
     else {
-        const float prev_fit = s.fitness, prev_rmse = s.rmse;
-        s.fitness = cnt / (float)n;                                          // icp.cu:185
-        s.rmse = sqrtf(err / cnt);                                           // icp.cu:186
-        if (iter == (uint32_t)crit.max_iteration) finished = true;           // icp.cu:189
-        else {
-            const float df = s.fitness - prev_fit, dr = s.rmse - prev_rmse;
-            if (((df < 0) ? -df : df) < crit.relative_fitness && ((dr < 0) ? -dr : dr) < crit.relative_rmse) finished = true;
-        }
-    }
-    if (finished) { s.done = 1; meta[pose].state = kSkip; }
-    else {
-        float A[36], bb[6], E[16];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) bb[i] = Ab[21 + i];
-        {
-            int k = 0;
-#pragma unroll
-            for (int y = 0; y < 6; ++y) {
-#pragma unroll
-                for (int x = y; x < 6; ++x) { A[x + y * 6] = Ab[k]; A[y + x * 6] = Ab[k]; ++k; }
-            }
-        }
-        prs::solve_666_impl(A, bb, E);
 #pragma unroll
         for (int i = 0; i < 12; ++i) meta[pose].xform[i] = E[i];
-        prs::mat4_mul_impl(E, s.T, s.T);
         meta[pose].state = kRunWithTransform;
     }
     st[pose] = s;
@@ -990,6 +1013,126 @@ __global__ void pack_results_kernel(const DevIcpState *__restrict__ st, pr_resul
     for (int k = 0; k < 16; ++k) r.T[k] = st[i].T[k];
     r.inlier_rmse = st[i].rmse; r.fitness = st[i].fitness;
     out[i] = r;
+}
+
+// ================================================================================================
+//  Dataflow ICP: ALL iterations of ALL hypotheses in one persistent launch.
+//
+//  The multi-launch loop serialises [pass over every pose] -> [solve of every pose] 21 times although pose i only ever
+//  waits for pose i: at 256 poses about a third of each pass and all of each solve launch is dependency latency.  Here
+//  every resident workgroup owns a fixed, strided set of virtual workgroups (pose, g) of the canonical tree and walks
+//  them iteration by iteration; the last workgroup to deliver a partial sum for a pose runs that pose's finalize + 6x6
+//  solve and publishes the update, everyone else picks it up when it next touches the pose.  Sums, solve and results are
+//  bit-identical to the multi-launch path (same tree, same code).
+//
+//  Cross-workgroup data (partials, PoseMeta, DevIcpState, counters) moves with system-scope (sc0 sc1) accesses, i.e.
+//  through memory, never through a possibly stale L1/L2 line; a producer drains its stores (s_waitcnt vmcnt(0)) before
+//  the arrival atomic / ready flag that publishes them (cdna_hip_programming.md G16, valid form "sc0 sc1 stores and loads
+//  both sides").  A cloud block is only ever touched by its owning workgroup, so plain accesses are fine there.
+//  Every spin is bounded; a timeout raises the abort flag and the whole grid drains.
+// ================================================================================================
+__device__ __forceinline__ uint32_t ld_sys_u32(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void st_sys_u32(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ float ld_sys_f32(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void st_sys_f32(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+
+template <class Scene, bool kNN, int kStack>
+__global__ __launch_bounds__(256, 5) void icp_flow_kernel(FlowArgs a, Scene scene)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    __shared__ float wsum[4][kAccStride];
+    __shared__ float Ab[kAccStride];
+    __shared__ uint32_t sm_meta[16];
+    __shared__ int sm_go;
+
+    const int4 *lds_topo = nullptr;
+    int *stk_node = nullptr; float *stk_lb = nullptr;
+    if constexpr (kNN && kStack == 0) {
+        int4 *dst = reinterpret_cast<int4 *>(lds_raw);
+        for (uint32_t i = threadIdx.x; i < scene.lds_nodes; i += kBlockThreads) dst[i] = scene.topo[i];
+        __syncthreads();
+        lds_topo = dst;
+    }
+    if constexpr (kNN && kStack > 0) {
+        stk_node = reinterpret_cast<int *>(lds_raw) + threadIdx.x;
+        stk_lb = reinterpret_cast<float *>(lds_raw) + (size_t)kStack * kBlockThreads + threadIdx.x;
+    }
+
+    const uint32_t ppb = a.steps * kPointsPerStep;
+    constexpr uint32_t kSpinLimit = 1u << 22;
+
+    for (uint32_t it = 0; it <= (uint32_t)a.crit.max_iteration; ++it) {
+        for (uint32_t v = blockIdx.x; v < a.n_vbs; v += gridDim.x) {
+            const uint2 d = a.vb_desc[v];                          // {pose, g}: uniform
+            const uint32_t pose = d.x, g = d.y;
+            if (threadIdx.x == 0) {
+                int go = 1;
+                uint32_t spins = 0;
+                while (ld_sys_u32(&a.ready[pose]) < it) {          // the solve that closes iteration it-1 of this pose
+                    __builtin_amdgcn_s_sleep(2);
+                    if (++spins > kSpinLimit || ((spins & 255u) == 0 && ld_sys_u32(a.abort_flag) != 0)) { st_sys_u32(a.abort_flag, 1u); go = -1; break; }
+                }
+                sm_go = go;
+            }
+            __syncthreads();
+            if (sm_go < 0) return;
+            if (threadIdx.x < 16) sm_meta[threadIdx.x] = ld_sys_u32(reinterpret_cast<const uint32_t *>(a.meta + pose) + threadIdx.x);
+            __syncthreads();
+            const uint32_t start = sm_meta[0], n = sm_meta[1];
+            const int32_t st = (int32_t)sm_meta[2];
+            const uint32_t first = g * ppb;
+            if (st != kSkip && first < n) {
+                const bool xf = (st == kRunWithTransform);
+                float M[12];
+#pragma unroll
+                for (int i = 0; i < 12; ++i) M[i] = __uint_as_float(__builtin_amdgcn_readfirstlane(sm_meta[4 + i]));
+                float acc[29];
+#pragma unroll
+                for (int i = 0; i < 29; ++i) acc[i] = 0.0f;
+                float *cl = reinterpret_cast<float *>(a.cloud + start);
+                vb_accumulate<Scene, kNN, kStack>(acc, cl, n, first, a.steps, xf, M, scene, lds_topo, stk_node, stk_lb);
+                const float t = vb_reduce(acc, wsum);
+                const uint32_t used = (n + ppb - 1) / ppb;
+                if (threadIdx.x < 29) st_sys_f32(&a.partial[((size_t)pose * a.nblk + g) * kAccStride + threadIdx.x], t);
+                if (threadIdx.x < 64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // wave 0 issued the stores
+                if (threadIdx.x == 0) {
+                    const uint32_t ticket = atomicAdd(&a.arrive[pose], 1u);
+                    sm_go = (ticket + 1u == used * (it + 1u)) ? 2 : 1;
+                }
+                __syncthreads();
+                if (sm_go == 2) {                                  // last arrival of this iteration: finalize + solve
+                    if (threadIdx.x < 29) {
+                        float total = 0.0f;
+                        const float *pp = a.partial + (size_t)pose * a.nblk * kAccStride + threadIdx.x;
+                        for (uint32_t k = 0; k < used; ++k) total += ld_sys_f32(pp + (size_t)k * kAccStride);
+                        Ab[threadIdx.x] = total;
+                    }
+                    __syncthreads();
+                    if (threadIdx.x == 0) {
+                        DevIcpState s;
+                        uint32_t *sw = reinterpret_cast<uint32_t *>(&s);
+                        uint32_t *gw = reinterpret_cast<uint32_t *>(a.st + pose);
+#pragma unroll
+                        for (uint32_t i = 0; i < sizeof(DevIcpState) / 4; ++i) sw[i] = ld_sys_u32(gw + i);
+                        float E[16];
+                        const bool finished = pose_iteration(Ab, n, s, a.crit, it, E);
+                        uint32_t *mw = reinterpret_cast<uint32_t *>(a.meta + pose);
+                        if (finished) { s.done = 1; st_sys_u32(mw + 2, (uint32_t)kSkip); }
+                        else {
+#pragma unroll
+                            for (int i = 0; i < 12; ++i) st_sys_f32(reinterpret_cast<float *>(mw + 4) + i, E[i]);
+                            st_sys_u32(mw + 2, (uint32_t)kRunWithTransform);
+                        }
+#pragma unroll
+                        for (uint32_t i = 0; i < sizeof(DevIcpState) / 4; ++i) st_sys_u32(gw + i, sw[i]);
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        st_sys_u32(&a.ready[pose], finished ? 0xffffffffu : it + 1u);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
 }
 
 // ================================================================================================
@@ -1215,6 +1358,33 @@ hipError_t launch_icp_pass_nn(const IcpBatch &b, const SceneNNDev &sc, uint32_t 
     if (sc.stack_depth == 16) return launch_pass<SceneNNDev, true, 16>(b, sc, n_poses, (size_t)16 * kBlockThreads * 8, s);
     if (sc.stack_depth == 24) return launch_pass<SceneNNDev, true, 24>(b, sc, n_poses, (size_t)24 * kBlockThreads * 8, s);
     return launch_pass<SceneNNDev, true, 0>(b, sc, n_poses, (size_t)sc.lds_nodes * sizeof(int4), s);
+}
+
+template <class Scene, bool kNN, int kStack>
+static hipError_t launch_flow_t(const FlowArgs &a, const Scene &sc, size_t lds_bytes, uint32_t n_cus, hipStream_t s, uint32_t *grid_out)
+{
+    int per_cu = 0;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(icp_flow_kernel<Scene, kNN, kStack>),
+                                                                (int)kBlockThreads, lds_bytes);
+    if (e != hipSuccess) return e;
+    if (per_cu < 1) return hipErrorInvalidValue;
+    if (per_cu > 8) per_cu = 8;
+    // every workgroup must be resident (they wait on each other): grid <= what one wave of dispatch can hold
+    uint32_t grid = n_cus * (uint32_t)per_cu;
+    if (grid > a.n_vbs) grid = a.n_vbs;
+    if (grid_out) *grid_out = grid;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(icp_flow_kernel<Scene, kNN, kStack>), dim3(grid), dim3(kBlockThreads), lds_bytes, s, a, sc);
+    return hipGetLastError();
+}
+hipError_t launch_icp_flow_proj_aos(const FlowArgs &a, const SceneProjAoS &sc, uint32_t n_cus, hipStream_t s, uint32_t *grid_out)
+{ return launch_flow_t<SceneProjAoS, false, 0>(a, sc, 0, n_cus, s, grid_out); }
+hipError_t launch_icp_flow_proj_packed(const FlowArgs &a, const SceneProjPacked &sc, uint32_t n_cus, hipStream_t s, uint32_t *grid_out)
+{ return launch_flow_t<SceneProjPacked, false, 0>(a, sc, 0, n_cus, s, grid_out); }
+hipError_t launch_icp_flow_nn(const FlowArgs &a, const SceneNNDev &sc, uint32_t n_cus, hipStream_t s, uint32_t *grid_out)
+{
+    if (sc.stack_depth == 16) return launch_flow_t<SceneNNDev, true, 16>(a, sc, (size_t)16 * kBlockThreads * 8, n_cus, s, grid_out);
+    if (sc.stack_depth == 24) return launch_flow_t<SceneNNDev, true, 24>(a, sc, (size_t)24 * kBlockThreads * 8, n_cus, s, grid_out);
+    return launch_flow_t<SceneNNDev, true, 0>(a, sc, (size_t)sc.lds_nodes * sizeof(int4), n_cus, s, grid_out);
 }
 
 hipError_t launch_icp_finalize(const float *partial, const PoseMeta *meta, uint32_t nblk,

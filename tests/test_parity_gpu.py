@@ -272,3 +272,23 @@ def test_nn_stack_and_stackless_traversals_agree(gpu, scenario, gscenes):
     api.set_option("nn_stack", 1)
     assert np.array_equal(out[0][0], out[1][0]) and out[0][1] == out[1][1] and out[0][2] == out[1][2]
     assert np.array_equal(out[0][3], out[1][3])
+
+
+@pytest.mark.parametrize("kind,P", [("proj", 70), ("nn", 5)])
+def test_dataflow_and_multilaunch_icp_agree_bitwise(gpu, model, scenario, gscenes, kind, P):
+    """The persistent dataflow kernel (all iterations in one launch, option icp_flow=1) and the launch-per-pass loop run the same
+    canonical tree and the same solver: results must be bit-identical, with fixed and with early-exit criteria."""
+    poses = synth.hypotheses(P)
+    api.set_option("solve", api.SOLVE_DEVICE)
+    try:
+        for crit in ((0.0, 0.0, 20), (1e-5, 1e-5, 30)):
+            out = []
+            for flow in (1, 0):
+                api.set_option("icp_flow", flow)
+                out.append(api.refine_batch(model, poses, W, H, scenario["proj"], scenario["K"], gscenes[kind],
+                                            api.ICPConvergenceCriteria(*crit)))
+            assert np.array_equal(out[0][1], out[1][1])
+            assert out[0][0].tobytes() == out[1][0].tobytes(), crit
+    finally:
+        api.set_option("icp_flow", 0)
+        api.set_option("solve", api.SOLVE_HOST)
