@@ -934,9 +934,16 @@ __global__ __launch_bounds__(256, PR_PASS_WAVES) void icp_pass_kernel(IcpBatch b
 // second stage: workgroup sums added sequentially in workgroup order, starting from 0
 __device__ __forceinline__ float sum_partials(const float *partial, uint32_t pose, uint32_t nblk, uint32_t used, uint32_t comp)
 {
+    // the loads of a chunk are independent and issued together; only the additions are ordered
     float total = 0.0f;
     const float *p = partial + (size_t)pose * nblk * kAccStride + comp;
-    for (uint32_t g = 0; g < used; ++g) total += p[(size_t)g * kAccStride];
+    for (uint32_t g0 = 0; g0 < used; g0 += 16) {
+        float v[16];
+#pragma unroll
+        for (uint32_t k = 0; k < 16; ++k) v[k] = (g0 + k < used) ? p[(size_t)(g0 + k) * kAccStride] : 0.0f;
+#pragma unroll
+        for (uint32_t k = 0; k < 16; ++k) if (g0 + k < used) total += v[k];
+    }
     return total;
 }
 
