@@ -42,7 +42,14 @@ struct Scene_projective {
         if (dst.z <= 0 || std__abs(src.z - dst.z) > max_dist_diff) return;
         valid = true; nrm = normal_ptr[idx];
     }
-    pr_scene_proj c_view() const { pr_scene_proj s; s.width = width; s.height = height; s.max_dist_diff = max_dist_diff;
-        for (int i = 0; i < 9; ++i) s.K[i] = K.data()[i]; s.pcd = reinterpret_cast<const pr_vec3 *>(pcd_ptr); s.normal = reinterpret_cast<const pr_vec3 *>(normal_ptr); return s; }
+    pr_scene_proj c_view() const
+    {
+        pr_scene_proj s;
+        s.width = width; s.height = height; s.max_dist_diff = max_dist_diff;
+        for (int i = 0; i < 9; ++i) s.K[i] = K.data()[i];
+        s.pcd = reinterpret_cast<const pr_vec3 *>(pcd_ptr);
+        s.normal = reinterpret_cast<const pr_vec3 *>(normal_ptr);
+        return s;
+    }
 };
 static_assert(sizeof(Scene_projective) == 72, "Scene_projective is passed by value; keep the reference's size");

@@ -3,6 +3,7 @@
 // scene graph members are gone (own ASCII-PLY reader behind pr_ply_load).
 #pragma once
 #include <cassert>
+#include <cstring>
 #include <iostream>
 #include <string>
 #include <utility>
@@ -152,7 +153,9 @@ inline std::vector<int32_t> render_cpu(const std::vector<Model::Triangle> &tris,
 {
     const size_t px = detail::out_pixels(width, height, roi);
     std::vector<int32_t> depth(poses.size() * px, 2147483647);
+#ifdef _OPENMP
 #pragma omp parallel for
+#endif
     for (long i = 0; i < (long)poses.size(); ++i)
         for (const auto &t : tris) {
             const Model::float3 cam[3] = { detail::mul3(poses[i], t.v0), detail::mul3(poses[i], t.v1), detail::mul3(poses[i], t.v2) };
@@ -162,6 +165,63 @@ inline std::vector<int32_t> render_cpu(const std::vector<Model::Triangle> &tris,
         }
     for (auto &d : depth) if (d == 2147483647) d = 0;
     return depth;
+}
+
+// ---- raw depth stack -> cv::Mat conversions (renderer.cu:354-439, renderer.cpp:300-366) ------------------------------------
+namespace detail {
+inline std::vector<cv::Mat> split_stack(const void *flat, size_t elem, int type, size_t width, size_t height, size_t poses)
+{
+    std::vector<cv::Mat> out(poses);
+    for (size_t i = 0; i < poses; ++i) {
+        out[i] = cv::Mat((int)height, (int)width, type);
+        std::memcpy(out[i].data, static_cast<const unsigned char *>(flat) + i * width * height * elem, width * height * elem);
+    }
+    return out;
+}
+}  // namespace detail
+inline std::vector<cv::Mat> raw2depth_uint16_cuda(device_vector_holder<int> &raw, size_t width, size_t height, size_t pose_size)
+{
+    assert(raw.size() == width * height * pose_size);
+    std::vector<uint16_t> d(raw.size());
+    detail::must(pr_raw2depth_mask(raw.data(), raw.size(), d.data(), nullptr));
+    return detail::split_stack(d.data(), 2, CV_16U, width, height, pose_size);
+}
+inline std::vector<cv::Mat> raw2mask_uint8_cuda(device_vector_holder<int> &raw, size_t width, size_t height, size_t pose_size)
+{
+    assert(raw.size() == width * height * pose_size);
+    std::vector<uint8_t> m(raw.size());
+    detail::must(pr_raw2depth_mask(raw.data(), raw.size(), nullptr, m.data()));
+    return detail::split_stack(m.data(), 1, CV_8U, width, height, pose_size);
+}
+inline std::vector<std::vector<cv::Mat>> raw2depth_mask_cuda(device_vector_holder<int> &raw, size_t width, size_t height, size_t pose_size)
+{
+    assert(raw.size() == width * height * pose_size);
+    std::vector<uint16_t> d(raw.size()); std::vector<uint8_t> m(raw.size());
+    detail::must(pr_raw2depth_mask(raw.data(), raw.size(), d.data(), m.data()));
+    auto dv = detail::split_stack(d.data(), 2, CV_16U, width, height, pose_size);
+    auto mv = detail::split_stack(m.data(), 1, CV_8U, width, height, pose_size);
+    std::vector<std::vector<cv::Mat>> out(pose_size);
+    for (size_t i = 0; i < pose_size; ++i) out[i] = { dv[i], mv[i] };
+    return out;
+}
+inline std::vector<cv::Mat> raw2depth_uint16_cpu(std::vector<int32_t> &raw, size_t width, size_t height, size_t pose_size)
+{
+    std::vector<uint16_t> d(raw.size());
+    for (size_t i = 0; i < raw.size(); ++i) d[i] = uint16_t(raw[i]);
+    return detail::split_stack(d.data(), 2, CV_16U, width, height, pose_size);
+}
+inline std::vector<cv::Mat> raw2mask_uint8_cpu(std::vector<int32_t> &raw, size_t width, size_t height, size_t pose_size)
+{
+    std::vector<uint8_t> m(raw.size());
+    for (size_t i = 0; i < raw.size(); ++i) m[i] = (raw[i] > 0) ? 255 : 0;
+    return detail::split_stack(m.data(), 1, CV_8U, width, height, pose_size);
+}
+inline std::vector<std::vector<cv::Mat>> raw2depth_mask_cpu(std::vector<int32_t> &raw, size_t width, size_t height, size_t pose_size)
+{
+    auto dv = raw2depth_uint16_cpu(raw, width, height, pose_size); auto mv = raw2mask_uint8_cpu(raw, width, height, pose_size);
+    std::vector<std::vector<cv::Mat>> out(pose_size);
+    for (size_t i = 0; i < pose_size; ++i) out[i] = { dv[i], mv[i] };
+    return out;
 }
 
 template <typename... Params> Int_holder render(Params &&...p) { return render_cuda_keep_in_gpu(std::forward<Params>(p)...); }          // renderer.h:230-238

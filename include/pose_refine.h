@@ -99,6 +99,11 @@ int pr_get_normal(const uint16_t *depth16, int width, int height, const float K[
 /* init_Scene_projective_cpu depth_scene.cpp:3-35: fills width*height pcd + normal host buffers */
 int pr_scene_proj_prepare(const void *depth, int depth_is_i32, const float K[9], size_t width, size_t height,
                           pr_vec3 *pcd_out, pr_vec3 *normal_out);
+/* SURVEY 8f rank 1 -- the same preparation entirely on the device (the reference's init_Scene_projective_cuda still runs it
+ * on the CPU, depth_scene.cu:8, and its README names that as the remaining bottleneck): depth_dev -> pcd_dev, normal_dev.
+ * Bit-identical to pr_scene_proj_prepare. */
+int pr_scene_proj_prepare_dev(const void *depth_dev, int depth_is_i32, const float K[9], size_t width, size_t height,
+                              pr_vec3 *pcd_dev_out, pr_vec3 *normal_dev_out);
 /* init_Scene_nn_cpu pcd_scene.cpp:4-37 + KDTree_cpu::build_tree pcd_scene.cpp:45-184.
  * pcd_out/normal_out need width*height entries, nodes_out 2*width*height+1 entries (worst case). */
 int pr_scene_nn_prepare(const void *depth, int depth_is_i32, const float K[9], int width, int height,
@@ -118,6 +123,10 @@ int pr_render(const pr_triangle *tris_dev, size_t n_tris, const pr_mat4 *poses_h
 /* render_cuda renderer.cu:189-267: same, result copied to the host */
 int pr_render_to_host(const pr_triangle *tris_dev, size_t n_tris, const pr_mat4 *poses_host, size_t n_poses,
                       size_t width, size_t height, const pr_mat4 *proj, pr_roi roi, int32_t *depth_host_out);
+
+/* raw2depth_uint16_cuda / raw2mask_uint8_cuda / raw2depth_mask_cuda renderer.cu:338-439: the int32 depth stack of a render ->
+ * uint16 depth (uint16_t(x)) and/or uint8 mask (x>0 ? 255 : 0) on the host; either output may be NULL. */
+int pr_raw2depth_mask(const int32_t *raw_dev, size_t count, uint16_t *depth_host_out, uint8_t *mask_host_out);
 
 /* ---- depth -> cloud (cuda_icp/icp.cu:228-291 depth2cloud_cuda<T>) ------------------------------ */
 /* Allocates *cloud_dev_out (release with pr_free); points in row-major pixel order, metres. */

@@ -69,6 +69,8 @@ SIGNATURES = {
     "pr_compute_proj": (None, [_vp, _i32, _i32, C.c_float, C.c_float, _vp]),
     "pr_get_normal": (_i32, [_vp, _i32, _i32, _vp, _vp]),
     "pr_scene_proj_prepare": (_i32, [_vp, _i32, _vp, _sz, _sz, _vp, _vp]),
+    "pr_scene_proj_prepare_dev": (_i32, [_vp, _i32, _vp, _sz, _sz, _vp, _vp]),
+    "pr_raw2depth_mask": (_i32, [_vp, _sz, _vp, _vp]),
     "pr_scene_nn_prepare": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _sz, C.POINTER(_u32), C.POINTER(_u32)]),
     "pr_kdtree_build": (_i32, [_vp, _vp, _sz, _i32, _vp, _sz, C.POINTER(_u32)]),
     "pr_solve_666": (None, [_vp, _vp, _vp]),

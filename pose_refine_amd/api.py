@@ -174,6 +174,16 @@ def render(tris, poses, width: int, height: int, proj, roi: Sequence[int] = (0, 
     return out
 
 
+def raw2depth_mask(raw: DeviceVector, want_depth: bool = True, want_mask: bool = True):
+    """``raw2depth_uint16_cuda`` / ``raw2mask_uint8_cuda`` / ``raw2depth_mask_cuda`` (renderer.cu:338-439) for a whole
+    render stack: returns (uint16 depth or None, uint8 mask or None) as flat host arrays."""
+    n = raw.size()
+    d = np.empty(n, np.uint16) if want_depth else None
+    m = np.empty(n, np.uint8) if want_mask else None
+    check(_lib.load().pr_raw2depth_mask(raw.data(), n, ptr(d) if want_depth else None, ptr(m) if want_mask else None))
+    return d, m
+
+
 def render_host(tris, poses, width: int, height: int, proj, roi: Sequence[int] = (0, 0, 0, 0)) -> np.ndarray:
     """``cuda_renderer::render_host`` -> ``render_cuda`` (renderer.cu:189-267): result on the host."""
     td = _tris_dev(tris)
@@ -246,6 +256,20 @@ class Scene_projective:
         self.pcd_host, self.normal_host = pcd, nrm
         self.pcd_buffer = DeviceVector.from_host(pcd.reshape(-1))
         self.normal_buffer = DeviceVector.from_host(nrm.reshape(-1))
+        return self
+
+    def init_Scene_projective_device(self, scene_depth_dev: "DeviceVector", scene_K, width: int = 640, height: int = 480,
+                                     max_dist_diff: float = 0.1):
+        """the same initialisation with the depth image already on the device and the
+        preparation (back-projection + normals) done by a kernel -- no CPU work, no PCIe traffic."""
+        if scene_depth_dev.dtype not in (np.uint16, np.int32):
+            raise ValueError("scene depth must be CV_16U or CV_32S")
+        self.width, self.height, self.max_dist_diff = width, height, max_dist_diff
+        self.K = _f32(scene_K, -1)
+        self.pcd_buffer = DeviceVector(width * height * 3, np.float32)
+        self.normal_buffer = DeviceVector(width * height * 3, np.float32)
+        check(_lib.load().pr_scene_proj_prepare_dev(scene_depth_dev.data(), int(scene_depth_dev.dtype == np.int32), ptr(self.K),
+                                                    width, height, self.pcd_buffer.data(), self.normal_buffer.data()))
         return self
 
     kind = SCENE_PROJ

@@ -94,7 +94,7 @@ struct Ctx {
     int n_cus = 256;
     const void *aabb_key = nullptr; size_t aabb_n = 0;
     // workspaces
-    DevBuf aabb, bbox, poses, depth, row_count, row_off, counts, cloud, meta, partial, sums, rec, topo, bmin, bmax, pts, nnrec, nndepth, dstate, dresults, vbdesc, flowsync;
+    DevBuf aabb, bbox, poses, depth, row_count, row_off, counts, cloud, meta, partial, sums, rec, topo, bmin, bmax, pts, nnrec, nndepth, dstate, dresults, vbdesc, flowsync, conv16, conv8;
     PinBuf h_sums, h_meta, h_counts, h_results, h_dstate, h_flow;
     // profiling
     std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
@@ -606,7 +606,7 @@ int pr_shutdown(void)
     if (!g.ready) return PR_OK;
     hipStreamSynchronize(g.stream);
     for (DevBuf *b : { &g.aabb, &g.bbox, &g.poses, &g.depth, &g.row_count, &g.row_off, &g.counts, &g.cloud, &g.meta, &g.partial,
-                       &g.sums, &g.rec, &g.topo, &g.bmin, &g.bmax, &g.pts, &g.nnrec, &g.nndepth, &g.dstate, &g.dresults, &g.vbdesc, &g.flowsync }) b->release();
+                       &g.sums, &g.rec, &g.topo, &g.bmin, &g.bmax, &g.pts, &g.nnrec, &g.nndepth, &g.dstate, &g.dresults, &g.vbdesc, &g.flowsync, &g.conv16, &g.conv8 }) b->release();
     for (PinBuf *b : { &g.h_sums, &g.h_meta, &g.h_counts, &g.h_results, &g.h_dstate, &g.h_flow }) b->release();
     drop_graphs();
     for (hipEvent_t e : g.ev_pool) hipEventDestroy(e);
@@ -706,6 +706,34 @@ int pr_depth2cloud_u16(const uint16_t *depth_dev, uint32_t width, uint32_t heigh
     std::lock_guard<std::mutex> lk(g_mu);
     PR_TRY(require_ctx());
     return depth2cloud_impl<uint16_t>(depth_dev, width, height, K, stride, tl_x, tl_y, cloud_dev_out, n_points);
+}
+
+int pr_scene_proj_prepare_dev(const void *depth_dev, int depth_is_i32, const float K[9], size_t width, size_t height,
+                              pr_vec3 *pcd_dev_out, pr_vec3 *normal_dev_out)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    PR_TRY(require_ctx());
+    if (!depth_dev || !K || !pcd_dev_out || !normal_dev_out || width == 0 || height == 0) { set_error("pr_scene_proj_prepare_dev: bad arguments"); return PR_ERR_INVALID; }
+    if (depth_is_i32) HIP_TRY(prk::launch_scene_proj_prepare<int32_t>(static_cast<const int32_t *>(depth_dev), (uint32_t)width, (uint32_t)height, K[0], K[4], K[2], K[5], pcd_dev_out, normal_dev_out, g.stream));
+    else HIP_TRY(prk::launch_scene_proj_prepare<uint16_t>(static_cast<const uint16_t *>(depth_dev), (uint32_t)width, (uint32_t)height, K[0], K[4], K[2], K[5], pcd_dev_out, normal_dev_out, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    return PR_OK;
+}
+
+int pr_raw2depth_mask(const int32_t *raw_dev, size_t count, uint16_t *depth_host_out, uint8_t *mask_host_out)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    PR_TRY(require_ctx());
+    if (!raw_dev || (!depth_host_out && !mask_host_out)) { set_error("pr_raw2depth_mask: bad arguments"); return PR_ERR_INVALID; }
+    if (count == 0) return PR_OK;
+    if (depth_host_out) PR_TRY(g.conv16.ensure(count * sizeof(uint16_t) + 16));
+    if (mask_host_out) PR_TRY(g.conv8.ensure(count + 16));
+    HIP_TRY(prk::launch_raw2depth_mask(raw_dev, count, depth_host_out ? g.conv16.as<uint16_t>() : nullptr, mask_host_out ? g.conv8.as<uint8_t>() : nullptr, g.stream));
+    // ONE copy per output for the whole stack (the reference issues one thrust::copy per pose, renderer.cu:370-373)
+    if (depth_host_out) HIP_TRY(hipMemcpyAsync(depth_host_out, g.conv16.p, count * sizeof(uint16_t), hipMemcpyDeviceToHost, g.stream));
+    if (mask_host_out) HIP_TRY(hipMemcpyAsync(mask_host_out, g.conv8.p, count, hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    return PR_OK;
 }
 
 int pr_icp_batch(pr_vec3 *clouds_dev, const uint32_t *offsets_host, uint32_t n_clouds, int scene_kind, const void *scene,

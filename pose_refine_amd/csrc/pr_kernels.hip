@@ -1143,6 +1143,76 @@ __global__ __launch_bounds__(256, 5) void icp_flow_kernel(FlowArgs a, Scene scen
 }
 
 // ================================================================================================
+//  scene preparation and raw-depth conversions on the device
+// ================================================================================================
+template <typename T> __device__ __forceinline__ uint16_t depth_as_u16(T d);
+template <> __device__ __forceinline__ uint16_t depth_as_u16<uint16_t>(uint16_t d) { return d; }
+template <> __device__ __forceinline__ uint16_t depth_as_u16<int32_t>(int32_t d) { return (uint16_t)(d < 0 ? 0 : (d > 65535 ? 65535 : d)); }  // cv saturate_cast
+
+// init_Scene_projective_cpu (depth_scene.cpp:3-35) per pixel: dep2pcd (common.h:47-61) + get_normal (common.cpp:17-107:
+// 8 taps at radius 5, 64-bit integer normal equations, |delta| < 50 and depth < 2000 gates, zero in a 5-pixel border).
+template <typename T>
+__global__ __launch_bounds__(256) void scene_proj_prepare_kernel(const T *__restrict__ depth, uint32_t W, uint32_t H, float fx, float fy,
+                                                                 float cx, float cy, pr_vec3 *__restrict__ pcd, pr_vec3 *__restrict__ normal)
+{
+    const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    const size_t at = (size_t)y * W + x;
+    const T raw = depth[at];
+    pr_vec3 p = { 0.0f, 0.0f, 0.0f };
+    // CV_32S is read through at<uint32_t> (depth_scene.cpp:26), CV_16U as is
+    const float dv = (sizeof(T) == 4) ? (float)(uint32_t)raw : (float)(int)raw;
+    if (raw != 0) {
+        const float z = dv / 1000.0f;
+        p.x = ((float)x - cx) / fx * z;
+        p.y = ((float)y - cy) / fy * z;
+        p.z = z;
+    }
+    pcd[at] = p;
+
+    pr_vec3 nrm = { 0.0f, 0.0f, 0.0f };
+    const int R = 5;
+    if ((int)y >= R && (int)y < (int)H - R - 1 && (int)x >= R && (int)x < (int)W - R - 1) {
+        const long long d0 = depth_as_u16<T>(raw);
+        if (d0 < 2000) {
+            long long sxx = 0, sxy = 0, syy = 0, bx = 0, by = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int ox = (k == 0 || k == 3 || k == 5) ? -R : ((k == 1 || k == 6) ? 0 : R);
+                const int oy = (k < 3) ? -R : ((k < 5) ? 0 : R);
+                const long long delta = (long long)depth_as_u16<T>(depth[at + ox + (long long)oy * W]) - d0;
+                const long long ad = delta < 0 ? -delta : delta;
+                if (ad < 50) { sxx += ox * ox; sxy += ox * oy; syy += oy * oy; bx += ox * delta; by += oy * delta; }
+            }
+            const long long det = sxx * syy - sxy * sxy;
+            const long long gx = syy * bx - sxy * by;
+            const long long gy = -sxy * bx + sxx * by;
+            const float nx = fx * (float)gx, ny = fy * (float)gy, nz = (float)(-det * d0);
+            const float len = sqrtf(nx * nx + ny * ny + nz * nz);
+            if (len > 0) { const float inv = 1.0f / len; nrm.x = nx * inv; nrm.y = ny * inv; nrm.z = nz * inv; }
+        }
+    }
+    normal[at] = nrm;
+}
+
+// raw2depth_uint16 / raw2mask_uint8 / raw2depth_mask (renderer.cu:338-439): uint16_t(x) truncation, mask = x>0 ? 255 : 0
+__global__ __launch_bounds__(256) void raw2depth_mask_kernel(const int32_t *__restrict__ raw, size_t n, uint16_t *__restrict__ depth16,
+                                                             uint8_t *__restrict__ mask8)
+{
+    size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    const size_t stride = (size_t)gridDim.x * 256 * 4;
+    for (; i < n; i += stride) {
+        if (i + 3 < n) {
+            const int4 v = *reinterpret_cast<const int4 *>(raw + i);
+            if (depth16) { ushort4 d; d.x = (uint16_t)v.x; d.y = (uint16_t)v.y; d.z = (uint16_t)v.z; d.w = (uint16_t)v.w; *reinterpret_cast<ushort4 *>(depth16 + i) = d; }
+            if (mask8) { uchar4 m; m.x = v.x > 0 ? 255 : 0; m.y = v.y > 0 ? 255 : 0; m.z = v.z > 0 ? 255 : 0; m.w = v.w > 0 ? 255 : 0; *reinterpret_cast<uchar4 *>(mask8 + i) = m; }
+        } else {
+            for (size_t k = i; k < n; ++k) { if (depth16) depth16[k] = (uint16_t)raw[k]; if (mask8) mask8[k] = raw[k] > 0 ? 255 : 0; }
+        }
+    }
+}
+
+// ================================================================================================
 //  scene repacking
 // ================================================================================================
 __global__ __launch_bounds__(256) void pack_proj_scene_kernel(const pr_vec3 *__restrict__ pcd, const pr_vec3 *__restrict__ normal,
@@ -1414,6 +1484,22 @@ hipError_t launch_pack_results(const DevIcpState *st, pr_result *out, uint32_t n
 {
     if (n_poses == 0) return hipSuccess;
     hipLaunchKernelGGL(pack_results_kernel, dim3((n_poses + 255) / 256), dim3(256), 0, s, st, out, n_poses);
+    return hipGetLastError();
+}
+
+template <typename T>
+hipError_t launch_scene_proj_prepare(const T *depth, uint32_t W, uint32_t H, float fx, float fy, float cx, float cy, pr_vec3 *pcd, pr_vec3 *normal, hipStream_t s)
+{
+    if (W == 0 || H == 0) return hipSuccess;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(scene_proj_prepare_kernel<T>), dim3((W + 63) / 64, (H + 3) / 4), dim3(256), 0, s, depth, W, H, fx, fy, cx, cy, pcd, normal);
+    return hipGetLastError();
+}
+template hipError_t launch_scene_proj_prepare<int32_t>(const int32_t *, uint32_t, uint32_t, float, float, float, float, pr_vec3 *, pr_vec3 *, hipStream_t);
+template hipError_t launch_scene_proj_prepare<uint16_t>(const uint16_t *, uint32_t, uint32_t, float, float, float, float, pr_vec3 *, pr_vec3 *, hipStream_t);
+hipError_t launch_raw2depth_mask(const int32_t *raw, size_t n, uint16_t *depth16, uint8_t *mask8, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(raw2depth_mask_kernel, dim3(cap_grid((n + 1023) / 1024)), dim3(256), 0, s, raw, n, depth16, mask8);
     return hipGetLastError();
 }
 

@@ -9,6 +9,7 @@
 
 #include "cuda_icp/icp.h"
 #include "cuda_renderer/renderer.h"
+#include "pose_renderer.h"
 
 static void matmul3(const float *a, const float *b, float *c)
 {   // cv::Mat CV_32F product: double accumulation, float result
@@ -54,7 +55,21 @@ int main(int argc, char **argv)
     Mat3x3f K_((float *)K.data);
     auto depth_cuda = cuda_renderer::render_cuda_keep_in_gpu(model.tris, mat4_v, width, height, proj);    // test.cpp:143
 
+    long long pr_depth_sum[2], pr_mask_px[2];
+    {   // PoseRenderer (pose_renderer.cpp:16-63): cv::Mat poses in, uint16 depth + uint8 mask out
+        PoseRenderer pr(prefix + "obj_06.ply");
+        pr.set_K_width_height(K, width, height);
+        float P0[16], P1[16];
+        for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) { P0[r * 4 + c] = R_ren[r * 3 + c]; P1[r * 4 + c] = R_ren2[r * 3 + c]; } P0[r * 4 + 3] = t_ren[r]; P1[r * 4 + 3] = t_ren2[r]; }
+        P0[12] = P0[13] = P0[14] = 0; P0[15] = 1; P1[12] = P1[13] = P1[14] = 0; P1[15] = 1;
+        std::vector<cv::Mat> poses = { cv::Mat(4, 4, CV_32F, P0), cv::Mat(4, 4, CV_32F, P1) };
+        auto dm = pr.render_depth_mask(poses);
+        long long ds[2] = { 0, 0 }, ms[2] = { 0, 0 };
+        for (int i = 0; i < 2; ++i) for (int k = 0; k < width * height; ++k) { ds[i] += dm[i][0].ptr<uint16_t>()[k]; ms[i] += dm[i][1].ptr<uint8_t>()[k]; }
+        for (int i = 0; i < 2; ++i) { pr_depth_sum[i] = ds[i]; pr_mask_px[i] = ms[i] / 255; }
+    }
     std::printf("{\n\"n_triangles\": %zu,\n", model.tris.size());
+    std::printf("\"pose_renderer\": {\"depth_sum\": [%lld, %lld], \"mask_px\": [%lld, %lld]},\n", pr_depth_sum[0], pr_depth_sum[1], pr_mask_px[0], pr_mask_px[1]);
     long long sum0 = 0, sum1 = 0;
     for (int i = 0; i < width * height; ++i) { sum0 += depth_host[i]; sum1 += depth_host[width * height + i]; }
     std::printf("\"depth_sum\": [%lld, %lld],\n", sum0, sum1);

@@ -36,6 +36,8 @@ def test_drop_in_driver_matches_oracle(scenario):
     got = json.loads(out[out.index("{"):])
     assert got["n_triangles"] == 31468 and got["cloud_points"] == len(scenario["cloud"])
     assert got["depth_sum"] == [int(scenario["depth"][0].sum()), int(scenario["depth"][1].sum())]
+    assert got["pose_renderer"]["depth_sum"] == got["depth_sum"]                 # PoseRenderer + raw2depth_mask
+    assert got["pose_renderer"]["mask_px"] == [int((scenario["depth"][i] > 0).sum()) for i in range(2)]
     for key, sk, crit in [("proj_default", "proj_scene", (1e-5, 1e-5, 30)), ("nn_fixed20", "nn_scene", (0.0, 0.0, 20))]:
         ref, _, _, _ = O.icp(scenario["cloud"], scenario[sk], crit, O.SUM_CANONICAL, 2048)
         assert np.float32(got[key]["fitness"]) == ref["fitness"]

@@ -292,3 +292,29 @@ def test_dataflow_and_multilaunch_icp_agree_bitwise(gpu, model, scenario, gscene
     finally:
         api.set_option("icp_flow", 0)
         api.set_option("solve", api.SOLVE_HOST)
+
+
+# ---- SURVEY 8f "next" rows: device scene preparation, raw2* conversions ---------------------------------
+@pytest.mark.parametrize("dtype", [np.int32, np.uint16])
+def test_device_scene_preparation_bit_exact(gpu, scenario, dtype):
+    d = scenario["depth"][1].astype(dtype)
+    d[100:120, 300:330] = 2500 if dtype == np.uint16 else 70000        # beyond the 2000 mm gate / uint16 saturation
+    host = api.Scene_projective().init_Scene_projective_cuda(d, scenario["K"])
+    dev = api.Scene_projective().init_Scene_projective_device(api.DeviceVector.from_host(d.reshape(-1)), scenario["K"])
+    assert np.array_equal(dev.pcd_buffer.to_host(), host.pcd_host.reshape(-1))
+    assert np.array_equal(dev.normal_buffer.to_host(), host.normal_host.reshape(-1))
+    ref = O.ProjScene(d, scenario["K"])
+    assert np.array_equal(dev.normal_buffer.to_host().reshape(-1, 3), ref.normal)
+
+
+def test_raw2depth_mask(gpu, model, scenario):
+    poses = scenario["poses"]
+    raw = api.render(model, poses, W, H, scenario["proj"])
+    d16, m8 = api.raw2depth_mask(raw)
+    ref = scenario["depth"].reshape(-1)
+    assert np.array_equal(d16, ref.astype(np.uint16)) and np.array_equal(m8, np.where(ref > 0, 255, 0).astype(np.uint8))
+    d_only, none = api.raw2depth_mask(raw, want_mask=False)
+    assert none is None and np.array_equal(d_only, d16)
+    big = api.DeviceVector.from_host(np.array([70000, -5, 0, 65535, 1, 2, 3], np.int32))      # truncation, not saturation
+    d, m = api.raw2depth_mask(big)
+    assert d.tolist() == [70000 % 65536, 65531, 0, 65535, 1, 2, 3] and m.tolist() == [255, 0, 0, 255, 255, 255, 255]
