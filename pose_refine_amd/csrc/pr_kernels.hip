@@ -147,6 +147,7 @@ __global__ __launch_bounds__(256) void raster_kernel(const pr_triangle *__restri
                                                      uint32_t rw, uint32_t rh, const int4 *__restrict__ boxes)
 {
     __shared__ float sh[4][kSetupWords][64];
+    __shared__ uint32_t shq[4][128];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t ti = blockIdx.x * 256 + threadIdx.x;
     const float *M = poses[blockIdx.y].m;                        // wave-uniform -> scalar loads
@@ -184,35 +185,52 @@ __global__ __launch_bounds__(256) void raster_kernel(const pr_triangle *__restri
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
-#ifdef PR_ABL_NOATOMIC
-    int sink = INT_MAX;
-#endif
-    for (int c = (int)lane; c < total; c += 64) {
-        int o = 0;
+    // Candidates that pass the inside test are rare (about one in four) -- they are queued per wavefront as packed
+    // (owner, x, y) words and drained 64 at a time, so the four IEEE divisions of the perspective depth and the
+    // atomicMin always run on full wavefronts.
+    uint32_t *queue = reinterpret_cast<uint32_t *>(shq[wave]);
+    int qn = 0;                                                    // wave-uniform fill level, < 64 between iterations
+    auto drain = [&](int first, int count) {
+        if ((int)lane < count) {
+            const uint32_t e = queue[first + lane];
+            const int o = (int)(e >> 26), x = (int)((e >> 13) & 0x1fffu), y = (int)(e & 0x1fffu);
+            const float px[3] = { w[0][o], w[2][o], w[4][o] }, py[3] = { w[1][o], w[3][o], w[5][o] };
+            float alpha, beta, gamma;
+            (void)tri_fragment(px, py, w[9][o], x, y, alpha, beta, gamma);
+            const int d = fragment_depth(alpha, beta, gamma, w[6][o], w[7][o], w[8][o]);
+            const uint32_t xw = (uint32_t)(x - roi.x);
+            const uint32_t yw = (uint32_t)((int)height - 1 - y - roi.y);
+            atomicMin(&img[xw + (size_t)yw * rw], d);
+        }
+    };
+    for (int c0 = 0; c0 < total; c0 += 64) {
+        const int c = c0 + (int)lane;
+        bool pass = false;
+        uint32_t entry = 0;
+        if (c < total) {
+            int o = 0;
 #pragma unroll
-        for (int s = 32; s > 0; s >>= 1) { if (__float_as_int(w[13][o + s]) <= c) o += s; }
-        const int k = c - __float_as_int(w[13][o]);
-        const int nx = __float_as_int(w[12][o]);
-        int q = (int)((float)k * __builtin_amdgcn_rcpf((float)nx));          // k / nx with a one-step correction
-        if (q * nx > k) --q;
-        if ((q + 1) * nx <= k) ++q;
-        const int x = __float_as_int(w[10][o]) + (k - q * nx);
-        const int y = __float_as_int(w[11][o]) + q;
-        const float px[3] = { w[0][o], w[2][o], w[4][o] }, py[3] = { w[1][o], w[3][o], w[5][o] };
-        float alpha, beta, gamma;
-        if (!tri_fragment(px, py, w[9][o], x, y, alpha, beta, gamma)) continue;
-        const int d = fragment_depth(alpha, beta, gamma, w[6][o], w[7][o], w[8][o]);
-        const uint32_t xw = (uint32_t)(x - roi.x);
-        const uint32_t yw = (uint32_t)((int)height - 1 - y - roi.y);
-#ifdef PR_ABL_NOATOMIC
-        sink = min(sink, d + (int)(xw + yw));
-#else
-        atomicMin(&img[xw + (size_t)yw * rw], d);
-#endif
+            for (int s = 32; s > 0; s >>= 1) { if (__float_as_int(w[13][o + s]) <= c) o += s; }
+            const int k = c - __float_as_int(w[13][o]);
+            const int nx = __float_as_int(w[12][o]);
+            int q = (int)((float)k * __builtin_amdgcn_rcpf((float)nx));      // k / nx with a one-step correction
+            if (q * nx > k) --q;
+            if ((q + 1) * nx <= k) ++q;
+            const int x = __float_as_int(w[10][o]) + (k - q * nx);
+            const int y = __float_as_int(w[11][o]) + q;
+            const float px[3] = { w[0][o], w[2][o], w[4][o] }, py[3] = { w[1][o], w[3][o], w[5][o] };
+            float alpha, beta, gamma;
+            pass = tri_fragment(px, py, w[9][o], x, y, alpha, beta, gamma);
+            entry = ((uint32_t)o << 26) | ((uint32_t)x << 13) | (uint32_t)y;
+        }
+        const unsigned long long m = __ballot(pass);
+        if (pass) queue[qn + (int)__popcll(m & ((1ull << lane) - 1ull))] = entry;
+        qn += (int)__popcll(m);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (qn >= 64) { drain(qn - 64, 64); qn -= 64; __builtin_amdgcn_wave_barrier(); }
     }
-#ifdef PR_ABL_NOATOMIC
-    if (sink == 12345) img[0] = sink;
-#endif
+    drain(0, qn);
 }
 
 // ================================================================================================
