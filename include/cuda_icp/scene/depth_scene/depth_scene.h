@@ -31,6 +31,20 @@ struct Scene_projective {
         pcd_buffer.upload(p); normal_buffer.upload(n);
         pcd_ptr = pcd_buffer.data(); normal_ptr = normal_buffer.data();
     }
+    // the same initialisation with the depth image already on the device (T = int32_t or uint16_t);
+    // back-projection and normals run as one kernel, bit-identical to the CPU preparation.
+    template <class T>
+    void init_Scene_projective_device(T *scene_depth_dev, Mat3x3f &scene_K, device_vector_holder<Vec3f> &pcd_buffer,
+                                      device_vector_holder<Vec3f> &normal_buffer, size_t width_ = 640, size_t height_ = 480, float max_dist_diff_ = 0.1f)
+    {
+        static_assert(sizeof(T) == 4 || sizeof(T) == 2, "depth must be int32 or uint16");
+        K = scene_K; width = width_; height = height_; max_dist_diff = max_dist_diff_;
+        pcd_buffer.__malloc(width * height); normal_buffer.__malloc(width * height);
+        pose_refine_detail::must(pr_scene_proj_prepare_dev(scene_depth_dev, sizeof(T) == 4, K.data(), width, height,
+                                                           reinterpret_cast<pr_vec3 *>(pcd_buffer.data()), reinterpret_cast<pr_vec3 *>(normal_buffer.data())),
+                                 "pr_scene_proj_prepare_dev");
+        pcd_ptr = pcd_buffer.data(); normal_ptr = normal_buffer.data();
+    }
     // depth_scene.h:29-48 (host evaluation; only meaningful when the pointers are host pointers)
     void query(const Vec3f &src, Vec3f &dst, Vec3f &nrm, bool &valid) const
     {

@@ -57,6 +57,17 @@ public:
         kdtree.pcd_buffer.upload(cpu.pcd_buffer); kdtree.normal_buffer.upload(cpu.normal_buffer); kdtree.nodes.upload(cpu.nodes);
         pcd_ptr = kdtree.pcd_buffer.data(); normal_ptr = kdtree.normal_buffer.data(); node_ptr = kdtree.nodes.data();
     }
+    // normals, valid-pixel gather and the level-order kd-tree build on the device (bit-identical tree)
+    template <class T>
+    void init_Scene_nn_device(T *scene_depth_dev, Mat3x3f &scene_K, int width, int height, KDTree_cuda &kdtree, int max_leaf = 10)
+    {
+        const size_t px = (size_t)width * height;
+        kdtree.pcd_buffer.__malloc(px); kdtree.normal_buffer.__malloc(px); kdtree.nodes.__malloc(2 * px + 1);
+        pose_refine_detail::must(pr_scene_nn_prepare_dev(scene_depth_dev, sizeof(T) == 4, scene_K.data(), width, height, max_leaf,
+                                                         reinterpret_cast<pr_vec3 *>(kdtree.pcd_buffer.data()), reinterpret_cast<pr_vec3 *>(kdtree.normal_buffer.data()),
+                                                         reinterpret_cast<pr_kdnode *>(kdtree.nodes.data()), 2 * px + 1, &n_points, &n_nodes), "pr_scene_nn_prepare_dev");
+        pcd_ptr = kdtree.pcd_buffer.data(); normal_ptr = kdtree.normal_buffer.data(); node_ptr = kdtree.nodes.data();
+    }
     // pcd_scene.h:60-136, host evaluation over host pointers
     void query(const Vec3f &src, Vec3f &dst, Vec3f &nrm, bool &valid) const
     {

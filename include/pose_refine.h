@@ -112,6 +112,14 @@ int pr_scene_nn_prepare(const void *depth, int depth_is_i32, const float K[9], i
 /* KDTree_cpu::build_tree on caller-provided points (reorders pcd/normal in place) */
 int pr_kdtree_build(pr_vec3 *pcd, pr_vec3 *normal, size_t n_points, int max_leaf,
                     pr_kdnode *nodes_out, size_t cap_nodes, uint32_t *n_nodes);
+/* SURVEY 8f rank 1 -- the same two functions on the device (bit-identical nodes, point order and normals): the level-order
+ * build runs one workgroup per node and level (block scans reproduce the stable two-ended partition and its tie rule).
+ * pcd/normal/nodes are device buffers sized like their host counterparts above. */
+int pr_kdtree_build_dev(pr_vec3 *pcd_dev, pr_vec3 *normal_dev, size_t n_points, int max_leaf,
+                        pr_kdnode *nodes_dev_out, size_t cap_nodes, uint32_t *n_nodes);
+int pr_scene_nn_prepare_dev(const void *depth_dev, int depth_is_i32, const float K[9], int width, int height, int max_leaf,
+                            pr_vec3 *pcd_dev_out, pr_vec3 *normal_dev_out, pr_kdnode *nodes_dev_out, size_t cap_nodes,
+                            uint32_t *n_points, uint32_t *n_nodes);
 /* eigen_slover_666 icp.cpp:29-45 (public in icp.h:54) */
 void pr_solve_666(const float A[36], const float b[6], pr_mat4 *T_out);
 

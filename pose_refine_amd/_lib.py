@@ -72,6 +72,8 @@ SIGNATURES = {
     "pr_scene_proj_prepare_dev": (_i32, [_vp, _i32, _vp, _sz, _sz, _vp, _vp]),
     "pr_raw2depth_mask": (_i32, [_vp, _sz, _vp, _vp]),
     "pr_scene_nn_prepare": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _sz, C.POINTER(_u32), C.POINTER(_u32)]),
+    "pr_kdtree_build_dev": (_i32, [_vp, _vp, _sz, _i32, _vp, _sz, C.POINTER(_u32)]),
+    "pr_scene_nn_prepare_dev": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _sz, C.POINTER(_u32), C.POINTER(_u32)]),
     "pr_kdtree_build": (_i32, [_vp, _vp, _sz, _i32, _vp, _sz, C.POINTER(_u32)]),
     "pr_solve_666": (None, [_vp, _vp, _vp]),
     "pr_render": (_i32, [_vp, _sz, _vp, _sz, _sz, _sz, _vp, Roi, _vp]),

@@ -311,9 +311,27 @@ class Scene_nn:
         self.nodes = DeviceVector.from_host(self.nodes_host)
         return self
 
+    def init_Scene_nn_device(self, scene_depth_dev: "DeviceVector", scene_K, width: int, height: int, max_leaf: int = 10,
+                             max_dist_diff: float = 0.1):
+        """normals, valid-pixel gather and the level-order kd-tree build all on the device."""
+        k = _f32(scene_K, -1)
+        px = width * height
+        self.pcd_buffer = DeviceVector(px * 3, np.float32)
+        self.normal_buffer = DeviceVector(px * 3, np.float32)
+        self.nodes = DeviceVector(2 * px + 1, KDNODE)
+        npts, nnodes = C.c_uint32(), C.c_uint32()
+        check(_lib.load().pr_scene_nn_prepare_dev(scene_depth_dev.data(), int(scene_depth_dev.dtype == np.int32), ptr(k), width, height, max_leaf,
+                                                  self.pcd_buffer.data(), self.normal_buffer.data(), self.nodes.data(), 2 * px + 1,
+                                                  C.byref(npts), C.byref(nnodes)))
+        self.max_dist_diff = max_dist_diff
+        self._n_points, self._n_nodes = npts.value, nnodes.value
+        self.pcd_host = self.normal_host = self.nodes_host = None
+        return self
+
     def desc(self) -> SceneNNDesc:
-        return SceneNNDesc(self.max_dist_diff, self.pcd_buffer.data(), self.normal_buffer.data(), self.nodes.data(),
-                           len(self.pcd_host), len(self.nodes_host))
+        n_pts = len(self.pcd_host) if self.pcd_host is not None else self._n_points
+        n_nodes = len(self.nodes_host) if self.nodes_host is not None else self._n_nodes
+        return SceneNNDesc(self.max_dist_diff, self.pcd_buffer.data(), self.normal_buffer.data(), self.nodes.data(), n_pts, n_nodes)
 
 
 def ICP_Point2Plane(model_pcd: DeviceVector, scene, criteria: ICPConvergenceCriteria = ICPConvergenceCriteria()) -> RegistrationResult:

@@ -94,7 +94,7 @@ struct Ctx {
     int n_cus = 256;
     const void *aabb_key = nullptr; size_t aabb_n = 0;
     // workspaces
-    DevBuf aabb, bbox, poses, depth, row_count, row_off, counts, cloud, meta, partial, sums, rec, topo, bmin, bmax, pts, nnrec, nndepth, dstate, dresults, vbdesc, flowsync, conv16, conv8;
+    DevBuf aabb, bbox, poses, depth, row_count, row_off, counts, cloud, meta, partial, sums, rec, topo, bmin, bmax, pts, nnrec, nndepth, dstate, dresults, vbdesc, flowsync, conv16, conv8, kd_idx, kd_scratch, kd_child, kd_ctrl, kd_tmp, nn_full;
     PinBuf h_sums, h_meta, h_counts, h_results, h_dstate, h_flow;
     // profiling
     std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
@@ -576,6 +576,61 @@ int refine_impl(const pr_triangle *tris_dev, size_t n_tris, const pr_mat4 *poses
     return PR_OK;
 }
 
+// KDTree_cpu::build_tree on the device: level loop driven from the host (one 16-byte read-back per level)
+int kd_build_dev(pr_vec3 *pcd, pr_vec3 *nrm, uint32_t n, int max_leaf, pr_kdnode *nodes, size_t cap, uint32_t *n_nodes)
+{
+    if (n == 0 || cap == 0) { set_error("kd-tree build: no points"); return PR_ERR_INVALID; }
+    const uint32_t cap32 = (uint32_t)std::min<size_t>(cap, 0x7fffffff);
+    PR_TRY(g.kd_idx.ensure(sizeof(int) * n));
+    PR_TRY(g.kd_scratch.ensure(sizeof(int) * n));
+    PR_TRY(g.kd_child.ensure(sizeof(int) * cap32));
+    PR_TRY(g.kd_ctrl.ensure(sizeof(uint32_t) * 4));
+    PR_TRY(g.kd_tmp.ensure(sizeof(pr_vec3) * 2 * (size_t)n));
+    HIP_TRY(prk::launch_kd_init(nodes, cap32, g.kd_idx.as<int>(), n, g.kd_ctrl.as<uint32_t>(), g.stream));
+    uint32_t ctrl[4] = { 0, 1, 1, 1 };
+    for (int level = 0; level < 4096; ++level) {
+        HIP_TRY(prk::launch_kd_level(nodes, g.kd_ctrl.as<uint32_t>(), max_leaf, g.kd_child.as<int>(), cap32, 0, pcd, g.kd_idx.as<int>(),
+                                     g.kd_scratch.as<int>(), /*plan_only=*/true, g.stream));
+        HIP_TRY(hipMemcpyAsync(ctrl, g.kd_ctrl.p, sizeof ctrl, hipMemcpyDeviceToHost, g.stream));
+        HIP_TRY(hipStreamSynchronize(g.stream));
+        if (ctrl[3] > cap32) { set_error("kd-tree build: node capacity %u too small", cap32); return PR_ERR_NOMEM; }
+        if (ctrl[3] == ctrl[2]) break;                             // no node of this level split: done (pcd_scene.cpp:166-168)
+        HIP_TRY(prk::launch_kd_level(nodes, g.kd_ctrl.as<uint32_t>(), max_leaf, g.kd_child.as<int>(), cap32, ctrl[1] - ctrl[0], pcd,
+                                     g.kd_idx.as<int>(), g.kd_scratch.as<int>(), /*plan_only=*/false, g.stream));
+    }
+    pr_vec3 *tp = g.kd_tmp.as<pr_vec3>(), *tn = tp + n;
+    HIP_TRY(prk::launch_kd_permute(pcd, nrm, g.kd_idx.as<int>(), n, tp, tn, g.stream));
+    HIP_TRY(hipMemcpyAsync(pcd, tp, sizeof(pr_vec3) * n, hipMemcpyDeviceToDevice, g.stream));
+    HIP_TRY(hipMemcpyAsync(nrm, tn, sizeof(pr_vec3) * n, hipMemcpyDeviceToDevice, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    if (n_nodes) *n_nodes = ctrl[2];
+    return PR_OK;
+}
+
+template <typename T>
+int scene_nn_prepare_dev_t(const T *depth, const float K[9], uint32_t W, uint32_t H, int max_leaf, pr_vec3 *pcd, pr_vec3 *nrm,
+                           pr_kdnode *nodes, size_t cap, uint32_t *n_points, uint32_t *n_nodes)
+{
+    const size_t px = (size_t)W * H;
+    PR_TRY(g.nn_full.ensure(sizeof(pr_vec3) * 2 * px));
+    PR_TRY(g.row_count.ensure(sizeof(uint32_t) * H));
+    PR_TRY(g.row_off.ensure(sizeof(uint32_t) * H));
+    PR_TRY(g.counts.ensure(sizeof(uint32_t)));
+    pr_vec3 *full_pcd = g.nn_full.as<pr_vec3>(), *full_nrm = full_pcd + px;
+    // normals of every pixel (get_normal sees the uint16 image), then the valid pixels in row-major order
+    HIP_TRY(prk::launch_scene_proj_prepare<T>(depth, W, H, K[0], K[4], K[2], K[5], full_pcd, full_nrm, g.stream));
+    HIP_TRY(prk::launch_nn_gather<T>(depth, W, H, K[0], K[4], K[2], K[5], full_nrm, g.row_count.as<uint32_t>(), g.row_off.as<uint32_t>(),
+                                     g.counts.as<uint32_t>(), nullptr, nullptr, false, g.stream));
+    uint32_t n = 0;
+    HIP_TRY(hipMemcpyAsync(&n, g.counts.p, sizeof n, hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    if (n_points) *n_points = n;
+    if (n == 0) { if (n_nodes) *n_nodes = 0; return PR_OK; }
+    HIP_TRY(prk::launch_nn_gather<T>(depth, W, H, K[0], K[4], K[2], K[5], full_nrm, g.row_count.as<uint32_t>(), g.row_off.as<uint32_t>(),
+                                     g.counts.as<uint32_t>(), pcd, nrm, true, g.stream));
+    return kd_build_dev(pcd, nrm, n, max_leaf, nodes, cap, n_nodes);
+}
+
 }  // namespace
 
 // =================================================================================================
@@ -606,7 +661,7 @@ int pr_shutdown(void)
     if (!g.ready) return PR_OK;
     hipStreamSynchronize(g.stream);
     for (DevBuf *b : { &g.aabb, &g.bbox, &g.poses, &g.depth, &g.row_count, &g.row_off, &g.counts, &g.cloud, &g.meta, &g.partial,
-                       &g.sums, &g.rec, &g.topo, &g.bmin, &g.bmax, &g.pts, &g.nnrec, &g.nndepth, &g.dstate, &g.dresults, &g.vbdesc, &g.flowsync, &g.conv16, &g.conv8 }) b->release();
+                       &g.sums, &g.rec, &g.topo, &g.bmin, &g.bmax, &g.pts, &g.nnrec, &g.nndepth, &g.dstate, &g.dresults, &g.vbdesc, &g.flowsync, &g.conv16, &g.conv8, &g.kd_idx, &g.kd_scratch, &g.kd_child, &g.kd_ctrl, &g.kd_tmp, &g.nn_full }) b->release();
     for (PinBuf *b : { &g.h_sums, &g.h_meta, &g.h_counts, &g.h_results, &g.h_dstate, &g.h_flow }) b->release();
     drop_graphs();
     for (hipEvent_t e : g.ev_pool) hipEventDestroy(e);
@@ -718,6 +773,27 @@ int pr_scene_proj_prepare_dev(const void *depth_dev, int depth_is_i32, const flo
     else HIP_TRY(prk::launch_scene_proj_prepare<uint16_t>(static_cast<const uint16_t *>(depth_dev), (uint32_t)width, (uint32_t)height, K[0], K[4], K[2], K[5], pcd_dev_out, normal_dev_out, g.stream));
     HIP_TRY(hipStreamSynchronize(g.stream));
     return PR_OK;
+}
+
+int pr_kdtree_build_dev(pr_vec3 *pcd_dev, pr_vec3 *normal_dev, size_t n_points, int max_leaf, pr_kdnode *nodes_dev_out, size_t cap_nodes, uint32_t *n_nodes)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    PR_TRY(require_ctx());
+    if (!pcd_dev || !normal_dev || !nodes_dev_out) { set_error("pr_kdtree_build_dev: bad arguments"); return PR_ERR_INVALID; }
+    return kd_build_dev(pcd_dev, normal_dev, (uint32_t)n_points, max_leaf, nodes_dev_out, cap_nodes, n_nodes);
+}
+
+int pr_scene_nn_prepare_dev(const void *depth_dev, int depth_is_i32, const float K[9], int width, int height, int max_leaf,
+                            pr_vec3 *pcd_dev_out, pr_vec3 *normal_dev_out, pr_kdnode *nodes_dev_out, size_t cap_nodes,
+                            uint32_t *n_points, uint32_t *n_nodes)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    PR_TRY(require_ctx());
+    if (!depth_dev || !K || !pcd_dev_out || !normal_dev_out || !nodes_dev_out || width <= 0 || height <= 0) { set_error("pr_scene_nn_prepare_dev: bad arguments"); return PR_ERR_INVALID; }
+    if (depth_is_i32) return scene_nn_prepare_dev_t<int32_t>(static_cast<const int32_t *>(depth_dev), K, (uint32_t)width, (uint32_t)height, max_leaf,
+                                                             pcd_dev_out, normal_dev_out, nodes_dev_out, cap_nodes, n_points, n_nodes);
+    return scene_nn_prepare_dev_t<uint16_t>(static_cast<const uint16_t *>(depth_dev), K, (uint32_t)width, (uint32_t)height, max_leaf,
+                                            pcd_dev_out, normal_dev_out, nodes_dev_out, cap_nodes, n_points, n_nodes);
 }
 
 int pr_raw2depth_mask(const int32_t *raw_dev, size_t count, uint16_t *depth_host_out, uint8_t *mask_host_out)

@@ -128,6 +128,13 @@ hipError_t launch_icp_finalize_solve(const float *partial, PoseMeta *meta, uint3
                                      uint32_t n_poses, hipStream_t s);
 hipError_t launch_pack_results(const DevIcpState *st, pr_result *out, uint32_t n_poses, hipStream_t s);
 
+hipError_t launch_kd_init(pr_kdnode *nodes, uint32_t cap, int *idx, uint32_t n, uint32_t *ctrl, hipStream_t s);
+hipError_t launch_kd_level(pr_kdnode *nodes, uint32_t *ctrl, int max_leaf, int *child_of, uint32_t cap, uint32_t level_nodes,
+                           const pr_vec3 *pcd, int *idx, int *scratch, bool plan_only, hipStream_t s);
+hipError_t launch_kd_permute(const pr_vec3 *pcd, const pr_vec3 *nrm, const int *idx, uint32_t n, pr_vec3 *pcd_out, pr_vec3 *nrm_out, hipStream_t s);
+template <typename T>
+hipError_t launch_nn_gather(const T *depth, uint32_t W, uint32_t H, float fx, float fy, float cx, float cy, const pr_vec3 *normal_full,
+                            uint32_t *row_count, uint32_t *row_off, uint32_t *count, pr_vec3 *pcd, pr_vec3 *nrm, bool emit, hipStream_t s);
 template <typename T>
 hipError_t launch_scene_proj_prepare(const T *depth, uint32_t W, uint32_t H, float fx, float fy, float cx, float cy, pr_vec3 *pcd, pr_vec3 *normal, hipStream_t s);
 hipError_t launch_raw2depth_mask(const int32_t *raw, size_t n, uint16_t *depth16, uint8_t *mask8, hipStream_t s);

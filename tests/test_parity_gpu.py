@@ -318,3 +318,38 @@ def test_raw2depth_mask(gpu, model, scenario):
     big = api.DeviceVector.from_host(np.array([70000, -5, 0, 65535, 1, 2, 3], np.int32))      # truncation, not saturation
     d, m = api.raw2depth_mask(big)
     assert d.tolist() == [70000 % 65536, 65531, 0, 65535, 1, 2, 3] and m.tolist() == [255, 0, 0, 255, 255, 255, 255]
+
+
+@pytest.mark.parametrize("dtype", [np.int32, np.uint16])
+def test_device_nn_scene_preparation_bit_exact(gpu, scenario, dtype):
+    """Device normals + gather + level-order kd-tree build == the CPU preparation, bit for bit (nodes, point order, normals)."""
+    d = scenario["depth"][1].astype(dtype)
+    host = api.Scene_nn().init_Scene_nn_cuda(d, scenario["K"])
+    dev = api.Scene_nn().init_Scene_nn_device(api.DeviceVector.from_host(d.reshape(-1)), scenario["K"], W, H)
+    n, m = len(host.pcd_host), len(host.nodes_host)
+    assert (dev._n_points, dev._n_nodes) == (n, m)
+    assert np.array_equal(dev.pcd_buffer.to_host()[:3 * n], host.pcd_host.reshape(-1))
+    assert np.array_equal(dev.normal_buffer.to_host()[:3 * n], host.normal_host.reshape(-1))
+    assert dev.nodes.to_host()[:m].tobytes() == host.nodes_host.tobytes()
+    # and ICP against the device-built scene gives the same answer
+    r0 = api.ICP_Point2Plane(api.DeviceVector.from_host(scenario["cloud"].reshape(-1)), host, api.ICPConvergenceCriteria(0.0, 0.0, 5))
+    r1 = api.ICP_Point2Plane(api.DeviceVector.from_host(scenario["cloud"].reshape(-1)), dev, api.ICPConvergenceCriteria(0.0, 0.0, 5))
+    assert np.array_equal(r0.transformation_, r1.transformation_) and r0.fitness_ == r1.fitness_
+
+
+@pytest.mark.parametrize("max_leaf,n", [(1, 700), (3, 700), (10, 5000), (64, 300), (10, 7)])
+def test_device_kdtree_build_random_points_with_ties(gpu, max_leaf, n):
+    import ctypes as C
+    from pose_refine_amd import _lib
+    rng = np.random.default_rng(n + max_leaf)
+    pts = np.round(rng.normal(size=(n, 3)), 1).astype(np.float32)          # coarse grid -> many equal coordinates (tie rule)
+    nrm = rng.normal(size=(n, 3)).astype(np.float32)
+    hp, hn = pts.copy(), nrm.copy()
+    hnodes = np.zeros(2 * n + 1, _lib.KDNODE); cnt = C.c_uint32()
+    _lib.check(_lib.load().pr_kdtree_build(hp.ctypes.data, hn.ctypes.data, n, max_leaf, hnodes.ctypes.data, len(hnodes), C.byref(cnt)))
+    dp, dn = api.DeviceVector.from_host(pts.reshape(-1)), api.DeviceVector.from_host(nrm.reshape(-1))
+    dnodes = api.DeviceVector(2 * n + 1, _lib.KDNODE); dcnt = C.c_uint32()
+    _lib.check(_lib.load().pr_kdtree_build_dev(dp.data(), dn.data(), n, max_leaf, dnodes.data(), 2 * n + 1, C.byref(dcnt)))
+    assert dcnt.value == cnt.value
+    assert dnodes.to_host()[:cnt.value].tobytes() == hnodes[:cnt.value].tobytes()
+    assert np.array_equal(dp.to_host(), hp.reshape(-1)) and np.array_equal(dn.to_host(), hn.reshape(-1))
