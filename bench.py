@@ -65,10 +65,18 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    # PR_BENCH_SHARE_DEVICE=1 is a TEST mode for boxes with one GPU: every rank uses device 0 and the gather runs over
+    # gloo on host copies (RCCL refuses two ranks on one device); everything else is the real N>1 code path.
+    share_device = os.environ.get("PR_BENCH_SHARE_DEVICE", "0") == "1"
+    if share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if share_device:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     api.init(local_rank)
     api.set_option("solve", api.SOLVE_DEVICE if args.solve == "device" else api.SOLVE_HOST)
 
@@ -82,15 +90,29 @@ def main():
     poses = synth.hypotheses(P, seed=6, first=rank * P)          # this rank's shard of the global batch
     crit = api.ICPConvergenceCriteria(0.0, 0.0, args.iters)
 
-    results = torch.zeros(P * 18, dtype=torch.float32, device="cuda")          # P x RegistrationResult (72 B)
+    # P x RegistrationResult (72 B) on the device, double-buffered: the gather of step k may still be in flight
+    # (it runs on RCCL's stream) while step k+1 refines into the other buffer
+    results = [torch.zeros(P * 18, dtype=torch.float32, device="cuda") for _ in range(2)]
+    pending = [None, None]
+    step_no = [0]
 
     def step():
-        _, sizes = api.refine_batch(model, poses, W, H, proj, K, scene, crit, results_dev=results.data_ptr())
-        if world > 1:
-            prd.gather_results(results, world, rank, dst=0)        # the single RCCL exchange of the job
+        b = step_no[0] & 1
+        step_no[0] += 1
+        if pending[b] is not None:                              # buffer b was handed to a gather two steps ago
+            pending[b].wait()
+            torch.cuda.current_stream().synchronize()
+            pending[b] = None
+        _, sizes = api.refine_batch(model, poses, W, H, proj, K, scene, crit, results_dev=results[b].data_ptr())
+        if world > 1:                                           # the single RCCL exchange of the job: P x 72 B per rank to rank 0
+            pending[b] = prd.gather_results(results[b].cpu() if share_device else results[b], world, rank, dst=0, async_op=True)
         return sizes
 
     def fence():
+        for b in (0, 1):
+            if pending[b] is not None:
+                pending[b].wait()
+                pending[b] = None
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -109,7 +131,7 @@ def main():
     prof = api.profile_read()
 
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share_device else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

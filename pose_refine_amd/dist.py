@@ -20,15 +20,29 @@ def shard_bounds(n_items: int, rank: int, world: int) -> Tuple[int, int]:
     return first, base + (1 if rank < extra else 0)
 
 
-def gather_results(local, world: int, rank: int, dst: int = 0, max_count: Optional[int] = None):
+class GatherWork:
+    """Handle of an in-flight gather: .wait() completes it, .out is the list of per-rank tensors on dst (None elsewhere)."""
+
+    def __init__(self, work, out, keep=None):
+        self._work, self.out, self._keep = work, out, keep     # keep: the (possibly padded) send buffer must outlive the op
+
+    def wait(self):
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+        return True
+
+
+def gather_results(local, world: int, rank: int, dst: int = 0, max_count: Optional[int] = None, async_op: bool = False):
     """Gather per-rank result tensors (count_r x 18 float32, on the device the process group uses)
     to `dst` with a single collective.  Shards may differ by one record, so every rank pads to
-    `max_count` records; returns the list of per-rank padded tensors on dst, None elsewhere."""
+    `max_count` records; returns the list of per-rank padded tensors on dst, None elsewhere.
+    With async_op=True returns a work handle with .wait() (and .out = the list on dst)."""
     import torch
     import torch.distributed as dist
 
     if world == 1:
-        return [local]
+        return GatherWork(None, [local]) if async_op else [local]
     n_local = local.numel() // RESULT_FLOATS
     cap = max_count if max_count is not None else n_local
     buf = local.reshape(-1)
@@ -36,6 +50,8 @@ def gather_results(local, world: int, rank: int, dst: int = 0, max_count: Option
         buf = torch.zeros(cap * RESULT_FLOATS, dtype=local.dtype, device=local.device)
         buf[: n_local * RESULT_FLOATS] = local.reshape(-1)
     out: Optional[List] = [torch.empty_like(buf) for _ in range(world)] if rank == dst else None
+    if async_op:
+        return GatherWork(dist.gather(buf, out, dst=dst, async_op=True), out, keep=buf)
     dist.gather(buf, out, dst=dst)
     return out
 

@@ -35,6 +35,12 @@ def _worker(rank, world, port, n_items, out_path):
     local = _fake_results(first, count)
     cap = max(prd.shard_bounds(n_items, r, world)[1] for r in range(world))
     got = prd.gather_results(local, world, rank, dst=0, max_count=cap)
+    work = prd.gather_results(local, world, rank, dst=0, max_count=cap, async_op=True)     # what bench.py uses
+    work.wait()
+    if rank == 0:
+        assert all(torch.equal(a, b) for a, b in zip(got, work.out))
+    else:
+        assert work.out is None
     if rank == 0:
         full = prd.assemble(got, n_items, world)
         np.save(out_path, full.numpy())
