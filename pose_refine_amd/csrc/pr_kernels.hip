@@ -891,11 +891,28 @@ __device__ __forceinline__ float vb_reduce(float (&acc)[29], float (*wsum)[kAccS
 #ifdef PR_ABL_NOREDUCE
     { float t = 0; for (int i = 0; i < 29; ++i) t += acc[i]; if (lane == 63) wsum[wave][0] = t; }
 #else
+#ifdef PR_TREE_VALUE_MAJOR
 #pragma unroll
     for (int i = 0; i < 29; ++i) {
         const float t = wave_tree_sum(acc[i]);
         if (lane == 63) wsum[wave][i] = t;
     }
+#else
+    // level-major: the 29 sums advance through each tree level together, so consecutive DPP instructions are independent
+    // (value-major order makes every instruction depend on the previous one and the compiler pads it with s_nop)
+#define PR_TREE_LEVEL(CTRL, MASK) _Pragma("unroll") for (int i = 0; i < 29; ++i) acc[i] += dpp_get<CTRL, MASK>(acc[i]);
+    PR_TREE_LEVEL(0x111, 0xf)      // row_shr:1
+    PR_TREE_LEVEL(0x112, 0xf)      // row_shr:2
+    PR_TREE_LEVEL(0x114, 0xf)      // row_shr:4
+    PR_TREE_LEVEL(0x118, 0xf)      // row_shr:8
+    PR_TREE_LEVEL(0x142, 0xa)      // row_bcast15 -> rows 1,3
+    PR_TREE_LEVEL(0x143, 0xc)      // row_bcast31 -> rows 2,3
+#undef PR_TREE_LEVEL
+    if (lane == 63) {
+#pragma unroll
+        for (int i = 0; i < 29; ++i) wsum[wave][i] = acc[i];
+    }
+#endif
 #endif
     __syncthreads();
     float t = 0.0f;
