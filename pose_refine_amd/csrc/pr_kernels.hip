@@ -299,33 +299,48 @@ __global__ __launch_bounds__(256) void pose_bbox_kernel(const float *__restrict_
 
 // INT_MAX-fill and per-row valid counts restricted to each hypothesis' pixel box (image rows are
 // the flipped raster rows).  One wavefront per image row; rows outside the box only write count 0.
+constexpr uint32_t kBoxRowsPerBlock = 16;                        // 4 wavefronts x 4 rows: few, fatter workgroups (dispatch-bound otherwise)
 __global__ __launch_bounds__(256) void fill_box_kernel(int32_t *__restrict__ depth, const int4 *__restrict__ bbox, uint32_t width, uint32_t height)
 {
-    const uint32_t row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (row >= height) return;
+    const uint32_t lane = threadIdx.x & 63;
     const int4 bb = bbox[blockIdx.y];
-    const int ry = (int)height - 1 - (int)row;                      // raster row of this image row
-    if (ry < bb.y || ry > bb.w) return;
-    int32_t *line = depth + ((size_t)blockIdx.y * height + row) * width;
-    for (int x = bb.x + (int)lane; x <= bb.z; x += 64) line[x] = INT_MAX;
+    for (uint32_t r = 0; r < 4; ++r) {
+        const uint32_t row = blockIdx.x * kBoxRowsPerBlock + (threadIdx.x >> 6) * 4 + r;
+        if (row >= height) return;
+        const int ry = (int)height - 1 - (int)row;                  // raster row of this image row
+        if (ry < bb.y || ry > bb.w) continue;
+        int32_t *line = depth + ((size_t)blockIdx.y * height + row) * width;
+        for (int x = bb.x + (int)lane; x <= bb.z; x += 64) line[x] = INT_MAX;
+    }
 }
 __global__ __launch_bounds__(256) void count_box_kernel(const int32_t *__restrict__ depth, const int4 *__restrict__ bbox, uint32_t width,
                                                         uint32_t height, uint32_t *__restrict__ row_count)
 {
-    const uint32_t row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (row >= height) return;
+    // latency-bound, not bandwidth-bound: every lane keeps 4 rows x 4 column chunks = 16 loads in flight before the first ballot
+    const uint32_t lane = threadIdx.x & 63;
     const int4 bb = bbox[blockIdx.y];
-    const int ry = (int)height - 1 - (int)row;
-    uint32_t cnt = 0;
-    if (ry >= bb.y && ry <= bb.w) {
-        const int32_t *line = depth + ((size_t)blockIdx.y * height + row) * width;
-        for (int x0 = bb.x; x0 <= bb.z; x0 += 64) {
-            const int x = x0 + (int)lane;
-            const bool v = (x <= bb.z) && line[x] > 0 && line[x] != INT_MAX;
-            cnt += (uint32_t)__popcll(__ballot(v));
+    const uint32_t row0 = blockIdx.x * kBoxRowsPerBlock + (threadIdx.x >> 6) * 4;
+    uint32_t cnt[4] = { 0, 0, 0, 0 };
+    for (int x0 = bb.x; x0 <= bb.z; x0 += 256) {
+        int32_t v[4][4];
+#pragma unroll
+        for (uint32_t r = 0; r < 4; ++r) {
+            const uint32_t row = row0 + r;
+            const int ry = (int)height - 1 - (int)row;
+            const bool live = row < height && ry >= bb.y && ry <= bb.w;
+            const int32_t *line = depth + ((size_t)blockIdx.y * height + (live ? row : 0)) * width;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const int x = x0 + 64 * j + (int)lane; v[r][j] = (live && x <= bb.z) ? line[x] : 0; }
         }
+#pragma unroll
+        for (uint32_t r = 0; r < 4; ++r)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) cnt[r] += (uint32_t)__popcll(__ballot(v[r][j] > 0 && v[r][j] != INT_MAX));
     }
-    if (lane == 0) row_count[(size_t)blockIdx.y * height + row] = cnt;
+    if (lane == 0) {
+#pragma unroll
+        for (uint32_t r = 0; r < 4; ++r) if (row0 + r < height) row_count[(size_t)blockIdx.y * height + row0 + r] = cnt[r];
+    }
 }
 
 // Persistent workgroups walk the (hypothesis, band) items; a band is a run of raster rows of the
@@ -420,30 +435,37 @@ __global__ __launch_bounds__(256) void d2c_emit_box_kernel(const int32_t *__rest
                                                            const uint32_t *__restrict__ row_count, const uint32_t *__restrict__ row_off,
                                                            pr_vec3 *__restrict__ cloud, size_t cloud_stride)
 {
-    const uint32_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63;
-    if (row >= height) return;
-    if (row_count[(size_t)blockIdx.y * height + row] == 0) return;
     const int4 bb = bbox[blockIdx.y];
-    const int32_t *line = depth + ((size_t)blockIdx.y * height + row) * width;
-    pr_vec3 *out = cloud + (size_t)blockIdx.y * cloud_stride + row_off[(size_t)blockIdx.y * height + row];
-    uint32_t done = 0;
-    for (int x0 = bb.x; x0 <= bb.z; x0 += 64) {
-        const int x = x0 + (int)lane;
-        int32_t d = 0;
-        if (x <= bb.z) d = line[x];
-        const bool v = (x <= bb.z) && d > 0 && d != INT_MAX;
-        const unsigned long long m = __ballot(v);
-        if (v) {
-            const uint32_t k = done + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-            const float z = d / 1000.0f;
-            pr_vec3 p;
-            p.x = ((float)(uint32_t)x - cx) / fx * z;
-            p.y = ((float)row - cy) / fy * z;
-            p.z = z;
-            out[k] = p;
+    for (uint32_t r = 0; r < 4; ++r) {
+        const uint32_t row = blockIdx.x * kBoxRowsPerBlock + (threadIdx.x >> 6) * 4 + r;
+        if (row >= height) return;
+        if (row_count[(size_t)blockIdx.y * height + row] == 0) continue;
+        const int32_t *line = depth + ((size_t)blockIdx.y * height + row) * width;
+        pr_vec3 *out = cloud + (size_t)blockIdx.y * cloud_stride + row_off[(size_t)blockIdx.y * height + row];
+        uint32_t done = 0;
+        for (int x0 = bb.x; x0 <= bb.z; x0 += 512) {             // 8 independent loads in flight per lane
+            int32_t dv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const int x = x0 + 64 * j + (int)lane; dv[j] = (x <= bb.z) ? line[x] : 0; }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int x = x0 + 64 * j + (int)lane;
+                const int32_t d = dv[j];
+                const bool v = d > 0 && d != INT_MAX;
+                const unsigned long long m = __ballot(v);
+                if (v) {
+                    const uint32_t k = done + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                    const float z = d / 1000.0f;
+                    pr_vec3 p;
+                    p.x = ((float)(uint32_t)x - cx) / fx * z;
+                    p.y = ((float)row - cy) / fy * z;
+                    p.z = z;
+                    out[k] = p;
+                }
+                done += (uint32_t)__popcll(m);
+            }
         }
-        done += (uint32_t)__popcll(m);
     }
 }
 
@@ -1590,10 +1612,10 @@ hipError_t launch_render_boxes(const pr_triangle *tris, uint32_t n_tris, const p
     for (uint32_t p0 = 0; p0 < n_poses; p0 += 32768) {
         const uint32_t np = (n_poses - p0 < 32768) ? (n_poses - p0) : 32768;
         const size_t off = (size_t)p0 * width * height;
-        hipLaunchKernelGGL(fill_box_kernel, dim3((height + 3) / 4, np), dim3(256), 0, s, depth + off, bbox + p0, width, height);
+        hipLaunchKernelGGL(fill_box_kernel, dim3((height + kBoxRowsPerBlock - 1) / kBoxRowsPerBlock, np), dim3(256), 0, s, depth + off, bbox + p0, width, height);
         hipLaunchKernelGGL(raster_kernel, dim3((n_tris + 255) / 256, np), dim3(256), 0, s, tris, n_tris, poses_dev + p0, depth + off,
                            width, height, proj, none, width, height, (const int4 *)(bbox + p0));
-        hipLaunchKernelGGL(count_box_kernel, dim3((height + 3) / 4, np), dim3(256), 0, s, depth + off, bbox + p0, width, height,
+        hipLaunchKernelGGL(count_box_kernel, dim3((height + kBoxRowsPerBlock - 1) / kBoxRowsPerBlock, np), dim3(256), 0, s, depth + off, bbox + p0, width, height,
                            row_count + (size_t)p0 * height);
     }
     hipLaunchKernelGGL(d2c_scan_kernel, dim3(n_poses), dim3(256), 0, s, row_count, height, row_off, counts);
@@ -1607,7 +1629,7 @@ hipError_t launch_emit_box(const int32_t *depth, uint32_t n_poses, uint32_t widt
     if (n_poses == 0) return hipSuccess;
     for (uint32_t i0 = 0; i0 < n_poses; i0 += 32768) {
         const uint32_t ni = (n_poses - i0 < 32768) ? (n_poses - i0) : 32768;
-        hipLaunchKernelGGL(d2c_emit_box_kernel, dim3((height + 3) / 4, ni), dim3(256), 0, s, depth + (size_t)i0 * width * height, width, height,
+        hipLaunchKernelGGL(d2c_emit_box_kernel, dim3((height + kBoxRowsPerBlock - 1) / kBoxRowsPerBlock, ni), dim3(256), 0, s, depth + (size_t)i0 * width * height, width, height,
                            bbox + i0, fx, fy, cx, cy, row_count + (size_t)i0 * height, row_off + (size_t)i0 * height,
                            cloud + (size_t)i0 * cloud_stride, cloud_stride);
     }
