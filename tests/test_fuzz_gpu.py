@@ -1,0 +1,115 @@
+"""Randomised differential tests (-m gpu): odd image sizes, random meshes (degenerate, behind-camera, huge and sub-pixel
+triangles), random intrinsics, ROI / stride / offsets, uint16 scenes -- HIP path vs the CPU oracle, bit for bit."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from pose_refine_amd import api
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    api.init(0)
+    return True
+
+
+def random_mesh(rng, n, scale):
+    """Triangle soup around the origin: mixed sizes, a few exactly degenerate triangles, duplicated triangles."""
+    centers = rng.normal(size=(n, 1, 3)) * scale
+    size = np.exp(rng.uniform(np.log(0.002), np.log(0.5), size=(n, 1, 1))) * scale
+    tris = (centers + rng.normal(size=(n, 3, 3)) * size).astype(np.float32)
+    tris[0, 1] = tris[0, 0]                         # two equal vertices -> zero area
+    tris[1, 2] = tris[1, 1] = tris[1, 0]            # a point
+    tris[2] = tris[3]                               # duplicate
+    return np.ascontiguousarray(tris)
+
+
+def random_pose(rng, dist):
+    a = rng.normal(size=3); a /= np.linalg.norm(a)
+    ang = rng.uniform(0, np.pi)
+    Kx = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+    R = np.eye(3) + np.sin(ang) * Kx + (1 - np.cos(ang)) * Kx @ Kx
+    T = np.eye(4, dtype=np.float32)
+    T[:3, :3] = R.astype(np.float32)
+    T[:3, 3] = (rng.normal(size=3) * dist * 0.08 + np.array([0, 0, dist])).astype(np.float32)
+    return T
+
+
+@pytest.mark.parametrize("seed,W,H", [(1, 97, 61), (2, 64, 48), (3, 333, 200), (4, 640, 480), (5, 130, 517), (6, 65, 65)])
+def test_render_random_scenes(gpu, seed, W, H):
+    rng = np.random.default_rng(seed)
+    K = np.array([rng.uniform(0.7, 1.6) * W, 0, W / 2 + rng.uniform(-9, 9), 0, rng.uniform(0.7, 1.6) * W, H / 2 + rng.uniform(-9, 9), 0, 0, 1], np.float32)
+    tris = random_mesh(rng, 400, 40.0)
+    poses = np.stack([random_pose(rng, d) for d in (300.0, 150.0, 90.0, 600.0, 45.0)])
+    poses[4, 2, 3] = 10.0                            # camera inside the soup: vertices behind the camera, huge boxes
+    proj = O.compute_proj(K, W, H)
+    assert np.array_equal(api.compute_proj(K, W, H), proj)
+    ref = O.render(tris, poses, W, H, proj)
+    model = api.Model(tris=tris)
+    assert np.array_equal(api.render_host(model, poses, W, H, proj), ref)
+    # ROI: random crop inside the image
+    x0, y0 = int(rng.integers(0, W // 2)), int(rng.integers(0, H // 2))
+    roi = (x0, y0, int(rng.integers(1, W - x0 + 1)), int(rng.integers(1, H - y0 + 1)))
+    assert np.array_equal(api.render_host(model, poses, W, H, proj, roi), O.render(tris, poses, W, H, proj, roi))
+
+
+@pytest.mark.parametrize("seed,W,H", [(11, 97, 61), (12, 333, 200), (13, 640, 480), (14, 70, 130)])
+def test_fused_pipeline_random_scenes(gpu, seed, W, H):
+    """render -> cloud -> ICP on random geometry: cloud sizes, inlier counts (fitness) and transforms vs the oracle, for both
+    associations, both solvers, both raster modes."""
+    rng = np.random.default_rng(seed)
+    f = rng.uniform(0.9, 1.3) * W
+    K = np.array([f, 0, W / 2 + rng.uniform(-5, 5), 0, f * rng.uniform(0.95, 1.05), H / 2 + rng.uniform(-5, 5), 0, 0, 1], np.float32)
+    tris = random_mesh(rng, 600, 45.0)
+    base = random_pose(rng, 320.0)
+    proj = O.compute_proj(K, W, H)
+    scene_depth = O.render(tris, base[None], W, H, proj)[0]
+    if seed % 2 == 0:
+        scene_depth = scene_depth.astype(np.uint16)                # CV_16U scenes
+    poses = []
+    for _ in range(7):
+        p = base.copy()
+        p[:3, 3] += rng.normal(size=3).astype(np.float32) * 6.0
+        poses.append(p)
+    off = base.copy(); off[0, 3] += 4000.0                           # renders nothing: empty cloud
+    poses = np.stack(poses + [off])
+    model = api.Model(tris=tris)
+    crit = (0.0, 0.0, 6)
+    for kind in ("proj", "nn"):
+        if kind == "proj":
+            gs = api.Scene_projective().init_Scene_projective_cuda(scene_depth, K, W, H)
+            osc = O.ProjScene(scene_depth, K)
+        else:
+            if int((scene_depth > 0).sum()) == 0:
+                continue
+            gs = api.Scene_nn().init_Scene_nn_cuda(scene_depth, K)
+            osc = O.NNScene(scene_depth, K)
+        ores, osizes, _ = O.refine_batch(tris, poses, W, H, proj, K, osc, crit, O.SUM_CANONICAL, api.get_option("points_per_block"))
+        for solve in (api.SOLVE_HOST, api.SOLVE_DEVICE):
+            for raster_mode in (0, 1):
+                api.set_option("solve", solve); api.set_option("raster_mode", raster_mode)
+                try:
+                    res, sizes = api.refine_batch(model, poses, W, H, proj, K, gs, api.ICPConvergenceCriteria(*crit))
+                finally:
+                    api.set_option("solve", api.SOLVE_HOST); api.set_option("raster_mode", 0)
+                assert np.array_equal(sizes, osizes), (kind, solve, raster_mode)
+                assert sizes[-1] == 0 and res["fitness"][-1] == 0
+                assert np.array_equal(res["fitness"], ores["fitness"]), (kind, solve, raster_mode)
+                assert np.allclose(res["T"], ores["T"], rtol=0, atol=1e-4), (kind, solve, raster_mode)
+
+
+@pytest.mark.parametrize("seed", [21, 22, 23])
+def test_depth2cloud_random_images(gpu, seed):
+    rng = np.random.default_rng(seed)
+    W, H = int(rng.integers(3, 300)), int(rng.integers(3, 300))
+    K = np.array([500.0, 0, W / 2, 0, 510.0, H / 2, 0, 0, 1], np.float32)
+    d = np.where(rng.random((H, W)) < 0.3, rng.integers(1, 3000, (H, W)), 0).astype(np.int32)
+    d[rng.integers(0, H), :] = -7                                  # negative depths are "not > 0"
+    for dtype in (np.int32, np.uint16):
+        dd = d.astype(dtype) if dtype == np.int32 else np.clip(d, 0, 65535).astype(np.uint16)
+        dev = api.DeviceVector.from_host(dd.reshape(-1))
+        for stride, tlx, tly in ((1, 0, 0), (1, 17, 5), (2, 0, 0), (3, 1, 2)):
+            got = api.depth2cloud(dev, W, H, K, stride, tlx, tly, dtype=dtype).to_host().reshape(-1, 3)
+            assert np.array_equal(got, O.depth2cloud(dd, K, stride, tlx, tly)), (dtype, stride)
