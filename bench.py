@@ -34,9 +34,9 @@ HBM_PEAK = 8.0e12                       # MI355X_MICROARCH.md: 8 TB/s spec
 # N*(21*36 + 20*12) = 996 N bytes per pose over 21 launches.
 BYTES_PER_POINT_PASS0, BYTES_PER_POINT_PASSK = 36.0, 48.0
 # HBM-side traffic of the correspondence kernel measured with rocprofv3 PMC passes (FETCH_SIZE x2 per the
-# gfx950 correction of MI355X_MICROARCH.md + WRITE_SIZE), profiles/r01/README.md: 24.6 B/point at P=256
-# (24.1 at P=1024).  bench.py cannot collect PMCs itself; it scales the committed measurement.
-PMC_TRAFFIC_BYTES_PER_POINT = {"proj": 24.6, "nn": None}
+# gfx950 correction of MI355X_MICROARCH.md + WRITE_SIZE), profiles/r01/README.md: 24.7 B/point at P=256
+# (24.2 at P=1024).  bench.py cannot collect PMCs itself; it scales the committed measurement.
+PMC_TRAFFIC_BYTES_PER_POINT = {"proj": 24.7, "nn": None}
 
 
 def main():
@@ -168,7 +168,7 @@ def main():
                          "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/r01/README.md",
                          "avg_launch_us": avg_launch_s * 1e6, "launches": int(launches),
                          "algorithmic_bytes_per_launch": bytes_per_launch, "points_per_launch": pts_per_launch,
-                         "timing": "HIP events on the library stream around one launch per step, rotating over the 21 passes"},
+                         "timing": "HIP events on the library stream around one launch every 8th step, rotating over the 21 passes"},
             "phase_ms_per_step": {"icp_kernel": prof["icp_kernel_ms"] / args.steps, "render": prof["render_ms"] / args.steps,
                                   "cloud": prof["cloud_ms"] / args.steps},
         }
