@@ -565,13 +565,33 @@ __global__ __launch_bounds__(256) void d2c_emit_kernel(const T *__restrict__ dep
 // ================================================================================================
 struct Corr { float dx, dy, dz, nx, ny, nz; };   // destination point and its normal
 
-// Scene_projective::query depth_scene.h:29-48 + pcd2dep common.h:63-73
+// Correctly rounded a / b for every operand pair whose quotient is in the normal range: the Newton/FMA sequence the
+// compiler emits for an IEEE f32 division (LLVM LowerFDIV32) without its div_scale / div_fmas / div_fixup range handling
+// (3 of 11 instructions).  Used only where an out-of-range or non-finite quotient is rejected right afterwards anyway.
+__device__ __forceinline__ float div_normal_range(float a, float b)
+{
+    float r = __builtin_amdgcn_rcpf(b);
+    const float e0 = __builtin_fmaf(-b, r, 1.0f);
+    r = __builtin_fmaf(e0, r, r);
+    float q = a * r;
+    const float e1 = __builtin_fmaf(-b, q, a);
+    q = __builtin_fmaf(e1, r, q);
+    const float e2 = __builtin_fmaf(-b, q, a);
+    return __builtin_fmaf(e2, r, q);
+}
+
+// Scene_projective::query depth_scene.h:29-48 + pcd2dep common.h:63-73.  The reference converts
+// int(x/z*fx + cx - tl_x + 0.5f) and then tests 0 <= px < width; truncation maps (-1, 0) to pixel 0, and NaN / out-of-range
+// values end up as INT_MIN on x86 (rejected).  The same decision is taken here on the float before converting: valid iff
+// -1 < v < width.  Whenever the quotient is outside the normal range (z = 0, denormal, inf, NaN) the point is rejected on
+// both sides -- by this range test or by the |src.z - dst.z| test -- so the cheaper division above cannot change a result.
 __device__ __forceinline__ bool proj_pixel(float sx, float sy, float sz, float fx, float fy, float cx, float cy,
                                            uint32_t width, uint32_t height, uint32_t &idx, int &px, int &py)
 {
-    px = f2i_x86(sx / sz * fx + cx - 0.0f + 0.5f);
-    py = f2i_x86(sy / sz * fy + cy - 0.0f + 0.5f);
-    if (px < 0 || py < 0 || (uint32_t)px >= width || (uint32_t)py >= height) return false;
+    const float vx = div_normal_range(sx, sz) * fx + cx - 0.0f + 0.5f;
+    const float vy = div_normal_range(sy, sz) * fy + cy - 0.0f + 0.5f;
+    if (!(vx > -1.0f && vx < (float)width && vy > -1.0f && vy < (float)height)) return false;
+    px = (int)vx; py = (int)vy;
     idx = (uint32_t)px + (uint32_t)py * width;
     return true;
 }
@@ -873,14 +893,24 @@ __device__ __forceinline__ void vb_accumulate(float (&acc)[29], float *cl, uint3
             // projective: all four gathers of the lane are issued back to back, unconditionally
             // (pixel 0 stands in for out-of-image points), and only then tested -- one memory round
             // trip per step instead of eight dependent ones.
-            Gathered gth[4];
-            bool in_img[4];
+#ifndef PR_GATHER_BATCH
+#define PR_GATHER_BATCH 4
+#endif
 #pragma unroll
-            for (uint32_t i = 0; i < 4; ++i) in_img[i] = gather_issue(scene, p[3 * i], p[3 * i + 1], p[3 * i + 2], i < cnt, gth[i]);
+            for (uint32_t i0 = 0; i0 < 4; i0 += PR_GATHER_BATCH) {
+                Gathered gth[PR_GATHER_BATCH];
+                bool in_img[PR_GATHER_BATCH];
 #pragma unroll
-            for (uint32_t i = 0; i < 4; ++i) {
-                Corr c;
-                if (gather_finish(scene, in_img[i], p[3 * i + 2], gth[i], c)) accumulate(acc, p[3 * i], p[3 * i + 1], p[3 * i + 2], c);
+                for (uint32_t k = 0; k < PR_GATHER_BATCH; ++k) {
+                    const uint32_t i = i0 + k;
+                    in_img[k] = gather_issue(scene, p[3 * i], p[3 * i + 1], p[3 * i + 2], i < cnt, gth[k]);
+                }
+#pragma unroll
+                for (uint32_t k = 0; k < PR_GATHER_BATCH; ++k) {
+                    const uint32_t i = i0 + k;
+                    Corr c;
+                    if (gather_finish(scene, in_img[k], p[3 * i + 2], gth[k], c)) accumulate(acc, p[3 * i], p[3 * i + 1], p[3 * i + 2], c);
+                }
             }
         }
     };
