@@ -48,6 +48,8 @@ def main():
     ap.add_argument("--scene", choices=["proj", "nn"], default="proj")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--solve", choices=["host", "device"], default=os.environ.get("PR_BENCH_SOLVE", "device"))
+    ap.add_argument("--pose-groups", type=int, default=2, help="streams the device-solve loop is split over (library default 2)")
+    ap.add_argument("--fused-solve", type=int, default=1, help="1: finalize+solve in the tail of the pass kernel (library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-poses", type=int, default=0, help="CPU baseline sample size (0 = auto)")
     args = ap.parse_args()
@@ -79,6 +81,8 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     api.init(local_rank)
     api.set_option("solve", api.SOLVE_DEVICE if args.solve == "device" else api.SOLVE_HOST)
+    api.set_option("pose_groups", args.pose_groups)
+    api.set_option("fused_solve", args.fused_solve)
 
     W, H, K = synth.WIDTH, synth.HEIGHT, synth.K_TEST
     P = args.poses
@@ -157,10 +161,11 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"obj_06.ply, {P}-pose batch per GPU, 640x480 synthetic depth, "
                                    f"{'projective' if args.scene == 'proj' else 'stackless kd-tree NN'} association, "
-                                   f"{args.iters} ICP iterations (21 passes), solve on {args.solve}",
+                                   f"{args.iters} ICP iterations (21 passes), solve on {args.solve}"
+                                   + (f", {args.pose_groups} pose groups" if args.solve == "device" else ""),
                        "poses_per_gpu": P, "global_batch": P * world, "points_per_pose_mean": float(np.mean(sizes)),
                        "parallelism": f"pose-shard x{world}, 1 RCCL gather"},
-            "roofline": {"bound": "hbm", "kernel": "icp_pass_kernel (correspondence + 29-term reduce)",
+            "roofline": {"bound": "hbm", "kernel": "icp_pass_kernel (correspondence + 29-term reduce" + (" + finalize/solve tail)" if args.fused_solve and args.solve == "device" else ")"),
                          "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK,
                          "traffic": (PMC_TRAFFIC_BYTES_PER_POINT[args.scene] * pts_per_launch
@@ -168,7 +173,8 @@ def main():
                          "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/r01/README.md",
                          "avg_launch_us": avg_launch_s * 1e6, "launches": int(launches),
                          "algorithmic_bytes_per_launch": bytes_per_launch, "points_per_launch": pts_per_launch,
-                         "timing": "HIP events on the library stream around one launch every 8th step, rotating over the 21 passes"},
+                         "timing": "HIP events on the library stream around one launch every 8th step, rotating over the 21 passes; "
+                                   "a timed step runs the batch as one pose group so the launch has the chip to itself"},
             "phase_ms_per_step": {"icp_kernel": prof["icp_kernel_ms"] / args.steps, "render": prof["render_ms"] / args.steps,
                                   "cloud": prof["cloud_ms"] / args.steps},
         }

@@ -76,25 +76,26 @@ struct Ctx {
     bool ready = false;
     int device = -1;
     hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;   // second lane of the device-solve loop (pose groups overlap pass and solve)
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    int pose_groups = 1;             // 2: split the batch over two streams so one group's solve overlaps the other's pass (+5 % poses/s,
-                                     // but launches then overlap and can no longer be timed one by one) -- opt-in
+    hipStream_t side[3] = { nullptr, nullptr, nullptr };   // extra lanes of the device-solve loop (pose groups overlap one group's solve tail with another group's pass)
+    hipEvent_t ev_fork = nullptr, ev_join[3] = { nullptr, nullptr, nullptr };
+    int pose_groups = 2;             // PR_SOLVE_DEVICE: split the batch over this many streams (1..4); 2 measured best (1.31 vs 1.45 ms/step at
+                                     // 256 poses); launches of different groups overlap, so timed calls fall back to one group
     // options
     int solve_mode = PR_SOLVE_HOST;
     int steps = 2;                   // 1024-point steps per workgroup -> 2048 points per workgroup
     int profile = 0;
     int nn_lds_nodes = 1024;
     int nn_stack = 1;                // kd-tree query: per-lane LDS stack (1) or the reference's stackless walk (0)
+    int fused_solve = 1;             // PR_SOLVE_DEVICE: the workgroup delivering a hypothesis' last partial sum also runs its finalize + solve (no second launch per iteration)
     int icp_flow = 0;                // PR_SOLVE_DEVICE: 1 = one persistent dataflow launch for all iterations (bit-identical; measured equal at
                                      // 256 poses and 35 % slower at 1024), 0 = one launch per pass + per solve
-    int use_graph = 1;               // PR_SOLVE_DEVICE: capture the whole iteration loop in a hipGraph and replay it: 2 % on a fast host, up to
-                                     // 25 % on a slow one (44 launches/step); calls that time a launch with HIP events use direct launches
+    int use_graph = 1;               // PR_SOLVE_DEVICE, single pose group only (the runtime serialises the branches of a captured multi-stream
+                                     // graph, which forfeits the overlap): capture the whole iteration loop in a hipGraph and replay it
     int raster_mode = 0;             // fused path: 0 = global atomicMin inside the per-pose pixel box (reference scheme), 1 = LDS depth bands
     int n_cus = 256;
     const void *aabb_key = nullptr; size_t aabb_n = 0;
     // workspaces
-    DevBuf aabb, bbox, poses, depth, row_count, row_off, counts, cloud, meta, partial, sums, rec, topo, bmin, bmax, pts, nnrec, nndepth, dstate, dresults, vbdesc, flowsync, conv16, conv8, kd_idx, kd_scratch, kd_child, kd_ctrl, kd_tmp, nn_full;
+    DevBuf aabb, bbox, poses, depth, row_count, row_off, counts, cloud, meta, partial, sums, rec, topo, bmin, bmax, pts, nnrec, nndepth, dstate, dresults, vbdesc, flowsync, arrive, conv16, conv8, kd_idx, kd_scratch, kd_child, kd_ctrl, kd_tmp, nn_full;
     PinBuf h_sums, h_meta, h_counts, h_results, h_dstate, h_flow;
     // profiling
     std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
@@ -143,9 +144,11 @@ int require_ctx()
     if (dev >= n) { set_error("device %d out of range (%d visible)", dev, n); return PR_ERR_NO_DEVICE; }
     HIP_TRY(hipSetDevice(dev));
     HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&g.stream2, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&g.ev_fork, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&g.ev_join, hipEventDisableTiming));
+    for (int i = 0; i < 3; ++i) {
+        HIP_TRY(hipStreamCreateWithFlags(&g.side[i], hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&g.ev_join[i], hipEventDisableTiming));
+    }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) g.n_cus = prop.multiProcessorCount;
     g.device = dev;
@@ -288,6 +291,8 @@ int icp_drive(pr_vec3 *cloud_base, const uint32_t *start_h, const uint32_t *coun
         pr_result *dres = results_dev;
         if (!dres) { PR_TRY(g.dresults.ensure(sizeof(pr_result) * P)); dres = g.dresults.as<pr_result>(); }
         const bool may_exit_early = (crit.relative_fitness > 0.0f && crit.relative_rmse > 0.0f);
+        const bool fused = g.fused_solve != 0;
+        if (fused) PR_TRY(g.arrive.ensure(sizeof(uint32_t) * P));
 
         if (g.icp_flow) {
             // ---- dataflow path: one persistent launch runs every iteration of every hypothesis ------------------
@@ -342,31 +347,40 @@ int icp_drive(pr_vec3 *cloud_base, const uint32_t *start_h, const uint32_t *coun
         const uint64_t tick = g.sample_clock++;
         const bool sample_call = (g.profile == 2) && (tick % 8 == 0);
         const uint32_t sample_it = (uint32_t)(((tick / 8) * 5 + 1) % (uint64_t)(crit.max_iteration + 1));
+        // Pose groups: the batch is split over up to four streams so that one group's serial solve tail (and the ragged end
+        // of its pass) overlaps another group's pass.  Timed launches (profile 1, the sampled call of profile 2) run as a
+        // single group so that the measured kernel has the chip to itself.
+        const bool timed_call = (g.profile == 1) || sample_call;
+        const uint32_t n_groups = timed_call ? 1u : std::max(1u, std::min({ (uint32_t)std::max(1, g.pose_groups), 4u, P / 32u }));
         // the fixed sequence: state upload, (max_iteration+1) x [correspondence pass, finalize+solve], result pack
         auto enqueue_all = [&](std::vector<hipEvent_t> *, bool host_checks) -> int {
             HIP_TRY(hipMemcpyAsync(g.dstate.p, init, sizeof(prk::DevIcpState) * P, hipMemcpyHostToDevice, g.stream));
             HIP_TRY(hipMemcpyAsync(g.meta.p, h_meta, sizeof(prk::PoseMeta) * P, hipMemcpyHostToDevice, g.stream));
+            if (fused) HIP_TRY(hipMemsetAsync(g.arrive.p, 0, sizeof(uint32_t) * P, g.stream));
             // Two pose groups on two streams: while the (latency-bound, one wavefront per pose) finalize+solve
             // of one group runs, the correspondence pass of the other group keeps the chip busy.
-            const uint32_t n_groups = (g.pose_groups >= 2 && P >= 64) ? 2u : 1u;
-            const uint32_t split = (n_groups == 2) ? (P + 1) / 2 : P;
-            if (n_groups == 2) { HIP_TRY(hipEventRecord(g.ev_fork, g.stream)); HIP_TRY(hipStreamWaitEvent(g.stream2, g.ev_fork, 0)); }
+            auto group_begin = [&](uint32_t grp) { return (uint32_t)(((uint64_t)P * grp) / n_groups); };
+            if (n_groups > 1) {
+                HIP_TRY(hipEventRecord(g.ev_fork, g.stream));
+                for (uint32_t k = 1; k < n_groups; ++k) HIP_TRY(hipStreamWaitEvent(g.side[k - 1], g.ev_fork, 0));
+            }
             for (uint32_t it = 0; it <= (uint32_t)crit.max_iteration; ++it) {
                 for (uint32_t grp = 0; grp < n_groups; ++grp) {
-                    const uint32_t p0 = grp ? split : 0, np = grp ? P - split : split;
-                    hipStream_t st = grp ? g.stream2 : g.stream;
+                    const uint32_t p0 = group_begin(grp), np = group_begin(grp + 1) - p0;
+                    hipStream_t st = grp ? g.side[grp - 1] : g.stream;
                     prk::IcpBatch bb = b;
                     bb.meta += p0; bb.partial += (size_t)p0 * nblk * prk::kAccStride;
+                    if (fused) { bb.fused = 1; bb.iter = it; bb.crit = crit; bb.st = g.dstate.as<prk::DevIcpState>() + p0; bb.arrive = g.arrive.as<uint32_t>() + p0; }
                     if (grp == 0 && (g.profile == 1 || (sample_call && it == sample_it))) {
                         SpanGuard sp(kSpanIcp); HIP_TRY(launch_pass(bb, sc, np, st));
                         uint64_t pts = 0; for (uint32_t i = p0; i < p0 + np; ++i) pts += count_h[i];
                         g.icp_points += pts; g.icp_bytes += pts * (it == 0 ? 36u : 48u);
                     } else HIP_TRY(launch_pass(bb, sc, np, st));
-                    HIP_TRY(prk::launch_icp_finalize_solve(bb.partial, g.meta.as<prk::PoseMeta>() + p0, nblk, steps,
-                                                           g.dstate.as<prk::DevIcpState>() + p0, crit, it, np, st));
+                    if (!fused) HIP_TRY(prk::launch_icp_finalize_solve(bb.partial, g.meta.as<prk::PoseMeta>() + p0, nblk, steps,
+                                                                       g.dstate.as<prk::DevIcpState>() + p0, crit, it, np, st));
                 }
                 if (host_checks && may_exit_early && (it & 3) == 3 && it < (uint32_t)crit.max_iteration) {
-                    if (n_groups == 2) HIP_TRY(hipStreamSynchronize(g.stream2));
+                    for (uint32_t k = 1; k < n_groups; ++k) HIP_TRY(hipStreamSynchronize(g.side[k - 1]));
                     HIP_TRY(hipMemcpyAsync(h_meta, g.meta.p, sizeof(prk::PoseMeta) * P, hipMemcpyDeviceToHost, g.stream));
                     HIP_TRY(hipStreamSynchronize(g.stream));
                     bool any = false;
@@ -374,17 +388,17 @@ int icp_drive(pr_vec3 *cloud_base, const uint32_t *start_h, const uint32_t *coun
                     if (!any) break;
                 }
             }
-            if (n_groups == 2) { HIP_TRY(hipEventRecord(g.ev_join, g.stream2)); HIP_TRY(hipStreamWaitEvent(g.stream, g.ev_join, 0)); }
+            for (uint32_t k = 1; k < n_groups; ++k) { HIP_TRY(hipEventRecord(g.ev_join[k - 1], g.side[k - 1])); HIP_TRY(hipStreamWaitEvent(g.stream, g.ev_join[k - 1], 0)); }
             HIP_TRY(prk::launch_pack_results(g.dstate.as<prk::DevIcpState>(), dres, P, g.stream));
             // results go to the pinned staging buffer (a pageable destination is not capturable)
             if (results_host) HIP_TRY(hipMemcpyAsync(res, dres, sizeof(pr_result) * P, hipMemcpyDeviceToHost, g.stream));
             return PR_OK;
         };
 
-        if (g.use_graph && g.pose_groups < 2 && (g.profile == 0 || (g.profile == 2 && !sample_call))) {   // HIP events recorded inside a captured graph cannot be timed
+        if (g.use_graph && n_groups == 1 && (g.profile == 0 || (g.profile == 2 && !sample_call))) {   // HIP events recorded inside a captured graph cannot be timed
             GraphKey key;
             key.add(P); key.add(nblk); key.add(steps); key.add(crit); key.add(sc); key.add(cloud_base); key.add(g.meta.p); key.add(g.partial.p);
-            key.add(g.dstate.p); key.add(dres); key.add(results_host != nullptr); key.add(res); key.add(h_meta); key.add(init); key.add(g.profile); key.add(g.pose_groups);
+            key.add(g.dstate.p); key.add(dres); key.add(results_host != nullptr); key.add(res); key.add(h_meta); key.add(init); key.add(g.profile); key.add(g.pose_groups); key.add(g.fused_solve); key.add(g.arrive.p);
             CachedGraph *hit = nullptr;
             for (auto &c : g_graphs) if (c.exec && c.key == key) { hit = &c; break; }
             if (!hit) {
@@ -661,16 +675,19 @@ int pr_shutdown(void)
     if (!g.ready) return PR_OK;
     hipStreamSynchronize(g.stream);
     for (DevBuf *b : { &g.aabb, &g.bbox, &g.poses, &g.depth, &g.row_count, &g.row_off, &g.counts, &g.cloud, &g.meta, &g.partial,
-                       &g.sums, &g.rec, &g.topo, &g.bmin, &g.bmax, &g.pts, &g.nnrec, &g.nndepth, &g.dstate, &g.dresults, &g.vbdesc, &g.flowsync, &g.conv16, &g.conv8, &g.kd_idx, &g.kd_scratch, &g.kd_child, &g.kd_ctrl, &g.kd_tmp, &g.nn_full }) b->release();
+                       &g.sums, &g.rec, &g.topo, &g.bmin, &g.bmax, &g.pts, &g.nnrec, &g.nndepth, &g.dstate, &g.dresults, &g.vbdesc, &g.flowsync, &g.arrive, &g.conv16, &g.conv8, &g.kd_idx, &g.kd_scratch, &g.kd_child, &g.kd_ctrl, &g.kd_tmp, &g.nn_full }) b->release();
     for (PinBuf *b : { &g.h_sums, &g.h_meta, &g.h_counts, &g.h_results, &g.h_dstate, &g.h_flow }) b->release();
     drop_graphs();
     for (hipEvent_t e : g.ev_pool) hipEventDestroy(e);
     g.ev_pool.clear(); g.ev_used = 0; g.spans.clear();
     hipStreamDestroy(g.stream);
-    if (g.stream2) hipStreamDestroy(g.stream2);
     if (g.ev_fork) hipEventDestroy(g.ev_fork);
-    if (g.ev_join) hipEventDestroy(g.ev_join);
-    g.stream2 = nullptr; g.ev_fork = g.ev_join = nullptr;
+    g.ev_fork = nullptr;
+    for (int i = 0; i < 3; ++i) {
+        if (g.side[i]) hipStreamDestroy(g.side[i]);
+        if (g.ev_join[i]) hipEventDestroy(g.ev_join[i]);
+        g.side[i] = nullptr; g.ev_join[i] = nullptr;
+    }
     g.stream = nullptr; g.ready = false; g.device = -1; g.aabb_key = nullptr; g.aabb_n = 0;
     return PR_OK;
 }
@@ -871,7 +888,8 @@ int pr_set_option(const char *name, int value)
     else if (n == "nn_stack") g.nn_stack = value ? 1 : 0;
     else if (n == "graph") g.use_graph = value ? 1 : 0;
     else if (n == "icp_flow") g.icp_flow = value ? 1 : 0;
-    else if (n == "pose_groups") g.pose_groups = (value >= 2) ? 2 : 1;
+    else if (n == "fused_solve") g.fused_solve = value ? 1 : 0;
+    else if (n == "pose_groups") g.pose_groups = std::min(4, std::max(1, value));
     else if (n == "raster_mode") { if (value != 0 && value != 1) { set_error("raster_mode must be 0 or 1"); return PR_ERR_INVALID; } g.raster_mode = value; }
     else { set_error("unknown option %s", name); return PR_ERR_INVALID; }
     return PR_OK;
@@ -889,6 +907,7 @@ int pr_get_option(const char *name, int *value)
     else if (n == "raster_mode") *value = g.raster_mode;
     else if (n == "graph") *value = g.use_graph;
     else if (n == "icp_flow") *value = g.icp_flow;
+    else if (n == "fused_solve") *value = g.fused_solve;
     else if (n == "pose_groups") *value = g.pose_groups;
     else { set_error("unknown option %s", name); return PR_ERR_INVALID; }
     return PR_OK;

@@ -30,6 +30,7 @@ struct alignas(64) PoseMeta {
 };
 static_assert(sizeof(PoseMeta) == 64, "PoseMeta must stay one 64-byte record");
 
+struct DevIcpState;
 // batch of model clouds handed to one correspondence pass
 struct IcpBatch {
     pr_vec3        *cloud;      // base of all clouds (dev)
@@ -37,6 +38,13 @@ struct IcpBatch {
     float          *partial;    // [P][nblk][kAccStride] workgroup sums (dev)
     uint32_t        nblk;       // workgroups per hypothesis (grid.x)
     uint32_t        steps;      // steps of 1024 points per workgroup
+    // PR_SOLVE_DEVICE with the solve fused into the pass (option "fused_solve"): the workgroup that delivers the last
+    // partial sum of a hypothesis also adds the partials up and runs that hypothesis' iteration logic
+    uint32_t        fused;      // 0 = separate icp_finalize_solve launch
+    uint32_t        iter;       // iteration index of this pass (icp.cu:178 loop variable)
+    DevIcpState    *st;         // [P]
+    uint32_t       *arrive;     // [P] zero before the first pass; the solving workgroup re-zeroes its entry
+    pr_criteria     crit;
 };
 
 // projective scene exactly as the reference API hands it over (two Vec3f arrays)

@@ -151,23 +151,10 @@ PR_HD inline void ldlt6(double *m /*36*/, const double *rhs, double *x)
 #undef MM
 }
 
-// A: 36 floats (symmetric, any major), b: 6 floats -> T: row-major 4x4 float
-PR_HD inline void solve_666_impl(const float *A, const float *b, float *T)
+// u = (rx, ry, rz, tx, ty, tz) and the sines / cosines of the three half angles -> T: row-major 4x4 float
+// (TransformVector6dToMatrix4d, icp.cpp:7-27)
+PR_HD inline void compose_update(const double *u, double sx, double cx, double sy, double cy, double sz, double cz, float *T)
 {
-    double m[36], rhs[6], u[6];
-#pragma unroll
-    for (int r = 0; r < 6; ++r) {
-#pragma unroll
-        for (int c = 0; c < 6; ++c) m[r * 6 + c] = (double)A[c * 6 + r] + (r == c ? 0.01 : 0.0);
-    }
-#pragma unroll
-    for (int i = 0; i < 6; ++i) rhs[i] = (double)b[i];
-    ldlt6(m, rhs, u);
-
-    double sx, cx, sy, cy, sz, cz;
-    sincos_d(0.5 * u[0], &sx, &cx);
-    sincos_d(0.5 * u[1], &sy, &cy);
-    sincos_d(0.5 * u[2], &sz, &cz);
     // q = qz * qy * qx with qz=(cz;0,0,sz), qy=(cy;0,sy,0), qx=(cx;sx,0,0), general Hamilton products
     // first qzy = qz*qy
     double aw = cz * cy - 0.0 * 0.0 - 0.0 * sy - sz * 0.0;
@@ -188,6 +175,26 @@ PR_HD inline void solve_666_impl(const float *A, const float *b, float *T)
     T[4] = (float)(txy + twz);         T[5] = (float)(1.0 - (txx + tzz)); T[6]  = (float)(tyz - twx);         T[7]  = (float)u[4];
     T[8] = (float)(txz - twy);         T[9] = (float)(tyz + twx);         T[10] = (float)(1.0 - (txx + tyy)); T[11] = (float)u[5];
     T[12] = 0.0f; T[13] = 0.0f; T[14] = 0.0f; T[15] = 1.0f;
+}
+
+// A: 36 floats (symmetric, any major), b: 6 floats -> T: row-major 4x4 float
+PR_HD inline void solve_666_impl(const float *A, const float *b, float *T)
+{
+    double m[36], rhs[6], u[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) m[r * 6 + c] = (double)A[c * 6 + r] + (r == c ? 0.01 : 0.0);
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) rhs[i] = (double)b[i];
+    ldlt6(m, rhs, u);
+
+    double sx, cx, sy, cy, sz, cz;
+    sincos_d(0.5 * u[0], &sx, &cx);
+    sincos_d(0.5 * u[1], &sy, &cy);
+    sincos_d(0.5 * u[2], &sz, &cz);
+    compose_update(u, sx, cx, sy, cy, sz, cz, T);
 }
 
 // result.T = E * result.T with the reference's summation order: index 3,2,1,0 from 0
