@@ -811,8 +811,62 @@ __device__ __forceinline__ bool query_nn_stack(const SceneNNDev &s, int *stk_nod
 // ================================================================================================
 //  29-term contribution (icp.h:138-206) accumulated straight into the lane's registers
 // ================================================================================================
-__device__ __forceinline__ void accumulate(float (&acc)[29], float sx, float sy, float sz, const Corr &c)
+// The 29 running sums of a lane are kept as 15 register pairs: v_pk_mul_f32 / v_pk_add_f32 do two IEEE single-precision
+// operations per issue slot (separate multiply and add, no contraction), so every sum sees exactly the operations of the
+// scalar form (pcd2Ab functor, icp.h:86-136) at roughly half the instruction count.
+typedef float float2v __attribute__((ext_vector_type(2)));
+#ifndef PR_PACKED_ACC
+#define PR_PACKED_ACC 1
+#endif
+#if PR_PACKED_ACC
+struct Acc29 { float2v pk[15]; };
+__device__ __forceinline__ void acc_clear(Acc29 &a) {
+#pragma unroll
+    for (int i = 0; i < 15; ++i) a.pk[i] = float2v{ 0.0f, 0.0f };
+}
+__device__ __forceinline__ void acc_export(const Acc29 &a, float (&out)[29]) {
+#pragma unroll
+    for (int i = 0; i < 29; ++i) out[i] = (i & 1) ? a.pk[i >> 1].y : a.pk[i >> 1].x;
+}
+__device__ __forceinline__ void accumulate(Acc29 &acc, float sx, float sy, float sz, const Corr &c)
 {
+    const float ex = c.dx - sx, ey = c.dy - sy, ez = c.dz - sz;
+    const float r = ex * c.nx + ey * c.ny + ez * c.nz;
+    const float J0 = c.nz * sy - c.ny * sz;
+    const float J1 = c.nx * sz - c.nz * sx;
+    const float J2 = c.ny * sx - c.nx * sy;
+    const float J3 = c.nx, J4 = c.ny, J5 = c.nz;
+    const float e2 = ex * ex + ey * ey + ez * ez;
+    // sums 0..20: J[a]*J[b] for a <= b, row-major; 21..26: J[a]*r; 27: squared distance; 28: count
+    acc.pk[0]  += float2v{ J0, J0 } * float2v{ J0, J1 };
+    acc.pk[1]  += float2v{ J0, J0 } * float2v{ J2, J3 };
+    acc.pk[2]  += float2v{ J0, J0 } * float2v{ J4, J5 };
+    acc.pk[3]  += float2v{ J1, J1 } * float2v{ J1, J2 };
+    acc.pk[4]  += float2v{ J1, J1 } * float2v{ J3, J4 };
+    acc.pk[5]  += float2v{ J1, J2 } * float2v{ J5, J2 };
+    acc.pk[6]  += float2v{ J2, J2 } * float2v{ J3, J4 };
+    acc.pk[7]  += float2v{ J2, J3 } * float2v{ J5, J3 };
+    acc.pk[8]  += float2v{ J3, J3 } * float2v{ J4, J5 };
+    acc.pk[9]  += float2v{ J4, J4 } * float2v{ J4, J5 };
+    acc.pk[10] += float2v{ J5, J0 } * float2v{ J5, r };
+    acc.pk[11] += float2v{ J1, J2 } * float2v{ r, r };
+    acc.pk[12] += float2v{ J3, J4 } * float2v{ r, r };
+    acc.pk[13] += float2v{ J5 * r, e2 };
+    acc.pk[14] += float2v{ 1.0f, 0.0f };
+}
+#else
+struct Acc29 { float v[29]; };
+__device__ __forceinline__ void acc_clear(Acc29 &a) {
+#pragma unroll
+    for (int i = 0; i < 29; ++i) a.v[i] = 0.0f;
+}
+__device__ __forceinline__ void acc_export(const Acc29 &a, float (&out)[29]) {
+#pragma unroll
+    for (int i = 0; i < 29; ++i) out[i] = a.v[i];
+}
+__device__ __forceinline__ void accumulate(Acc29 &a, float sx, float sy, float sz, const Corr &c)
+{
+    float (&acc)[29] = a.v;
     const float ex = c.dx - sx, ey = c.dy - sy, ez = c.dz - sz;
     const float r = ex * c.nx + ey * c.ny + ez * c.nz;
     float J[6];
@@ -830,6 +884,7 @@ __device__ __forceinline__ void accumulate(float (&acc)[29], float sx, float sy,
     acc[27] += ex * ex + ey * ey + ez * ez;
     acc[28] += 1.0f;
 }
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // wave64 sum with a fixed balanced pairwise tree in lane order, result in lane 63:
@@ -1023,11 +1078,13 @@ __device__ __forceinline__ bool pose_iteration_wave(float total, uint32_t n, Dev
 // One virtual workgroup of the canonical tree: accumulate the 29 sums of points [first, first + steps*1024) of one
 // cloud into the lane's registers (pending transform applied and written back first when xf).
 template <class Scene, bool kNN, int kStack>
-__device__ __forceinline__ void vb_accumulate(float (&acc)[29], float *cl, uint32_t n, uint32_t first, uint32_t steps, bool xf,
+__device__ __forceinline__ void vb_accumulate(float (&acc_out)[29], float *cl, uint32_t n, uint32_t first, uint32_t steps, bool xf,
                                               const float (&M)[12], const Scene &scene, const int4 *lds_topo, int *stk_node, float *stk_lb)
 {
     const bool vec_ok = ((reinterpret_cast<uintptr_t>(cl) & 15u) == 0);
     struct { uint32_t steps; } b{ steps };
+    Acc29 acc;                                                   // the caller's sums start at zero
+    acc_clear(acc);
     (void)lds_topo; (void)stk_node; (void)stk_lb;
     // one 1024-point step of this lane: 4 consecutive points = 48 contiguous bytes
     auto load_step = [&](uint32_t s, float (&p)[12], uint32_t &j0, uint32_t &cnt, bool &full) {
@@ -1120,7 +1177,7 @@ __device__ __forceinline__ void vb_accumulate(float (&acc)[29], float *cl, uint3
         if (cnt == 0) break;
         process_step(p, j0, cnt, full);
     }
-
+    acc_export(acc, acc_out);
 }
 
 // canonical tree, second half: wave (balanced pairwise over lanes) -> ((w0+w1)+w2)+w3.  Returns, in threads 0..28, the
