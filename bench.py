@@ -36,7 +36,7 @@ BYTES_PER_POINT_PASS0, BYTES_PER_POINT_PASSK = 36.0, 48.0
 # HBM-side traffic of the correspondence kernel measured with rocprofv3 PMC passes (FETCH_SIZE x2 per the
 # gfx950 correction of MI355X_MICROARCH.md + WRITE_SIZE), profiles/r01/README.md: 24.7 B/point at P=256
 # (24.2 at P=1024).  bench.py cannot collect PMCs itself; it scales the committed measurement.
-PMC_TRAFFIC_BYTES_PER_POINT = {"proj": 24.7, "nn": None}
+PMC_TRAFFIC_BYTES_PER_POINT = {"proj": 25.0, "nn": None}
 
 
 def main():
