@@ -85,6 +85,7 @@ struct Ctx {
     int steps = 2;                   // 1024-point steps per workgroup -> 2048 points per workgroup
     int profile = 0;
     int nn_lds_nodes = 1024;
+    int nn_lds_records = 0;          // stack traversal: leading 64-byte node records staged in LDS; measured 0/64/128/256/512 -> 42.2/41.6/45.2/45.4/58.2 ms per step (occupancy lost to the extra LDS outweighs the saved L1 lookups)
     int nn_stack = 1;                // kd-tree query: per-lane LDS stack (1) or the reference's stackless walk (0)
     int fused_solve = 1;             // PR_SOLVE_DEVICE: the workgroup delivering a hypothesis' last partial sum also runs its finalize + solve (no second launch per iteration)
     int icp_flow = 0;                // PR_SOLVE_DEVICE: 1 = one persistent dataflow launch for all iterations (bit-identical; measured equal at
@@ -232,6 +233,7 @@ int make_scene(int kind, const void *scene, bool want_packed, SceneSel &out)
         // pending far children on the stack never exceed the tree depth; deeper trees use the stackless walk
         uint32_t stack = 0;
         if (g.nn_stack) stack = (depth <= 16) ? 16u : ((depth <= 24) ? 24u : 0u);
+        if (stack) lds = std::min<uint32_t>({ (uint32_t)std::max(0, g.nn_lds_records), s->n_nodes, (65536u - stack * 2048u) / 64u });   // stacks + records <= 64 KiB
         out.nn = prk::SceneNNDev{ s->max_dist_diff, g.topo.as<int4>(), g.bmin.as<float4>(), g.bmax.as<float4>(), g.pts.as<float4>(),
                                   s->pcd, s->normal, s->n_nodes, lds, g.nnrec.as<float4>(), stack };
         return PR_OK;
@@ -885,6 +887,7 @@ int pr_set_option(const char *name, int value)
     else if (n == "points_per_block") { if (value < 1024 || value % 1024) { set_error("points_per_block must be a multiple of 1024"); return PR_ERR_INVALID; } g.steps = value / 1024; }
     else if (n == "profile") { if (value < 0 || value > 2) { set_error("profile must be 0, 1 (every launch) or 2 (one sampled launch per call)"); return PR_ERR_INVALID; } g.profile = value; }
     else if (n == "nn_lds_nodes") g.nn_lds_nodes = std::max(0, value);
+    else if (n == "nn_lds_records") g.nn_lds_records = std::max(0, value);
     else if (n == "nn_stack") g.nn_stack = value ? 1 : 0;
     else if (n == "graph") g.use_graph = value ? 1 : 0;
     else if (n == "icp_flow") g.icp_flow = value ? 1 : 0;
@@ -903,6 +906,7 @@ int pr_get_option(const char *name, int *value)
     else if (n == "points_per_block") *value = g.steps * 1024;
     else if (n == "profile") *value = g.profile;
     else if (n == "nn_lds_nodes") *value = g.nn_lds_nodes;
+    else if (n == "nn_lds_records") *value = g.nn_lds_records;
     else if (n == "nn_stack") *value = g.nn_stack;
     else if (n == "raster_mode") *value = g.raster_mode;
     else if (n == "graph") *value = g.use_graph;

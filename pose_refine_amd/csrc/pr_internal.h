@@ -68,7 +68,7 @@ struct SceneNNDev {
     const float4 *pts;          // per point {x,y,z,0}
     const pr_vec3 *pcd, *normal;
     uint32_t n_nodes;
-    uint32_t lds_nodes;         // stackless variant: how many leading (top-level) nodes the kernel stages in LDS
+    uint32_t lds_nodes;         // how many leading (top-level) nodes the kernel stages in LDS (stackless: 16-byte topo entries; stack: 64-byte records)
     const float4 *rec;          // stack variant: 64-byte record per node (4 x float4), see nn_records_kernel
     uint32_t stack_depth;       // 0 = stackless traversal, else per-lane LDS stack entries (>= tree depth)
 };

@@ -747,7 +747,7 @@ constexpr int kLeafBatch = PR_LEAF_BATCH;
 #endif
 
 template <int kDepth>
-__device__ __forceinline__ bool query_nn_stack(const SceneNNDev &s, int *stk_node, float *stk_lb, float sx, float sy, float sz, Corr &c)
+__device__ __forceinline__ bool query_nn_stack(const SceneNNDev &s, const float4 *lds_rec, int *stk_node, float *stk_lb, float sx, float sy, float sz, Corr &c)
 {
     int cur = 0, sp = 0, best_i = 0;
 #if PR_NN_BOUNDED
@@ -759,7 +759,16 @@ __device__ __forceinline__ bool query_nn_stack(const SceneNNDev &s, int *stk_nod
     float best = FLT_MAX;
 #endif
     for (;;) {
-        const float4 h = s.rec[(size_t)cur * 4];
+        // the leading (top-level) records are staged in LDS: the kernel is bound by the texture-addresser / L1 tag rate
+        // (one cache-line lookup per lane per 16-byte load), which LDS reads do not touch
+        float4 h, b0, b1, b2;
+        if ((uint32_t)cur < s.lds_nodes) {
+            const float4 *q = lds_rec + (size_t)cur * 4;
+            h = q[0]; b0 = q[1]; b1 = q[2]; b2 = q[3];
+        } else {
+            const float4 *q = s.rec + (size_t)cur * 4;
+            h = q[0]; b0 = q[1]; b1 = q[2]; b2 = q[3];
+        }
         const int hz = __float_as_int(h.z);
         if (hz < 0) {                                            // leaf: points [left, right)
             const int lo = __float_as_int(h.x), hi = __float_as_int(h.y);
@@ -787,7 +796,6 @@ __device__ __forceinline__ bool query_nn_stack(const SceneNNDev &s, int *stk_nod
             }
             if (!found) break;
         } else {
-            const float4 b0 = s.rec[(size_t)cur * 4 + 1], b1 = s.rec[(size_t)cur * 4 + 2], b2 = s.rec[(size_t)cur * 4 + 3];
             const int dim = __float_as_int(h.w);
             const float q = (dim == 0) ? sx : ((dim == 1) ? sy : sz);
             const float diff = q - h.x;
@@ -1129,7 +1137,7 @@ __device__ __forceinline__ void vb_accumulate(float (&acc_out)[29], float *cl, u
                 if (i < cnt) {
                     Corr c;
                     bool ok;
-                    if constexpr (kStack > 0) ok = query_nn_stack<kStack>(scene, stk_node, stk_lb, p[3 * i], p[3 * i + 1], p[3 * i + 2], c);
+                    if constexpr (kStack > 0) ok = query_nn_stack<kStack>(scene, reinterpret_cast<const float4 *>(lds_topo), stk_node, stk_lb, p[3 * i], p[3 * i + 1], p[3 * i + 2], c);
                     else ok = query_nn<true>(scene, lds_topo, p[3 * i], p[3 * i + 1], p[3 * i + 2], c);
                     if (ok) accumulate(acc, p[3 * i], p[3 * i + 1], p[3 * i + 2], c);
                 }
@@ -1244,9 +1252,13 @@ __global__ __launch_bounds__(256, PR_PASS_WAVES) void icp_pass_kernel(IcpBatch b
         __syncthreads();
         lds_topo = dst;
     }
-    if constexpr (kNN && kStack > 0) {                           // per-lane stacks: [entry][lane]
+    if constexpr (kNN && kStack > 0) {                           // per-lane stacks: [entry][lane], then the staged records
         stk_node = reinterpret_cast<int *>(lds_raw) + threadIdx.x;
         stk_lb = reinterpret_cast<float *>(lds_raw) + (size_t)kStack * kBlockThreads + threadIdx.x;
+        float4 *recs = reinterpret_cast<float4 *>(lds_raw + (size_t)kStack * kBlockThreads * 8);
+        for (uint32_t i = threadIdx.x; i < scene.lds_nodes * 4; i += kBlockThreads) recs[i] = scene.rec[i];
+        __syncthreads();
+        lds_topo = reinterpret_cast<const int4 *>(recs);
     }
 
     float *cl = reinterpret_cast<float *>(b.cloud + pm.start);
@@ -1421,6 +1433,10 @@ __global__ __launch_bounds__(256, 5) void icp_flow_kernel(FlowArgs a, Scene scen
     if constexpr (kNN && kStack > 0) {
         stk_node = reinterpret_cast<int *>(lds_raw) + threadIdx.x;
         stk_lb = reinterpret_cast<float *>(lds_raw) + (size_t)kStack * kBlockThreads + threadIdx.x;
+        float4 *recs = reinterpret_cast<float4 *>(lds_raw + (size_t)kStack * kBlockThreads * 8);
+        for (uint32_t i = threadIdx.x; i < scene.lds_nodes * 4; i += kBlockThreads) recs[i] = scene.rec[i];
+        __syncthreads();
+        lds_topo = reinterpret_cast<const int4 *>(recs);
     }
 
     const uint32_t ppb = a.steps * kPointsPerStep;
@@ -1989,8 +2005,8 @@ hipError_t launch_icp_pass_proj_packed(const IcpBatch &b, const SceneProjPacked 
 { return launch_pass<SceneProjPacked, false>(b, sc, n_poses, 0, s); }
 hipError_t launch_icp_pass_nn(const IcpBatch &b, const SceneNNDev &sc, uint32_t n_poses, hipStream_t s)
 {
-    if (sc.stack_depth == 16) return launch_pass<SceneNNDev, true, 16>(b, sc, n_poses, (size_t)16 * kBlockThreads * 8, s);
-    if (sc.stack_depth == 24) return launch_pass<SceneNNDev, true, 24>(b, sc, n_poses, (size_t)24 * kBlockThreads * 8, s);
+    if (sc.stack_depth == 16) return launch_pass<SceneNNDev, true, 16>(b, sc, n_poses, (size_t)16 * kBlockThreads * 8 + (size_t)sc.lds_nodes * 64, s);
+    if (sc.stack_depth == 24) return launch_pass<SceneNNDev, true, 24>(b, sc, n_poses, (size_t)24 * kBlockThreads * 8 + (size_t)sc.lds_nodes * 64, s);
     return launch_pass<SceneNNDev, true, 0>(b, sc, n_poses, (size_t)sc.lds_nodes * sizeof(int4), s);
 }
 
@@ -2016,8 +2032,8 @@ hipError_t launch_icp_flow_proj_packed(const FlowArgs &a, const SceneProjPacked 
 { return launch_flow_t<SceneProjPacked, false, 0>(a, sc, 0, n_cus, s, grid_out); }
 hipError_t launch_icp_flow_nn(const FlowArgs &a, const SceneNNDev &sc, uint32_t n_cus, hipStream_t s, uint32_t *grid_out)
 {
-    if (sc.stack_depth == 16) return launch_flow_t<SceneNNDev, true, 16>(a, sc, (size_t)16 * kBlockThreads * 8, n_cus, s, grid_out);
-    if (sc.stack_depth == 24) return launch_flow_t<SceneNNDev, true, 24>(a, sc, (size_t)24 * kBlockThreads * 8, n_cus, s, grid_out);
+    if (sc.stack_depth == 16) return launch_flow_t<SceneNNDev, true, 16>(a, sc, (size_t)16 * kBlockThreads * 8 + (size_t)sc.lds_nodes * 64, n_cus, s, grid_out);
+    if (sc.stack_depth == 24) return launch_flow_t<SceneNNDev, true, 24>(a, sc, (size_t)24 * kBlockThreads * 8 + (size_t)sc.lds_nodes * 64, n_cus, s, grid_out);
     return launch_flow_t<SceneNNDev, true, 0>(a, sc, (size_t)sc.lds_nodes * sizeof(int4), n_cus, s, grid_out);
 }
 
