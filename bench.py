@@ -94,11 +94,23 @@ def main():
     poses = synth.hypotheses(P, seed=6, first=rank * P)          # this rank's shard of the global batch
     crit = api.ICPConvergenceCriteria(0.0, 0.0, args.iters)
 
-    # P x RegistrationResult (72 B) on the device, double-buffered: the gather of step k may still be in flight
-    # (it runs on RCCL's stream) while step k+1 refines into the other buffer
+    # P x RegistrationResult (72 B) on the device, double-buffered.  Step k is SUBMITTED on slot k&1 (everything enqueued, no
+    # host round trip) and only then is step k-1 waited for and its results handed to the gather -- the GPU always has the
+    # next batch queued, and the gather of step k-1 (RCCL's stream) overlaps step k.
     results = [torch.zeros(P * 18, dtype=torch.float32, device="cuda") for _ in range(2)]
-    pending = [None, None]
+    pending = [None, None]                                       # gather handle per buffer
+    inflight = [False, False]                                    # submitted, not yet waited for
     step_no = [0]
+    last_sizes = [None]
+
+    def retire(b):
+        if not inflight[b]:
+            return
+        _, sizes = api.refine_wait(b)
+        inflight[b] = False
+        last_sizes[0] = sizes
+        if world > 1:                                           # the single RCCL exchange of the job: P x 72 B per rank to rank 0
+            pending[b] = prd.gather_results(results[b].cpu() if share_device else results[b], world, rank, dst=0, async_op=True)
 
     def step():
         b = step_no[0] & 1
@@ -107,12 +119,13 @@ def main():
             pending[b].wait()
             torch.cuda.current_stream().synchronize()
             pending[b] = None
-        _, sizes = api.refine_batch(model, poses, W, H, proj, K, scene, crit, results_dev=results[b].data_ptr())
-        if world > 1:                                           # the single RCCL exchange of the job: P x 72 B per rank to rank 0
-            pending[b] = prd.gather_results(results[b].cpu() if share_device else results[b], world, rank, dst=0, async_op=True)
-        return sizes
+        api.refine_submit(b, model, poses, W, H, proj, K, scene, crit, results_dev=results[b].data_ptr())
+        inflight[b] = True
+        retire(1 - b)
 
     def fence():
+        for b in (0, 1):
+            retire(b)
         for b in (0, 1):
             if pending[b] is not None:
                 pending[b].wait()
@@ -122,15 +135,16 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        sizes = step()
+        step()
     api.set_option("profile", 2)          # HIP events around ONE correspondence launch per step (rotating iteration)
     api.profile_reset()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        sizes = step()
+        step()
     fence()
     elapsed = time.perf_counter() - t0
+    sizes = last_sizes[0]
     api.set_option("profile", 0)
     prof = api.profile_read()
 
@@ -175,8 +189,7 @@ def main():
                          "algorithmic_bytes_per_launch": bytes_per_launch, "points_per_launch": pts_per_launch,
                          "timing": "HIP events on the library stream around one launch every 8th step, rotating over the 21 passes; "
                                    "a timed step runs the batch as one pose group so the launch has the chip to itself"},
-            "phase_ms_per_step": {"icp_kernel": prof["icp_kernel_ms"] / args.steps, "render": prof["render_ms"] / args.steps,
-                                  "cloud": prof["cloud_ms"] / args.steps},
+            "phase_ms_per_timed_step": {"render": prof["render_ms"] / launches, "cloud": prof["cloud_ms"] / launches},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, model.tris, poses, scene_depth, K, W, H)

@@ -165,6 +165,18 @@ int pr_refine_batch_dev(const pr_triangle *tris_dev, size_t n_tris, const pr_mat
                         int scene_kind, const void *scene, pr_criteria crit,
                         pr_result *results_dev, uint32_t *cloud_sizes_host);
 
+/* Asynchronous form of the two calls above (no counterpart in the reference, whose ICP() blocks): pr_refine_submit
+ * enqueues one batch on `slot` (0 or 1) and returns; pr_refine_wait(slot) blocks until that batch is finished and
+ * fills results_host / cloud_sizes_host (results_dev is complete at that point as well).  Exactly one of results_host /
+ * results_dev may be NULL.  poses_host is copied before the call returns; tris_dev, the scene arrays and every output
+ * pointer must stay valid until the wait.  Two slots let a host enqueue batch k+1 while batch k runs.  Batches the
+ * asynchronous path does not cover (host solve, kd-tree scenes, timed calls) run to completion inside pr_refine_submit. */
+int pr_refine_submit(int slot, const pr_triangle *tris_dev, size_t n_tris, const pr_mat4 *poses_host, uint32_t n_poses,
+                     uint32_t width, uint32_t height, const pr_mat4 *proj, const float K[9],
+                     int scene_kind, const void *scene, pr_criteria crit,
+                     pr_result *results_host, pr_result *results_dev, uint32_t *cloud_sizes_host);
+int pr_refine_wait(int slot);
+
 /* ---- sharding of a hypothesis batch over ranks (contiguous blocks) ---------------- */
 void pr_shard_range(uint32_t n_items, uint32_t rank, uint32_t world, uint32_t *first, uint32_t *count);
 

@@ -85,6 +85,8 @@ SIGNATURES = {
     "pr_icp_batch": (_i32, [_vp, _vp, _u32, _i32, _vp, Criteria, _vp]),
     "pr_refine_batch": (_i32, [_vp, _sz, _vp, _u32, _u32, _u32, _vp, _vp, _i32, _vp, Criteria, _vp, _vp]),
     "pr_refine_batch_dev": (_i32, [_vp, _sz, _vp, _u32, _u32, _u32, _vp, _vp, _i32, _vp, Criteria, _vp, _vp]),
+    "pr_refine_submit": (_i32, [_i32, _vp, _sz, _vp, _u32, _u32, _u32, _vp, _vp, _i32, _vp, Criteria, _vp, _vp, _vp]),
+    "pr_refine_wait": (_i32, [_i32]),
     "pr_shard_range": (None, [_u32, _u32, _u32, C.POINTER(_u32), C.POINTER(_u32)]),
     "pr_set_option": (_i32, [C.c_char_p, _i32]),
     "pr_get_option": (_i32, [C.c_char_p, C.POINTER(_i32)]),

@@ -371,6 +371,32 @@ def refine_batch(tris, poses, width: int, height: int, proj, K, scene,
     return None, sizes
 
 
+_inflight = {}
+
+
+def refine_submit(slot: int, tris, poses, width: int, height: int, proj, K, scene,
+                  criteria: ICPConvergenceCriteria = ICPConvergenceCriteria(), results_dev: Optional[int] = None):
+    """Asynchronous ``refine_batch``: enqueue the batch on ``slot`` (0 or 1) and return at once; ``refine_wait(slot)``
+    delivers what ``refine_batch`` returns.  With two slots, batch k+1 is enqueued while batch k runs."""
+    td = _tris_dev(tris)
+    poses = _f32(poses, (-1, 16))
+    pj, k = _f32(proj, -1), _f32(K, -1)
+    sizes = np.zeros(len(poses), np.uint32)
+    res = np.zeros(len(poses), RESULT) if results_dev is None else None
+    d = scene.desc()
+    check(_lib.load().pr_refine_submit(int(slot), td.data(), td.size() // 9, ptr(poses), len(poses), width, height, ptr(pj), ptr(k),
+                                       scene.kind, C.addressof(d), criteria.c(), ptr(res) if res is not None else None,
+                                       int(results_dev) if results_dev is not None else None, ptr(sizes)))
+    _inflight[int(slot)] = (res, sizes, td, scene)              # keep the output arrays (and the inputs' owners) alive
+
+
+def refine_wait(slot: int):
+    """Block until the batch submitted on ``slot`` is finished; returns (records or None, cloud sizes)."""
+    check(_lib.load().pr_refine_wait(int(slot)))
+    res, sizes, _, _ = _inflight.pop(int(slot))
+    return res, sizes
+
+
 def eigen_slover_666(A, b) -> np.ndarray:
     """``cuda_icp::eigen_slover_666`` (icp.cpp:29-45, public in icp.h:54)."""
     T = np.zeros(16, np.float32)

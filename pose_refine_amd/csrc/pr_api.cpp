@@ -7,6 +7,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <cfloat>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -95,6 +96,7 @@ struct Ctx {
     int raster_mode = 0;             // fused path: 0 = global atomicMin inside the per-pose pixel box (reference scheme), 1 = LDS depth bands
     int n_cus = 256;
     const void *aabb_key = nullptr; size_t aabb_n = 0;
+    float aabb_host[6] = { 0, 0, 0, 0, 0, 0 }; bool aabb_host_valid = false;
     // workspaces
     DevBuf aabb, bbox, poses, depth, row_count, row_off, counts, cloud, meta, partial, sums, rec, topo, bmin, bmax, pts, nnrec, nndepth, dstate, dresults, vbdesc, flowsync, arrive, conv16, conv8, kd_idx, kd_scratch, kd_child, kd_ctrl, kd_tmp, nn_full;
     PinBuf h_sums, h_meta, h_counts, h_results, h_dstate, h_flow;
@@ -193,8 +195,10 @@ struct SceneSel {
     prk::SceneNNDev nn{};
 };
 
-int make_scene(int kind, const void *scene, bool want_packed, SceneSel &out)
+int make_scene(int kind, const void *scene, bool want_packed, SceneSel &out, DevBuf *rec_buf = nullptr, hipStream_t st = nullptr)
 {
+    DevBuf &rec = rec_buf ? *rec_buf : g.rec;
+    if (!st) st = g.stream;
     out.kind = kind;
     if (kind == PR_SCENE_PROJ) {
         const pr_scene_proj *s = static_cast<const pr_scene_proj *>(scene);
@@ -203,13 +207,13 @@ int make_scene(int kind, const void *scene, bool want_packed, SceneSel &out)
         out.packed = want_packed;
         if (want_packed) {
             const size_t n = (size_t)s->width * s->height;
-            PR_TRY(g.rec.ensure(n * sizeof(float4) + (s->width + s->height) * sizeof(float)));
-            float *colf = reinterpret_cast<float *>(g.rec.as<float4>() + n);
+            PR_TRY(rec.ensure(n * sizeof(float4) + (s->width + s->height) * sizeof(float)));
+            float *colf = reinterpret_cast<float *>(rec.as<float4>() + n);
             float *rowf = colf + s->width;
-            HIP_TRY(prk::launch_pack_proj_scene(s->pcd, s->normal, g.rec.as<float4>(), n, colf, rowf, (uint32_t)s->width, (uint32_t)s->height,
-                                                s->K[0], s->K[4], s->K[2], s->K[5], g.stream));
+            HIP_TRY(prk::launch_pack_proj_scene(s->pcd, s->normal, rec.as<float4>(), n, colf, rowf, (uint32_t)s->width, (uint32_t)s->height,
+                                                s->K[0], s->K[4], s->K[2], s->K[5], st));
             out.pk = prk::SceneProjPacked{ (uint32_t)s->width, (uint32_t)s->height, s->max_dist_diff, s->K[0], s->K[4], s->K[2], s->K[5],
-                                           g.rec.as<float4>(), colf, rowf };
+                                           rec.as<float4>(), colf, rowf };
         }
         return PR_OK;
     }
@@ -559,7 +563,7 @@ int refine_impl(const pr_triangle *tris_dev, size_t n_tris, const pr_mat4 *poses
         PR_TRY(g.poses.ensure(sizeof(pr_mat4) * np));
         if (g.aabb_key != tris_dev || g.aabb_n != n_tris) {
             HIP_TRY(prk::launch_model_aabb(tris_dev, (uint32_t)n_tris, g.aabb.as<float>(), g.stream));
-            g.aabb_key = tris_dev; g.aabb_n = n_tris;
+            g.aabb_key = tris_dev; g.aabb_n = n_tris; g.aabb_host_valid = false;
         }
         {
             SpanGuard sp(kSpanRender);
@@ -589,6 +593,207 @@ int refine_impl(const pr_triangle *tris_dev, size_t n_tris, const pr_mat4 *poses
         PR_TRY(icp_drive(g.cloud.as<pr_vec3>(), start.data(), count.data(), np, sc, crit,
                          results_host ? results_host + p0 : nullptr, results_dev ? results_dev + p0 : nullptr));
     }
+    return PR_OK;
+}
+
+// ---- asynchronous fused refinement: two slots, everything of a batch enqueued without a host round trip -------------------
+// The synchronous path above reads the cloud sizes back in the middle of a step (they size the cloud stride and the grid),
+// uploads the start state and returns only after the results are in: ≈150 µs of a 1.3 ms step during which the GPU idles.
+// Here the host computes the per-pose pixel boxes itself (same arithmetic as pose_bbox_kernel, 8 corners per pose), which
+// bounds every cloud by its box area, the start state is written by a kernel from the device-side counts, and a batch is
+// only waited for when its results are wanted -- so the next batch can be enqueued while this one runs.
+struct Slot {
+    DevBuf poses_bbox, depth, row_count, row_off, counts, cloud, meta, partial, dstate, dresults, arrive, rec;
+    PinBuf h_in, h_out;
+    hipStream_t stream = nullptr, side[3] = { nullptr, nullptr, nullptr };
+    hipEvent_t fork = nullptr, join[3] = { nullptr, nullptr, nullptr }, done = nullptr;
+    bool pending = false, delivered = false;
+    uint32_t P = 0;
+    pr_result *user_results_host = nullptr;
+    uint32_t *user_sizes = nullptr;
+};
+constexpr int kSlots = 2;
+Slot g_slots[kSlots];
+
+int slot_streams(Slot &sl)
+{
+    if (sl.stream) return PR_OK;
+    HIP_TRY(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&sl.fork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    for (int i = 0; i < 3; ++i) {
+        HIP_TRY(hipStreamCreateWithFlags(&sl.side[i], hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&sl.join[i], hipEventDisableTiming));
+    }
+    return PR_OK;
+}
+void slot_release(Slot &sl)
+{
+    if (sl.stream) hipStreamSynchronize(sl.stream);
+    for (DevBuf *b : { &sl.poses_bbox, &sl.depth, &sl.row_count, &sl.row_off, &sl.counts, &sl.cloud, &sl.meta, &sl.partial, &sl.dstate,
+                       &sl.dresults, &sl.arrive, &sl.rec }) b->release();
+    sl.h_in.release(); sl.h_out.release();
+    for (int i = 0; i < 3; ++i) {
+        if (sl.side[i]) hipStreamDestroy(sl.side[i]);
+        if (sl.join[i]) hipEventDestroy(sl.join[i]);
+        sl.side[i] = nullptr; sl.join[i] = nullptr;
+    }
+    if (sl.fork) hipEventDestroy(sl.fork);
+    if (sl.done) hipEventDestroy(sl.done);
+    if (sl.stream) hipStreamDestroy(sl.stream);
+    sl.fork = sl.done = nullptr; sl.stream = nullptr; sl.pending = false;
+}
+
+// pose_bbox_kernel on the host (same operations in the same order; any conservative box gives the same images and clouds)
+void pose_bbox_host(const float *aabb, const pr_mat4 &pose, const pr_mat4 &proj, uint32_t width, uint32_t height, int32_t out[4])
+{
+    const float *M = pose.m;
+    float mnx = FLT_MAX, mny = FLT_MAX, mxx = -FLT_MAX, mxy = -FLT_MAX;
+    bool all_front = true;
+    for (int c = 0; c < 8; ++c) {
+        const float x = aabb[(c & 1) ? 3 : 0], y = aabb[(c & 2) ? 4 : 1], z = aabb[(c & 4) ? 5 : 2];
+        const float lx = M[0] * x + M[1] * y + M[2] * z + M[3];
+        const float ly = M[4] * x + M[5] * y + M[6] * z + M[7];
+        const float lz = M[8] * x + M[9] * y + M[10] * z + M[11];
+        if (!(lz > 1e-3f)) all_front = false;
+        const float cxp = proj.m[0] * lx + proj.m[1] * ly + proj.m[2] * lz + proj.m[3];
+        const float cyp = proj.m[4] * lx + proj.m[5] * ly + proj.m[6] * lz + proj.m[7];
+        const float sx = cxp / lz * (float)width / 2.0f + (float)width / 2.0f;
+        const float sy = cyp / lz * (float)height / 2.0f + (float)height / 2.0f;
+        mnx = fminf(mnx, sx); mxx = fmaxf(mxx, sx); mny = fminf(mny, sy); mxy = fmaxf(mxy, sy);
+    }
+    int x0 = 0, y0 = 0, x1 = (int)width - 1, y1 = (int)height - 1;
+    const bool finite = (mnx > -1e8f) && (mxx < 1e8f) && (mny > -1e8f) && (mxy < 1e8f);
+    if (all_front && finite) {
+        x0 = std::max(0, (int)floorf(mnx) - 2);  x1 = std::min((int)width - 1, (int)ceilf(mxx) + 2);
+        y0 = std::max(0, (int)floorf(mny) - 2);  y1 = std::min((int)height - 1, (int)ceilf(mxy) + 2);
+    }
+    out[0] = x0; out[1] = y0; out[2] = x1; out[3] = y1;
+}
+
+int refine_wait(int slot)
+{
+    if (slot < 0 || slot >= kSlots) { set_error("slot must be 0..%d", kSlots - 1); return PR_ERR_INVALID; }
+    Slot &sl = g_slots[slot];
+    if (!sl.pending) { set_error("pr_refine_wait: nothing was submitted on slot %d", slot); return PR_ERR_INVALID; }
+    sl.pending = false;
+    if (sl.delivered) return PR_OK;
+    HIP_TRY(hipEventSynchronize(sl.done));
+    const uint32_t *h_counts = sl.h_out.as<uint32_t>();
+    if (sl.user_sizes) std::memcpy(sl.user_sizes, h_counts, sizeof(uint32_t) * sl.P);
+    if (sl.user_results_host) std::memcpy(sl.user_results_host, reinterpret_cast<const unsigned char *>(h_counts) + (((size_t)sl.P * 4 + 63) & ~(size_t)63),
+                                          sizeof(pr_result) * sl.P);
+    return PR_OK;
+}
+
+int refine_submit(int slot, const pr_triangle *tris_dev, size_t n_tris, const pr_mat4 *poses_host, uint32_t P, uint32_t W, uint32_t H,
+                  const pr_mat4 *proj, const float K[9], int scene_kind, const void *scene, pr_criteria crit,
+                  pr_result *results_host, pr_result *results_dev, uint32_t *sizes_host)
+{
+    if (slot < 0 || slot >= kSlots) { set_error("slot must be 0..%d", kSlots - 1); return PR_ERR_INVALID; }
+    Slot &sl = g_slots[slot];
+    if (sl.pending) { set_error("pr_refine_submit: slot %d still holds an unfinished batch (call pr_refine_wait)", slot); return PR_ERR_INVALID; }
+    if (!tris_dev || !poses_host || !proj || !K || W == 0 || H == 0 || (!results_host && !results_dev)) { set_error("pr_refine_submit: bad arguments"); return PR_ERR_INVALID; }
+    if (crit.max_iteration < 0) { set_error("max_iteration must be >= 0"); return PR_ERR_INVALID; }
+    sl.P = P; sl.user_results_host = results_host; sl.user_sizes = sizes_host; sl.delivered = false;
+    const size_t img = (size_t)W * H;
+    const bool sample_call = (g.profile == 2) && (g.sample_clock % 8 == 0);
+    const bool async_ok = P > 0 && g.solve_mode == PR_SOLVE_DEVICE && !g.icp_flow && g.raster_mode == 0 && scene_kind == PR_SCENE_PROJ
+                          && img * sizeof(int32_t) * P <= ((size_t)4 << 30) && (g.profile == 0 || (g.profile == 2 && !sample_call));
+    if (!async_ok) {
+        // the synchronous path (host solve, kd-tree scenes, timed calls, oversized batches): let the other slot drain first so
+        // that a timed launch has the chip to itself, then run to completion; pr_refine_wait has nothing left to do
+        for (Slot &o : g_slots) if (o.pending && !o.delivered && o.done) HIP_TRY(hipEventSynchronize(o.done));
+        PR_TRY(refine_impl(tris_dev, n_tris, poses_host, P, W, H, proj, K, scene_kind, scene, crit, results_host, results_dev, sizes_host));
+        sl.pending = true; sl.delivered = true;
+        return PR_OK;
+    }
+    g.sample_clock++;
+    PR_TRY(slot_streams(sl));
+    SceneSel sc;
+    std::memset(static_cast<void *>(&sc), 0, sizeof sc);
+    PR_TRY(make_scene(scene_kind, scene, /*want_packed=*/true, sc, &sl.rec, sl.stream));
+
+    // model box on the host (once per triangle buffer)
+    if (g.aabb_key != tris_dev || g.aabb_n != n_tris || !g.aabb_host_valid) {
+        PR_TRY(g.aabb.ensure(6 * sizeof(float)));
+        HIP_TRY(prk::launch_model_aabb(tris_dev, (uint32_t)n_tris, g.aabb.as<float>(), g.stream));
+        HIP_TRY(hipMemcpyAsync(g.aabb_host, g.aabb.p, sizeof g.aabb_host, hipMemcpyDeviceToHost, g.stream));
+        HIP_TRY(hipStreamSynchronize(g.stream));
+        g.aabb_key = tris_dev; g.aabb_n = n_tris; g.aabb_host_valid = true;
+    }
+    // staging: [poses][boxes]; the cloud stride and the grid come from the largest box
+    const size_t in_bytes = (sizeof(pr_mat4) + sizeof(int4)) * (size_t)P;
+    PR_TRY(sl.h_in.ensure(in_bytes));
+    PR_TRY(sl.poses_bbox.ensure(in_bytes));
+    pr_mat4 *h_poses = sl.h_in.as<pr_mat4>();
+    int32_t *h_box = reinterpret_cast<int32_t *>(h_poses + P);
+    std::memcpy(h_poses, poses_host, sizeof(pr_mat4) * P);
+    size_t max_area = 1;
+    for (uint32_t i = 0; i < P; ++i) {
+        pose_bbox_host(g.aabb_host, h_poses[i], *proj, W, H, h_box + 4 * (size_t)i);
+        const int32_t *b = h_box + 4 * (size_t)i;
+        max_area = std::max(max_area, (size_t)std::max(0, b[2] - b[0] + 1) * (size_t)std::max(0, b[3] - b[1] + 1));   // an off-screen pose has an empty box
+    }
+    const size_t cstride = (max_area + 3) & ~(size_t)3;
+    const uint32_t steps = (uint32_t)std::max(1, g.steps);
+    const uint32_t ppb = steps * prk::kPointsPerStep;
+    const uint32_t nblk = (uint32_t)((max_area + ppb - 1) / ppb);
+    if (cstride * (size_t)P > 0xffffffffull) { set_error("pr_refine_submit: batch too large for 32-bit cloud offsets"); return PR_ERR_INVALID; }
+
+    PR_TRY(sl.depth.ensure(sizeof(int32_t) * img * P));
+    PR_TRY(sl.row_count.ensure(sizeof(uint32_t) * (size_t)H * P));
+    PR_TRY(sl.row_off.ensure(sizeof(uint32_t) * (size_t)H * P));
+    PR_TRY(sl.counts.ensure(sizeof(uint32_t) * P));
+    PR_TRY(sl.cloud.ensure(sizeof(pr_vec3) * cstride * P));
+    PR_TRY(sl.meta.ensure(sizeof(prk::PoseMeta) * P));
+    PR_TRY(sl.partial.ensure(sizeof(float) * prk::kAccStride * (size_t)nblk * P));
+    PR_TRY(sl.dstate.ensure(sizeof(prk::DevIcpState) * P));
+    PR_TRY(sl.arrive.ensure(sizeof(uint32_t) * P));
+    const size_t res_off = ((size_t)P * 4 + 63) & ~(size_t)63;
+    PR_TRY(sl.h_out.ensure(res_off + sizeof(pr_result) * P));
+    pr_result *dres = results_dev;
+    if (!dres) { PR_TRY(sl.dresults.ensure(sizeof(pr_result) * P)); dres = sl.dresults.as<pr_result>(); }
+
+    hipStream_t st = sl.stream;
+    pr_mat4 *d_poses = sl.poses_bbox.as<pr_mat4>();
+    int4 *d_box = reinterpret_cast<int4 *>(d_poses + P);
+    HIP_TRY(hipMemcpyAsync(d_poses, h_poses, in_bytes, hipMemcpyHostToDevice, st));
+    HIP_TRY(prk::launch_render_boxes(tris_dev, (uint32_t)n_tris, d_poses, P, nullptr, d_box, sl.depth.as<int32_t>(), sl.row_count.as<uint32_t>(),
+                                     sl.row_off.as<uint32_t>(), sl.counts.as<uint32_t>(), W, H, *proj, st, /*compute_boxes=*/false));
+    HIP_TRY(prk::launch_emit_box(sl.depth.as<int32_t>(), P, W, H, d_box, K[0], K[4], K[2], K[5], sl.row_count.as<uint32_t>(),
+                                 sl.row_off.as<uint32_t>(), sl.cloud.as<pr_vec3>(), cstride, st));
+    HIP_TRY(prk::launch_icp_init(sl.meta.as<prk::PoseMeta>(), sl.dstate.as<prk::DevIcpState>(), sl.arrive.as<uint32_t>(), sl.counts.as<uint32_t>(),
+                                 (uint32_t)cstride, P, st));
+
+    // the iteration loop: (max_iteration+1) x [pass (+ fused finalize/solve)], pose groups on the slot's side streams
+    const bool fused = g.fused_solve != 0;
+    const uint32_t n_groups = std::max(1u, std::min({ (uint32_t)std::max(1, g.pose_groups), 4u, P / 32u }));
+    auto group_begin = [&](uint32_t grp) { return (uint32_t)(((uint64_t)P * grp) / n_groups); };
+    if (n_groups > 1) {
+        HIP_TRY(hipEventRecord(sl.fork, st));
+        for (uint32_t k = 1; k < n_groups; ++k) HIP_TRY(hipStreamWaitEvent(sl.side[k - 1], sl.fork, 0));
+    }
+    prk::IcpBatch b{};
+    b.cloud = sl.cloud.as<pr_vec3>(); b.nblk = nblk; b.steps = steps;
+    for (uint32_t it = 0; it <= (uint32_t)crit.max_iteration; ++it) {
+        for (uint32_t grp = 0; grp < n_groups; ++grp) {
+            const uint32_t p0 = group_begin(grp), np = group_begin(grp + 1) - p0;
+            hipStream_t gs = grp ? sl.side[grp - 1] : st;
+            prk::IcpBatch bb = b;
+            bb.meta = sl.meta.as<prk::PoseMeta>() + p0; bb.partial = sl.partial.as<float>() + (size_t)p0 * nblk * prk::kAccStride;
+            if (fused) { bb.fused = 1; bb.iter = it; bb.crit = crit; bb.st = sl.dstate.as<prk::DevIcpState>() + p0; bb.arrive = sl.arrive.as<uint32_t>() + p0; }
+            HIP_TRY(launch_pass(bb, sc, np, gs));
+            if (!fused) HIP_TRY(prk::launch_icp_finalize_solve(bb.partial, sl.meta.as<prk::PoseMeta>() + p0, nblk, steps,
+                                                               sl.dstate.as<prk::DevIcpState>() + p0, crit, it, np, gs));
+        }
+    }
+    for (uint32_t k = 1; k < n_groups; ++k) { HIP_TRY(hipEventRecord(sl.join[k - 1], sl.side[k - 1])); HIP_TRY(hipStreamWaitEvent(st, sl.join[k - 1], 0)); }
+    HIP_TRY(prk::launch_pack_results(sl.dstate.as<prk::DevIcpState>(), dres, P, st));
+    HIP_TRY(hipMemcpyAsync(sl.h_out.p, sl.counts.p, sizeof(uint32_t) * P, hipMemcpyDeviceToHost, st));
+    if (results_host) HIP_TRY(hipMemcpyAsync(static_cast<unsigned char *>(sl.h_out.p) + res_off, dres, sizeof(pr_result) * P, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipEventRecord(sl.done, st));
+    sl.pending = true;
     return PR_OK;
 }
 
@@ -676,6 +881,7 @@ int pr_shutdown(void)
     std::lock_guard<std::mutex> lk(g_mu);
     if (!g.ready) return PR_OK;
     hipStreamSynchronize(g.stream);
+    for (Slot &sl : g_slots) slot_release(sl);
     for (DevBuf *b : { &g.aabb, &g.bbox, &g.poses, &g.depth, &g.row_count, &g.row_off, &g.counts, &g.cloud, &g.meta, &g.partial,
                        &g.sums, &g.rec, &g.topo, &g.bmin, &g.bmax, &g.pts, &g.nnrec, &g.nndepth, &g.dstate, &g.dresults, &g.vbdesc, &g.flowsync, &g.arrive, &g.conv16, &g.conv8, &g.kd_idx, &g.kd_scratch, &g.kd_child, &g.kd_ctrl, &g.kd_tmp, &g.nn_full }) b->release();
     for (PinBuf *b : { &g.h_sums, &g.h_meta, &g.h_counts, &g.h_results, &g.h_dstate, &g.h_flow }) b->release();
@@ -866,7 +1072,9 @@ int pr_refine_batch(const pr_triangle *tris_dev, size_t n_tris, const pr_mat4 *p
     std::lock_guard<std::mutex> lk(g_mu);
     PR_TRY(require_ctx());
     if (!results_host) { set_error("pr_refine_batch: results_host is null"); return PR_ERR_INVALID; }
-    return refine_impl(tris_dev, n_tris, poses_host, n_poses, width, height, proj, K, scene_kind, scene, crit, results_host, nullptr, cloud_sizes_host);
+    if (n_poses == 0) return PR_OK;
+    PR_TRY(refine_submit(0, tris_dev, n_tris, poses_host, n_poses, width, height, proj, K, scene_kind, scene, crit, results_host, nullptr, cloud_sizes_host));
+    return refine_wait(0);
 }
 int pr_refine_batch_dev(const pr_triangle *tris_dev, size_t n_tris, const pr_mat4 *poses_host, uint32_t n_poses, uint32_t width, uint32_t height,
                         const pr_mat4 *proj, const float K[9], int scene_kind, const void *scene, pr_criteria crit,
@@ -875,7 +1083,23 @@ int pr_refine_batch_dev(const pr_triangle *tris_dev, size_t n_tris, const pr_mat
     std::lock_guard<std::mutex> lk(g_mu);
     PR_TRY(require_ctx());
     if (!results_dev) { set_error("pr_refine_batch_dev: results_dev is null"); return PR_ERR_INVALID; }
-    return refine_impl(tris_dev, n_tris, poses_host, n_poses, width, height, proj, K, scene_kind, scene, crit, nullptr, results_dev, cloud_sizes_host);
+    if (n_poses == 0) return PR_OK;
+    PR_TRY(refine_submit(0, tris_dev, n_tris, poses_host, n_poses, width, height, proj, K, scene_kind, scene, crit, nullptr, results_dev, cloud_sizes_host));
+    return refine_wait(0);
+}
+int pr_refine_submit(int slot, const pr_triangle *tris_dev, size_t n_tris, const pr_mat4 *poses_host, uint32_t n_poses, uint32_t width, uint32_t height,
+                     const pr_mat4 *proj, const float K[9], int scene_kind, const void *scene, pr_criteria crit,
+                     pr_result *results_host, pr_result *results_dev, uint32_t *cloud_sizes_host)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    PR_TRY(require_ctx());
+    return refine_submit(slot, tris_dev, n_tris, poses_host, n_poses, width, height, proj, K, scene_kind, scene, crit, results_host, results_dev, cloud_sizes_host);
+}
+int pr_refine_wait(int slot)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    PR_TRY(require_ctx());
+    return refine_wait(slot);
 }
 
 int pr_set_option(const char *name, int value)

@@ -117,7 +117,8 @@ hipError_t launch_render_bands(const pr_triangle *tris, uint32_t n_tris, const p
                                uint32_t width, uint32_t height, const pr_mat4 &proj, uint32_t n_cus, hipStream_t s);
 hipError_t launch_render_boxes(const pr_triangle *tris, uint32_t n_tris, const pr_mat4 *poses_dev, uint32_t n_poses, const float *aabb,
                                int4 *bbox, int32_t *depth, uint32_t *row_count, uint32_t *row_off, uint32_t *counts,
-                               uint32_t width, uint32_t height, const pr_mat4 &proj, hipStream_t s);
+                               uint32_t width, uint32_t height, const pr_mat4 &proj, hipStream_t s, bool compute_boxes = true);
+hipError_t launch_icp_init(PoseMeta *meta, DevIcpState *st, uint32_t *arrive, const uint32_t *counts, uint32_t cloud_stride, uint32_t n, hipStream_t s);
 hipError_t launch_emit_box(const int32_t *depth, uint32_t n_poses, uint32_t width, uint32_t height, const int4 *bbox, float fx, float fy,
                            float cx, float cy, const uint32_t *row_count, const uint32_t *row_off, pr_vec3 *cloud, size_t cloud_stride,
                            hipStream_t s);

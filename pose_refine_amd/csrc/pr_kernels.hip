@@ -1386,6 +1386,27 @@ __global__ __launch_bounds__(64) void icp_finalize_solve_kernel(const float *__r
     st[pose] = s;
 }
 
+// start state of a fused batch, written on the device so that the host never has to see the cloud sizes before the loop
+// (icp.h:29-31 identity / zero result; an empty cloud is finished before it starts, icp.cu:183)
+__global__ __launch_bounds__(256) void icp_init_kernel(PoseMeta *__restrict__ meta, DevIcpState *__restrict__ st, uint32_t *__restrict__ arrive,
+                                                       const uint32_t *__restrict__ counts, uint32_t cloud_stride, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t c = counts[i];
+    PoseMeta m;
+    m.start = i * cloud_stride; m.count = c; m.state = c > 0 ? kRun : kSkip; m.pad = 0;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) m.xform[k] = 0.0f;
+    meta[i] = m;
+    DevIcpState s;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s.T[k] = (k % 5 == 0) ? 1.0f : 0.0f;
+    s.fitness = 0.0f; s.rmse = 0.0f; s.done = c > 0 ? 0 : 1; s.passes = 0;
+    st[i] = s;
+    arrive[i] = 0u;
+}
+
 __global__ void pack_results_kernel(const DevIcpState *__restrict__ st, pr_result *__restrict__ out, uint32_t n)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1921,10 +1942,11 @@ hipError_t launch_render_bands(const pr_triangle *tris, uint32_t n_tris, const p
 // fused-path render, reference scheme (global int32 atomicMin) but only inside each hypothesis' box
 hipError_t launch_render_boxes(const pr_triangle *tris, uint32_t n_tris, const pr_mat4 *poses_dev, uint32_t n_poses, const float *aabb,
                                int4 *bbox, int32_t *depth, uint32_t *row_count, uint32_t *row_off, uint32_t *counts,
-                               uint32_t width, uint32_t height, const pr_mat4 &proj, hipStream_t s)
+                               uint32_t width, uint32_t height, const pr_mat4 &proj, hipStream_t s, bool compute_boxes)
 {
     if (n_poses == 0) return hipSuccess;
-    hipLaunchKernelGGL(pose_bbox_kernel, dim3((n_poses + 255) / 256), dim3(256), 0, s, aabb, poses_dev, n_poses, proj, width, height, bbox);
+    if (compute_boxes)
+        hipLaunchKernelGGL(pose_bbox_kernel, dim3((n_poses + 255) / 256), dim3(256), 0, s, aabb, poses_dev, n_poses, proj, width, height, bbox);
     const pr_roi none{ 0, 0, 0, 0 };
     for (uint32_t p0 = 0; p0 < n_poses; p0 += 32768) {
         const uint32_t np = (n_poses - p0 < 32768) ? (n_poses - p0) : 32768;
@@ -2051,6 +2073,12 @@ hipError_t launch_icp_finalize_solve(const float *partial, PoseMeta *meta, uint3
     if (n_poses == 0) return hipSuccess;
     hipLaunchKernelGGL(icp_finalize_solve_kernel, dim3(n_poses), dim3(64), 0, s, partial, meta, nblk,
                        steps * kPointsPerStep, st, crit, iter);
+    return hipGetLastError();
+}
+hipError_t launch_icp_init(PoseMeta *meta, DevIcpState *st, uint32_t *arrive, const uint32_t *counts, uint32_t cloud_stride, uint32_t n, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(icp_init_kernel, dim3((n + 255) / 256), dim3(256), 0, s, meta, st, arrive, counts, cloud_stride, n);
     return hipGetLastError();
 }
 hipError_t launch_pack_results(const DevIcpState *st, pr_result *out, uint32_t n_poses, hipStream_t s)

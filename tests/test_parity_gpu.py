@@ -294,6 +294,40 @@ def test_dataflow_and_multilaunch_icp_agree_bitwise(gpu, model, scenario, gscene
         api.set_option("solve", api.SOLVE_HOST)
 
 
+@pytest.mark.parametrize("P", [5, 96])
+def test_async_slots_match_synchronous_path_bitwise(gpu, model, scenario, gscenes, P):
+    """pr_refine_submit / pr_refine_wait (host-computed pixel boxes, device-side start state, no mid-step read-back, two batches
+    in flight) against the synchronous path (profile=1 forces it): records and cloud sizes must be bit-identical, with fixed
+    and with early-exit criteria, for host and device result buffers, with an empty-cloud hypothesis in the batch."""
+    poses_a = synth.hypotheses(P, seed=11)
+    poses_b = synth.hypotheses(P, seed=12)
+    poses_b[1] = poses_b[1].copy()
+    poses_b[1].reshape(4, 4)[0, 3] += 1.0e6                      # a kilometre to the side: off-screen -> empty cloud -> identity result
+    api.set_option("solve", api.SOLVE_DEVICE)
+    try:
+        for crit in ((0.0, 0.0, 20), (1e-5, 1e-5, 30)):
+            c = api.ICPConvergenceCriteria(*crit)
+            api.set_option("profile", 1)
+            ref_a = api.refine_batch(model, poses_a, W, H, scenario["proj"], scenario["K"], gscenes["proj"], c)
+            ref_b = api.refine_batch(model, poses_b, W, H, scenario["proj"], scenario["K"], gscenes["proj"], c)
+            api.set_option("profile", 0)
+            api.refine_submit(0, model, poses_a, W, H, scenario["proj"], scenario["K"], gscenes["proj"], c)
+            dev_b = api.DeviceVector(P * 18, np.float32)
+            api.refine_submit(1, model, poses_b, W, H, scenario["proj"], scenario["K"], gscenes["proj"], c, results_dev=dev_b.data())
+            got_a = api.refine_wait(0)
+            _, sizes_b = api.refine_wait(1)
+            got_b = np.frombuffer(dev_b.to_host().tobytes(), dtype=ref_b[0].dtype)
+            assert np.array_equal(got_a[1], ref_a[1]) and np.array_equal(sizes_b, ref_b[1])
+            assert got_a[0].tobytes() == ref_a[0].tobytes(), crit
+            assert got_b.tobytes() == ref_b[0].tobytes(), crit
+            assert ref_b[1][1] == 0 and np.array_equal(ref_b[0]["T"][1].reshape(4, 4), np.eye(4, dtype=np.float32))
+        with pytest.raises(api.PoseRefineError):
+            api.refine_wait(0)                                   # nothing pending
+    finally:
+        api.set_option("profile", 0)
+        api.set_option("solve", api.SOLVE_HOST)
+
+
 # ---- SURVEY 8f "next" rows: device scene preparation, raw2* conversions ---------------------------------
 @pytest.mark.parametrize("dtype", [np.int32, np.uint16])
 def test_device_scene_preparation_bit_exact(gpu, scenario, dtype):
