@@ -36,7 +36,8 @@ struct IcpBatch {
     pr_vec3        *cloud;      // base of all clouds (dev)
     const PoseMeta *meta;       // [P] (dev)
     float          *partial;    // [P][nblk][kAccStride] workgroup sums (dev)
-    uint32_t        nblk;       // workgroups per hypothesis (grid.x)
+    uint32_t        nblk;       // 2048-point blocks a hypothesis may have = stride of `partial` (and grid.x unless grid_x is set)
+    uint32_t        grid_x;     // 0, or the number of workgroups per hypothesis when it differs from nblk (workgroups then loop over blocks)
     uint32_t        steps;      // steps of 1024 points per workgroup
     // PR_SOLVE_DEVICE with the solve fused into the pass (option "fused_solve"): the workgroup that delivers the last
     // partial sum of a hypothesis also adds the partials up and runs that hypothesis' iteration logic
@@ -117,8 +118,11 @@ hipError_t launch_render_bands(const pr_triangle *tris, uint32_t n_tris, const p
                                uint32_t width, uint32_t height, const pr_mat4 &proj, uint32_t n_cus, hipStream_t s);
 hipError_t launch_render_boxes(const pr_triangle *tris, uint32_t n_tris, const pr_mat4 *poses_dev, uint32_t n_poses, const float *aabb,
                                int4 *bbox, int32_t *depth, uint32_t *row_count, uint32_t *row_off, uint32_t *counts,
-                               uint32_t width, uint32_t height, const pr_mat4 &proj, hipStream_t s, bool compute_boxes = true);
-hipError_t launch_icp_init(PoseMeta *meta, DevIcpState *st, uint32_t *arrive, const uint32_t *counts, uint32_t cloud_stride, uint32_t n, hipStream_t s);
+                               uint32_t width, uint32_t height, const pr_mat4 &proj, hipStream_t s, bool compute_boxes = true,
+                               PoseMeta *meta = nullptr, DevIcpState *st = nullptr, uint32_t *arrive = nullptr, uint32_t cloud_stride = 0);
+hipError_t launch_pack_export(const DevIcpState *st, pr_result *out, const uint32_t *counts, uint32_t *host_counts, pr_result *host_results,
+                              uint32_t n, hipStream_t s);
+hipError_t launch_stage_words(const void *src_host_mapped, void *dst, size_t bytes, hipStream_t s);
 hipError_t launch_emit_box(const int32_t *depth, uint32_t n_poses, uint32_t width, uint32_t height, const int4 *bbox, float fx, float fy,
                            float cx, float cy, const uint32_t *row_count, const uint32_t *row_off, pr_vec3 *cloud, size_t cloud_stride,
                            hipStream_t s);

@@ -497,14 +497,10 @@ __global__ __launch_bounds__(256) void d2c_count_kernel(const T *__restrict__ de
 }
 
 // one workgroup per image: exclusive scan of the row counts (serial carry over chunks of 256 rows)
-__global__ __launch_bounds__(256) void d2c_scan_kernel(const uint32_t *__restrict__ row_count, uint32_t gh,
-                                                       uint32_t *__restrict__ row_off, uint32_t *__restrict__ counts)
+// exclusive scan of one image's row counts (256 lanes, Hillis-Steele per 256-row chunk); returns the total in every lane
+__device__ __forceinline__ uint32_t row_scan_block(const uint32_t *__restrict__ rc, uint32_t *__restrict__ ro, uint32_t gh, uint32_t *buf, uint32_t *carry)
 {
-    __shared__ uint32_t buf[256];
-    __shared__ uint32_t carry;
-    const uint32_t *rc = row_count + (size_t)blockIdx.x * gh;
-    uint32_t *ro = row_off + (size_t)blockIdx.x * gh;
-    if (threadIdx.x == 0) carry = 0;
+    if (threadIdx.x == 0) *carry = 0;
     __syncthreads();
     for (uint32_t base = 0; base < gh; base += 256) {
         const uint32_t r = base + threadIdx.x;
@@ -517,12 +513,47 @@ __global__ __launch_bounds__(256) void d2c_scan_kernel(const uint32_t *__restric
             buf[threadIdx.x] += t;
             __syncthreads();
         }
-        if (r < gh) ro[r] = carry + buf[threadIdx.x] - v;
+        if (r < gh) ro[r] = *carry + buf[threadIdx.x] - v;
         __syncthreads();
-        if (threadIdx.x == 255) carry += buf[255];
+        if (threadIdx.x == 255) *carry += buf[255];
         __syncthreads();
     }
-    if (threadIdx.x == 0) counts[blockIdx.x] = carry;
+    return *carry;
+}
+__global__ __launch_bounds__(256) void d2c_scan_kernel(const uint32_t *__restrict__ row_count, uint32_t gh,
+                                                       uint32_t *__restrict__ row_off, uint32_t *__restrict__ counts)
+{
+    __shared__ uint32_t buf[256];
+    __shared__ uint32_t carry;
+    const uint32_t total = row_scan_block(row_count + (size_t)blockIdx.x * gh, row_off + (size_t)blockIdx.x * gh, gh, buf, &carry);
+    if (threadIdx.x == 0) counts[blockIdx.x] = total;
+}
+// the same scan, and the start state of the hypothesis' ICP written from the count while it is at hand (asynchronous fused
+// path: the host never sees the cloud sizes before the loop; icp.h:29-31 identity / zero result, an empty cloud is finished
+// before it starts, icp.cu:183)
+__global__ __launch_bounds__(256) void d2c_scan_init_kernel(const uint32_t *__restrict__ row_count, uint32_t gh, uint32_t *__restrict__ row_off,
+                                                            uint32_t *__restrict__ counts, PoseMeta *__restrict__ meta, DevIcpState *__restrict__ st,
+                                                            uint32_t *__restrict__ arrive, uint32_t cloud_stride)
+{
+    __shared__ uint32_t buf[256];
+    __shared__ uint32_t carry;
+    const uint32_t i = blockIdx.x;
+    const uint32_t c = row_scan_block(row_count + (size_t)i * gh, row_off + (size_t)i * gh, gh, buf, &carry);
+    if (threadIdx.x == 0) {
+        counts[i] = c;
+        arrive[i] = 0u;
+        PoseMeta m;
+        m.start = i * cloud_stride; m.count = c; m.state = c > 0 ? kRun : kSkip; m.pad = 0;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) m.xform[k] = 0.0f;
+        meta[i] = m;
+    }
+    if (threadIdx.x < 20) {                                      // DevIcpState: T[16], fitness, rmse, done, passes
+        uint32_t w = 0;
+        if (threadIdx.x < 16) w = (threadIdx.x % 5 == 0) ? __float_as_uint(1.0f) : 0u;
+        else if (threadIdx.x == 18) w = c > 0 ? 0u : 1u;
+        reinterpret_cast<uint32_t *>(st + i)[threadIdx.x] = w;
+    }
 }
 
 template <typename T>
@@ -1241,8 +1272,7 @@ __global__ __launch_bounds__(256, PR_PASS_WAVES) void icp_pass_kernel(IcpBatch b
     if (st == kSkip) return;
     const uint32_t n = pm.count;
     const uint32_t ppb = b.steps * kPointsPerStep;
-    const uint32_t first = blockIdx.x * ppb;
-    if (first >= n) return;
+    if ((uint64_t)blockIdx.x * ppb >= n) return;
 
     const int4 *lds_topo = nullptr;
     int *stk_node = nullptr; float *stk_lb = nullptr;
@@ -1267,43 +1297,51 @@ __global__ __launch_bounds__(256, PR_PASS_WAVES) void icp_pass_kernel(IcpBatch b
 #pragma unroll
     for (int i = 0; i < 12; ++i) M[i] = xf ? pm.xform[i] : 0.0f;
 
-    float acc[29];
+    // One virtual workgroup of the canonical tree per trip.  The grid normally holds one workgroup per 2048-point block; the
+    // asynchronous fused path sizes its grid from the previous batch's cloud sizes (the current ones are still on the device),
+    // so a workgroup may have to take more than one block -- partial sums are per virtual block either way.
+    const uint32_t used = (n + ppb - 1) / ppb;
+    for (uint32_t vb = blockIdx.x; vb < used; vb += gridDim.x) {
+        if (vb != blockIdx.x) __syncthreads();                   // wsum of the previous trip has been read
+        float acc[29];
 #pragma unroll
-    for (int i = 0; i < 29; ++i) acc[i] = 0.0f;
-    vb_accumulate<Scene, kNN, kStack>(acc, cl, n, first, b.steps, xf, M, scene, lds_topo, stk_node, stk_lb);
-    const float t = vb_reduce(acc, wsum);
-    float *slot = b.partial + ((size_t)pose * b.nblk + blockIdx.x) * kAccStride;
-    if (!b.fused) {
-        if (threadIdx.x < 29) slot[threadIdx.x] = t;
+        for (int i = 0; i < 29; ++i) acc[i] = 0.0f;
+        vb_accumulate<Scene, kNN, kStack>(acc, cl, n, vb * ppb, b.steps, xf, M, scene, lds_topo, stk_node, stk_lb);
+        const float t = vb_reduce(acc, wsum);
+        float *slot = b.partial + ((size_t)pose * b.nblk + vb) * kAccStride;
+        if (!b.fused) {
+            if (threadIdx.x < 29) slot[threadIdx.x] = t;
+            continue;
+        }
+        // Fused finalize + solve: partial sums cross workgroups (and XCDs) through memory with system-scope accesses on both
+        // sides; wave 0 drains its stores before the arrival atomic that publishes them.  The workgroup that delivers the last
+        // partial sum of the pose (it cannot have another block left) adds the partials in block order (same sequence as
+        // icp_finalize_solve_kernel) and runs the iteration logic.  PoseMeta / DevIcpState are only read again by the next
+        // launch, so plain accesses suffice for them.
+        if (threadIdx.x >= 64) continue;
+        if (threadIdx.x < 29) st_sys_f32(slot + threadIdx.x, t);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        uint32_t ticket = 0;
+        if (threadIdx.x == 0) ticket = atomicAdd(&b.arrive[pose], 1u);
+        ticket = __builtin_amdgcn_readfirstlane(ticket);
+        if (ticket + 1u != used) continue;
+        if (threadIdx.x == 0) st_sys_u32(&b.arrive[pose], 0u);
+        DevIcpState s = b.st[pose];                              // uniform; in flight together with the partial sums
+        float total = 0.0f;
+        if (threadIdx.x < 29) total = sum_partials_sys(b.partial, pose, b.nblk, used, threadIdx.x);
+        float E[16];
+        const bool finished = pose_iteration_wave(total, n, s, b.crit, b.iter, E);
+        if (threadIdx.x != 0) return;
+        PoseMeta *wm = const_cast<PoseMeta *>(b.meta) + pose;
+        if (finished) { s.done = 1; wm->state = kSkip; }
+        else {
+#pragma unroll
+            for (int i = 0; i < 12; ++i) wm->xform[i] = E[i];
+            wm->state = kRunWithTransform;
+        }
+        b.st[pose] = s;
         return;
     }
-    // Fused finalize + solve: partial sums cross workgroups (and XCDs) through memory with system-scope accesses on both
-    // sides; wave 0 drains its stores before the arrival atomic that publishes them.  The last workgroup to arrive adds the
-    // partials in workgroup order (same sequence as icp_finalize_solve_kernel) and runs the iteration logic on one lane.
-    // PoseMeta / DevIcpState are only read again by the next launch, so plain accesses suffice for them.
-    if (threadIdx.x >= 64) return;
-    if (threadIdx.x < 29) st_sys_f32(slot + threadIdx.x, t);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    uint32_t ticket = 0;
-    if (threadIdx.x == 0) ticket = atomicAdd(&b.arrive[pose], 1u);
-    ticket = __builtin_amdgcn_readfirstlane(ticket);
-    const uint32_t used = (n + ppb - 1) / ppb;
-    if (ticket + 1u != used) return;
-    if (threadIdx.x == 0) st_sys_u32(&b.arrive[pose], 0u);
-    DevIcpState s = b.st[pose];                                  // uniform; in flight together with the partial sums
-    float total = 0.0f;
-    if (threadIdx.x < 29) total = sum_partials_sys(b.partial, pose, b.nblk, used, threadIdx.x);
-    float E[16];
-    const bool finished = pose_iteration_wave(total, n, s, b.crit, b.iter, E);
-    if (threadIdx.x != 0) return;
-    PoseMeta *wm = const_cast<PoseMeta *>(b.meta) + pose;
-    if (finished) { s.done = 1; wm->state = kSkip; }
-    else {
-#pragma unroll
-        for (int i = 0; i < 12; ++i) wm->xform[i] = E[i];
-        wm->state = kRunWithTransform;
-    }
-    b.st[pose] = s;
 }
 
 // second stage: workgroup sums added sequentially in workgroup order, starting from 0
@@ -1386,27 +1424,6 @@ __global__ __launch_bounds__(64) void icp_finalize_solve_kernel(const float *__r
     st[pose] = s;
 }
 
-// start state of a fused batch, written on the device so that the host never has to see the cloud sizes before the loop
-// (icp.h:29-31 identity / zero result; an empty cloud is finished before it starts, icp.cu:183)
-__global__ __launch_bounds__(256) void icp_init_kernel(PoseMeta *__restrict__ meta, DevIcpState *__restrict__ st, uint32_t *__restrict__ arrive,
-                                                       const uint32_t *__restrict__ counts, uint32_t cloud_stride, uint32_t n)
-{
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t c = counts[i];
-    PoseMeta m;
-    m.start = i * cloud_stride; m.count = c; m.state = c > 0 ? kRun : kSkip; m.pad = 0;
-#pragma unroll
-    for (int k = 0; k < 12; ++k) m.xform[k] = 0.0f;
-    meta[i] = m;
-    DevIcpState s;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) s.T[k] = (k % 5 == 0) ? 1.0f : 0.0f;
-    s.fitness = 0.0f; s.rmse = 0.0f; s.done = c > 0 ? 0 : 1; s.passes = 0;
-    st[i] = s;
-    arrive[i] = 0u;
-}
-
 __global__ void pack_results_kernel(const DevIcpState *__restrict__ st, pr_result *__restrict__ out, uint32_t n)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1415,6 +1432,25 @@ __global__ void pack_results_kernel(const DevIcpState *__restrict__ st, pr_resul
     for (int k = 0; k < 16; ++k) r.T[k] = st[i].T[k];
     r.inlier_rmse = st[i].rmse; r.fitness = st[i].fitness;
     out[i] = r;
+}
+// results to the device buffer and, in the same launch, results / cloud sizes to pinned host staging (stores over the host link)
+__global__ void pack_export_kernel(const DevIcpState *__restrict__ st, pr_result *__restrict__ out, const uint32_t *__restrict__ counts,
+                                   uint32_t *__restrict__ host_counts, pr_result *__restrict__ host_results, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    pr_result r;
+    for (int k = 0; k < 16; ++k) r.T[k] = st[i].T[k];
+    r.inlier_rmse = st[i].rmse; r.fitness = st[i].fitness;
+    out[i] = r;
+    host_counts[i] = counts[i];
+    if (host_results) host_results[i] = r;
+}
+// small host-staged inputs (poses, pixel boxes) pulled into device memory by a kernel: an SDMA copy of 20 KB costs ~20 us of latency
+__global__ void stage_words_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, uint32_t n16)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n16) dst[i] = src[i];
 }
 
 // ================================================================================================
@@ -1942,7 +1978,8 @@ hipError_t launch_render_bands(const pr_triangle *tris, uint32_t n_tris, const p
 // fused-path render, reference scheme (global int32 atomicMin) but only inside each hypothesis' box
 hipError_t launch_render_boxes(const pr_triangle *tris, uint32_t n_tris, const pr_mat4 *poses_dev, uint32_t n_poses, const float *aabb,
                                int4 *bbox, int32_t *depth, uint32_t *row_count, uint32_t *row_off, uint32_t *counts,
-                               uint32_t width, uint32_t height, const pr_mat4 &proj, hipStream_t s, bool compute_boxes)
+                               uint32_t width, uint32_t height, const pr_mat4 &proj, hipStream_t s, bool compute_boxes,
+                               PoseMeta *meta, DevIcpState *st, uint32_t *arrive, uint32_t cloud_stride)
 {
     if (n_poses == 0) return hipSuccess;
     if (compute_boxes)
@@ -1957,7 +1994,8 @@ hipError_t launch_render_boxes(const pr_triangle *tris, uint32_t n_tris, const p
         hipLaunchKernelGGL(count_box_kernel, dim3((height + kBoxRowsPerBlock - 1) / kBoxRowsPerBlock, np), dim3(256), 0, s, depth + off, bbox + p0, width, height,
                            row_count + (size_t)p0 * height);
     }
-    hipLaunchKernelGGL(d2c_scan_kernel, dim3(n_poses), dim3(256), 0, s, row_count, height, row_off, counts);
+    if (meta) hipLaunchKernelGGL(d2c_scan_init_kernel, dim3(n_poses), dim3(256), 0, s, row_count, height, row_off, counts, meta, st, arrive, cloud_stride);
+    else hipLaunchKernelGGL(d2c_scan_kernel, dim3(n_poses), dim3(256), 0, s, row_count, height, row_off, counts);
     return hipGetLastError();
 }
 
@@ -2017,7 +2055,7 @@ static hipError_t launch_pass(const IcpBatch &b, const Scene &sc, uint32_t n_pos
         IcpBatch bb = b;
         bb.meta += p0;
         bb.partial += (size_t)p0 * b.nblk * kAccStride;
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(icp_pass_kernel<Scene, kNN, kStack>), dim3(b.nblk, np), dim3(kBlockThreads), lds_bytes, s, bb, sc);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(icp_pass_kernel<Scene, kNN, kStack>), dim3(b.grid_x ? b.grid_x : b.nblk, np), dim3(kBlockThreads), lds_bytes, s, bb, sc);
     }
     return hipGetLastError();
 }
@@ -2075,10 +2113,18 @@ hipError_t launch_icp_finalize_solve(const float *partial, PoseMeta *meta, uint3
                        steps * kPointsPerStep, st, crit, iter);
     return hipGetLastError();
 }
-hipError_t launch_icp_init(PoseMeta *meta, DevIcpState *st, uint32_t *arrive, const uint32_t *counts, uint32_t cloud_stride, uint32_t n, hipStream_t s)
+hipError_t launch_pack_export(const DevIcpState *st, pr_result *out, const uint32_t *counts, uint32_t *host_counts, pr_result *host_results,
+                              uint32_t n, hipStream_t s)
 {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(icp_init_kernel, dim3((n + 255) / 256), dim3(256), 0, s, meta, st, arrive, counts, cloud_stride, n);
+    hipLaunchKernelGGL(pack_export_kernel, dim3((n + 255) / 256), dim3(256), 0, s, st, out, counts, host_counts, host_results, n);
+    return hipGetLastError();
+}
+hipError_t launch_stage_words(const void *src_host_mapped, void *dst, size_t bytes, hipStream_t s)
+{
+    const uint32_t n16 = (uint32_t)((bytes + 15) / 16);
+    if (n16 == 0) return hipSuccess;
+    hipLaunchKernelGGL(stage_words_kernel, dim3((n16 + 255) / 256), dim3(256), 0, s, static_cast<const uint4 *>(src_host_mapped), static_cast<uint4 *>(dst), n16);
     return hipGetLastError();
 }
 hipError_t launch_pack_results(const DevIcpState *st, pr_result *out, uint32_t n_poses, hipStream_t s)

@@ -311,6 +311,12 @@ def test_async_slots_match_synchronous_path_bitwise(gpu, model, scenario, gscene
             ref_a = api.refine_batch(model, poses_a, W, H, scenario["proj"], scenario["K"], gscenes["proj"], c)
             ref_b = api.refine_batch(model, poses_b, W, H, scenario["proj"], scenario["K"], gscenes["proj"], c)
             api.set_option("profile", 0)
+            # the grid of an asynchronous batch is sized from the clouds of the batch before it: make that a batch of tiny
+            # clouds (3 m farther away) so that every workgroup of the next one has to walk several 2048-point blocks
+            far = poses_a.copy()
+            far.reshape(-1, 4, 4)[:, 2, 3] += 3000.0
+            _, far_sizes = api.refine_batch(model, far, W, H, scenario["proj"], scenario["K"], gscenes["proj"], c)
+            assert 0 < far_sizes.max() < 2048 < ref_a[1].max()
             api.refine_submit(0, model, poses_a, W, H, scenario["proj"], scenario["K"], gscenes["proj"], c)
             dev_b = api.DeviceVector(P * 18, np.float32)
             api.refine_submit(1, model, poses_b, W, H, scenario["proj"], scenario["K"], gscenes["proj"], c, results_dev=dev_b.data())
