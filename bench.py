@@ -42,8 +42,8 @@ PMC_TRAFFIC_BYTES_PER_POINT = {"proj": 25.0, "nn": None}
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--poses", type=int, default=256, help="hypotheses per GPU per step")
     ap.add_argument("--scene", choices=["proj", "nn"], default="proj")
     ap.add_argument("--iters", type=int, default=20)
@@ -187,8 +187,8 @@ def main():
                          "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/r01/README.md",
                          "avg_launch_us": avg_launch_s * 1e6, "launches": int(launches),
                          "algorithmic_bytes_per_launch": bytes_per_launch, "points_per_launch": pts_per_launch,
-                         "timing": "HIP events on the library stream around one launch every 8th step, rotating over the 21 passes; "
-                                   "a timed step runs the batch as one pose group so the launch has the chip to itself"},
+                         "timing": "HIP events on the library stream around one launch every 16th step, rotating over the 21 passes; "
+                                   "a timed step runs synchronously as one pose group (other slot drained) so the launch has the chip to itself"},
             "phase_ms_per_timed_step": {"render": prof["render_ms"] / launches, "cloud": prof["cloud_ms"] / launches},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -88,6 +88,7 @@ struct Ctx {
     int nn_lds_nodes = 1024;
     int nn_lds_records = 0;          // stack traversal: leading 64-byte node records staged in LDS; measured 0/64/128/256/512 -> 42.2/41.6/45.2/45.4/58.2 ms per step (occupancy lost to the extra LDS outweighs the saved L1 lookups)
     int nn_stack = 1;                // kd-tree query: per-lane LDS stack (1) or the reference's stackless walk (0)
+    int sub_batch = 512;             // asynchronous fused path: hypotheses per sub-batch (cache residency of the clouds)
     int fused_solve = 1;             // PR_SOLVE_DEVICE: the workgroup delivering a hypothesis' last partial sum also runs its finalize + solve (no second launch per iteration)
     int icp_flow = 0;                // PR_SOLVE_DEVICE: 1 = one persistent dataflow launch for all iterations (bit-identical; measured equal at
                                      // 256 poses and 35 % slower at 1024), 0 = one launch per pass + per solve
@@ -109,6 +110,7 @@ struct Ctx {
 };
 Ctx g;
 std::mutex g_mu;
+constexpr uint64_t kSamplePeriod = 16;     // profile 2: one timed (synchronous, single-group) call in this many
 
 // ---- hipGraph cache for the device-solve iteration loop ------------------------------------------
 struct GraphKey {
@@ -350,10 +352,10 @@ int icp_drive(pr_vec3 *cloud_base, const uint32_t *start_h, const uint32_t *coun
         }
 
         // profile==2: time ONE correspondence launch per call, at an iteration index that rotates from call to call
-        // (and only every 8th call, so that the other calls can replay the captured graph)
+        // (and only every kSamplePeriod-th call: a timed call runs synchronously, as one pose group, with the other slot drained)
         const uint64_t tick = g.sample_clock++;
-        const bool sample_call = (g.profile == 2) && (tick % 8 == 0);
-        const uint32_t sample_it = (uint32_t)(((tick / 8) * 5 + 1) % (uint64_t)(crit.max_iteration + 1));
+        const bool sample_call = (g.profile == 2) && (tick % kSamplePeriod == 0);
+        const uint32_t sample_it = (uint32_t)(((tick / kSamplePeriod) * 5 + 1) % (uint64_t)(crit.max_iteration + 1));
         // Pose groups: the batch is split over up to four streams so that one group's serial solve tail (and the ragged end
         // of its pass) overlaps another group's pass.  Timed launches (profile 1, the sampled call of profile 2) run as a
         // single group so that the measured kernel has the chip to itself.
@@ -705,9 +707,9 @@ int refine_submit(int slot, const pr_triangle *tris_dev, size_t n_tris, const pr
     if (crit.max_iteration < 0) { set_error("max_iteration must be >= 0"); return PR_ERR_INVALID; }
     sl.P = P; sl.user_results_host = results_host; sl.user_sizes = sizes_host; sl.delivered = false;
     const size_t img = (size_t)W * H;
-    const bool sample_call = (g.profile == 2) && (g.sample_clock % 8 == 0);
+    const bool sample_call = (g.profile == 2) && (g.sample_clock % kSamplePeriod == 0);
     const bool async_ok = P > 0 && g.solve_mode == PR_SOLVE_DEVICE && !g.icp_flow && g.raster_mode == 0 && scene_kind == PR_SCENE_PROJ
-                          && img * sizeof(int32_t) * P <= ((size_t)4 << 30) && (g.profile == 0 || (g.profile == 2 && !sample_call));
+                          && img * sizeof(int32_t) * std::min<size_t>(P, (size_t)std::max(32, g.sub_batch)) <= ((size_t)4 << 30) && (g.profile == 0 || (g.profile == 2 && !sample_call));
     if (!async_ok) {
         // the synchronous path (host solve, kd-tree scenes, timed calls, oversized batches): let the other slot drain first so
         // that a timed launch has the chip to itself, then run to completion; pr_refine_wait has nothing left to do
@@ -752,15 +754,21 @@ int refine_submit(int slot, const pr_triangle *tris_dev, size_t n_tris, const pr
     // grid: one workgroup per block of the largest cloud of the previous batch (workgroups loop if this batch's clouds are
     // larger, surplus workgroups exit at once); the box bound itself would launch ~60 % empty workgroups (-2.5 % poses/s)
     const uint32_t grid_x = g.cloud_hint ? std::min(nblk, (g.cloud_hint + ppb - 1) / ppb) : nblk;
-    if (cstride * (size_t)P > 0xffffffffull) { set_error("pr_refine_submit: batch too large for 32-bit cloud offsets"); return PR_ERR_INVALID; }
+    if (cstride * (size_t)std::min<size_t>(P, (size_t)std::max(32, g.sub_batch)) > 0xffffffffull) { set_error("pr_refine_submit: batch too large for 32-bit cloud offsets"); return PR_ERR_INVALID; }
 
-    PR_TRY(sl.depth.ensure(sizeof(int32_t) * img * P));
-    PR_TRY(sl.row_count.ensure(sizeof(uint32_t) * (size_t)H * P));
-    PR_TRY(sl.row_off.ensure(sizeof(uint32_t) * (size_t)H * P));
+    // Large batches run as consecutive sub-batches that reuse the same depth / cloud / partial-sum memory: the clouds of
+    // <= 512 hypotheses (~140 MB touched) stay in the 256 MiB Infinity Cache over their 21 passes (1024 poses as one batch:
+    // 199 k poses/s, as 2 x 512: see DESIGN.md)
+    const uint32_t sub_cap = (uint32_t)std::max(32, g.sub_batch);
+    const uint32_t n_sub = (P + sub_cap - 1) / sub_cap;
+    const uint32_t sub = (P + n_sub - 1) / n_sub;
+    PR_TRY(sl.depth.ensure(sizeof(int32_t) * img * sub));
+    PR_TRY(sl.row_count.ensure(sizeof(uint32_t) * (size_t)H * sub));
+    PR_TRY(sl.row_off.ensure(sizeof(uint32_t) * (size_t)H * sub));
     PR_TRY(sl.counts.ensure(sizeof(uint32_t) * P));
-    PR_TRY(sl.cloud.ensure(sizeof(pr_vec3) * cstride * P));
+    PR_TRY(sl.cloud.ensure(sizeof(pr_vec3) * cstride * sub));
     PR_TRY(sl.meta.ensure(sizeof(prk::PoseMeta) * P));
-    PR_TRY(sl.partial.ensure(sizeof(float) * prk::kAccStride * (size_t)nblk * P));
+    PR_TRY(sl.partial.ensure(sizeof(float) * prk::kAccStride * (size_t)nblk * sub));
     PR_TRY(sl.dstate.ensure(sizeof(prk::DevIcpState) * P));
     PR_TRY(sl.arrive.ensure(sizeof(uint32_t) * P));
     const size_t res_off = ((size_t)P * 4 + 63) & ~(size_t)63;
@@ -775,36 +783,41 @@ int refine_submit(int slot, const pr_triangle *tris_dev, size_t n_tris, const pr
     HIP_TRY(hipHostGetDevicePointer(&h_in_dev, sl.h_in.p, 0));
     HIP_TRY(hipHostGetDevicePointer(&h_out_dev, sl.h_out.p, 0));
     HIP_TRY(prk::launch_stage_words(h_in_dev, d_poses, in_bytes, st));
-    HIP_TRY(prk::launch_render_boxes(tris_dev, (uint32_t)n_tris, d_poses, P, nullptr, d_box, sl.depth.as<int32_t>(), sl.row_count.as<uint32_t>(),
-                                     sl.row_off.as<uint32_t>(), sl.counts.as<uint32_t>(), W, H, *proj, st, /*compute_boxes=*/false,
-                                     sl.meta.as<prk::PoseMeta>(), sl.dstate.as<prk::DevIcpState>(), sl.arrive.as<uint32_t>(), (uint32_t)cstride));
-    HIP_TRY(prk::launch_emit_box(sl.depth.as<int32_t>(), P, W, H, d_box, K[0], K[4], K[2], K[5], sl.row_count.as<uint32_t>(),
-                                 sl.row_off.as<uint32_t>(), sl.cloud.as<pr_vec3>(), cstride, st));
-    HIP_TRY(hipStreamWaitEvent(st, sl.scene_ready, 0));
-
-    // the iteration loop: (max_iteration+1) x [pass (+ fused finalize/solve)], pose groups on the slot's side streams
     const bool fused = g.fused_solve != 0;
-    const uint32_t n_groups = std::max(1u, std::min({ (uint32_t)std::max(1, g.pose_groups), 4u, P / 32u }));
-    auto group_begin = [&](uint32_t grp) { return (uint32_t)(((uint64_t)P * grp) / n_groups); };
-    if (n_groups > 1) {
-        HIP_TRY(hipEventRecord(sl.fork, st));
-        for (uint32_t k = 1; k < n_groups; ++k) HIP_TRY(hipStreamWaitEvent(sl.side[k - 1], sl.fork, 0));
-    }
-    prk::IcpBatch b{};
-    b.cloud = sl.cloud.as<pr_vec3>(); b.nblk = nblk; b.grid_x = grid_x; b.steps = steps;
-    for (uint32_t it = 0; it <= (uint32_t)crit.max_iteration; ++it) {
-        for (uint32_t grp = 0; grp < n_groups; ++grp) {
-            const uint32_t p0 = group_begin(grp), np = group_begin(grp + 1) - p0;
-            hipStream_t gs = grp ? sl.side[grp - 1] : st;
-            prk::IcpBatch bb = b;
-            bb.meta = sl.meta.as<prk::PoseMeta>() + p0; bb.partial = sl.partial.as<float>() + (size_t)p0 * nblk * prk::kAccStride;
-            if (fused) { bb.fused = 1; bb.iter = it; bb.crit = crit; bb.st = sl.dstate.as<prk::DevIcpState>() + p0; bb.arrive = sl.arrive.as<uint32_t>() + p0; }
-            HIP_TRY(launch_pass(bb, sc, np, gs));
-            if (!fused) HIP_TRY(prk::launch_icp_finalize_solve(bb.partial, sl.meta.as<prk::PoseMeta>() + p0, nblk, steps,
-                                                               sl.dstate.as<prk::DevIcpState>() + p0, crit, it, np, gs));
+    for (uint32_t q0 = 0; q0 < P; q0 += sub) {
+        const uint32_t nq = std::min(sub, P - q0);
+        prk::PoseMeta *meta = sl.meta.as<prk::PoseMeta>() + q0;
+        prk::DevIcpState *dstate = sl.dstate.as<prk::DevIcpState>() + q0;
+        uint32_t *arrive = sl.arrive.as<uint32_t>() + q0;
+        HIP_TRY(prk::launch_render_boxes(tris_dev, (uint32_t)n_tris, d_poses + q0, nq, nullptr, d_box + q0, sl.depth.as<int32_t>(),
+                                         sl.row_count.as<uint32_t>(), sl.row_off.as<uint32_t>(), sl.counts.as<uint32_t>() + q0, W, H, *proj, st,
+                                         /*compute_boxes=*/false, meta, dstate, arrive, (uint32_t)cstride));
+        HIP_TRY(prk::launch_emit_box(sl.depth.as<int32_t>(), nq, W, H, d_box + q0, K[0], K[4], K[2], K[5], sl.row_count.as<uint32_t>(),
+                                     sl.row_off.as<uint32_t>(), sl.cloud.as<pr_vec3>(), cstride, st));
+        if (q0 == 0) HIP_TRY(hipStreamWaitEvent(st, sl.scene_ready, 0));
+
+        // the iteration loop: (max_iteration+1) x [pass (+ fused finalize/solve)], pose groups on the slot's side streams
+        const uint32_t n_groups = std::max(1u, std::min({ (uint32_t)std::max(1, g.pose_groups), 4u, nq / 32u }));
+        auto group_begin = [&](uint32_t grp) { return (uint32_t)(((uint64_t)nq * grp) / n_groups); };
+        if (n_groups > 1) {
+            HIP_TRY(hipEventRecord(sl.fork, st));
+            for (uint32_t k = 1; k < n_groups; ++k) HIP_TRY(hipStreamWaitEvent(sl.side[k - 1], sl.fork, 0));
         }
+        prk::IcpBatch b{};
+        b.cloud = sl.cloud.as<pr_vec3>(); b.nblk = nblk; b.grid_x = grid_x; b.steps = steps;
+        for (uint32_t it = 0; it <= (uint32_t)crit.max_iteration; ++it) {
+            for (uint32_t grp = 0; grp < n_groups; ++grp) {
+                const uint32_t p0 = group_begin(grp), np = group_begin(grp + 1) - p0;
+                hipStream_t gs = grp ? sl.side[grp - 1] : st;
+                prk::IcpBatch bb = b;
+                bb.meta = meta + p0; bb.partial = sl.partial.as<float>() + (size_t)p0 * nblk * prk::kAccStride;
+                if (fused) { bb.fused = 1; bb.iter = it; bb.crit = crit; bb.st = dstate + p0; bb.arrive = arrive + p0; }
+                HIP_TRY(launch_pass(bb, sc, np, gs));
+                if (!fused) HIP_TRY(prk::launch_icp_finalize_solve(bb.partial, meta + p0, nblk, steps, dstate + p0, crit, it, np, gs));
+            }
+        }
+        for (uint32_t k = 1; k < n_groups; ++k) { HIP_TRY(hipEventRecord(sl.join[k - 1], sl.side[k - 1])); HIP_TRY(hipStreamWaitEvent(st, sl.join[k - 1], 0)); }
     }
-    for (uint32_t k = 1; k < n_groups; ++k) { HIP_TRY(hipEventRecord(sl.join[k - 1], sl.side[k - 1])); HIP_TRY(hipStreamWaitEvent(st, sl.join[k - 1], 0)); }
     HIP_TRY(prk::launch_pack_export(sl.dstate.as<prk::DevIcpState>(), dres, sl.counts.as<uint32_t>(), static_cast<uint32_t *>(h_out_dev),
                                     results_host ? reinterpret_cast<pr_result *>(static_cast<unsigned char *>(h_out_dev) + res_off) : nullptr, P, st));
     HIP_TRY(hipEventRecord(sl.done, st));
@@ -1131,6 +1144,7 @@ int pr_set_option(const char *name, int value)
     else if (n == "graph") g.use_graph = value ? 1 : 0;
     else if (n == "icp_flow") g.icp_flow = value ? 1 : 0;
     else if (n == "fused_solve") g.fused_solve = value ? 1 : 0;
+    else if (n == "sub_batch") g.sub_batch = std::max(32, value);
     else if (n == "pose_groups") g.pose_groups = std::min(4, std::max(1, value));
     else if (n == "raster_mode") { if (value != 0 && value != 1) { set_error("raster_mode must be 0 or 1"); return PR_ERR_INVALID; } g.raster_mode = value; }
     else { set_error("unknown option %s", name); return PR_ERR_INVALID; }
@@ -1151,6 +1165,7 @@ int pr_get_option(const char *name, int *value)
     else if (n == "graph") *value = g.use_graph;
     else if (n == "icp_flow") *value = g.icp_flow;
     else if (n == "fused_solve") *value = g.fused_solve;
+    else if (n == "sub_batch") *value = g.sub_batch;
     else if (n == "pose_groups") *value = g.pose_groups;
     else { set_error("unknown option %s", name); return PR_ERR_INVALID; }
     return PR_OK;

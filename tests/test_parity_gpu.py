@@ -304,6 +304,7 @@ def test_async_slots_match_synchronous_path_bitwise(gpu, model, scenario, gscene
     poses_b[1] = poses_b[1].copy()
     poses_b[1].reshape(4, 4)[0, 3] += 1.0e6                      # a kilometre to the side: off-screen -> empty cloud -> identity result
     api.set_option("solve", api.SOLVE_DEVICE)
+    api.set_option("sub_batch", 40)                              # P=96 runs as three sub-batches of 32 that reuse the same workspace
     try:
         for crit in ((0.0, 0.0, 20), (1e-5, 1e-5, 30)):
             c = api.ICPConvergenceCriteria(*crit)
@@ -331,6 +332,7 @@ def test_async_slots_match_synchronous_path_bitwise(gpu, model, scenario, gscene
             api.refine_wait(0)                                   # nothing pending
     finally:
         api.set_option("profile", 0)
+        api.set_option("sub_batch", 512)
         api.set_option("solve", api.SOLVE_HOST)
 
 
