@@ -98,6 +98,7 @@ struct Ctx {
     int n_cus = 256;
     const void *aabb_key = nullptr; size_t aabb_n = 0;
     float aabb_host[6] = { 0, 0, 0, 0, 0, 0 }; bool aabb_host_valid = false;
+    const void *mesh_key = nullptr; size_t mesh_n = 0;   // triangle buffer aabb_host belongs to
     uint32_t cloud_hint = 0;          // largest cloud of the latest finished asynchronous batch: sizes the next batch's grid
     // workspaces
     DevBuf aabb, bbox, poses, depth, row_count, row_off, counts, cloud, meta, partial, sums, rec, topo, bmin, bmax, pts, nnrec, nndepth, dstate, dresults, vbdesc, flowsync, arrive, conv16, conv8, kd_idx, kd_scratch, kd_child, kd_ctrl, kd_tmp, nn_full;
@@ -651,6 +652,23 @@ void slot_release(Slot &sl)
     sl.fork = sl.done = sl.scene_ready = nullptr; sl.stream = sl.aux = nullptr; sl.pending = false;
 }
 
+// Host-side box of a triangle buffer, once per (pointer, size): it feeds the per-pose pixel boxes computed on the host.
+// (An indexed form of the soup with a per-pose vertex stage was built and measured as well: three divergent 16-byte gathers
+// per triangle cost the texture addresser more than the 170 saved VALU instructions give back -- 1.27 -> 1.32 ms per step.)
+int ensure_model_box(const pr_triangle *tris_dev, size_t n_tris)
+{
+    if (g.mesh_key == tris_dev && g.mesh_n == n_tris && g.aabb_host_valid) return PR_OK;
+    std::vector<pr_triangle> h(n_tris);
+    HIP_TRY(hipMemcpy(h.data(), tris_dev, sizeof(pr_triangle) * n_tris, hipMemcpyDeviceToHost));
+    const float *f = reinterpret_cast<const float *>(h.data());
+    float lo[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, hi[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
+    for (size_t v = 0; v < n_tris * 3; ++v)
+        for (int d = 0; d < 3; ++d) { lo[d] = fminf(lo[d], f[3 * v + d]); hi[d] = fmaxf(hi[d], f[3 * v + d]); }
+    for (int d = 0; d < 3; ++d) { g.aabb_host[d] = lo[d]; g.aabb_host[3 + d] = hi[d]; }
+    g.mesh_key = tris_dev; g.mesh_n = n_tris; g.aabb_host_valid = true;
+    return PR_OK;
+}
+
 // pose_bbox_kernel on the host (same operations in the same order; any conservative box gives the same images and clouds)
 void pose_bbox_host(const float *aabb, const pr_mat4 &pose, const pr_mat4 &proj, uint32_t width, uint32_t height, int32_t out[4])
 {
@@ -726,14 +744,7 @@ int refine_submit(int slot, const pr_triangle *tris_dev, size_t n_tris, const pr
     PR_TRY(make_scene(scene_kind, scene, /*want_packed=*/true, sc, &sl.rec, sl.aux));
     HIP_TRY(hipEventRecord(sl.scene_ready, sl.aux));
 
-    // model box on the host (once per triangle buffer)
-    if (g.aabb_key != tris_dev || g.aabb_n != n_tris || !g.aabb_host_valid) {
-        PR_TRY(g.aabb.ensure(6 * sizeof(float)));
-        HIP_TRY(prk::launch_model_aabb(tris_dev, (uint32_t)n_tris, g.aabb.as<float>(), g.stream));
-        HIP_TRY(hipMemcpyAsync(g.aabb_host, g.aabb.p, sizeof g.aabb_host, hipMemcpyDeviceToHost, g.stream));
-        HIP_TRY(hipStreamSynchronize(g.stream));
-        g.aabb_key = tris_dev; g.aabb_n = n_tris; g.aabb_host_valid = true;
-    }
+    PR_TRY(ensure_model_box(tris_dev, n_tris));                 // once per triangle buffer
     // staging: [poses][boxes]; the cloud stride and the grid come from the largest box
     const size_t in_bytes = (sizeof(pr_mat4) + sizeof(int4)) * (size_t)P;
     PR_TRY(sl.h_in.ensure(in_bytes + 16));
@@ -944,12 +955,20 @@ int pr_malloc(void **dev_ptr, size_t bytes)
     HIP_TRY(hipMalloc(dev_ptr, bytes ? bytes : 1));
     return PR_OK;
 }
+// the per-model boxes are keyed by the triangle buffer's address: writing to or freeing that buffer through this library
+// drops them
+static void forget_model(const void *dev_ptr)
+{
+    if (dev_ptr == g.mesh_key) { g.mesh_key = nullptr; g.aabb_host_valid = false; }
+    if (dev_ptr == g.aabb_key) g.aabb_key = nullptr;
+}
 int pr_free(void *dev_ptr)
 {
     std::lock_guard<std::mutex> lk(g_mu);
     if (!dev_ptr) return PR_OK;
     PR_TRY(require_ctx());
     HIP_TRY(hipStreamSynchronize(g.stream));
+    forget_model(dev_ptr);
     HIP_TRY(hipFree(dev_ptr));
     return PR_OK;
 }
@@ -957,6 +976,7 @@ static int copy_sync(void *dst, const void *src, size_t bytes, hipMemcpyKind kin
 {
     std::lock_guard<std::mutex> lk(g_mu);
     PR_TRY(require_ctx());
+    if (kind != hipMemcpyDeviceToHost) forget_model(dst);
     if (bytes == 0) return PR_OK;
     HIP_TRY(hipMemcpyAsync(dst, src, bytes, kind, g.stream));
     HIP_TRY(hipStreamSynchronize(g.stream));
