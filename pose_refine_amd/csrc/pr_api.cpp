@@ -381,6 +381,7 @@ int icp_drive(pr_vec3 *cloud_base, const uint32_t *start_h, const uint32_t *coun
                     prk::IcpBatch bb = b;
                     bb.meta += p0; bb.partial += (size_t)p0 * nblk * prk::kAccStride;
                     if (fused) { bb.fused = 1; bb.iter = it; bb.crit = crit; bb.st = g.dstate.as<prk::DevIcpState>() + p0; bb.arrive = g.arrive.as<uint32_t>() + p0; }
+                    bb.score_only = (it == (uint32_t)crit.max_iteration) ? 1u : 0u;
                     if (grp == 0 && (g.profile == 1 || (sample_call && it == sample_it))) {
                         SpanGuard sp(kSpanIcp); HIP_TRY(launch_pass(bb, sc, np, st));
                         uint64_t pts = 0; for (uint32_t i = p0; i < p0 + np; ++i) pts += count_h[i];
@@ -823,6 +824,7 @@ int refine_submit(int slot, const pr_triangle *tris_dev, size_t n_tris, const pr
                 prk::IcpBatch bb = b;
                 bb.meta = meta + p0; bb.partial = sl.partial.as<float>() + (size_t)p0 * nblk * prk::kAccStride;
                 if (fused) { bb.fused = 1; bb.iter = it; bb.crit = crit; bb.st = dstate + p0; bb.arrive = arrive + p0; }
+                bb.score_only = (it == (uint32_t)crit.max_iteration) ? 1u : 0u;
                 HIP_TRY(launch_pass(bb, sc, np, gs));
                 if (!fused) HIP_TRY(prk::launch_icp_finalize_solve(bb.partial, meta + p0, nblk, steps, dstate + p0, crit, it, np, gs));
             }

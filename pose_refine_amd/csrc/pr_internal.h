@@ -41,6 +41,7 @@ struct IcpBatch {
     uint32_t        steps;      // steps of 1024 points per workgroup
     // PR_SOLVE_DEVICE with the solve fused into the pass (option "fused_solve"): the workgroup that delivers the last
     // partial sum of a hypothesis also adds the partials up and runs that hypothesis' iteration logic
+    uint32_t        score_only; // 1 on the pass of iteration == max_iteration (PR_SOLVE_DEVICE): only sums 27 (error) and 28 (count) are formed
     uint32_t        fused;      // 0 = separate icp_finalize_solve launch
     uint32_t        iter;       // iteration index of this pass (icp.cu:178 loop variable)
     DevIcpState    *st;         // [P]

@@ -925,6 +925,21 @@ __device__ __forceinline__ void accumulate(Acc29 &a, float sx, float sy, float s
 }
 #endif
 
+// the last pass of an ICP (iteration == max_iteration, icp.cu:189) only feeds fitness and rmse: sums 27 (squared distance)
+// and 28 (count), each updated by exactly the operation the full form applies to it
+__device__ __forceinline__ void accumulate_score(Acc29 &acc, float sx, float sy, float sz, const Corr &c)
+{
+    const float ex = c.dx - sx, ey = c.dy - sy, ez = c.dz - sz;
+    const float e2 = ex * ex + ey * ey + ez * ez;
+#if PR_PACKED_ACC
+    acc.pk[13].y += e2;
+    acc.pk[14].x += 1.0f;
+#else
+    acc.v[27] += e2;
+    acc.v[28] += 1.0f;
+#endif
+}
+
 // ------------------------------------------------------------------------------------------------
 // wave64 sum with a fixed balanced pairwise tree in lane order, result in lane 63:
 //   row_shr:1,2,4,8 inside each 16-lane row, row_bcast15 into rows 1 and 3, row_bcast31 into rows 2,3.
@@ -1116,7 +1131,7 @@ __device__ __forceinline__ bool pose_iteration_wave(float total, uint32_t n, Dev
 
 // One virtual workgroup of the canonical tree: accumulate the 29 sums of points [first, first + steps*1024) of one
 // cloud into the lane's registers (pending transform applied and written back first when xf).
-template <class Scene, bool kNN, int kStack>
+template <class Scene, bool kNN, int kStack, bool kScoreOnly = false>
 __device__ __forceinline__ void vb_accumulate(float (&acc_out)[29], float *cl, uint32_t n, uint32_t first, uint32_t steps, bool xf,
                                               const float (&M)[12], const Scene &scene, const int4 *lds_topo, int *stk_node, float *stk_lb)
 {
@@ -1170,7 +1185,7 @@ __device__ __forceinline__ void vb_accumulate(float (&acc_out)[29], float *cl, u
                     bool ok;
                     if constexpr (kStack > 0) ok = query_nn_stack<kStack>(scene, reinterpret_cast<const float4 *>(lds_topo), stk_node, stk_lb, p[3 * i], p[3 * i + 1], p[3 * i + 2], c);
                     else ok = query_nn<true>(scene, lds_topo, p[3 * i], p[3 * i + 1], p[3 * i + 2], c);
-                    if (ok) accumulate(acc, p[3 * i], p[3 * i + 1], p[3 * i + 2], c);
+                    if (ok) { if constexpr (kScoreOnly) accumulate_score(acc, p[3 * i], p[3 * i + 1], p[3 * i + 2], c); else accumulate(acc, p[3 * i], p[3 * i + 1], p[3 * i + 2], c); }
                 }
             }
         } else {
@@ -1193,7 +1208,10 @@ __device__ __forceinline__ void vb_accumulate(float (&acc_out)[29], float *cl, u
                 for (uint32_t k = 0; k < PR_GATHER_BATCH; ++k) {
                     const uint32_t i = i0 + k;
                     Corr c;
-                    if (gather_finish(scene, in_img[k], p[3 * i + 2], gth[k], c)) accumulate(acc, p[3 * i], p[3 * i + 1], p[3 * i + 2], c);
+                    if (gather_finish(scene, in_img[k], p[3 * i + 2], gth[k], c)) {
+                        if constexpr (kScoreOnly) accumulate_score(acc, p[3 * i], p[3 * i + 1], p[3 * i + 2], c);
+                        else accumulate(acc, p[3 * i], p[3 * i + 1], p[3 * i + 2], c);
+                    }
                 }
             }
         }
@@ -1221,8 +1239,10 @@ __device__ __forceinline__ void vb_accumulate(float (&acc_out)[29], float *cl, u
 
 // canonical tree, second half: wave (balanced pairwise over lanes) -> ((w0+w1)+w2)+w3.  Returns, in threads 0..28, the
 // workgroup sum of component threadIdx.x.  Contains one __syncthreads().
+template <bool kScoreOnly = false>
 __device__ __forceinline__ float vb_reduce(float (&acc)[29], float (*wsum)[kAccStride])
 {
+    constexpr int kFirst = kScoreOnly ? 27 : 0;                  // score-only passes carry zeros in sums 0..26
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #ifdef PR_ABL_NOREDUCE
     { float t = 0; for (int i = 0; i < 29; ++i) t += acc[i]; if (lane == 63) wsum[wave][0] = t; }
@@ -1236,7 +1256,7 @@ __device__ __forceinline__ float vb_reduce(float (&acc)[29], float (*wsum)[kAccS
 #else
     // level-major: the 29 sums advance through each tree level together, so consecutive DPP instructions are independent
     // (value-major order makes every instruction depend on the previous one and the compiler pads it with s_nop)
-#define PR_TREE_LEVEL(CTRL, MASK) _Pragma("unroll") for (int i = 0; i < 29; ++i) acc[i] += dpp_get<CTRL, MASK>(acc[i]);
+#define PR_TREE_LEVEL(CTRL, MASK) _Pragma("unroll") for (int i = kFirst; i < 29; ++i) acc[i] += dpp_get<CTRL, MASK>(acc[i]);
     PR_TREE_LEVEL(0x111, 0xf)      // row_shr:1
     PR_TREE_LEVEL(0x112, 0xf)      // row_shr:2
     PR_TREE_LEVEL(0x114, 0xf)      // row_shr:4
@@ -1306,8 +1326,14 @@ __global__ __launch_bounds__(256, PR_PASS_WAVES) void icp_pass_kernel(IcpBatch b
         float acc[29];
 #pragma unroll
         for (int i = 0; i < 29; ++i) acc[i] = 0.0f;
-        vb_accumulate<Scene, kNN, kStack>(acc, cl, n, vb * ppb, b.steps, xf, M, scene, lds_topo, stk_node, stk_lb);
-        const float t = vb_reduce(acc, wsum);
+        float t;
+        if (b.score_only) {                                      // uniform: the final pass needs sums 27 and 28 only
+            vb_accumulate<Scene, kNN, kStack, true>(acc, cl, n, vb * ppb, b.steps, xf, M, scene, lds_topo, stk_node, stk_lb);
+            t = vb_reduce<true>(acc, wsum);
+        } else {
+            vb_accumulate<Scene, kNN, kStack>(acc, cl, n, vb * ppb, b.steps, xf, M, scene, lds_topo, stk_node, stk_lb);
+            t = vb_reduce(acc, wsum);
+        }
         float *slot = b.partial + ((size_t)pose * b.nblk + vb) * kAccStride;
         if (!b.fused) {
             if (threadIdx.x < 29) slot[threadIdx.x] = t;
