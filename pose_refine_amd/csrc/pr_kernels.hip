@@ -1239,6 +1239,9 @@ __device__ __forceinline__ void vb_accumulate(float (&acc_out)[29], float *cl, u
 
 // canonical tree, second half: wave (balanced pairwise over lanes) -> ((w0+w1)+w2)+w3.  Returns, in threads 0..28, the
 // workgroup sum of component threadIdx.x.  Contains one __syncthreads().
+#ifndef PR_TREE_PACKED
+#define PR_TREE_PACKED 1
+#endif
 template <bool kScoreOnly = false>
 __device__ __forceinline__ float vb_reduce(float (&acc)[29], float (*wsum)[kAccStride])
 {
@@ -1254,6 +1257,54 @@ __device__ __forceinline__ float vb_reduce(float (&acc)[29], float (*wsum)[kAccS
         if (lane == 63) wsum[wave][i] = t;
     }
 #else
+#if PR_TREE_PACKED
+    if constexpr (!kScoreOnly) {
+        // Same balanced pairwise tree, but after every level the live partial sums of two registers are interleaved into one
+        // (a level's results sit in the upper half of each 2^k-lane group; the lower half is free to carry another sum's
+        // results, fetched from its upper half with a row_shl).  29 -> 15 -> 8 -> 4 -> 2 registers, so levels 2..4 cost
+        // 15 + 8 + 4 adds instead of 3 x 29; the two cross-row levels run on the 2 remaining registers with ds_bpermute.
+        // Every sum still sees acc(lane) + acc(lane - d) at each level, i.e. bit-identical results.
+        // Final layout: sum j = 16 h + t ends in register h at lane 63 - t.
+        const bool b1 = (lane & 1u) != 0, b2 = (lane & 2u) != 0;
+        float p1[16], p2[8], p3[4], p4[2];
+#pragma unroll
+        for (int i = 0; i < 29; ++i) acc[i] += dpp_get<0x111, 0xf>(acc[i]);                   // row_shr:1, results in odd lanes
+#pragma unroll
+        for (int k = 0; k < 15; ++k) {
+            const float hi = acc[2 * k], lo = (2 * k + 1 < 29) ? dpp_get<0x101, 0xf>(acc[2 * k + 1 < 29 ? 2 * k + 1 : 28]) : 0.0f;   // row_shl:1
+            p1[k] = b1 ? hi : lo;
+        }
+        p1[15] = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 15; ++k) p1[k] += dpp_get<0x112, 0xf>(p1[k]);                     // row_shr:2
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const float lo = dpp_get<0x102, 0xf>(p1[2 * m + 1]);                               // row_shl:2
+            p2[m] = b2 ? p1[2 * m] : lo;
+        }
+#pragma unroll
+        for (int m = 0; m < 8; ++m) p2[m] += dpp_get<0x114, 0xf>(p2[m]);                      // row_shr:4
+#pragma unroll
+        for (int q = 0; q < 4; ++q)                                                            // lanes 0-3, 8-11 <- row_shl:4 of the odd register
+            p3[q] = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(p2[2 * q]), __float_as_int(p2[2 * q + 1]), 0x104, 0xf, 0x5, false));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) p3[q] += dpp_get<0x118, 0xf>(p3[q]);                      // row_shr:8
+#pragma unroll
+        for (int h = 0; h < 2; ++h)                                                            // lanes 0-7 <- row_shl:8 of the odd register
+            p4[h] = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(p3[2 * h]), __float_as_int(p3[2 * h + 1]), 0x108, 0xf, 0x3, false));
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            p4[h] += __int_as_float(__builtin_amdgcn_ds_bpermute((int)((lane - 16u) & 63u) << 2, __float_as_int(p4[h])));   // rows 1,3 += rows 0,2
+            p4[h] += __int_as_float(__builtin_amdgcn_ds_bpermute((int)((lane - 32u) & 63u) << 2, __float_as_int(p4[h])));   // row 3 += row 1
+        }
+        if (lane >= 48) {
+            const uint32_t t = 63u - lane;
+            wsum[wave][t] = p4[0];
+            if (16u + t < 29u) wsum[wave][16u + t] = p4[1];
+        }
+    } else
+#endif
+    {
     // level-major: the 29 sums advance through each tree level together, so consecutive DPP instructions are independent
     // (value-major order makes every instruction depend on the previous one and the compiler pads it with s_nop)
 #define PR_TREE_LEVEL(CTRL, MASK) _Pragma("unroll") for (int i = kFirst; i < 29; ++i) acc[i] += dpp_get<CTRL, MASK>(acc[i]);
@@ -1267,6 +1318,7 @@ __device__ __forceinline__ float vb_reduce(float (&acc)[29], float (*wsum)[kAccS
     if (lane == 63) {
 #pragma unroll
         for (int i = 0; i < 29; ++i) wsum[wave][i] = acc[i];
+    }
     }
 #endif
 #endif
