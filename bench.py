@@ -50,6 +50,9 @@ def main():
     ap.add_argument("--solve", choices=["host", "device"], default=os.environ.get("PR_BENCH_SOLVE", "device"))
     ap.add_argument("--pose-groups", type=int, default=2, help="streams the device-solve loop is split over (library default 2)")
     ap.add_argument("--fused-solve", type=int, default=1, help="1: finalize+solve in the tail of the pass kernel (library default)")
+    ap.add_argument("--sequential", action="store_true",
+                    help="every step through the synchronous single-group path with HIP events around EVERY correspondence launch "
+                         "(profile 1): the mode in which rocprofv3's per-launch average and the event average measure the same thing")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-poses", type=int, default=0, help="CPU baseline sample size (0 = auto)")
     args = ap.parse_args()
@@ -136,7 +139,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    api.set_option("profile", 2)          # HIP events around ONE correspondence launch per step (rotating iteration)
+    api.set_option("profile", 1 if args.sequential else 2)   # 2: HIP events around ONE launch of one step in 16 (rotating iteration)
     api.profile_reset()
     fence()
     t0 = time.perf_counter()
@@ -187,8 +190,9 @@ def main():
                          "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/r01/README.md",
                          "avg_launch_us": avg_launch_s * 1e6, "launches": int(launches),
                          "algorithmic_bytes_per_launch": bytes_per_launch, "points_per_launch": pts_per_launch,
-                         "timing": "HIP events on the library stream around one launch every 16th step, rotating over the 21 passes; "
-                                   "a timed step runs synchronously as one pose group (other slot drained) so the launch has the chip to itself"},
+                         "timing": ("HIP events on the library stream around every launch (--sequential: synchronous single-group steps)" if args.sequential else
+                                    "HIP events on the library stream around one launch every 16th step, rotating over the 21 passes; "
+                                    "a timed step runs synchronously as one pose group (other slot drained) so the launch has the chip to itself")},
             "phase_ms_per_timed_step": {"render": prof["render_ms"] / launches, "cloud": prof["cloud_ms"] / launches},
         }
         if world == 1 and not args.no_cpu_baseline:
