@@ -87,6 +87,7 @@ struct Ctx {
     int profile = 0;
     int nn_lds_nodes = 1024;
     int nn_lds_records = 0;          // stack traversal: leading 64-byte node records staged in LDS; measured 0/64/128/256/512 -> 42.2/41.6/45.2/45.4/58.2 ms per step (occupancy lost to the extra LDS outweighs the saved L1 lookups)
+    int nn_compact = 1;              // stack traversal: 32-byte node records with 16-bit outward-rounded child boxes (half the L1 traffic)
     int nn_stack = 1;                // kd-tree query: per-lane LDS stack (1) or the reference's stackless walk (0)
     int sub_batch = 512;             // asynchronous fused path: hypotheses per sub-batch (cache residency of the clouds)
     int fused_solve = 1;             // PR_SOLVE_DEVICE: the workgroup delivering a hypothesis' last partial sum also runs its finalize + solve (no second launch per iteration)
@@ -101,7 +102,7 @@ struct Ctx {
     const void *mesh_key = nullptr; size_t mesh_n = 0;   // triangle buffer aabb_host belongs to
     uint32_t cloud_hint = 0;          // largest cloud of the latest finished asynchronous batch: sizes the next batch's grid
     // workspaces
-    DevBuf aabb, bbox, poses, depth, row_count, row_off, counts, cloud, meta, partial, sums, rec, topo, bmin, bmax, pts, nnrec, nndepth, dstate, dresults, vbdesc, flowsync, arrive, conv16, conv8, kd_idx, kd_scratch, kd_child, kd_ctrl, kd_tmp, nn_full;
+    DevBuf aabb, bbox, poses, depth, row_count, row_off, counts, cloud, meta, partial, sums, rec, topo, bmin, bmax, pts, nnrec, nnrec32, nndepth, dstate, dresults, vbdesc, flowsync, arrive, conv16, conv8, kd_idx, kd_scratch, kd_child, kd_ctrl, kd_tmp, nn_full;
     PinBuf h_sums, h_meta, h_counts, h_results, h_dstate, h_flow;
     // profiling
     std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
@@ -114,11 +115,10 @@ std::mutex g_mu;
 constexpr uint64_t kSamplePeriod = 16;     // profile 2: one timed (synchronous, single-group) call in this many
 
 // ---- hipGraph cache for the device-solve iteration loop ------------------------------------------
-struct GraphKey {
-    unsigned char bytes[256];
-    size_t len = 0;
-    template <class T> void add(const T &v) { if (len + sizeof(T) <= sizeof bytes) { std::memcpy(bytes + len, &v, sizeof(T)); len += sizeof(T); } }
-    bool operator==(const GraphKey &o) const { return len == o.len && std::memcmp(bytes, o.bytes, len) == 0; }
+struct GraphKey {                    // every value a captured launch depends on, byte for byte (grows as needed)
+    std::vector<unsigned char> bytes;
+    template <class T> void add(const T &v) { const unsigned char *p = reinterpret_cast<const unsigned char *>(&v); bytes.insert(bytes.end(), p, p + sizeof(T)); }
+    bool operator==(const GraphKey &o) const { return bytes == o.bytes; }
 };
 struct CachedGraph {
     GraphKey key; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
@@ -229,12 +229,15 @@ int make_scene(int kind, const void *scene, bool want_packed, SceneSel &out, Dev
         PR_TRY(g.bmax.ensure((size_t)s->n_nodes * sizeof(float4)));
         PR_TRY(g.pts.ensure((size_t)s->n_points * sizeof(float4)));
         PR_TRY(g.nnrec.ensure((size_t)s->n_nodes * 4 * sizeof(float4)));
-        PR_TRY(g.nndepth.ensure(sizeof(uint32_t)));
+        PR_TRY(g.nndepth.ensure(8 * sizeof(uint32_t)));
+        PR_TRY(g.nnrec32.ensure((size_t)s->n_nodes * 2 * sizeof(uint4)));
         HIP_TRY(prk::launch_build_nn_accel(s->nodes, s->n_nodes, s->pcd, s->n_points, g.topo.as<int4>(), g.bmin.as<float4>(),
-                                           g.bmax.as<float4>(), g.pts.as<float4>(), g.nnrec.as<float4>(), g.nndepth.as<uint32_t>(), g.stream));
-        uint32_t depth = 0;
-        HIP_TRY(hipMemcpyAsync(&depth, g.nndepth.p, sizeof depth, hipMemcpyDeviceToHost, g.stream));
+                                           g.bmax.as<float4>(), g.pts.as<float4>(), g.nnrec.as<float4>(), g.nnrec32.as<uint4>(),
+                                           g.nndepth.as<uint32_t>(), g.stream));
+        uint32_t info[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+        HIP_TRY(hipMemcpyAsync(info, g.nndepth.p, sizeof info, hipMemcpyDeviceToHost, g.stream));
         HIP_TRY(hipStreamSynchronize(g.stream));
+        const uint32_t depth = info[0];
         uint32_t lds = (uint32_t)std::max(0, g.nn_lds_nodes);
         lds = std::min(lds, s->n_nodes);
         lds = std::min<uint32_t>(lds, 8192);                      // <= 128 KiB of LDS
@@ -243,7 +246,11 @@ int make_scene(int kind, const void *scene, bool want_packed, SceneSel &out, Dev
         if (g.nn_stack) stack = (depth <= 16) ? 16u : ((depth <= 24) ? 24u : 0u);
         if (stack) lds = std::min<uint32_t>({ (uint32_t)std::max(0, g.nn_lds_records), s->n_nodes, (65536u - stack * 2048u) / 64u });   // stacks + records <= 64 KiB
         out.nn = prk::SceneNNDev{ s->max_dist_diff, g.topo.as<int4>(), g.bmin.as<float4>(), g.bmax.as<float4>(), g.pts.as<float4>(),
-                                  s->pcd, s->normal, s->n_nodes, lds, g.nnrec.as<float4>(), stack };
+                                  s->pcd, s->normal, s->n_nodes, lds, g.nnrec.as<float4>(), stack, nullptr, { 0, 0, 0 }, { 0, 0, 0 } };
+        if (stack && g.nn_compact && info[1] == 1u) {
+            out.nn.rec32 = g.nnrec32.as<uint4>();
+            for (int a = 0; a < 3; ++a) { std::memcpy(&out.nn.qmin[a], &info[2 + a], 4); std::memcpy(&out.nn.qscale[a], &info[5 + a], 4); }
+        }
         return PR_OK;
     }
     set_error("unknown scene kind %d", kind);
@@ -924,7 +931,7 @@ int pr_shutdown(void)
     hipStreamSynchronize(g.stream);
     for (Slot &sl : g_slots) slot_release(sl);
     for (DevBuf *b : { &g.aabb, &g.bbox, &g.poses, &g.depth, &g.row_count, &g.row_off, &g.counts, &g.cloud, &g.meta, &g.partial,
-                       &g.sums, &g.rec, &g.topo, &g.bmin, &g.bmax, &g.pts, &g.nnrec, &g.nndepth, &g.dstate, &g.dresults, &g.vbdesc, &g.flowsync, &g.arrive, &g.conv16, &g.conv8, &g.kd_idx, &g.kd_scratch, &g.kd_child, &g.kd_ctrl, &g.kd_tmp, &g.nn_full }) b->release();
+                       &g.sums, &g.rec, &g.topo, &g.bmin, &g.bmax, &g.pts, &g.nnrec, &g.nnrec32, &g.nndepth, &g.dstate, &g.dresults, &g.vbdesc, &g.flowsync, &g.arrive, &g.conv16, &g.conv8, &g.kd_idx, &g.kd_scratch, &g.kd_child, &g.kd_ctrl, &g.kd_tmp, &g.nn_full }) b->release();
     for (PinBuf *b : { &g.h_sums, &g.h_meta, &g.h_counts, &g.h_results, &g.h_dstate, &g.h_flow }) b->release();
     drop_graphs();
     for (hipEvent_t e : g.ev_pool) hipEventDestroy(e);
@@ -1162,6 +1169,7 @@ int pr_set_option(const char *name, int value)
     else if (n == "profile") { if (value < 0 || value > 2) { set_error("profile must be 0, 1 (every launch) or 2 (one sampled launch per call)"); return PR_ERR_INVALID; } g.profile = value; }
     else if (n == "nn_lds_nodes") g.nn_lds_nodes = std::max(0, value);
     else if (n == "nn_lds_records") g.nn_lds_records = std::max(0, value);
+    else if (n == "nn_compact") g.nn_compact = value ? 1 : 0;
     else if (n == "nn_stack") g.nn_stack = value ? 1 : 0;
     else if (n == "graph") g.use_graph = value ? 1 : 0;
     else if (n == "icp_flow") g.icp_flow = value ? 1 : 0;
@@ -1182,6 +1190,7 @@ int pr_get_option(const char *name, int *value)
     else if (n == "profile") *value = g.profile;
     else if (n == "nn_lds_nodes") *value = g.nn_lds_nodes;
     else if (n == "nn_lds_records") *value = g.nn_lds_records;
+    else if (n == "nn_compact") *value = g.nn_compact;
     else if (n == "nn_stack") *value = g.nn_stack;
     else if (n == "raster_mode") *value = g.raster_mode;
     else if (n == "graph") *value = g.use_graph;

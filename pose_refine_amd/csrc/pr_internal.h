@@ -73,6 +73,10 @@ struct SceneNNDev {
     uint32_t lds_nodes;         // how many leading (top-level) nodes the kernel stages in LDS (stackless: 16-byte topo entries; stack: 64-byte records)
     const float4 *rec;          // stack variant: 64-byte record per node (4 x float4), see nn_records_kernel
     uint32_t stack_depth;       // 0 = stackless traversal, else per-lane LDS stack entries (>= tree depth)
+    // stack variant, compact form: 32-byte record per node (see nn_records32_kernel) with the two child boxes quantised to
+    // 16 bits in the frame of the root box, rounded outwards; null when the tree cannot be expressed that way
+    const uint4 *rec32;
+    float qmin[3], qscale[3];   // dequantisation: qmin[a] + (float)q * qscale[a]
 };
 
 // device-side solver state for PR_SOLVE_DEVICE (one record per hypothesis)
@@ -154,8 +158,9 @@ hipError_t launch_scene_proj_prepare(const T *depth, uint32_t W, uint32_t H, flo
 hipError_t launch_raw2depth_mask(const int32_t *raw, size_t n, uint16_t *depth16, uint8_t *mask8, hipStream_t s);
 hipError_t launch_pack_proj_scene(const pr_vec3 *pcd, const pr_vec3 *normal, float4 *rec, size_t n, float *colf, float *rowf,
                                   uint32_t width, uint32_t height, float fx, float fy, float cx, float cy, hipStream_t s);
+// info[0] = tree depth, info[1] = 1 when the 32-byte records are valid, info[2..7] = qmin[3], qscale[3] (float bits)
 hipError_t launch_build_nn_accel(const pr_kdnode *nodes, uint32_t n_nodes, const pr_vec3 *pcd, uint32_t n_points,
-                                 int4 *topo, float4 *bmin, float4 *bmax, float4 *pts, float4 *rec, uint32_t *max_depth, hipStream_t s);
+                                 int4 *topo, float4 *bmin, float4 *bmax, float4 *pts, float4 *rec, uint4 *rec32, uint32_t *info, hipStream_t s);
 
 }  // namespace prk
 

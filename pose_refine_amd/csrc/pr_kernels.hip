@@ -715,6 +715,8 @@ __device__ __forceinline__ bool gather_finish(const SceneNNDev &, bool, float, c
 // the current node's box.  That prunes a superset of what the reference prunes and can only skip
 // subtrees whose every point is farther than the current best, so winner and distance are
 // identical (DESIGN.md "kd-tree bound").
+// dequantisation of a compact-record box coordinate (nn_records32_kernel): one multiply, one add
+__device__ __forceinline__ float nn_deq(uint32_t q, float qmin, float qscale) { return qmin + (float)q * qscale; }
 __device__ __forceinline__ float box_dist_sq(float sx, float sy, float sz, const float4 lo, const float4 hi)
 {
     float lb = 0;
@@ -777,9 +779,12 @@ constexpr int kLeafBatch = PR_LEAF_BATCH;
 #define PR_NN_BOUNDED 1
 #endif
 
-template <int kDepth>
+// kCode = stack entries per lane (16 / 24), + 0x100 when the scene's compact 32-byte records are used
+template <int kCode>
 __device__ __forceinline__ bool query_nn_stack(const SceneNNDev &s, const float4 *lds_rec, int *stk_node, float *stk_lb, float sx, float sy, float sz, Corr &c)
 {
+    constexpr int kDepth = kCode & 0xff;
+    constexpr bool kCompact = (kCode & 0x100) != 0;
     int cur = 0, sp = 0, best_i = 0;
 #if PR_NN_BOUNDED
     // a winner is only accepted below max_dist_diff^2 (pcd_scene.h query tail), so the search can start from that bound:
@@ -790,9 +795,30 @@ __device__ __forceinline__ bool query_nn_stack(const SceneNNDev &s, const float4
     float best = FLT_MAX;
 #endif
     for (;;) {
-        // the leading (top-level) records are staged in LDS: the kernel is bound by the texture-addresser / L1 tag rate
-        // (one cache-line lookup per lane per 16-byte load), which LDS reads do not touch
         float4 h, b0, b1, b2;
+        if constexpr (kCompact) {
+            // compact records: half the bytes through the L1 (the kernel is bound by the texture-addresser / L1 rate of its
+            // divergent loads, not by latency or HBM); only the far child's box is decoded
+            const uint4 A = s.rec32[(size_t)cur * 2], B = s.rec32[(size_t)cur * 2 + 1];
+            const uint32_t tag = A.y >> 30;
+            if (tag == 3u) { h = make_float4(__uint_as_float(A.x), __uint_as_float(A.y & 0x3fffffffu), __int_as_float(-1), 0.0f); b0 = b1 = b2 = h; }
+            else {
+                const float q = (tag == 0u) ? sx : ((tag == 1u) ? sy : sz);
+                const bool left_near = (q - __uint_as_float(A.x)) < 0;
+                const uint32_t c1 = A.y & 0x3fffffffu;
+                const uint32_t u0 = left_near ? B.y : A.z, u1 = left_near ? B.z : A.w, u2 = left_near ? B.w : B.x;
+                const float4 lo = make_float4(nn_deq(u0 & 0xffffu, s.qmin[0], s.qscale[0]), nn_deq(u0 >> 16, s.qmin[1], s.qscale[1]),
+                                              nn_deq(u1 & 0xffffu, s.qmin[2], s.qscale[2]), 0.0f);
+                const float4 hi = make_float4(nn_deq(u1 >> 16, s.qmin[0], s.qscale[0]), nn_deq(u2 & 0xffffu, s.qmin[1], s.qscale[1]),
+                                              nn_deq(u2 >> 16, s.qmin[2], s.qscale[2]), 0.0f);
+                const float lb = box_dist_sq(sx, sy, sz, lo, hi);
+                const int near_c = (int)(left_near ? c1 : c1 + 1u), far_c = (int)(left_near ? c1 + 1u : c1);
+                if (lb <= best && sp < kDepth) { stk_node[sp * kBlockThreads] = far_c; stk_lb[sp * kBlockThreads] = lb; ++sp; }
+                cur = near_c;
+                continue;
+            }
+        } else
+        // 64-byte records; the leading (top-level) ones may be staged in LDS
         if ((uint32_t)cur < s.lds_nodes) {
             const float4 *q = lds_rec + (size_t)cur * 4;
             h = q[0]; b0 = q[1]; b1 = q[2]; b2 = q[3];
@@ -1356,9 +1382,9 @@ __global__ __launch_bounds__(256, PR_PASS_WAVES) void icp_pass_kernel(IcpBatch b
     }
     if constexpr (kNN && kStack > 0) {                           // per-lane stacks: [entry][lane], then the staged records
         stk_node = reinterpret_cast<int *>(lds_raw) + threadIdx.x;
-        stk_lb = reinterpret_cast<float *>(lds_raw) + (size_t)kStack * kBlockThreads + threadIdx.x;
-        float4 *recs = reinterpret_cast<float4 *>(lds_raw + (size_t)kStack * kBlockThreads * 8);
-        for (uint32_t i = threadIdx.x; i < scene.lds_nodes * 4; i += kBlockThreads) recs[i] = scene.rec[i];
+        stk_lb = reinterpret_cast<float *>(lds_raw) + (size_t)(kStack & 0xff) * kBlockThreads + threadIdx.x;
+        float4 *recs = reinterpret_cast<float4 *>(lds_raw + (size_t)(kStack & 0xff) * kBlockThreads * 8);
+        if constexpr ((kStack & 0x100) == 0) for (uint32_t i = threadIdx.x; i < scene.lds_nodes * 4; i += kBlockThreads) recs[i] = scene.rec[i];
         __syncthreads();
         lds_topo = reinterpret_cast<const int4 *>(recs);
     }
@@ -1567,9 +1593,9 @@ __global__ __launch_bounds__(256, 5) void icp_flow_kernel(FlowArgs a, Scene scen
     }
     if constexpr (kNN && kStack > 0) {
         stk_node = reinterpret_cast<int *>(lds_raw) + threadIdx.x;
-        stk_lb = reinterpret_cast<float *>(lds_raw) + (size_t)kStack * kBlockThreads + threadIdx.x;
-        float4 *recs = reinterpret_cast<float4 *>(lds_raw + (size_t)kStack * kBlockThreads * 8);
-        for (uint32_t i = threadIdx.x; i < scene.lds_nodes * 4; i += kBlockThreads) recs[i] = scene.rec[i];
+        stk_lb = reinterpret_cast<float *>(lds_raw) + (size_t)(kStack & 0xff) * kBlockThreads + threadIdx.x;
+        float4 *recs = reinterpret_cast<float4 *>(lds_raw + (size_t)(kStack & 0xff) * kBlockThreads * 8);
+        if constexpr ((kStack & 0x100) == 0) for (uint32_t i = threadIdx.x; i < scene.lds_nodes * 4; i += kBlockThreads) recs[i] = scene.rec[i];
         __syncthreads();
         lds_topo = reinterpret_cast<const int4 *>(recs);
     }
@@ -1986,6 +2012,63 @@ __global__ __launch_bounds__(256) void nn_records_kernel(const int4 *__restrict_
     atomicMax(max_depth, depth);
 }
 
+// Compact traversal records: 32 bytes per node.
+//   word 0: split value (internal) | first point (leaf)
+//   word 1: child1 | dim << 30 (internal; child2 = child1 + 1, as KDTree_cpu::build_tree appends children pairwise) | end point | 3 << 30 (leaf)
+//   words 2..7: the boxes of child1 and child2 as 12 uint16 {lo.x lo.y lo.z hi.x hi.y hi.z} x 2, quantised in the frame of
+//   the root box and rounded OUTWARDS (checked with the very dequantisation arithmetic the query uses).  A looser box can
+//   only make the search visit a subtree it could have skipped -- a subtree whose every point is farther than the current
+//   best -- so winners, distances and tie-breaks are those of the exact boxes.
+__global__ void nn_frame_kernel(const float4 *__restrict__ bmin, const float4 *__restrict__ bmax, uint32_t *__restrict__ info)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const float lo[3] = { bmin[0].x, bmin[0].y, bmin[0].z }, hi[3] = { bmax[0].x, bmax[0].y, bmax[0].z };
+    for (int a = 0; a < 3; ++a) {
+        float sc = (hi[a] - lo[a]) / 65535.0f * 1.000001f;
+        if (!(sc > 1e-30f)) sc = 1e-30f;
+        info[2 + a] = __float_as_uint(lo[a]);
+        info[5 + a] = __float_as_uint(sc);
+    }
+    info[1] = 1u;
+}
+__global__ __launch_bounds__(256) void nn_records32_kernel(const int4 *__restrict__ topo, const float4 *__restrict__ bmin,
+                                                           const float4 *__restrict__ bmax, uint32_t n_nodes, uint4 *__restrict__ rec32,
+                                                           uint32_t *__restrict__ info)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_nodes) return;
+    const int4 t = topo[i];
+    uint32_t w[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    bool ok = true;
+    if (t.z < 0) { w[0] = (uint32_t)t.x; w[1] = (uint32_t)t.y | (3u << 30); ok = ((uint32_t)t.y < (1u << 30)); }
+    else {
+        const uint32_t dim = (uint32_t)t.w >> 30;
+        w[0] = (uint32_t)t.x; w[1] = (uint32_t)t.y | (dim << 30);
+        ok = (t.z == t.y + 1) && ((uint32_t)t.y < (1u << 30)) && dim < 3;
+        uint32_t q[12];
+        for (int c = 0; c < 2; ++c) {
+            const int ch = c ? t.z : t.y;
+            const float lo[3] = { bmin[ch].x, bmin[ch].y, bmin[ch].z }, hi[3] = { bmax[ch].x, bmax[ch].y, bmax[ch].z };
+            for (int a = 0; a < 3; ++a) {
+                const float qmin = __uint_as_float(info[2 + a]), qs = __uint_as_float(info[5 + a]);
+                float fl = floorf((lo[a] - qmin) / qs) - 1.0f;
+                uint32_t ql = fl > 0.0f ? (fl < 65535.0f ? (uint32_t)fl : 65535u) : 0u;
+                while (ql > 0 && !(nn_deq(ql, qmin, qs) <= lo[a])) --ql;
+                if (!(nn_deq(ql, qmin, qs) <= lo[a])) ok = false;
+                float fh = ceilf((hi[a] - qmin) / qs) + 1.0f;
+                uint32_t qh = fh > 0.0f ? (fh < 65535.0f ? (uint32_t)fh : 65535u) : 0u;
+                while (qh < 65535u && !(nn_deq(qh, qmin, qs) >= hi[a])) ++qh;
+                if (!(nn_deq(qh, qmin, qs) >= hi[a])) ok = false;
+                q[c * 6 + a] = ql; q[c * 6 + 3 + a] = qh;
+            }
+        }
+        for (int k = 0; k < 6; ++k) w[2 + k] = q[2 * k] | (q[2 * k + 1] << 16);
+    }
+    rec32[(size_t)i * 2] = make_uint4(w[0], w[1], w[2], w[3]);
+    rec32[(size_t)i * 2 + 1] = make_uint4(w[4], w[5], w[6], w[7]);
+    if (!ok) info[1] = 0u;                                       // any node that does not fit: the 64-byte records are used instead
+}
+
 // ================================================================================================
 //  launchers
 // ================================================================================================
@@ -2143,6 +2226,8 @@ hipError_t launch_icp_pass_proj_packed(const IcpBatch &b, const SceneProjPacked 
 { return launch_pass<SceneProjPacked, false>(b, sc, n_poses, 0, s); }
 hipError_t launch_icp_pass_nn(const IcpBatch &b, const SceneNNDev &sc, uint32_t n_poses, hipStream_t s)
 {
+    if (sc.stack_depth == 16 && sc.rec32) return launch_pass<SceneNNDev, true, 16 + 0x100>(b, sc, n_poses, (size_t)16 * kBlockThreads * 8, s);
+    if (sc.stack_depth == 24 && sc.rec32) return launch_pass<SceneNNDev, true, 24 + 0x100>(b, sc, n_poses, (size_t)24 * kBlockThreads * 8, s);
     if (sc.stack_depth == 16) return launch_pass<SceneNNDev, true, 16>(b, sc, n_poses, (size_t)16 * kBlockThreads * 8 + (size_t)sc.lds_nodes * 64, s);
     if (sc.stack_depth == 24) return launch_pass<SceneNNDev, true, 24>(b, sc, n_poses, (size_t)24 * kBlockThreads * 8 + (size_t)sc.lds_nodes * 64, s);
     return launch_pass<SceneNNDev, true, 0>(b, sc, n_poses, (size_t)sc.lds_nodes * sizeof(int4), s);
@@ -2273,14 +2358,16 @@ hipError_t launch_pack_proj_scene(const pr_vec3 *pcd, const pr_vec3 *normal, flo
     return hipGetLastError();
 }
 hipError_t launch_build_nn_accel(const pr_kdnode *nodes, uint32_t n_nodes, const pr_vec3 *pcd, uint32_t n_points,
-                                 int4 *topo, float4 *bmin, float4 *bmax, float4 *pts, float4 *rec, uint32_t *max_depth, hipStream_t s)
+                                 int4 *topo, float4 *bmin, float4 *bmax, float4 *pts, float4 *rec, uint4 *rec32, uint32_t *info, hipStream_t s)
 {
     const uint32_t m = (n_nodes > n_points) ? n_nodes : n_points;
     if (m == 0) return hipSuccess;
     hipLaunchKernelGGL(nn_accel_kernel, dim3((m + 255) / 256), dim3(256), 0, s, nodes, n_nodes, pcd, n_points, topo, bmin, bmax, pts);
-    hipError_t e = hipMemsetAsync(max_depth, 0, sizeof(uint32_t), s);
+    hipError_t e = hipMemsetAsync(info, 0, 8 * sizeof(uint32_t), s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(nn_records_kernel, dim3((n_nodes + 255) / 256), dim3(256), 0, s, topo, bmin, bmax, n_nodes, rec, max_depth);
+    hipLaunchKernelGGL(nn_records_kernel, dim3((n_nodes + 255) / 256), dim3(256), 0, s, topo, bmin, bmax, n_nodes, rec, info);
+    hipLaunchKernelGGL(nn_frame_kernel, dim3(1), dim3(64), 0, s, bmin, bmax, info);
+    hipLaunchKernelGGL(nn_records32_kernel, dim3((n_nodes + 255) / 256), dim3(256), 0, s, topo, bmin, bmax, n_nodes, rec32, info);
     return hipGetLastError();
 }
 

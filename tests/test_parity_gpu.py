@@ -240,7 +240,7 @@ def test_no_device_option_errors(gpu):
 
 
 def test_fused_raster_modes_agree(gpu, model, scenario, gscenes):
-    """LDS-band raster (default) vs the reference-style global atomicMin raster inside the fused path:
+    """LDS-band raster (raster_mode=1) vs the reference-style global atomicMin raster (default) inside the fused path:
     identical cloud sizes and bit-identical results; includes a close-up pose whose pixel box needs
     several LDS bands and a pose partly outside the image."""
     poses = synth.hypotheses(12)
@@ -253,7 +253,7 @@ def test_fused_raster_modes_agree(gpu, model, scenario, gscenes):
     for mode in (1, 0):
         api.set_option("raster_mode", mode)
         out.append(api.refine_batch(model, poses, W, H, scenario["proj"], scenario["K"], gscenes["proj"], crit))
-    api.set_option("raster_mode", 1)
+    api.set_option("raster_mode", 0)                             # library default
     assert np.array_equal(out[0][1], out[1][1])
     assert out[0][0].tobytes() == out[1][0].tobytes()
     ref = O.render(scenario["tris"], poses[-3:], W, H, scenario["proj"])
@@ -261,17 +261,21 @@ def test_fused_raster_modes_agree(gpu, model, scenario, gscenes):
 
 
 def test_nn_stack_and_stackless_traversals_agree(gpu, scenario, gscenes):
-    """The per-lane-stack kd query (default) and the reference-style stackless walk give bit-identical ICP
-    results (same winners, same tie-breaks) -- 21 passes on the test.cpp cloud."""
+    """The per-lane-stack kd query with compact 32-byte node records (default: child boxes quantised to 16 bits, rounded
+    outwards), the same with exact 64-byte records, and the reference-style stackless walk give bit-identical ICP results
+    (same winners, same tie-breaks) -- 21 passes on the test.cpp cloud, whose first passes start centimetres off the surface."""
     out = []
-    for mode in (1, 0):
-        api.set_option("nn_stack", mode)
+    for stack, compact in ((1, 1), (1, 0), (0, 0)):
+        api.set_option("nn_stack", stack)
+        api.set_option("nn_compact", compact)
         dev = api.DeviceVector.from_host(scenario["cloud"].reshape(-1))
         r = api.ICP_Point2Plane(dev, gscenes["nn"], api.ICPConvergenceCriteria(0.0, 0.0, 20))
         out.append((r.transformation_.copy(), r.fitness_, r.inlier_rmse_, dev.to_host()))
     api.set_option("nn_stack", 1)
-    assert np.array_equal(out[0][0], out[1][0]) and out[0][1] == out[1][1] and out[0][2] == out[1][2]
-    assert np.array_equal(out[0][3], out[1][3])
+    api.set_option("nn_compact", 1)
+    for o in out[1:]:
+        assert np.array_equal(out[0][0], o[0]) and out[0][1] == o[1] and out[0][2] == o[2]
+        assert np.array_equal(out[0][3], o[3])
 
 
 @pytest.mark.parametrize("kind,P", [("proj", 70), ("nn", 5)])
@@ -294,8 +298,8 @@ def test_dataflow_and_multilaunch_icp_agree_bitwise(gpu, model, scenario, gscene
         api.set_option("solve", api.SOLVE_HOST)
 
 
-@pytest.mark.parametrize("P", [5, 96])
-def test_async_slots_match_synchronous_path_bitwise(gpu, model, scenario, gscenes, P):
+@pytest.mark.parametrize("P,raster_mode", [(5, 0), (96, 0), (5, 1)])
+def test_async_slots_match_synchronous_path_bitwise(gpu, model, scenario, gscenes, P, raster_mode):
     """pr_refine_submit / pr_refine_wait (host-computed pixel boxes, device-side start state, no mid-step read-back, two batches
     in flight) against the synchronous path (profile=1 forces it): records and cloud sizes must be bit-identical, with fixed
     and with early-exit criteria, for host and device result buffers, with an empty-cloud hypothesis in the batch."""
@@ -304,6 +308,7 @@ def test_async_slots_match_synchronous_path_bitwise(gpu, model, scenario, gscene
     poses_b[1] = poses_b[1].copy()
     poses_b[1].reshape(4, 4)[0, 3] += 1.0e6                      # a kilometre to the side: off-screen -> empty cloud -> identity result
     api.set_option("solve", api.SOLVE_DEVICE)
+    api.set_option("raster_mode", raster_mode)                   # 1: not covered by the asynchronous path -> submit runs synchronously (replayed graphs)
     api.set_option("sub_batch", 40)                              # P=96 runs as three sub-batches of 32 that reuse the same workspace
     try:
         for crit in ((0.0, 0.0, 20), (1e-5, 1e-5, 30)):
@@ -332,6 +337,7 @@ def test_async_slots_match_synchronous_path_bitwise(gpu, model, scenario, gscene
             api.refine_wait(0)                                   # nothing pending
     finally:
         api.set_option("profile", 0)
+        api.set_option("raster_mode", 0)
         api.set_option("sub_batch", 512)
         api.set_option("solve", api.SOLVE_HOST)
 
