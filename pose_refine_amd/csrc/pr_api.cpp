@@ -498,10 +498,18 @@ int icp_drive(pr_vec3 *cloud_base, const uint32_t *start_h, const uint32_t *coun
     return PR_OK;
 }
 
+// the raster packs pixel coordinates into 13 bits each and enumerates a triangle's candidate pixels with 24-bit arithmetic
+bool frame_size_ok(size_t W, size_t H)
+{
+    if (W > 8192 || H > 8192 || W * H > ((size_t)1 << 24)) { set_error("frames larger than 8192 on a side or 2^24 pixels are not supported (got %zux%zu)", W, H); return false; }
+    return true;
+}
+
 int render_impl(const pr_triangle *tris_dev, size_t n_tris, const pr_mat4 *poses_host, size_t P, size_t W, size_t H,
                 const pr_mat4 *proj, pr_roi roi, int32_t *depth_dev, bool zero_empty)
 {
     if (!tris_dev || !poses_host || !proj || !depth_dev || W == 0 || H == 0) { set_error("pr_render: bad arguments"); return PR_ERR_INVALID; }
+    if (!frame_size_ok(W, H)) return PR_ERR_INVALID;
     size_t rw = W, rh = H;
     if (roi.width > 0 && roi.height > 0) {
         if (roi.x < 0 || roi.y < 0 || (size_t)(roi.x + roi.width) > W || (size_t)(roi.y + roi.height) > H) {
@@ -552,6 +560,7 @@ int refine_impl(const pr_triangle *tris_dev, size_t n_tris, const pr_mat4 *poses
                 pr_result *results_host, pr_result *results_dev, uint32_t *sizes_host)
 {
     if (!K || W == 0 || H == 0) { set_error("pr_refine_batch: bad arguments"); return PR_ERR_INVALID; }
+    if (!frame_size_ok(W, H)) return PR_ERR_INVALID;
     if (P == 0) return PR_OK;
     SceneSel sc;
     std::memset(static_cast<void *>(&sc), 0, sizeof sc);           // also zeroes padding: sc is part of the graph-cache key
@@ -731,6 +740,7 @@ int refine_submit(int slot, const pr_triangle *tris_dev, size_t n_tris, const pr
     if (sl.pending) { set_error("pr_refine_submit: slot %d still holds an unfinished batch (call pr_refine_wait)", slot); return PR_ERR_INVALID; }
     if (!tris_dev || !poses_host || !proj || !K || W == 0 || H == 0 || (!results_host && !results_dev)) { set_error("pr_refine_submit: bad arguments"); return PR_ERR_INVALID; }
     if (crit.max_iteration < 0) { set_error("max_iteration must be >= 0"); return PR_ERR_INVALID; }
+    if (!frame_size_ok(W, H)) return PR_ERR_INVALID;
     sl.P = P; sl.user_results_host = results_host; sl.user_sizes = sizes_host; sl.delivered = false;
     const size_t img = (size_t)W * H;
     const bool sample_call = (g.profile == 2) && (g.sample_clock % kSamplePeriod == 0);

@@ -140,7 +140,7 @@ __device__ __forceinline__ int fragment_depth(float alpha, float beta, float gam
 // pixels (exclusive scan of the per-triangle trip counts) and walks that list 64 candidates at a
 // time: every lane finds the owner of its candidate by a 6-step search over the scanned offsets and
 // reads the owner's setup back from LDS.  Same arithmetic per candidate, same int32 atomicMin.
-constexpr int kSetupWords = 14;
+constexpr int kSetupWords = 15;
 __global__ __launch_bounds__(256) void raster_kernel(const pr_triangle *__restrict__ tris, uint32_t n_tris,
                                                      const pr_mat4 *__restrict__ poses, int32_t *__restrict__ depth,
                                                      uint32_t width, uint32_t height, pr_mat4 proj, pr_roi roi,
@@ -181,6 +181,7 @@ __global__ __launch_bounds__(256) void raster_kernel(const pr_triangle *__restri
     w[6][lane] = t.w3[0]; w[7][lane] = t.w3[1]; w[8][lane] = t.w3[2]; w[9][lane] = t.base_inv;
     w[10][lane] = __int_as_float(t.x0); w[11][lane] = __int_as_float(t.y0); w[12][lane] = __int_as_float(t.nx > 0 ? t.nx : 1);
     w[13][lane] = __int_as_float(excl);
+    w[14][lane] = __builtin_amdgcn_rcpf((float)(t.nx > 0 ? t.nx : 1));
     // the four wavefronts only touch their own slice; a wave-level fence is enough for LDS ordering
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -213,10 +214,12 @@ __global__ __launch_bounds__(256) void raster_kernel(const pr_triangle *__restri
             for (int s = 32; s > 0; s >>= 1) { if (__float_as_int(w[13][o + s]) <= c) o += s; }
             const int k = c - __float_as_int(w[13][o]);
             const int nx = __float_as_int(w[12][o]);
-            int q = (int)((float)k * __builtin_amdgcn_rcpf((float)nx));      // k / nx with a one-step correction
-            if (q * nx > k) --q;
-            if ((q + 1) * nx <= k) ++q;
-            const int x = __float_as_int(w[10][o]) + (k - q * nx);
+            // k / nx from the owner's reciprocal with a one-step correction; k, nx, q*nx < 2^24 (a frame has < 2^24 pixels),
+            // so the 24-bit multiplier (full rate, v_mul_lo_u32 is quarter rate) is exact
+            int q = (int)((float)k * w[14][o]);
+            if ((int)__umul24((unsigned)q, (unsigned)nx) > k) --q;
+            if ((int)__umul24((unsigned)(q + 1), (unsigned)nx) <= k) ++q;
+            const int x = __float_as_int(w[10][o]) + (k - (int)__umul24((unsigned)q, (unsigned)nx));
             const int y = __float_as_int(w[11][o]) + q;
             const float px[3] = { w[0][o], w[2][o], w[4][o] }, py[3] = { w[1][o], w[3][o], w[5][o] };
             float alpha, beta, gamma;
