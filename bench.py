@@ -25,6 +25,11 @@ import os
 import sys
 import time
 
+# The pipelined loop keeps four streams busy side by side (two slots x two pose groups).  The HIP runtime maps every stream of
+# the process onto GPU_MAX_HW_QUEUES hardware queues (default 4, shared with torch's and RCCL's streams) and streams that share
+# a queue serialise, so ask for 8 -- before torch initialises the runtime.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -50,6 +55,7 @@ def main():
     ap.add_argument("--solve", choices=["host", "device"], default=os.environ.get("PR_BENCH_SOLVE", "device"))
     ap.add_argument("--pose-groups", type=int, default=2, help="streams the device-solve loop is split over (library default 2)")
     ap.add_argument("--fused-solve", type=int, default=1, help="1: finalize+solve in the tail of the pass kernel (library default)")
+    ap.add_argument("--overlap-pass", type=int, default=-1, help="library option overlap_pass (-1: library default)")
     ap.add_argument("--sequential", action="store_true",
                     help="every step through the synchronous single-group path with HIP events around EVERY correspondence launch "
                          "(profile 1): the mode in which rocprofv3's per-launch average and the event average measure the same thing")
@@ -86,6 +92,8 @@ def main():
     api.set_option("solve", api.SOLVE_DEVICE if args.solve == "device" else api.SOLVE_HOST)
     api.set_option("pose_groups", args.pose_groups)
     api.set_option("fused_solve", args.fused_solve)
+    if args.overlap_pass >= 0:
+        api.set_option("overlap_pass", args.overlap_pass)
 
     W, H, K = synth.WIDTH, synth.HEIGHT, synth.K_TEST
     P = args.poses

@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -89,6 +90,8 @@ struct Ctx {
     int nn_lds_records = 0;          // stack traversal: leading 64-byte node records staged in LDS; measured 0/64/128/256/512 -> 42.2/41.6/45.2/45.4/58.2 ms per step (occupancy lost to the extra LDS outweighs the saved L1 lookups)
     int nn_compact = 1;              // stack traversal: 32-byte node records with 16-bit outward-rounded child boxes (half the L1 traffic)
     int nn_stack = 1;                // kd-tree query: per-lane LDS stack (1) or the reference's stackless walk (0)
+    int overlap_pass = -1;           // asynchronous path: the other slot's render may start once this slot has issued this pass of its loop
+                                     // (-1: 70 % of the passes -- measured best of 6/10/14/17 at 256 and 512 poses per batch)
     int sub_batch = 512;             // asynchronous fused path: hypotheses per sub-batch (cache residency of the clouds)
     int fused_solve = 1;             // PR_SOLVE_DEVICE: the workgroup delivering a hypothesis' last partial sum also runs its finalize + solve (no second launch per iteration)
     int icp_flow = 0;                // PR_SOLVE_DEVICE: 1 = one persistent dataflow launch for all iterations (bit-identical; measured equal at
@@ -152,10 +155,6 @@ int require_ctx()
     HIP_TRY(hipSetDevice(dev));
     HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&g.ev_fork, hipEventDisableTiming));
-    for (int i = 0; i < 3; ++i) {
-        HIP_TRY(hipStreamCreateWithFlags(&g.side[i], hipStreamNonBlocking));
-        HIP_TRY(hipEventCreateWithFlags(&g.ev_join[i], hipEventDisableTiming));
-    }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) g.n_cus = prop.multiProcessorCount;
     g.device = dev;
@@ -263,6 +262,16 @@ hipError_t launch_pass(const prk::IcpBatch &b, const SceneSel &sc, uint32_t P, h
     if (sc.kind == PR_SCENE_NN) return prk::launch_icp_pass_nn(b, sc.nn, P, st);
     if (sc.packed) return prk::launch_icp_pass_proj_packed(b, sc.pk, P, st);
     return prk::launch_icp_pass_proj_aos(b, sc.aos, P, st);
+}
+
+// Streams are created only when they are first needed: the runtime multiplexes all streams of a process onto a handful of
+// hardware queues (4 by default) in creation order, and two streams that share a queue serialise -- with every possible
+// stream created up front, a slot's render stream ended up behind the other slot's 21 queued passes.
+int ensure_stream(hipStream_t &st, hipEvent_t *ev = nullptr)
+{
+    if (!st) HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    if (ev && !*ev) HIP_TRY(hipEventCreateWithFlags(ev, hipEventDisableTiming));
+    return PR_OK;
 }
 
 // ---- the batched ICP driver -----------------------------------------------------------------------
@@ -378,6 +387,7 @@ int icp_drive(pr_vec3 *cloud_base, const uint32_t *start_h, const uint32_t *coun
             // of one group runs, the correspondence pass of the other group keeps the chip busy.
             auto group_begin = [&](uint32_t grp) { return (uint32_t)(((uint64_t)P * grp) / n_groups); };
             if (n_groups > 1) {
+                for (uint32_t k = 1; k < n_groups; ++k) PR_TRY(ensure_stream(g.side[k - 1], &g.ev_join[k - 1]));
                 HIP_TRY(hipEventRecord(g.ev_fork, g.stream));
                 for (uint32_t k = 1; k < n_groups; ++k) HIP_TRY(hipStreamWaitEvent(g.side[k - 1], g.ev_fork, 0));
             }
@@ -626,8 +636,9 @@ int refine_impl(const pr_triangle *tris_dev, size_t n_tris, const pr_mat4 *poses
 struct Slot {
     DevBuf poses_bbox, depth, row_count, row_off, counts, cloud, meta, partial, dstate, dresults, arrive, rec;
     PinBuf h_in, h_out;
-    hipStream_t stream = nullptr, side[3] = { nullptr, nullptr, nullptr }, aux = nullptr;
-    hipEvent_t fork = nullptr, join[3] = { nullptr, nullptr, nullptr }, done = nullptr, scene_ready = nullptr;
+    hipStream_t stream = nullptr, side[3] = { nullptr, nullptr, nullptr };
+    hipEvent_t fork = nullptr, join[3] = { nullptr, nullptr, nullptr }, done = nullptr, scene_ready = nullptr, progress = nullptr;
+    bool progress_valid = false;
     bool pending = false, delivered = false;
     uint32_t P = 0;
     pr_result *user_results_host = nullptr;
@@ -640,15 +651,11 @@ int slot_streams(Slot &sl)
 {
     if (sl.stream) return PR_OK;
     HIP_TRY(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&sl.aux, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&sl.scene_ready, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&sl.fork, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
-    for (int i = 0; i < 3; ++i) {
-        HIP_TRY(hipStreamCreateWithFlags(&sl.side[i], hipStreamNonBlocking));
-        HIP_TRY(hipEventCreateWithFlags(&sl.join[i], hipEventDisableTiming));
-    }
-    return PR_OK;
+    HIP_TRY(hipEventCreateWithFlags(&sl.progress, hipEventDisableTiming));
+    return PR_OK;                                                // side streams: ensure_stream, when a batch has pose groups
 }
 void slot_release(Slot &sl)
 {
@@ -664,9 +671,10 @@ void slot_release(Slot &sl)
     if (sl.fork) hipEventDestroy(sl.fork);
     if (sl.done) hipEventDestroy(sl.done);
     if (sl.scene_ready) hipEventDestroy(sl.scene_ready);
-    if (sl.aux) hipStreamDestroy(sl.aux);
+    if (sl.progress) hipEventDestroy(sl.progress);
+    sl.progress = nullptr; sl.progress_valid = false;
     if (sl.stream) hipStreamDestroy(sl.stream);
-    sl.fork = sl.done = sl.scene_ready = nullptr; sl.stream = sl.aux = nullptr; sl.pending = false;
+    sl.fork = sl.done = sl.scene_ready = nullptr; sl.stream = nullptr; sl.pending = false;
 }
 
 // Host-side box of a triangle buffer, once per (pointer, size): it feeds the per-pose pixel boxes computed on the host.
@@ -758,9 +766,13 @@ int refine_submit(int slot, const pr_triangle *tris_dev, size_t n_tris, const pr
     PR_TRY(slot_streams(sl));
     SceneSel sc;
     std::memset(static_cast<void *>(&sc), 0, sizeof sc);
-    // the packed copy of the scene does not depend on the render: it is built on its own stream, the loop waits for it
-    PR_TRY(make_scene(scene_kind, scene, /*want_packed=*/true, sc, &sl.rec, sl.aux));
-    HIP_TRY(hipEventRecord(sl.scene_ready, sl.aux));
+    // the packed copy of the scene does not depend on the render: it is built on the first side stream (idle until the loop
+    // forks), the loop waits for it; batches without pose groups build it in line
+    const uint32_t groups_hint = std::max(1u, std::min({ (uint32_t)std::max(1, g.pose_groups), 4u, std::min<uint32_t>(P, (uint32_t)std::max(32, g.sub_batch)) / 32u }));
+    for (uint32_t k = 1; k < groups_hint; ++k) PR_TRY(ensure_stream(sl.side[k - 1], &sl.join[k - 1]));
+    hipStream_t scene_stream = groups_hint > 1 ? sl.side[0] : sl.stream;
+    PR_TRY(make_scene(scene_kind, scene, /*want_packed=*/true, sc, &sl.rec, scene_stream));
+    HIP_TRY(hipEventRecord(sl.scene_ready, scene_stream));
 
     PR_TRY(ensure_model_box(tris_dev, n_tris));                 // once per triangle buffer
     // staging: [poses][boxes]; the cloud stride and the grid come from the largest box
@@ -811,6 +823,12 @@ int refine_submit(int slot, const pr_triangle *tris_dev, size_t n_tris, const pr
     void *h_in_dev = nullptr, *h_out_dev = nullptr;              // the pinned staging buffers as the device sees them
     HIP_TRY(hipHostGetDevicePointer(&h_in_dev, sl.h_in.p, 0));
     HIP_TRY(hipHostGetDevicePointer(&h_out_dev, sl.h_out.p, 0));
+    // Both phases are bound by the same units, so a batch that renders while the other slot is in the middle of its ICP loop
+    // slows that loop by more than it gains; its render is therefore held back until the other slot has issued pass
+    // `overlap_pass` of its (last sub-batch's) loop -- late enough to disturb little, early enough that the GPU never idles.
+    for (Slot &o : g_slots)
+        if (&o != &sl && o.pending && !o.delivered && o.progress_valid) HIP_TRY(hipStreamWaitEvent(st, o.progress, 0));
+    sl.progress_valid = false;
     HIP_TRY(prk::launch_stage_words(h_in_dev, d_poses, in_bytes, st));
     const bool fused = g.fused_solve != 0;
     for (uint32_t q0 = 0; q0 < P; q0 += sub) {
@@ -829,6 +847,7 @@ int refine_submit(int slot, const pr_triangle *tris_dev, size_t n_tris, const pr
         const uint32_t n_groups = std::max(1u, std::min({ (uint32_t)std::max(1, g.pose_groups), 4u, nq / 32u }));
         auto group_begin = [&](uint32_t grp) { return (uint32_t)(((uint64_t)nq * grp) / n_groups); };
         if (n_groups > 1) {
+            for (uint32_t k = 1; k < n_groups; ++k) PR_TRY(ensure_stream(sl.side[k - 1], &sl.join[k - 1]));
             HIP_TRY(hipEventRecord(sl.fork, st));
             for (uint32_t k = 1; k < n_groups; ++k) HIP_TRY(hipStreamWaitEvent(sl.side[k - 1], sl.fork, 0));
         }
@@ -844,6 +863,10 @@ int refine_submit(int slot, const pr_triangle *tris_dev, size_t n_tris, const pr
                 bb.score_only = (it == (uint32_t)crit.max_iteration) ? 1u : 0u;
                 HIP_TRY(launch_pass(bb, sc, np, gs));
                 if (!fused) HIP_TRY(prk::launch_icp_finalize_solve(bb.partial, meta + p0, nblk, steps, dstate + p0, crit, it, np, gs));
+            }
+            if (q0 + sub >= P && it == std::min<uint32_t>((uint32_t)crit.max_iteration, g.overlap_pass >= 0 ? (uint32_t)g.overlap_pass : (uint32_t)((crit.max_iteration + 1) * 7 / 10))) {
+                HIP_TRY(hipEventRecord(sl.progress, st));
+                sl.progress_valid = true;
             }
         }
         for (uint32_t k = 1; k < n_groups; ++k) { HIP_TRY(hipEventRecord(sl.join[k - 1], sl.side[k - 1])); HIP_TRY(hipStreamWaitEvent(st, sl.join[k - 1], 0)); }
@@ -931,6 +954,11 @@ int pr_init(int device)
     if (g.ready && g.device == device) return PR_OK;
     if (g.ready) { set_error("pr_init: already initialised on device %d", g.device); return PR_ERR_INVALID; }
     g.device = device;
+    // The two asynchronous slots and their pose groups need four streams that really run side by side; the runtime maps all
+    // streams of a process onto GPU_MAX_HW_QUEUES hardware queues (default 4, shared with every other stream of the process),
+    // and streams that share a queue serialise.  This only takes effect if the HIP runtime has not been initialised yet --
+    // hosts that initialise it earlier (PyTorch) set the variable themselves, as bench.py does.
+    setenv("GPU_MAX_HW_QUEUES", "8", /*overwrite=*/0);
     return require_ctx();
 }
 
@@ -1185,6 +1213,7 @@ int pr_set_option(const char *name, int value)
     else if (n == "icp_flow") g.icp_flow = value ? 1 : 0;
     else if (n == "fused_solve") g.fused_solve = value ? 1 : 0;
     else if (n == "sub_batch") g.sub_batch = std::max(32, value);
+    else if (n == "overlap_pass") g.overlap_pass = std::max(-1, value);
     else if (n == "pose_groups") g.pose_groups = std::min(4, std::max(1, value));
     else if (n == "raster_mode") { if (value != 0 && value != 1) { set_error("raster_mode must be 0 or 1"); return PR_ERR_INVALID; } g.raster_mode = value; }
     else { set_error("unknown option %s", name); return PR_ERR_INVALID; }
@@ -1207,6 +1236,7 @@ int pr_get_option(const char *name, int *value)
     else if (n == "icp_flow") *value = g.icp_flow;
     else if (n == "fused_solve") *value = g.fused_solve;
     else if (n == "sub_batch") *value = g.sub_batch;
+    else if (n == "overlap_pass") *value = g.overlap_pass;
     else if (n == "pose_groups") *value = g.pose_groups;
     else { set_error("unknown option %s", name); return PR_ERR_INVALID; }
     return PR_OK;
