@@ -115,7 +115,7 @@ struct Ctx {
 };
 Ctx g;
 std::mutex g_mu;
-constexpr uint64_t kSamplePeriod = 16;     // profile 2: one timed (synchronous, single-group) call in this many
+constexpr uint64_t kSamplePeriod = 32;     // profile 2: one timed (synchronous, single-group) call in this many
 
 // ---- hipGraph cache for the device-solve iteration loop ------------------------------------------
 struct GraphKey {                    // every value a captured launch depends on, byte for byte (grows as needed)
