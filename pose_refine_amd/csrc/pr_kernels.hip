@@ -648,11 +648,7 @@ __device__ __forceinline__ bool query(const SceneProjPacked &s, float sx, float 
 {
     uint32_t idx; int px, py;
     if (!proj_pixel(sx, sy, sz, s.fx, s.fy, s.cx, s.cy, s.width, s.height, idx, px, py)) return false;
-#ifdef PR_ABL_NOGATHER
-    const float4 r = make_float4(0.f, 0.f, 1.f, sz + 1e-3f * (float)(idx & 7));
-#else
     const float4 r = s.rec[idx];                                 // one 16-byte gather: {nx, ny, nz, z}
-#endif
     const float dz = r.w;
     const float diff = sz - dz;
     const float adiff = (diff > 0) ? diff : -diff;
@@ -985,16 +981,6 @@ __device__ __forceinline__ float dpp_get(float v)
 {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), kCtrl, kRowMask, 0xf, true));
 }
-__device__ __forceinline__ float wave_tree_sum(float v)
-{
-    v += dpp_get<0x111, 0xf>(v);     // row_shr:1
-    v += dpp_get<0x112, 0xf>(v);     // row_shr:2
-    v += dpp_get<0x114, 0xf>(v);     // row_shr:4
-    v += dpp_get<0x118, 0xf>(v);     // row_shr:8
-    v += dpp_get<0x142, 0xa>(v);     // row_bcast15 -> rows 1,3
-    v += dpp_get<0x143, 0xc>(v);     // row_bcast31 -> rows 2,3
-    return v;
-}
 
 __device__ __forceinline__ uint32_t ld_sys_u32(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ __forceinline__ void st_sys_u32(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
@@ -1201,7 +1187,6 @@ __device__ __forceinline__ void vb_accumulate(float (&acc_out)[29], float *cl, u
                 p[3 * i + 1] = M[4] * x + M[5] * y + M[6]  * z + M[7];
                 p[3 * i + 2] = M[8] * x + M[9] * y + M[10] * z + M[11];
             }
-#ifndef PR_ABL_NOSTORE
             if (full) {
                 float4 *dst = reinterpret_cast<float4 *>(cl + (size_t)j0 * 3);
                 dst[0] = make_float4(p[0], p[1], p[2], p[3]);
@@ -1211,7 +1196,6 @@ __device__ __forceinline__ void vb_accumulate(float (&acc_out)[29], float *cl, u
 #pragma unroll
                 for (uint32_t i = 0; i < 12; ++i) if (i < cnt * 3) cl[(size_t)j0 * 3 + i] = p[i];
             }
-#endif
         }
         if constexpr (kNN) {
 #pragma unroll
@@ -1253,16 +1237,6 @@ __device__ __forceinline__ void vb_accumulate(float (&acc_out)[29], float *cl, u
         }
     };
 
-#if defined(PR_PASS_PREFETCH)
-    if (!kNN && b.steps == 2) {                                  // both steps' point loads in flight before any use
-        float pa[12], pb[12];
-        uint32_t ja, jb, ca, cb; bool fa, fb;
-        load_step(0, pa, ja, ca, fa);
-        load_step(1, pb, jb, cb, fb);
-        process_step(pa, ja, ca, fa);
-        process_step(pb, jb, cb, fb);
-    } else
-#endif
     for (uint32_t s = 0; s < b.steps; ++s) {
         float p[12];
         uint32_t j0, cnt; bool full;
@@ -1283,16 +1257,6 @@ __device__ __forceinline__ float vb_reduce(float (&acc)[29], float (*wsum)[kAccS
 {
     constexpr int kFirst = kScoreOnly ? 27 : 0;                  // score-only passes carry zeros in sums 0..26
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#ifdef PR_ABL_NOREDUCE
-    { float t = 0; for (int i = 0; i < 29; ++i) t += acc[i]; if (lane == 63) wsum[wave][0] = t; }
-#else
-#ifdef PR_TREE_VALUE_MAJOR
-#pragma unroll
-    for (int i = 0; i < 29; ++i) {
-        const float t = wave_tree_sum(acc[i]);
-        if (lane == 63) wsum[wave][i] = t;
-    }
-#else
 #if PR_TREE_PACKED
     if constexpr (!kScoreOnly) {
         // Same balanced pairwise tree, but after every level the live partial sums of two registers are interleaved into one
@@ -1356,8 +1320,6 @@ __device__ __forceinline__ float vb_reduce(float (&acc)[29], float (*wsum)[kAccS
         for (int i = 0; i < 29; ++i) wsum[wave][i] = acc[i];
     }
     }
-#endif
-#endif
     __syncthreads();
     float t = 0.0f;
     if (threadIdx.x < 29) t = ((wsum[0][threadIdx.x] + wsum[1][threadIdx.x]) + wsum[2][threadIdx.x]) + wsum[3][threadIdx.x];
