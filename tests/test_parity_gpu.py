@@ -342,6 +342,30 @@ def test_async_slots_match_synchronous_path_bitwise(gpu, model, scenario, gscene
         api.set_option("solve", api.SOLVE_HOST)
 
 
+def test_submit_wait_contract_errors(gpu, model, scenario, gscenes):
+    """A slot holds one batch at a time; waiting on an idle slot, an out-of-range slot and frames beyond the raster's
+    coordinate packing (8192 per side, 2^24 pixels) are refused with PR_ERR_INVALID, and the slot stays usable."""
+    poses = synth.hypotheses(3)
+    c = api.ICPConvergenceCriteria(0.0, 0.0, 2)
+    api.set_option("solve", api.SOLVE_DEVICE)
+    try:
+        api.refine_submit(0, model, poses, W, H, scenario["proj"], scenario["K"], gscenes["proj"], c)
+        with pytest.raises(api.PoseRefineError):
+            api.refine_submit(0, model, poses, W, H, scenario["proj"], scenario["K"], gscenes["proj"], c)   # still pending
+        res, sizes = api.refine_wait(0)
+        assert (sizes > 0).all() and np.isfinite(res["T"]).all()
+        with pytest.raises(api.PoseRefineError):
+            api.refine_wait(0)
+        with pytest.raises(api.PoseRefineError):
+            api.refine_submit(2, model, poses, W, H, scenario["proj"], scenario["K"], gscenes["proj"], c)
+        with pytest.raises(api.PoseRefineError):
+            api.refine_batch(model, poses, 8200, 16, scenario["proj"], scenario["K"], gscenes["proj"], c)
+        again, _ = api.refine_batch(model, poses, W, H, scenario["proj"], scenario["K"], gscenes["proj"], c)
+        assert again.tobytes() == res.tobytes()
+    finally:
+        api.set_option("solve", api.SOLVE_HOST)
+
+
 # ---- SURVEY 8f "next" rows: device scene preparation, raw2* conversions ---------------------------------
 @pytest.mark.parametrize("dtype", [np.int32, np.uint16])
 def test_device_scene_preparation_bit_exact(gpu, scenario, dtype):
