@@ -113,3 +113,52 @@ def test_depth2cloud_random_images(gpu, seed):
         for stride, tlx, tly in ((1, 0, 0), (1, 17, 5), (2, 0, 0), (3, 1, 2)):
             got = api.depth2cloud(dev, W, H, K, stride, tlx, tly, dtype=dtype).to_host().reshape(-1, 3)
             assert np.array_equal(got, O.depth2cloud(dd, K, stride, tlx, tly)), (dtype, stride)
+
+
+def test_async_slots_random_job_stream(gpu):
+    """Random batch sizes / poses / criteria alternate over the two asynchronous slots (workspaces grow and shrink, the grid
+    hint of a batch comes from whatever ran before it, sub-batches of 256, hypotheses with empty clouds) and every batch
+    is compared bit for bit with the synchronous path."""
+    import os
+    from pose_refine_amd import synth
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    model = api.Model(os.path.join(root, "tests", "golden", "obj_06.ply"))
+    K = synth.K_TEST; W, H = 640, 480
+    proj = api.compute_proj(K, W, H)
+    sd = api.render_host(model, synth.scene_pose()[None], W, H, proj)[0]
+    scene = api.Scene_projective().init_Scene_projective_cuda(sd, K)
+    rng = np.random.default_rng(7)
+    jobs = []
+    for i in range(14):
+        P = int(rng.choice([1, 3, 31, 33, 64, 65, 200, 300, 513]))
+        poses = synth.hypotheses(P, seed=100 + i)
+        if rng.random() < 0.5:
+            poses.reshape(-1, 4, 4)[:, 2, 3] += float(rng.choice([0.0, 400.0, 1500.0, -300.0]))
+        if P > 2 and rng.random() < 0.3:
+            poses.reshape(-1, 4, 4)[1, 0, 3] += 1e6                # off-screen hypothesis -> empty cloud
+        crit = (api.ICPConvergenceCriteria(0.0, 0.0, int(rng.choice([0, 3, 20]))) if rng.random() < 0.7
+                else api.ICPConvergenceCriteria(1e-5, 1e-5, 30))
+        jobs.append((poses, crit))
+    api.set_option("solve", api.SOLVE_DEVICE)
+    api.set_option("sub_batch", 256)
+    try:
+        api.set_option("profile", 1)                               # forces the synchronous path
+        refs = [api.refine_batch(model, p, W, H, proj, K, scene, c) for p, c in jobs]
+        api.set_option("profile", 0)
+        got, inflight = [None] * len(jobs), [None, None]
+        for i, (p, c) in enumerate(jobs):
+            b = i & 1
+            if inflight[b] is not None:
+                got[inflight[b]] = api.refine_wait(b)
+            api.refine_submit(b, model, p, W, H, proj, K, scene, c)
+            inflight[b] = i
+        for b in (0, 1):
+            if inflight[b] is not None:
+                got[inflight[b]] = api.refine_wait(b)
+        for i, (g, r) in enumerate(zip(got, refs)):
+            assert np.array_equal(g[1], r[1]), i
+            assert g[0].tobytes() == r[0].tobytes(), (i, len(jobs[i][0]))
+    finally:
+        api.set_option("profile", 0)
+        api.set_option("sub_batch", 512)
+        api.set_option("solve", api.SOLVE_HOST)

@@ -1,0 +1,47 @@
+#!/usr/bin/env python
+"""Stress of the asynchronous slots: random batch sizes / poses alternate over the two slots (growing and shrinking
+workspaces, changing grid hints, sub-batches, empty clouds) and every batch is compared bit for bit with the synchronous path."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+from pose_refine_amd import api, synth
+api.init(0); api.set_option("solve", 1)
+model = api.Model(os.path.join(ROOT, "tests/golden/obj_06.ply"))
+K = synth.K_TEST; W, H = 640, 480; proj = api.compute_proj(K, W, H)
+sd = api.render_host(model, synth.scene_pose()[None], W, H, proj)[0]
+scene = api.Scene_projective().init_Scene_projective_cuda(sd, K)
+rng = np.random.default_rng(7)
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+jobs = []
+for i in range(N):
+    P = int(rng.choice([1, 3, 31, 33, 64, 65, 200, 256, 300, 513, 700]))
+    poses = synth.hypotheses(P, seed=100 + i)
+    if rng.random() < 0.5:
+        poses.reshape(-1, 4, 4)[:, 2, 3] += float(rng.choice([0.0, 400.0, 1500.0, -300.0]))
+    if P > 2 and rng.random() < 0.3:
+        poses.reshape(-1, 4, 4)[1, 0, 3] += 1e6
+    crit = api.ICPConvergenceCriteria(0.0, 0.0, int(rng.choice([0, 3, 20]))) if rng.random() < 0.7 else api.ICPConvergenceCriteria(1e-5, 1e-5, 30)
+    jobs.append((poses, crit))
+api.set_option("sub_batch", 256)
+api.set_option("profile", 1)
+refs = [api.refine_batch(model, p, W, H, proj, K, scene, c) for p, c in jobs]
+api.set_option("profile", 0)
+got = [None] * N
+infl = [None, None]
+for i, (p, c) in enumerate(jobs):
+    b = i & 1
+    if infl[b] is not None:
+        got[infl[b]] = api.refine_wait(b)
+    api.refine_submit(b, model, p, W, H, proj, K, scene, c)
+    infl[b] = i
+for b in (0, 1):
+    if infl[b] is not None:
+        got[infl[b]] = api.refine_wait(b)
+bad = 0
+for i in range(N):
+    ok = np.array_equal(got[i][1], refs[i][1]) and got[i][0].tobytes() == refs[i][0].tobytes()
+    bad += (not ok)
+    if not ok: print("MISMATCH job", i, "P", len(jobs[i][0]))
+print(f"{N} jobs, {bad} mismatches")
+sys.exit(1 if bad else 0)
