@@ -134,41 +134,19 @@ __device__ __forceinline__ int fragment_depth(float alpha, float beta, float gam
     return f2i_x86(frag + 0.5f);
 }
 
-// Wave-cooperative raster.  Thread-per-triangle pixel loops waste most lanes (the average triangle
-// of obj_06 tests 7 pixel centres, the largest 36), so each wavefront first sets up its 64
-// (triangle, hypothesis) pairs -- one per lane -- then expands them into one dense list of candidate
-// pixels (exclusive scan of the per-triangle trip counts) and walks that list 64 candidates at a
-// time: every lane finds the owner of its candidate by a 6-step search over the scanned offsets and
-// reads the owner's setup back from LDS.  Same arithmetic per candidate, same int32 atomicMin.
+// Wave-cooperative raster of up to 64 set-up triangles (one per lane, n = candidate pixels of the lane's triangle, 0 for none).
+// Thread-per-triangle pixel loops waste most lanes (the average triangle of obj_06 tests 7 pixel centres, the largest 36), so
+// the wavefront expands its triangles into one dense list of candidate pixels (exclusive scan of the per-triangle counts) and
+// walks that list 64 candidates at a time: every lane finds the owner of its candidate by a 6-step search over the scanned
+// offsets and reads the owner's setup back from LDS.  Candidates that pass the inside test are rare (about one in four) --
+// they are queued per wavefront as packed (owner, x, y) words and drained 64 at a time, so the four IEEE divisions of the
+// perspective depth and the depth update (`sink(x, y, depth)`) always run on full wavefronts.  Same arithmetic per candidate
+// as renderer.cu:124-140.  `w` / `queue` are this wavefront's private LDS scratch.
 constexpr int kSetupWords = 15;
-__global__ __launch_bounds__(256) void raster_kernel(const pr_triangle *__restrict__ tris, uint32_t n_tris,
-                                                     const pr_mat4 *__restrict__ poses, int32_t *__restrict__ depth,
-                                                     uint32_t width, uint32_t height, pr_mat4 proj, pr_roi roi,
-                                                     uint32_t rw, uint32_t rh, const int4 *__restrict__ boxes)
+template <class Sink>
+__device__ __forceinline__ void wave_raster(const TriSetup &t, int n, float (*w)[64], uint32_t *queue, Sink sink)
 {
-    __shared__ float sh[4][kSetupWords][64];
-    __shared__ uint32_t shq[4][128];
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t ti = blockIdx.x * 256 + threadIdx.x;
-    const float *M = poses[blockIdx.y].m;                        // wave-uniform -> scalar loads
-    int32_t *img = depth + (size_t)blockIdx.y * rw * rh;
-
-    float cmin0 = 0.0f, cmin1 = 0.0f, cmax0 = (float)(width - 1), cmax1 = (float)(height - 1);
-    if (roi.width > 0 && roi.height > 0) {                       // renderer.cu:106-113 (image is flipped in y)
-        cmin0 = (float)roi.x;
-        cmin1 = (float)((unsigned long long)(height - 1) - (unsigned long long)(long long)(roi.y + roi.height - 1));
-        cmax0 = (float)((roi.x + roi.width) - 1);
-        cmax1 = (float)((unsigned long long)(height - 1) - (unsigned long long)(long long)roi.y);
-    }
-    (void)boxes;
-
-    TriSetup t;
-    int n = 0;
-    if (ti < n_tris) {
-        tri_setup(reinterpret_cast<const float *>(tris + ti), M, proj, width, height, cmin0, cmin1, cmax0, cmax1, t);
-        n = t.nx * t.ny;
-    } else { t.nx = t.ny = 0; t.x0 = t.y0 = 0; t.base_inv = 0; for (int k = 0; k < 3; ++k) t.px[k] = t.py[k] = t.w3[k] = 0; }
-
+    const uint32_t lane = threadIdx.x & 63;
     // exclusive scan of n over the wavefront
     int incl = n;
 #pragma unroll
@@ -176,20 +154,15 @@ __global__ __launch_bounds__(256) void raster_kernel(const pr_triangle *__restri
     const int excl = incl - n;
     const int total = __shfl(incl, 63);
 
-    float (*w)[64] = sh[wave];
     w[0][lane] = t.px[0]; w[1][lane] = t.py[0]; w[2][lane] = t.px[1]; w[3][lane] = t.py[1]; w[4][lane] = t.px[2]; w[5][lane] = t.py[2];
     w[6][lane] = t.w3[0]; w[7][lane] = t.w3[1]; w[8][lane] = t.w3[2]; w[9][lane] = t.base_inv;
     w[10][lane] = __int_as_float(t.x0); w[11][lane] = __int_as_float(t.y0); w[12][lane] = __int_as_float(t.nx > 0 ? t.nx : 1);
     w[13][lane] = __int_as_float(excl);
     w[14][lane] = __builtin_amdgcn_rcpf((float)(t.nx > 0 ? t.nx : 1));
-    // the four wavefronts only touch their own slice; a wave-level fence is enough for LDS ordering
+    // wavefronts only touch their own slice; a wave-level fence is enough for LDS ordering
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
-    // Candidates that pass the inside test are rare (about one in four) -- they are queued per wavefront as packed
-    // (owner, x, y) words and drained 64 at a time, so the four IEEE divisions of the perspective depth and the
-    // atomicMin always run on full wavefronts.
-    uint32_t *queue = reinterpret_cast<uint32_t *>(shq[wave]);
     int qn = 0;                                                    // wave-uniform fill level, < 64 between iterations
     auto drain = [&](int first, int count) {
         if ((int)lane < count) {
@@ -198,10 +171,7 @@ __global__ __launch_bounds__(256) void raster_kernel(const pr_triangle *__restri
             const float px[3] = { w[0][o], w[2][o], w[4][o] }, py[3] = { w[1][o], w[3][o], w[5][o] };
             float alpha, beta, gamma;
             (void)tri_fragment(px, py, w[9][o], x, y, alpha, beta, gamma);
-            const int d = fragment_depth(alpha, beta, gamma, w[6][o], w[7][o], w[8][o]);
-            const uint32_t xw = (uint32_t)(x - roi.x);
-            const uint32_t yw = (uint32_t)((int)height - 1 - y - roi.y);
-            atomicMin(&img[xw + (size_t)yw * rw], d);
+            sink(x, y, fragment_depth(alpha, beta, gamma, w[6][o], w[7][o], w[8][o]));
         }
     };
     for (int c0 = 0; c0 < total; c0 += 64) {
@@ -234,6 +204,43 @@ __global__ __launch_bounds__(256) void raster_kernel(const pr_triangle *__restri
         if (qn >= 64) { drain(qn - 64, 64); qn -= 64; __builtin_amdgcn_wave_barrier(); }
     }
     drain(0, qn);
+    __builtin_amdgcn_wave_barrier();                             // the scratch may be refilled by the caller's next chunk
+}
+
+// one lane = one (triangle, hypothesis); depth resolved with int32 atomicMin in global memory (the reference scheme)
+__global__ __launch_bounds__(256) void raster_kernel(const pr_triangle *__restrict__ tris, uint32_t n_tris,
+                                                     const pr_mat4 *__restrict__ poses, int32_t *__restrict__ depth,
+                                                     uint32_t width, uint32_t height, pr_mat4 proj, pr_roi roi,
+                                                     uint32_t rw, uint32_t rh, const int4 *__restrict__ boxes)
+{
+    __shared__ float sh[4][kSetupWords][64];
+    __shared__ uint32_t shq[4][128];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t ti = blockIdx.x * 256 + threadIdx.x;
+    const float *M = poses[blockIdx.y].m;                        // wave-uniform -> scalar loads
+    int32_t *img = depth + (size_t)blockIdx.y * rw * rh;
+
+    float cmin0 = 0.0f, cmin1 = 0.0f, cmax0 = (float)(width - 1), cmax1 = (float)(height - 1);
+    if (roi.width > 0 && roi.height > 0) {                       // renderer.cu:106-113 (image is flipped in y)
+        cmin0 = (float)roi.x;
+        cmin1 = (float)((unsigned long long)(height - 1) - (unsigned long long)(long long)(roi.y + roi.height - 1));
+        cmax0 = (float)((roi.x + roi.width) - 1);
+        cmax1 = (float)((unsigned long long)(height - 1) - (unsigned long long)(long long)roi.y);
+    }
+    (void)boxes;
+
+    TriSetup t;
+    int n = 0;
+    if (ti < n_tris) {
+        tri_setup(reinterpret_cast<const float *>(tris + ti), M, proj, width, height, cmin0, cmin1, cmax0, cmax1, t);
+        n = t.nx * t.ny;
+    } else { t.nx = t.ny = 0; t.x0 = t.y0 = 0; t.base_inv = 0; for (int k = 0; k < 3; ++k) t.px[k] = t.py[k] = t.w3[k] = 0; }
+
+    wave_raster(t, n, sh[wave], shq[wave], [&](int x, int y, int d) {
+        const uint32_t xw = (uint32_t)(x - roi.x);
+        const uint32_t yw = (uint32_t)((int)height - 1 - y - roi.y);
+        atomicMin(&img[xw + (size_t)yw * rw], d);
+    });
 }
 
 // ================================================================================================
