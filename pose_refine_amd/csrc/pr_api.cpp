@@ -88,6 +88,7 @@ struct Ctx {
     int profile = 0;
     int nn_lds_nodes = 1024;
     int nn_lds_records = 0;          // stack traversal: leading 64-byte node records staged in LDS; measured 0/64/128/256/512 -> 42.2/41.6/45.2/45.4/58.2 ms per step (occupancy lost to the extra LDS outweighs the saved L1 lookups)
+    int nn_seed = 1;                 // compact kd records: start every search from the previous pass' winner distance
     int nn_compact = 1;              // stack traversal: 32-byte node records with 16-bit outward-rounded child boxes (half the L1 traffic)
     int nn_stack = 1;                // kd-tree query: per-lane LDS stack (1) or the reference's stackless walk (0)
     int overlap_pass = -1;           // asynchronous path: the other slot's render may start once this slot has issued this pass of its loop
@@ -105,7 +106,7 @@ struct Ctx {
     const void *mesh_key = nullptr; size_t mesh_n = 0;   // triangle buffer aabb_host belongs to
     uint32_t cloud_hint = 0;          // largest cloud of the latest finished asynchronous batch: sizes the next batch's grid
     // workspaces
-    DevBuf aabb, bbox, poses, depth, row_count, row_off, counts, cloud, meta, partial, sums, rec, topo, bmin, bmax, pts, nnrec, nnrec32, nndepth, dstate, dresults, vbdesc, flowsync, arrive, conv16, conv8, kd_idx, kd_scratch, kd_child, kd_ctrl, kd_tmp, nn_full;
+    DevBuf aabb, bbox, poses, depth, row_count, row_off, counts, cloud, meta, partial, sums, rec, topo, bmin, bmax, pts, nnrec, nnrec32, nndesc, nn_prev, nndepth, dstate, dresults, vbdesc, flowsync, arrive, conv16, conv8, kd_idx, kd_scratch, kd_child, kd_ctrl, kd_tmp, nn_full;
     PinBuf h_sums, h_meta, h_counts, h_results, h_dstate, h_flow;
     // profiling
     std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
@@ -230,9 +231,10 @@ int make_scene(int kind, const void *scene, bool want_packed, SceneSel &out, Dev
         PR_TRY(g.nnrec.ensure((size_t)s->n_nodes * 4 * sizeof(float4)));
         PR_TRY(g.nndepth.ensure(8 * sizeof(uint32_t)));
         PR_TRY(g.nnrec32.ensure((size_t)s->n_nodes * 2 * sizeof(uint4)));
+        PR_TRY(g.nndesc.ensure((size_t)s->n_nodes * sizeof(uint2)));
         HIP_TRY(prk::launch_build_nn_accel(s->nodes, s->n_nodes, s->pcd, s->n_points, g.topo.as<int4>(), g.bmin.as<float4>(),
                                            g.bmax.as<float4>(), g.pts.as<float4>(), g.nnrec.as<float4>(), g.nnrec32.as<uint4>(),
-                                           g.nndepth.as<uint32_t>(), g.stream));
+                                           g.nndesc.as<uint2>(), g.nndepth.as<uint32_t>(), g.stream));
         uint32_t info[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
         HIP_TRY(hipMemcpyAsync(info, g.nndepth.p, sizeof info, hipMemcpyDeviceToHost, g.stream));
         HIP_TRY(hipStreamSynchronize(g.stream));
@@ -245,7 +247,7 @@ int make_scene(int kind, const void *scene, bool want_packed, SceneSel &out, Dev
         if (g.nn_stack) stack = (depth <= 16) ? 16u : ((depth <= 24) ? 24u : 0u);
         if (stack) lds = std::min<uint32_t>({ (uint32_t)std::max(0, g.nn_lds_records), s->n_nodes, (65536u - stack * 2048u) / 64u });   // stacks + records <= 64 KiB
         out.nn = prk::SceneNNDev{ s->max_dist_diff, g.topo.as<int4>(), g.bmin.as<float4>(), g.bmax.as<float4>(), g.pts.as<float4>(),
-                                  s->pcd, s->normal, s->n_nodes, lds, g.nnrec.as<float4>(), stack, nullptr, { 0, 0, 0 }, { 0, 0, 0 } };
+                                  s->pcd, s->normal, s->n_nodes, lds, g.nnrec.as<float4>(), stack, nullptr, { 0, 0, 0 }, { 0, 0, 0 }, g.nndesc.as<uint2>() };
         if (stack && g.nn_compact && info[1] == 1u) {
             out.nn.rec32 = g.nnrec32.as<uint4>();
             for (int a = 0; a < 3; ++a) { std::memcpy(&out.nn.qmin[a], &info[2 + a], 4); std::memcpy(&out.nn.qscale[a], &info[5 + a], 4); }
@@ -298,6 +300,12 @@ int icp_drive(pr_vec3 *cloud_base, const uint32_t *start_h, const uint32_t *coun
     prk::IcpBatch b{};
     b.cloud = cloud_base; b.meta = g.meta.as<prk::PoseMeta>(); b.partial = g.partial.as<float>();
     b.nblk = nblk; b.steps = steps;
+    if (sc.kind == PR_SCENE_NN && sc.nn.rec32 && g.nn_seed) {     // previous winners, indexed like the cloud points
+        size_t span = 1;
+        for (uint32_t i = 0; i < P; ++i) span = std::max(span, (size_t)start_h[i] + count_h[i]);
+        PR_TRY(g.nn_prev.ensure(sizeof(uint32_t) * span));
+        b.nn_prev = g.nn_prev.as<uint32_t>();
+    }
 
     prk::PoseMeta *h_meta = g.h_meta.as<prk::PoseMeta>();
     float *h_sums = g.h_sums.as<float>();
@@ -426,7 +434,7 @@ int icp_drive(pr_vec3 *cloud_base, const uint32_t *start_h, const uint32_t *coun
         if (g.use_graph && n_groups == 1 && (g.profile == 0 || (g.profile == 2 && !sample_call))) {   // HIP events recorded inside a captured graph cannot be timed
             GraphKey key;
             key.add(P); key.add(nblk); key.add(steps); key.add(crit); key.add(sc); key.add(cloud_base); key.add(g.meta.p); key.add(g.partial.p);
-            key.add(g.dstate.p); key.add(dres); key.add(results_host != nullptr); key.add(res); key.add(h_meta); key.add(init); key.add(g.profile); key.add(g.pose_groups); key.add(g.fused_solve); key.add(g.arrive.p);
+            key.add(g.dstate.p); key.add(dres); key.add(results_host != nullptr); key.add(res); key.add(h_meta); key.add(init); key.add(g.profile); key.add(g.pose_groups); key.add(g.fused_solve); key.add(g.arrive.p); key.add(b.nn_prev);
             CachedGraph *hit = nullptr;
             for (auto &c : g_graphs) if (c.exec && c.key == key) { hit = &c; break; }
             if (!hit) {
@@ -969,7 +977,7 @@ int pr_shutdown(void)
     hipStreamSynchronize(g.stream);
     for (Slot &sl : g_slots) slot_release(sl);
     for (DevBuf *b : { &g.aabb, &g.bbox, &g.poses, &g.depth, &g.row_count, &g.row_off, &g.counts, &g.cloud, &g.meta, &g.partial,
-                       &g.sums, &g.rec, &g.topo, &g.bmin, &g.bmax, &g.pts, &g.nnrec, &g.nnrec32, &g.nndepth, &g.dstate, &g.dresults, &g.vbdesc, &g.flowsync, &g.arrive, &g.conv16, &g.conv8, &g.kd_idx, &g.kd_scratch, &g.kd_child, &g.kd_ctrl, &g.kd_tmp, &g.nn_full }) b->release();
+                       &g.sums, &g.rec, &g.topo, &g.bmin, &g.bmax, &g.pts, &g.nnrec, &g.nnrec32, &g.nndesc, &g.nn_prev, &g.nndepth, &g.dstate, &g.dresults, &g.vbdesc, &g.flowsync, &g.arrive, &g.conv16, &g.conv8, &g.kd_idx, &g.kd_scratch, &g.kd_child, &g.kd_ctrl, &g.kd_tmp, &g.nn_full }) b->release();
     for (PinBuf *b : { &g.h_sums, &g.h_meta, &g.h_counts, &g.h_results, &g.h_dstate, &g.h_flow }) b->release();
     drop_graphs();
     for (hipEvent_t e : g.ev_pool) hipEventDestroy(e);
@@ -1208,6 +1216,7 @@ int pr_set_option(const char *name, int value)
     else if (n == "nn_lds_nodes") g.nn_lds_nodes = std::max(0, value);
     else if (n == "nn_lds_records") g.nn_lds_records = std::max(0, value);
     else if (n == "nn_compact") g.nn_compact = value ? 1 : 0;
+    else if (n == "nn_seed") g.nn_seed = value ? 1 : 0;
     else if (n == "nn_stack") g.nn_stack = value ? 1 : 0;
     else if (n == "graph") g.use_graph = value ? 1 : 0;
     else if (n == "icp_flow") g.icp_flow = value ? 1 : 0;
@@ -1230,6 +1239,7 @@ int pr_get_option(const char *name, int *value)
     else if (n == "nn_lds_nodes") *value = g.nn_lds_nodes;
     else if (n == "nn_lds_records") *value = g.nn_lds_records;
     else if (n == "nn_compact") *value = g.nn_compact;
+    else if (n == "nn_seed") *value = g.nn_seed;
     else if (n == "nn_stack") *value = g.nn_stack;
     else if (n == "raster_mode") *value = g.raster_mode;
     else if (n == "graph") *value = g.use_graph;

@@ -46,6 +46,7 @@ struct IcpBatch {
     uint32_t        iter;       // iteration index of this pass (icp.cu:178 loop variable)
     DevIcpState    *st;         // [P]
     uint32_t       *arrive;     // [P] zero before the first pass; the solving workgroup re-zeroes its entry
+    uint32_t       *nn_prev;    // kd-tree scenes: per cloud point (same indexing as `cloud`) the scene index of the previous pass' winner, or null
     pr_criteria     crit;
 };
 
@@ -77,6 +78,8 @@ struct SceneNNDev {
     // 16 bits in the frame of the root box, rounded outwards; null when the tree cannot be expressed that way
     const uint4 *rec32;
     float qmin[3], qscale[3];   // dequantisation: qmin[a] + (float)q * qscale[a]
+    const uint2 *desc;          // first 8 bytes of every compact record on their own (split | child | dim): all a descent needs when the
+                                // split plane alone already rules the far side out
 };
 
 // device-side solver state for PR_SOLVE_DEVICE (one record per hypothesis)
@@ -160,7 +163,7 @@ hipError_t launch_pack_proj_scene(const pr_vec3 *pcd, const pr_vec3 *normal, flo
                                   uint32_t width, uint32_t height, float fx, float fy, float cx, float cy, hipStream_t s);
 // info[0] = tree depth, info[1] = 1 when the 32-byte records are valid, info[2..7] = qmin[3], qscale[3] (float bits)
 hipError_t launch_build_nn_accel(const pr_kdnode *nodes, uint32_t n_nodes, const pr_vec3 *pcd, uint32_t n_points,
-                                 int4 *topo, float4 *bmin, float4 *bmax, float4 *pts, float4 *rec, uint4 *rec32, uint32_t *info, hipStream_t s);
+                                 int4 *topo, float4 *bmin, float4 *bmax, float4 *pts, float4 *rec, uint4 *rec32, uint2 *desc, uint32_t *info, hipStream_t s);
 
 }  // namespace prk
 

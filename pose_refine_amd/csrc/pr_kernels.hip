@@ -787,14 +787,19 @@ constexpr int kLeafBatch = PR_LEAF_BATCH;
 #ifndef PR_NN_LEAF12
 #define PR_NN_LEAF12 1
 #endif
+#ifndef PR_NN_WIDE_BOUND
+#define PR_NN_WIDE_BOUND 4.0e-6f                                // (2 mm)^2: above it a node's whole record is fetched at once
+#endif
+constexpr uint32_t kNoPrev = 0xffffffffu;
 
 // kCode = stack entries per lane (16 / 24), + 0x100 when the scene's compact 32-byte records are used
 template <int kCode>
-__device__ __forceinline__ bool query_nn_stack(const SceneNNDev &s, const float4 *lds_rec, int *stk_node, float *stk_lb, float sx, float sy, float sz, Corr &c)
+__device__ __forceinline__ bool query_nn_stack(const SceneNNDev &s, const float4 *lds_rec, int *stk_node, float *stk_lb, float sx, float sy, float sz, Corr &c,
+                                               uint32_t seed, uint32_t &winner)
 {
     constexpr int kDepth = kCode & 0xff;
     constexpr bool kCompact = (kCode & 0x100) != 0;
-    int cur = 0, sp = 0, best_i = 0;
+    int cur = 0, sp = 0, best_i = -1;                            // -1: no point below the starting bound yet
 #if PR_NN_BOUNDED
     // a winner is only accepted below max_dist_diff^2 (pcd_scene.h query tail), so the search can start from that bound:
     // subtrees and points at or beyond it could only produce a neighbour the final test rejects
@@ -803,26 +808,50 @@ __device__ __forceinline__ bool query_nn_stack(const SceneNNDev &s, const float4
 #else
     float best = FLT_MAX;
 #endif
+    if constexpr (kCompact) {
+        // Temporal seed: the previous pass' winner for this cloud point is still a scene point, so its distance (inflated by one
+        // part in a million, so that the point itself -- or an equal one visited earlier -- is still found by the search) bounds
+        // the answer from the start.  The bound only removes subtrees and points that are strictly farther than an existing
+        // point; winner, distance and tie-break are those of the unseeded search.
+        if (seed != kNoPrev) {
+            const pr_vec3 p = s.pcd[seed];
+            const float d2 = (sx - p.x) * (sx - p.x) + (sy - p.y) * (sy - p.y) + (sz - p.z) * (sz - p.z);
+            const float b = d2 * 1.000001f + 1e-30f;
+            if (b < best) best = b;
+        }
+    }
+    winner = kNoPrev;
     for (;;) {
         float4 h, b0, b1, b2;
         if constexpr (kCompact) {
             // compact records: half the bytes through the L1 (the kernel is bound by the texture-addresser / L1 rate of its
             // divergent loads, not by latency or HBM); only the far child's box is decoded
-            const uint4 A = s.rec32[(size_t)cur * 2], B = s.rec32[(size_t)cur * 2 + 1];
+            // While the bound is wide (first passes, first descent) the whole 32-byte record is fetched at once.  Once it is
+            // tight, 8 bytes (split | child | dim) are enough for most nodes: every point of the far side lies beyond the
+            // split plane (left_max <= split <= right_min, pcd_scene.cpp:140-160), so (q - split)^2 is a lower bound of its
+            // distance in the same float arithmetic, and only if that bound does not exceed `best` is the far box needed.
+            const bool wide = best > PR_NN_WIDE_BOUND;
+            uint4 A, B;
+            if (wide) { A = s.rec32[(size_t)cur * 2]; B = s.rec32[(size_t)cur * 2 + 1]; }
+            else { const uint2 d = s.desc[cur]; A = make_uint4(d.x, d.y, 0u, 0u); B = make_uint4(0u, 0u, 0u, 0u); }
             const uint32_t tag = A.y >> 30;
             if (tag == 3u) { h = make_float4(__uint_as_float(A.x), __uint_as_float(A.y & 0x3fffffffu), __int_as_float(-1), 0.0f); b0 = b1 = b2 = h; }
             else {
                 const float q = (tag == 0u) ? sx : ((tag == 1u) ? sy : sz);
-                const bool left_near = (q - __uint_as_float(A.x)) < 0;
+                const float diff = q - __uint_as_float(A.x);
+                const bool left_near = diff < 0;
                 const uint32_t c1 = A.y & 0x3fffffffu;
-                const uint32_t u0 = left_near ? B.y : A.z, u1 = left_near ? B.z : A.w, u2 = left_near ? B.w : B.x;
-                const float4 lo = make_float4(nn_deq(u0 & 0xffffu, s.qmin[0], s.qscale[0]), nn_deq(u0 >> 16, s.qmin[1], s.qscale[1]),
-                                              nn_deq(u1 & 0xffffu, s.qmin[2], s.qscale[2]), 0.0f);
-                const float4 hi = make_float4(nn_deq(u1 >> 16, s.qmin[0], s.qscale[0]), nn_deq(u2 & 0xffffu, s.qmin[1], s.qscale[1]),
-                                              nn_deq(u2 >> 16, s.qmin[2], s.qscale[2]), 0.0f);
-                const float lb = box_dist_sq(sx, sy, sz, lo, hi);
                 const int near_c = (int)(left_near ? c1 : c1 + 1u), far_c = (int)(left_near ? c1 + 1u : c1);
-                if (lb <= best && sp < kDepth) { stk_node[sp * kBlockThreads] = far_c; stk_lb[sp * kBlockThreads] = lb; ++sp; }
+                if (diff * diff <= best && sp < kDepth) {
+                    if (!wide) { A = s.rec32[(size_t)cur * 2]; B = s.rec32[(size_t)cur * 2 + 1]; }
+                    const uint32_t u0 = left_near ? B.y : A.z, u1 = left_near ? B.z : A.w, u2 = left_near ? B.w : B.x;
+                    const float4 lo = make_float4(nn_deq(u0 & 0xffffu, s.qmin[0], s.qscale[0]), nn_deq(u0 >> 16, s.qmin[1], s.qscale[1]),
+                                                  nn_deq(u1 & 0xffffu, s.qmin[2], s.qscale[2]), 0.0f);
+                    const float4 hi = make_float4(nn_deq(u1 >> 16, s.qmin[0], s.qscale[0]), nn_deq(u2 & 0xffffu, s.qmin[1], s.qscale[1]),
+                                                  nn_deq(u2 >> 16, s.qmin[2], s.qscale[2]), 0.0f);
+                    const float lb = box_dist_sq(sx, sy, sz, lo, hi);
+                    if (lb <= best) { stk_node[sp * kBlockThreads] = far_c; stk_lb[sp * kBlockThreads] = lb; ++sp; }
+                }
                 cur = near_c;
                 continue;
             }
@@ -879,7 +908,8 @@ __device__ __forceinline__ bool query_nn_stack(const SceneNNDev &s, const float4
             cur = near_c;
         }
     }
-    if (!(best < s.max_dist_diff * s.max_dist_diff)) return false;
+    if (!(best < s.max_dist_diff * s.max_dist_diff) || best_i < 0) return false;
+    winner = (uint32_t)best_i;
     const float4 d = s.pts[best_i];                              // {x,y,z,0} copy of pcd[best_i]
     const float *n = reinterpret_cast<const float *>(s.normal + best_i);
     c.dx = d.x; c.dy = d.y; c.dz = d.z; c.nx = n[0]; c.ny = n[1]; c.nz = n[2];
@@ -1162,8 +1192,10 @@ __device__ __forceinline__ bool pose_iteration_wave(float total, uint32_t n, Dev
 // cloud into the lane's registers (pending transform applied and written back first when xf).
 template <class Scene, bool kNN, int kStack, bool kScoreOnly = false>
 __device__ __forceinline__ void vb_accumulate(float (&acc_out)[29], float *cl, uint32_t n, uint32_t first, uint32_t steps, bool xf,
-                                              const float (&M)[12], const Scene &scene, const int4 *lds_topo, int *stk_node, float *stk_lb)
+                                              const float (&M)[12], const Scene &scene, const int4 *lds_topo, int *stk_node, float *stk_lb,
+                                              uint32_t *nn_prev = nullptr, bool nn_seeded = false)
 {
+    (void)nn_prev; (void)nn_seeded;
     const bool vec_ok = ((reinterpret_cast<uintptr_t>(cl) & 15u) == 0);
     struct { uint32_t steps; } b{ steps };
     Acc29 acc;                                                   // the caller's sums start at zero
@@ -1210,8 +1242,12 @@ __device__ __forceinline__ void vb_accumulate(float (&acc_out)[29], float *cl, u
                 if (i < cnt) {
                     Corr c;
                     bool ok;
-                    if constexpr (kStack > 0) ok = query_nn_stack<kStack>(scene, reinterpret_cast<const float4 *>(lds_topo), stk_node, stk_lb, p[3 * i], p[3 * i + 1], p[3 * i + 2], c);
-                    else ok = query_nn<true>(scene, lds_topo, p[3 * i], p[3 * i + 1], p[3 * i + 2], c);
+                    if constexpr (kStack > 0) {
+                        const uint32_t seed = (nn_prev && nn_seeded) ? nn_prev[j0 + i] : kNoPrev;
+                        uint32_t winner;
+                        ok = query_nn_stack<kStack>(scene, reinterpret_cast<const float4 *>(lds_topo), stk_node, stk_lb, p[3 * i], p[3 * i + 1], p[3 * i + 2], c, seed, winner);
+                        if (nn_prev) nn_prev[j0 + i] = ok ? winner : kNoPrev;
+                    } else ok = query_nn<true>(scene, lds_topo, p[3 * i], p[3 * i + 1], p[3 * i + 2], c);
                     if (ok) { if constexpr (kScoreOnly) accumulate_score(acc, p[3 * i], p[3 * i + 1], p[3 * i + 2], c); else accumulate(acc, p[3 * i], p[3 * i + 1], p[3 * i + 2], c); }
                 }
             }
@@ -1369,7 +1405,8 @@ __global__ __launch_bounds__(256, PR_PASS_WAVES) void icp_pass_kernel(IcpBatch b
     }
 
     float *cl = reinterpret_cast<float *>(b.cloud + pm.start);
-    const bool xf = (st == kRunWithTransform);
+    const bool xf = (st == kRunWithTransform);                   // also: not the first pass of this cloud (a seed exists)
+    uint32_t *nn_prev = (kNN && b.nn_prev) ? b.nn_prev + pm.start : nullptr;
     float M[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) M[i] = xf ? pm.xform[i] : 0.0f;
@@ -1385,10 +1422,10 @@ __global__ __launch_bounds__(256, PR_PASS_WAVES) void icp_pass_kernel(IcpBatch b
         for (int i = 0; i < 29; ++i) acc[i] = 0.0f;
         float t;
         if (b.score_only) {                                      // uniform: the final pass needs sums 27 and 28 only
-            vb_accumulate<Scene, kNN, kStack, true>(acc, cl, n, vb * ppb, b.steps, xf, M, scene, lds_topo, stk_node, stk_lb);
+            vb_accumulate<Scene, kNN, kStack, true>(acc, cl, n, vb * ppb, b.steps, xf, M, scene, lds_topo, stk_node, stk_lb, nn_prev, xf);
             t = vb_reduce<true>(acc, wsum);
         } else {
-            vb_accumulate<Scene, kNN, kStack>(acc, cl, n, vb * ppb, b.steps, xf, M, scene, lds_topo, stk_node, stk_lb);
+            vb_accumulate<Scene, kNN, kStack>(acc, cl, n, vb * ppb, b.steps, xf, M, scene, lds_topo, stk_node, stk_lb, nn_prev, xf);
             t = vb_reduce(acc, wsum);
         }
         float *slot = b.partial + ((size_t)pose * b.nblk + vb) * kAccStride;
@@ -2012,7 +2049,7 @@ __global__ void nn_frame_kernel(const float4 *__restrict__ bmin, const float4 *_
 }
 __global__ __launch_bounds__(256) void nn_records32_kernel(const int4 *__restrict__ topo, const float4 *__restrict__ bmin,
                                                            const float4 *__restrict__ bmax, uint32_t n_nodes, uint4 *__restrict__ rec32,
-                                                           uint32_t *__restrict__ info)
+                                                           uint2 *__restrict__ desc, uint32_t *__restrict__ info)
 {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n_nodes) return;
@@ -2045,6 +2082,7 @@ __global__ __launch_bounds__(256) void nn_records32_kernel(const int4 *__restric
     }
     rec32[(size_t)i * 2] = make_uint4(w[0], w[1], w[2], w[3]);
     rec32[(size_t)i * 2 + 1] = make_uint4(w[4], w[5], w[6], w[7]);
+    desc[i] = make_uint2(w[0], w[1]);
     if (!ok) info[1] = 0u;                                       // any node that does not fit: the 64-byte records are used instead
 }
 
@@ -2337,7 +2375,7 @@ hipError_t launch_pack_proj_scene(const pr_vec3 *pcd, const pr_vec3 *normal, flo
     return hipGetLastError();
 }
 hipError_t launch_build_nn_accel(const pr_kdnode *nodes, uint32_t n_nodes, const pr_vec3 *pcd, uint32_t n_points,
-                                 int4 *topo, float4 *bmin, float4 *bmax, float4 *pts, float4 *rec, uint4 *rec32, uint32_t *info, hipStream_t s)
+                                 int4 *topo, float4 *bmin, float4 *bmax, float4 *pts, float4 *rec, uint4 *rec32, uint2 *desc, uint32_t *info, hipStream_t s)
 {
     const uint32_t m = (n_nodes > n_points) ? n_nodes : n_points;
     if (m == 0) return hipSuccess;
@@ -2346,7 +2384,7 @@ hipError_t launch_build_nn_accel(const pr_kdnode *nodes, uint32_t n_nodes, const
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(nn_records_kernel, dim3((n_nodes + 255) / 256), dim3(256), 0, s, topo, bmin, bmax, n_nodes, rec, info);
     hipLaunchKernelGGL(nn_frame_kernel, dim3(1), dim3(64), 0, s, bmin, bmax, info);
-    hipLaunchKernelGGL(nn_records32_kernel, dim3((n_nodes + 255) / 256), dim3(256), 0, s, topo, bmin, bmax, n_nodes, rec32, info);
+    hipLaunchKernelGGL(nn_records32_kernel, dim3((n_nodes + 255) / 256), dim3(256), 0, s, topo, bmin, bmax, n_nodes, rec32, desc, info);
     return hipGetLastError();
 }
 
