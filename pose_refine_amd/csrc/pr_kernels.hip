@@ -795,7 +795,7 @@ constexpr uint32_t kNoPrev = 0xffffffffu;
 // kCode = stack entries per lane (16 / 24), + 0x100 when the scene's compact 32-byte records are used
 template <int kCode>
 __device__ __forceinline__ bool query_nn_stack(const SceneNNDev &s, const float4 *lds_rec, int *stk_node, float *stk_lb, float sx, float sy, float sz, Corr &c,
-                                               uint32_t seed, uint32_t &winner)
+                                               uint32_t seed, uint32_t seed2, uint32_t &winner)
 {
     constexpr int kDepth = kCode & 0xff;
     constexpr bool kCompact = (kCode & 0x100) != 0;
@@ -813,9 +813,18 @@ __device__ __forceinline__ bool query_nn_stack(const SceneNNDev &s, const float4
         // part in a million, so that the point itself -- or an equal one visited earlier -- is still found by the search) bounds
         // the answer from the start.  The bound only removes subtrees and points that are strictly farther than an existing
         // point; winner, distance and tie-break are those of the unseeded search.
+        // seed  = the previous pass' winner of this cloud point (temporal),
+        // seed2 = the winner of the cloud point this lane handled just before (its neighbour in the image, 1-2 mm away): on
+        //         the first passes, when the cloud is still centimetres off the surface, that neighbour's answer is a far
+        //         tighter bound than anything the descent finds early
+        const pr_vec3 pa = s.pcd[seed != kNoPrev ? seed : 0u], pb = s.pcd[seed2 != kNoPrev ? seed2 : 0u];
         if (seed != kNoPrev) {
-            const pr_vec3 p = s.pcd[seed];
-            const float d2 = (sx - p.x) * (sx - p.x) + (sy - p.y) * (sy - p.y) + (sz - p.z) * (sz - p.z);
+            const float d2 = (sx - pa.x) * (sx - pa.x) + (sy - pa.y) * (sy - pa.y) + (sz - pa.z) * (sz - pa.z);
+            const float b = d2 * 1.000001f + 1e-30f;
+            if (b < best) best = b;
+        }
+        if (seed2 != kNoPrev) {
+            const float d2 = (sx - pb.x) * (sx - pb.x) + (sy - pb.y) * (sy - pb.y) + (sz - pb.z) * (sz - pb.z);
             const float b = d2 * 1.000001f + 1e-30f;
             if (b < best) best = b;
         }
@@ -1200,6 +1209,8 @@ __device__ __forceinline__ void vb_accumulate(float (&acc_out)[29], float *cl, u
     struct { uint32_t steps; } b{ steps };
     Acc29 acc;                                                   // the caller's sums start at zero
     acc_clear(acc);
+    uint32_t lane_winner = kNoPrev;                              // kd-tree scenes: the last neighbour this lane found (spatial seed)
+    (void)lane_winner;
     (void)lds_topo; (void)stk_node; (void)stk_lb;
     // one 1024-point step of this lane: 4 consecutive points = 48 contiguous bytes
     auto load_step = [&](uint32_t s, float (&p)[12], uint32_t &j0, uint32_t &cnt, bool &full) {
@@ -1245,8 +1256,10 @@ __device__ __forceinline__ void vb_accumulate(float (&acc_out)[29], float *cl, u
                     if constexpr (kStack > 0) {
                         const uint32_t seed = (nn_prev && nn_seeded) ? nn_prev[j0 + i] : kNoPrev;
                         uint32_t winner;
-                        ok = query_nn_stack<kStack>(scene, reinterpret_cast<const float4 *>(lds_topo), stk_node, stk_lb, p[3 * i], p[3 * i + 1], p[3 * i + 2], c, seed, winner);
+                        ok = query_nn_stack<kStack>(scene, reinterpret_cast<const float4 *>(lds_topo), stk_node, stk_lb, p[3 * i], p[3 * i + 1], p[3 * i + 2], c,
+                                                    seed, nn_prev ? lane_winner : kNoPrev, winner);
                         if (nn_prev) nn_prev[j0 + i] = ok ? winner : kNoPrev;
+                        if (ok) lane_winner = winner;
                     } else ok = query_nn<true>(scene, lds_topo, p[3 * i], p[3 * i + 1], p[3 * i + 2], c);
                     if (ok) { if constexpr (kScoreOnly) accumulate_score(acc, p[3 * i], p[3 * i + 1], p[3 * i + 2], c); else accumulate(acc, p[3 * i], p[3 * i + 1], p[3 * i + 2], c); }
                 }
