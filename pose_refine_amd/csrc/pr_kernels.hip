@@ -787,6 +787,9 @@ constexpr int kLeafBatch = PR_LEAF_BATCH;
 #ifndef PR_NN_LEAF12
 #define PR_NN_LEAF12 1
 #endif
+#ifndef PR_NN_NEAR_TEST
+#define PR_NN_NEAR_TEST 1
+#endif
 #ifndef PR_NN_WIDE_BOUND
 #define PR_NN_WIDE_BOUND 4.0e-6f                                // (2 mm)^2: above it a node's whole record is fetched at once
 #endif
@@ -861,6 +864,26 @@ __device__ __forceinline__ bool query_nn_stack(const SceneNNDev &s, const float4
                     const float lb = box_dist_sq(sx, sy, sz, lo, hi);
                     if (lb <= best) { stk_node[sp * kBlockThreads] = far_c; stk_lb[sp * kBlockThreads] = lb; ++sp; }
                 }
+#if PR_NN_NEAR_TEST
+                // While the bound is wide the record is in registers anyway: the near child is entered only if its own box is
+                // within the bound (the reference walks into it unconditionally and finds nothing there).
+                if (wide) {
+                    const uint32_t v0 = left_near ? A.z : B.y, v1 = left_near ? A.w : B.z, v2 = left_near ? B.x : B.w;
+                    const float4 nlo = make_float4(nn_deq(v0 & 0xffffu, s.qmin[0], s.qscale[0]), nn_deq(v0 >> 16, s.qmin[1], s.qscale[1]),
+                                                   nn_deq(v1 & 0xffffu, s.qmin[2], s.qscale[2]), 0.0f);
+                    const float4 nhi = make_float4(nn_deq(v1 >> 16, s.qmin[0], s.qscale[0]), nn_deq(v2 & 0xffffu, s.qmin[1], s.qscale[1]),
+                                                   nn_deq(v2 >> 16, s.qmin[2], s.qscale[2]), 0.0f);
+                    if (!(box_dist_sq(sx, sy, sz, nlo, nhi) <= best)) {
+                        bool found = false;
+                        while (sp > 0) {
+                            --sp;
+                            if (stk_lb[sp * kBlockThreads] <= best) { cur = stk_node[sp * kBlockThreads]; found = true; break; }
+                        }
+                        if (!found) break;
+                        continue;
+                    }
+                }
+#endif
                 cur = near_c;
                 continue;
             }
