@@ -2203,6 +2203,7 @@ hipError_t launch_render_boxes(const pr_triangle *tris, uint32_t n_tris, const p
         const uint32_t np = (n_poses - p0 < 32768) ? (n_poses - p0) : 32768;
         const size_t off = (size_t)p0 * width * height;
         hipLaunchKernelGGL(fill_box_kernel, dim3((height + kBoxRowsPerBlock - 1) / kBoxRowsPerBlock, np), dim3(256), 0, s, depth + off, bbox + p0, width, height);
+        if (n_tris > 0)                                          // an empty mesh renders nothing: every cloud is empty
         hipLaunchKernelGGL(raster_kernel, dim3((n_tris + 255) / 256, np), dim3(256), 0, s, tris, n_tris, poses_dev + p0, depth + off,
                            width, height, proj, none, width, height, (const int4 *)(bbox + p0));
         hipLaunchKernelGGL(count_box_kernel, dim3((height + kBoxRowsPerBlock - 1) / kBoxRowsPerBlock, np), dim3(256), 0, s, depth + off, bbox + p0, width, height,
