@@ -147,7 +147,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    api.set_option("profile", 1 if args.sequential else 2)   # 2: HIP events around ONE launch of one step in 32 (rotating iteration)
+    api.set_option("profile", 1 if args.sequential else 2)   # 2: HIP events around every launch of one step in 32
     api.profile_reset()
     fence()
     t0 = time.perf_counter()
@@ -199,9 +199,10 @@ def main():
                          "avg_launch_us": avg_launch_s * 1e6, "launches": int(launches),
                          "algorithmic_bytes_per_launch": bytes_per_launch, "points_per_launch": pts_per_launch,
                          "timing": ("HIP events on the library stream around every launch (--sequential: synchronous single-group steps)" if args.sequential else
-                                    "HIP events on the library stream around one launch every 32nd step, rotating over the 21 passes; "
+                                    "HIP events on the library stream around every launch of one step in 32; "
                                     "a timed step runs synchronously as one pose group (other slot drained) so the launch has the chip to itself")},
-            "phase_ms_per_timed_step": {"render": prof["render_ms"] / launches, "cloud": prof["cloud_ms"] / launches},
+            "phase_ms_per_timed_step": {"render": prof["render_ms"] / max(1, launches // (args.iters + 1)),
+                                        "cloud": prof["cloud_ms"] / max(1, launches // (args.iters + 1))},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, model.tris, poses, scene_depth, K, W, H)

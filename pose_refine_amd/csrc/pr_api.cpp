@@ -376,11 +376,10 @@ int icp_drive(pr_vec3 *cloud_base, const uint32_t *start_h, const uint32_t *coun
             return PR_OK;
         }
 
-        // profile==2: time ONE correspondence launch per call, at an iteration index that rotates from call to call
-        // (and only every kSamplePeriod-th call: a timed call runs synchronously, as one pose group, with the other slot drained)
+        // profile==2: every kSamplePeriod-th call is a timed call -- it runs synchronously, as one pose group, with the other slot
+        // drained, and times every correspondence launch of its loop
         const uint64_t tick = g.sample_clock++;
         const bool sample_call = (g.profile == 2) && (tick % kSamplePeriod == 0);
-        const uint32_t sample_it = (uint32_t)(((tick / kSamplePeriod) * 5 + 1) % (uint64_t)(crit.max_iteration + 1));
         // Pose groups: the batch is split over up to four streams so that one group's serial solve tail (and the ragged end
         // of its pass) overlaps another group's pass.  Timed launches (profile 1, the sampled call of profile 2) run as a
         // single group so that the measured kernel has the chip to itself.
@@ -407,10 +406,13 @@ int icp_drive(pr_vec3 *cloud_base, const uint32_t *start_h, const uint32_t *coun
                     bb.meta += p0; bb.partial += (size_t)p0 * nblk * prk::kAccStride;
                     if (fused) { bb.fused = 1; bb.iter = it; bb.crit = crit; bb.st = g.dstate.as<prk::DevIcpState>() + p0; bb.arrive = g.arrive.as<uint32_t>() + p0; }
                     bb.score_only = (it == (uint32_t)crit.max_iteration) ? 1u : 0u;
-                    if (grp == 0 && (g.profile == 1 || (sample_call && it == sample_it))) {
+                    if (grp == 0 && (g.profile == 1 || sample_call)) {           // a timed call times every launch of its loop
                         SpanGuard sp(kSpanIcp); HIP_TRY(launch_pass(bb, sc, np, st));
                         uint64_t pts = 0; for (uint32_t i = p0; i < p0 + np; ++i) pts += count_h[i];
-                        g.icp_points += pts; g.icp_bytes += pts * (it == 0 ? 36u : 48u);
+                        // algorithmic bytes per point: 12 read + 24 gathered, + 12 written back once a transform is
+                        // pending; the score-only last pass needs the scene point but not its normal (12 + 12 + 12)
+                        const bool first = (it == 0), last = (it == (uint32_t)crit.max_iteration);
+                        g.icp_points += pts; g.icp_bytes += pts * ((first || last) ? 36u : 48u);
                     } else HIP_TRY(launch_pass(bb, sc, np, st));
                     if (!fused) HIP_TRY(prk::launch_icp_finalize_solve(bb.partial, g.meta.as<prk::PoseMeta>() + p0, nblk, steps,
                                                                        g.dstate.as<prk::DevIcpState>() + p0, crit, it, np, st));
