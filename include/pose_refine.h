@@ -181,12 +181,28 @@ int pr_refine_wait(int slot);
 void pr_shard_range(uint32_t n_items, uint32_t rank, uint32_t world, uint32_t *first, uint32_t *count);
 
 /* ---- options / instrumentation ----------------------------------------------------------------- */
-int  pr_set_option(const char *name, int value);    /* "solve" = PR_SOLVE_HOST|PR_SOLVE_DEVICE, "points_per_block", "profile", "nn_lds_nodes", "raster_mode" (fused path: 0 = global atomicMin inside the pose box, 1 = LDS depth bands), "pose_groups" (1|2 streams in the device-solve loop), "graph" (device solve: replay the iteration loop as a hipGraph), "icp_flow" (device solve: 1 = one persistent dataflow launch, 0 = launch per pass), "nn_stack" */
+/* pr_set_option names (all int; defaults in brackets).  None of them changes a result bit, except "points_per_block", which
+ * selects the reduction tree and therefore the last bits of the sums (DESIGN.md "canonical tree").
+ *   "solve"            [PR_SOLVE_HOST] PR_SOLVE_HOST = reference-style host solve per iteration, PR_SOLVE_DEVICE = loop on the device
+ *   "points_per_block" [2048]  points per workgroup of the correspondence pass (multiple of 1024)
+ *   "fused_solve"      [1]     device solve: finalize + 6x6 solve in the tail of the pass kernel instead of a second launch
+ *   "pose_groups"      [2]     device solve: streams the batch is split over (1..4)
+ *   "graph"            [1]     device solve, one pose group, synchronous path: replay the loop as a hipGraph
+ *   "icp_flow"         [0]     device solve: one persistent dataflow launch for all iterations
+ *   "sub_batch"        [512]   asynchronous path: hypotheses per sub-batch (cache residency of the clouds)
+ *   "overlap_pass"     [-1]    asynchronous path: the other slot's render may start after this pass of a slot's loop (-1 = 70 %)
+ *   "raster_mode"      [0]     fused render: 0 = global atomicMin inside the pose's pixel box, 1 = LDS depth bands (synchronous path)
+ *   "nn_stack"         [1]     kd-tree query: per-lane LDS stack (1) or the reference's stackless walk (0)
+ *   "nn_compact"       [1]     stack query on 32-byte node records with 16-bit outward-rounded boxes (0: exact 64-byte records)
+ *   "nn_seed"          [1]     compact records: start every search from the previous pass' / previous point's winner distance
+ *   "nn_lds_nodes"     [1024]  stackless query: leading nodes staged in LDS;  "nn_lds_records" [0]: the same for 64-byte records
+ *   "profile"          [0]     see below */
+int  pr_set_option(const char *name, int value);
 int  pr_get_option(const char *name, int *value);
-/* HIP-event timing of the correspondence kernel on the library stream: option "profile" = 1 times
- * every launch, 2 times one launch per call at a rotating iteration index (negligible overhead).
- * Accumulated since the last reset: launches timed, model points they processed, and their
- * algorithmic bytes (36 B/point on the first pass of a cloud, 48 B/point afterwards). */
+/* HIP-event timing of the correspondence kernel on the library stream: option "profile" = 1 times every launch (all calls run
+ * synchronously as one pose group), 2 does so for one call in 32 (the other calls are unaffected).
+ * Accumulated since the last reset: launches timed, model points they processed, and their algorithmic bytes (36 B/point on
+ * the first pass of a cloud and on the score-only last pass, 48 B/point in between). */
 int  pr_profile_reset(void);
 int  pr_profile_read(double *kernel_ms, uint64_t *launches, uint64_t *points, uint64_t *algorithmic_bytes,
                      double *render_ms, double *cloud_ms);

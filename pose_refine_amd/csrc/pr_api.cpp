@@ -1214,7 +1214,7 @@ int pr_set_option(const char *name, int value)
     const std::string n(name);
     if (n == "solve") { if (value != PR_SOLVE_HOST && value != PR_SOLVE_DEVICE) { set_error("solve must be 0 or 1"); return PR_ERR_INVALID; } g.solve_mode = value; }
     else if (n == "points_per_block") { if (value < 1024 || value % 1024) { set_error("points_per_block must be a multiple of 1024"); return PR_ERR_INVALID; } g.steps = value / 1024; }
-    else if (n == "profile") { if (value < 0 || value > 2) { set_error("profile must be 0, 1 (every launch) or 2 (one sampled launch per call)"); return PR_ERR_INVALID; } g.profile = value; }
+    else if (n == "profile") { if (value < 0 || value > 2) { set_error("profile must be 0, 1 (every launch) or 2 (every launch of one call in 32)"); return PR_ERR_INVALID; } g.profile = value; }
     else if (n == "nn_lds_nodes") g.nn_lds_nodes = std::max(0, value);
     else if (n == "nn_lds_records") g.nn_lds_records = std::max(0, value);
     else if (n == "nn_compact") g.nn_compact = value ? 1 : 0;
