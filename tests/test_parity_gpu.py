@@ -174,7 +174,7 @@ def test_icp_degenerate_clouds(gpu, scenario, gscenes):
 
 
 # ---- fused batch: BASELINE.json configs[1]/[2] at parity-test size -----------------------------------
-@pytest.mark.parametrize("kind,P", [("proj", 24), ("nn", 6)])
+@pytest.mark.parametrize("kind,P", [("proj", 24), ("nn", 6), ("nn", 24)])
 @pytest.mark.parametrize("solve", [api.SOLVE_HOST, api.SOLVE_DEVICE])
 def test_refine_batch_against_oracle(gpu, model, scenario, gscenes, kind, P, solve):
     api.set_option("solve", solve)
