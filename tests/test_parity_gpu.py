@@ -425,3 +425,44 @@ def test_device_kdtree_build_random_points_with_ties(gpu, max_leaf, n):
     assert dcnt.value == cnt.value
     assert dnodes.to_host()[:cnt.value].tobytes() == hnodes[:cnt.value].tobytes()
     assert np.array_equal(dp.to_host(), hp.reshape(-1)) and np.array_equal(dn.to_host(), hn.reshape(-1))
+
+
+@pytest.mark.parametrize("seed,n,max_leaf", [(1, 4000, 10), (2, 900, 3), (3, 6000, 10)])
+def test_nn_variants_agree_on_tie_heavy_clouds(gpu, seed, n, max_leaf):
+    """Scene and model points on a coarse lattice with duplicates: many candidate neighbours are at EXACTLY the same distance,
+    so the winner is decided by the traversal order alone.  The compact/seeded/near-test stack search, the exact 64-byte
+    stack search and the reference-style stackless walk must pick the same neighbours through all passes (bitwise equal
+    transforms, scores and transformed clouds), with fixed and with early-exit criteria."""
+    import ctypes as C
+    from pose_refine_amd import _lib
+    rng = np.random.default_rng(seed)
+    pts = (np.round(rng.uniform(-0.2, 0.2, size=(n, 3)) * 50) / 50).astype(np.float32)      # 8 mm lattice
+    pts = np.concatenate([pts, pts[: n // 10]])                                             # exact duplicates
+    nrm = rng.normal(size=pts.shape).astype(np.float32)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    nodes = np.zeros(2 * len(pts) + 1, _lib.KDNODE); cnt = C.c_uint32()
+    _lib.check(_lib.load().pr_kdtree_build(pts.ctypes.data, nrm.ctypes.data, len(pts), max_leaf, nodes.ctypes.data, len(nodes), C.byref(cnt)))
+    scene = api.Scene_nn()
+    scene.max_dist_diff = 0.1
+    scene.pcd_host, scene.normal_host, scene.nodes_host = pts, nrm, np.ascontiguousarray(nodes[:cnt.value])
+    scene.pcd_buffer = api.DeviceVector.from_host(pts.reshape(-1))
+    scene.normal_buffer = api.DeviceVector.from_host(nrm.reshape(-1))
+    scene.nodes = api.DeviceVector.from_host(scene.nodes_host)
+    cloud = (np.round(rng.uniform(-0.2, 0.2, size=(3000, 3)) * 100) / 100 + np.float32(0.004)).astype(np.float32)   # 4 mm off the lattice planes
+    try:
+        for solve in (api.SOLVE_HOST, api.SOLVE_DEVICE):
+            api.set_option("solve", solve)
+            for crit in ((0.0, 0.0, 12), (1e-5, 1e-5, 30)):
+                out = []
+                for stack, compact, seeded in ((1, 1, 1), (1, 1, 0), (1, 0, 0), (0, 0, 0)):
+                    api.set_option("nn_stack", stack); api.set_option("nn_compact", compact); api.set_option("nn_seed", seeded)
+                    dev = api.DeviceVector.from_host(cloud.reshape(-1))
+                    r = api.ICP_Point2Plane(dev, scene, api.ICPConvergenceCriteria(*crit))
+                    out.append((r.transformation_.copy(), r.fitness_, r.inlier_rmse_, dev.to_host()))
+                assert out[-1][1] > 0.5                                                      # the searches do find neighbours
+                for o in out[:-1]:
+                    assert np.array_equal(out[-1][0], o[0]) and out[-1][1] == o[1] and out[-1][2] == o[2], (solve, crit)
+                    assert np.array_equal(out[-1][3], o[3]), (solve, crit)
+    finally:
+        api.set_option("nn_stack", 1); api.set_option("nn_compact", 1); api.set_option("nn_seed", 1)
+        api.set_option("solve", api.SOLVE_HOST)
