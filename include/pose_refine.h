@@ -12,8 +12,24 @@
  * else is host memory.  All functions return PR_OK (0) or a negative error code; the message of
  * the last failure on the calling thread is available from pr_last_error().  There is NO CPU
  * fallback: every device entry point fails with PR_ERR_NO_DEVICE when no gfx950 device is usable.
- * Work is issued on one library-owned HIP stream per device context; calls are synchronous with
- * respect to the host unless stated otherwise.
+ * Work is issued on one library-owned HIP stream per context; calls are synchronous with respect to the host unless
+ * stated otherwise.
+ *
+ * Contexts and threads.  There is one shared context per device, created by pr_init(device) (or on first use: device 0).
+ * A host thread works on the context it last selected with pr_init / pr_set_device; threads that never selected one use the
+ * device of the process' first pr_init.  Calls on one context are serialised (a mutex per context); contexts of different
+ * devices run side by side, which is how a C++ host drives N GPUs: one thread per device, pr_set_device(d) first.  Threads
+ * that each refine their own hypotheses on the SAME device (the reference's usage, README.md:15 / icp.cu:170 per-thread
+ * streams) call pr_thread_context(1) once to get a private context (own stream and workspaces) instead of queueing on the
+ * shared one.  Options (pr_set_option) are process-wide.
+ *
+ * Caches and caller-owned memory.  Derived data is cached by the address of the buffers it was derived from: the packed copy
+ * of a projective scene (pcd / normal arrays), the traversal records of a kd-tree scene (pcd / nodes arrays) and the model box
+ * of a triangle buffer.  The model box is re-verified on the device by every batch that uses it, so a rewritten mesh is never
+ * rendered with a stale box.  The scene caches are dropped by every write that goes through this library (pr_memcpy_*,
+ * pr_fill_i32, pr_free, pr_render, the *_prepare_dev / *_build_dev / *_crop_dev functions); a caller that rewrites a scene
+ * array by other means (its own kernels, raw hipMemcpy) MUST announce it with pr_invalidate(ptr, bytes) before the next ICP /
+ * refine call, or switch the caches off with pr_set_option("scene_cache", 0).
  */
 #ifndef POSE_REFINE_H
 #define POSE_REFINE_H
@@ -31,6 +47,7 @@ extern "C" {
 #define PR_ERR_INVALID       -3
 #define PR_ERR_IO            -4
 #define PR_ERR_NOMEM         -5
+#define PR_ERR_COMM          -6     /* RCCL: library not loadable, communicator missing, or a collective failed */
 
 /* ---- POD mirrors of the reference types (layouts verified by static_assert in the adapters) -- */
 typedef struct { float x, y, z; } pr_vec3;                         /* ::Vec3f geometry.h:83-103; Model::float3 renderer.h:50-57 (12 B) */
@@ -65,8 +82,17 @@ typedef struct {
     uint32_t n_points, n_nodes;
 } pr_scene_nn;
 
-#define PR_SCENE_PROJ 0
-#define PR_SCENE_NN   1
+/* A Scene_projective whose arrays cover only a window of the frame: pcd2dep(src, K, tl_x, tl_y) / dep2pcd(x, y, d, K, tl_x, tl_y)
+ * (common.h:47-73) with the offsets the reference declares but never passes.  view.width / view.height are
+ * the window's size, pixel (x, y) of the arrays is frame pixel (x + tl_x, y + tl_y). */
+typedef struct {
+    pr_scene_proj view;
+    uint32_t tl_x, tl_y;
+} pr_scene_proj_crop;
+
+#define PR_SCENE_PROJ      0
+#define PR_SCENE_NN        1
+#define PR_SCENE_PROJ_CROP 2      /* scene argument is a pr_scene_proj_crop */
 
 /* where the 6x6 solve of every ICP iteration runs (icp.cu:207 does it on the host) */
 #define PR_SOLVE_HOST   0
@@ -76,9 +102,11 @@ typedef struct {
 const char *pr_last_error(void);
 const char *pr_version(void);
 int pr_device_count(void);                       /* number of visible HIP devices (0 if none)              */
-int pr_init(int device);                         /* select device, create the stream (test.cpp:12-20 warm-up) */
-int pr_shutdown(void);                           /* release cached workspaces + stream                      */
-int pr_sync(void);                               /* wait for the library stream                              */
+int pr_init(int device);                         /* bind the calling thread to the device's shared context, create its stream (test.cpp:12-20 warm-up) */
+int pr_set_device(int device);                   /* same (cudaSetDevice, which test.cpp:14 leaves commented out)                 */
+int pr_thread_context(int enable);               /* 1: private context for the calling thread on its current device; 0: release it */
+int pr_shutdown(void);                           /* release the calling thread's context: workspaces, streams, communicator    */
+int pr_sync(void);                               /* wait for the context's stream                                               */
 
 /* device_vector_holder<T> storage: common.cu:3-40, renderer.cu:15-50 */
 int pr_malloc(void **dev_ptr, size_t bytes);
@@ -87,6 +115,8 @@ int pr_memcpy_h2d(void *dev_dst, const void *host_src, size_t bytes);
 int pr_memcpy_d2h(void *host_dst, const void *dev_src, size_t bytes);
 int pr_memcpy_d2d(void *dev_dst, const void *dev_src, size_t bytes);
 int pr_fill_i32(int32_t *dev_dst, size_t count, int32_t value);   /* holder(size, init) fill ctor */
+/* [dev_ptr, dev_ptr + bytes) was written behind the library's back (bytes = 0: the whole allocation) -- see "Caches" above */
+int pr_invalidate(const void *dev_ptr, size_t bytes);
 
 /* ---- host-side model / scene preparation (CPU in the reference too) --------------------------- */
 /* Model::Model(fileName) renderer.cpp:11-58: ASCII PLY -> triangle list (only tris feed this path). */
@@ -104,6 +134,9 @@ int pr_scene_proj_prepare(const void *depth, int depth_is_i32, const float K[9],
  * Bit-identical to pr_scene_proj_prepare. */
 int pr_scene_proj_prepare_dev(const void *depth_dev, int depth_is_i32, const float K[9], size_t width, size_t height,
                               pr_vec3 *pcd_dev_out, pr_vec3 *normal_dev_out);
+/* A window of a prepared full-frame scene as arrays of its own (rows of `window`, window.width * window.height entries each) */
+int pr_scene_proj_crop_dev(const pr_vec3 *pcd_full_dev, const pr_vec3 *normal_full_dev, size_t width, size_t height, pr_roi window,
+                           pr_vec3 *pcd_out_dev, pr_vec3 *normal_out_dev);
 /* init_Scene_nn_cpu pcd_scene.cpp:4-37 + KDTree_cpu::build_tree pcd_scene.cpp:45-184.
  * pcd_out/normal_out need width*height entries, nodes_out 2*width*height+1 entries (worst case). */
 int pr_scene_nn_prepare(const void *depth, int depth_is_i32, const float K[9], int width, int height,
@@ -165,6 +198,14 @@ int pr_refine_batch_dev(const pr_triangle *tris_dev, size_t n_tris, const pr_mat
                         int scene_kind, const void *scene, pr_criteria crit,
                         pr_result *results_dev, uint32_t *cloud_sizes_host);
 
+/* The same with the hypotheses rendered only inside `roi` (renderer.h:199 ROI {x, y, width, height} in image rows, renderer.cu:106-113)
+ * and the clouds extracted with tl_x = roi.x, tl_y = roi.y (icp.h:57-60): clouds hold the rendered pixels inside the window, with
+ * the coordinates they have in the full frame.  roi.width / roi.height <= 0 means no ROI. */
+int pr_refine_batch_roi(const pr_triangle *tris_dev, size_t n_tris, const pr_mat4 *poses_host, uint32_t n_poses,
+                        uint32_t width, uint32_t height, const pr_mat4 *proj, const float K[9],
+                        int scene_kind, const void *scene, pr_criteria crit, pr_roi roi,
+                        pr_result *results_host, uint32_t *cloud_sizes_host);
+
 /* Asynchronous form of the two calls above (no counterpart in the reference, whose ICP() blocks): pr_refine_submit
  * enqueues one batch on `slot` (0 or 1) and returns; pr_refine_wait(slot) blocks until that batch is finished and
  * fills results_host / cloud_sizes_host (results_dev is complete at that point as well).  Exactly one of results_host /
@@ -175,10 +216,29 @@ int pr_refine_submit(int slot, const pr_triangle *tris_dev, size_t n_tris, const
                      uint32_t width, uint32_t height, const pr_mat4 *proj, const float K[9],
                      int scene_kind, const void *scene, pr_criteria crit,
                      pr_result *results_host, pr_result *results_dev, uint32_t *cloud_sizes_host);
+int pr_refine_submit_roi(int slot, const pr_triangle *tris_dev, size_t n_tris, const pr_mat4 *poses_host, uint32_t n_poses,
+                         uint32_t width, uint32_t height, const pr_mat4 *proj, const float K[9],
+                         int scene_kind, const void *scene, pr_criteria crit, pr_roi roi,
+                         pr_result *results_host, pr_result *results_dev, uint32_t *cloud_sizes_host);
 int pr_refine_wait(int slot);
 
 /* ---- sharding of a hypothesis batch over ranks (contiguous blocks) ---------------- */
 void pr_shard_range(uint32_t n_items, uint32_t rank, uint32_t world, uint32_t *first, uint32_t *count);
+
+/* ---- the job's one collective: gather of the solved transforms over RCCL / xGMI -- */
+/* The reference is single-GPU (test.cpp:14).  Hypotheses are independent, so ranks never exchange data on the path itself;
+ * the P/G x 72-byte RegistrationResult records of every rank are gathered once.  librccl is opened on first use.
+ *   one process, one host thread per GPU:  pr_comm_init_all(G) once, then thread d: pr_set_device(d) ... pr_gather_results(...)
+ *   one process per GPU:  rank 0 calls pr_comm_id and hands the 128 bytes to the others (any channel), all call pr_comm_init_rank */
+#define PR_COMM_ID_BYTES 128
+int pr_comm_id(unsigned char id_out[PR_COMM_ID_BYTES]);                                   /* ncclGetUniqueId */
+int pr_comm_init_rank(const unsigned char id[PR_COMM_ID_BYTES], int rank, int world);     /* the calling thread's context becomes rank `rank` */
+int pr_comm_init_all(int n_devices);                                                      /* shared contexts of devices 0..n-1, rank = device */
+int pr_comm_rank(int *rank, int *world);
+int pr_comm_destroy(void);
+/* rank r sends its pr_shard_range(n_total, r, world) block (n_local records, device memory); recv_dev (root only, n_total
+ * records) receives all blocks in global hypothesis order.  Enqueued on the context's stream: pr_sync / pr_memcpy_d2h order after it. */
+int pr_gather_results(const pr_result *send_dev, uint32_t n_local, uint32_t n_total, int root, pr_result *recv_dev);
 
 /* ---- options / instrumentation ----------------------------------------------------------------- */
 /* pr_set_option names (all int; defaults in brackets).  None of them changes a result bit, except "points_per_block", which
@@ -196,11 +256,12 @@ void pr_shard_range(uint32_t n_items, uint32_t rank, uint32_t world, uint32_t *f
  *   "nn_compact"       [1]     stack query on 32-byte node records with 16-bit outward-rounded boxes (0: exact 64-byte records)
  *   "nn_seed"          [1]     compact records: start every search from the previous pass' / previous point's winner distance
  *   "nn_lds_nodes"     [1024]  stackless query: leading nodes staged in LDS;  "nn_lds_records" [0]: the same for 64-byte records
- *   "profile"          [0]     see below */
+ *   "profile"          [0]     see below;  "sample_period" [32]: profile 2 times one call in this many
+ *   "scene_cache"      [1]     keep derived scene data between calls (see "Caches" at the top) */
 int  pr_set_option(const char *name, int value);
 int  pr_get_option(const char *name, int *value);
 /* HIP-event timing of the correspondence kernel on the library stream: option "profile" = 1 times every launch (all calls run
- * synchronously as one pose group), 2 does so for one call in 32 (the other calls are unaffected).
+ * synchronously as one pose group), 2 does so for one call in `sample_period` (the other calls are unaffected).
  * Accumulated since the last reset: launches timed, model points they processed, and their algorithmic bytes (36 B/point on
  * the first pass of a cloud and on the score-only last pass, 48 B/point in between). */
 int  pr_profile_reset(void);

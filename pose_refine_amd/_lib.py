@@ -15,8 +15,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libpose_refine_hip.so")
 
 PR_OK = 0
-PR_ERR_NO_DEVICE, PR_ERR_HIP, PR_ERR_INVALID, PR_ERR_IO, PR_ERR_NOMEM = -1, -2, -3, -4, -5
-SCENE_PROJ, SCENE_NN = 0, 1
+PR_ERR_NO_DEVICE, PR_ERR_HIP, PR_ERR_INVALID, PR_ERR_IO, PR_ERR_NOMEM, PR_ERR_COMM = -1, -2, -3, -4, -5, -6
+SCENE_PROJ, SCENE_NN, SCENE_PROJ_CROP = 0, 1, 2
+COMM_ID_BYTES = 128
 SOLVE_HOST, SOLVE_DEVICE = 0, 1
 
 KDNODE = np.dtype([("parent", "<i4"), ("child1", "<i4"), ("child2", "<i4"), ("split_v", "<f4"),
@@ -44,6 +45,10 @@ class SceneProjDesc(C.Structure):
                 ("pcd", C.c_void_p), ("normal", C.c_void_p)]
 
 
+class SceneProjCropDesc(C.Structure):
+    _fields_ = [("view", SceneProjDesc), ("tl_x", C.c_uint32), ("tl_y", C.c_uint32)]
+
+
 class SceneNNDesc(C.Structure):
     _fields_ = [("max_dist_diff", C.c_float), ("pcd", C.c_void_p), ("normal", C.c_void_p), ("nodes", C.c_void_p),
                 ("n_points", C.c_uint32), ("n_nodes", C.c_uint32)]
@@ -56,6 +61,8 @@ SIGNATURES = {
     "pr_version": (C.c_char_p, []),
     "pr_device_count": (_i32, []),
     "pr_init": (_i32, [_i32]),
+    "pr_set_device": (_i32, [_i32]),
+    "pr_thread_context": (_i32, [_i32]),
     "pr_shutdown": (_i32, []),
     "pr_sync": (_i32, []),
     "pr_malloc": (_i32, [C.POINTER(_vp), _sz]),
@@ -64,6 +71,8 @@ SIGNATURES = {
     "pr_memcpy_d2h": (_i32, [_vp, _vp, _sz]),
     "pr_memcpy_d2d": (_i32, [_vp, _vp, _sz]),
     "pr_fill_i32": (_i32, [_vp, _sz, C.c_int32]),
+    "pr_invalidate": (_i32, [_vp, _sz]),
+    "pr_scene_proj_crop_dev": (_i32, [_vp, _vp, _sz, _sz, Roi, _vp, _vp]),
     "pr_ply_count": (_i32, [C.c_char_p, C.POINTER(_sz), C.POINTER(_sz)]),
     "pr_ply_load": (_i32, [C.c_char_p, _vp, _sz, C.POINTER(_sz)]),
     "pr_compute_proj": (None, [_vp, _i32, _i32, C.c_float, C.c_float, _vp]),
@@ -86,7 +95,15 @@ SIGNATURES = {
     "pr_refine_batch": (_i32, [_vp, _sz, _vp, _u32, _u32, _u32, _vp, _vp, _i32, _vp, Criteria, _vp, _vp]),
     "pr_refine_batch_dev": (_i32, [_vp, _sz, _vp, _u32, _u32, _u32, _vp, _vp, _i32, _vp, Criteria, _vp, _vp]),
     "pr_refine_submit": (_i32, [_i32, _vp, _sz, _vp, _u32, _u32, _u32, _vp, _vp, _i32, _vp, Criteria, _vp, _vp, _vp]),
+    "pr_refine_batch_roi": (_i32, [_vp, _sz, _vp, _u32, _u32, _u32, _vp, _vp, _i32, _vp, Criteria, Roi, _vp, _vp]),
+    "pr_refine_submit_roi": (_i32, [_i32, _vp, _sz, _vp, _u32, _u32, _u32, _vp, _vp, _i32, _vp, Criteria, Roi, _vp, _vp, _vp]),
     "pr_refine_wait": (_i32, [_i32]),
+    "pr_comm_id": (_i32, [_vp]),
+    "pr_comm_init_rank": (_i32, [_vp, _i32, _i32]),
+    "pr_comm_init_all": (_i32, [_i32]),
+    "pr_comm_rank": (_i32, [C.POINTER(_i32), C.POINTER(_i32)]),
+    "pr_comm_destroy": (_i32, []),
+    "pr_gather_results": (_i32, [_vp, _u32, _u32, _i32, _vp]),
     "pr_shard_range": (None, [_u32, _u32, _u32, C.POINTER(_u32), C.POINTER(_u32)]),
     "pr_set_option": (_i32, [C.c_char_p, _i32]),
     "pr_get_option": (_i32, [C.c_char_p, C.POINTER(_i32)]),

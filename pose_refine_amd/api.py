@@ -23,8 +23,8 @@ from typing import Optional, Sequence
 import numpy as np
 
 from . import _lib
-from ._lib import (Criteria, KDNODE, RESULT, Roi, SCENE_NN, SCENE_PROJ, SOLVE_DEVICE, SOLVE_HOST, PoseRefineError,
-                   SceneNNDesc, SceneProjDesc, check, ptr)
+from ._lib import (COMM_ID_BYTES, Criteria, KDNODE, RESULT, Roi, SCENE_NN, SCENE_PROJ, SCENE_PROJ_CROP, SOLVE_DEVICE, SOLVE_HOST,
+                   PoseRefineError, SceneNNDesc, SceneProjCropDesc, SceneProjDesc, check, ptr)
 
 
 def _f32(a, shape=None):
@@ -39,8 +39,60 @@ def init(device: int = 0):
     check(_lib.load().pr_init(device))
 
 
+def set_device(device: int):
+    """Bind the calling thread to the shared context of ``device`` (one host thread per GPU)."""
+    check(_lib.load().pr_set_device(device))
+
+
+def thread_context(enable: bool = True):
+    """Private context (own stream / workspaces) for the calling thread: the reference's "many host threads,
+    each driving its own pose" usage (README.md:15) without queueing on the device's shared context."""
+    check(_lib.load().pr_thread_context(1 if enable else 0))
+
+
+def invalidate(dev_ptr: int, nbytes: int = 0):
+    """Announce a write to device memory the library could not see (drops derived scene data cached by address)."""
+    check(_lib.load().pr_invalidate(int(dev_ptr), int(nbytes)))
+
+
 def device_count() -> int:
     return _lib.load().pr_device_count()
+
+
+# ---- the job's one collective (C ABI over RCCL) -------------------------------------------------------------------------
+def comm_id() -> bytes:
+    buf = (C.c_ubyte * COMM_ID_BYTES)()
+    check(_lib.load().pr_comm_id(buf))
+    return bytes(buf)
+
+
+def comm_init_rank(comm_id_bytes: bytes, rank: int, world: int):
+    buf = (C.c_ubyte * COMM_ID_BYTES).from_buffer_copy(comm_id_bytes)
+    check(_lib.load().pr_comm_init_rank(buf, rank, world))
+
+
+def comm_init_all(n_devices: int):
+    check(_lib.load().pr_comm_init_all(n_devices))
+
+
+def comm_destroy():
+    check(_lib.load().pr_comm_destroy())
+
+
+def comm_rank():
+    r, w = C.c_int(), C.c_int()
+    check(_lib.load().pr_comm_rank(C.byref(r), C.byref(w)))
+    return r.value, w.value
+
+
+def gather_results(send_dev: int, n_local: int, n_total: int, root: int = 0, recv_dev: Optional[int] = None):
+    """``pr_gather_results``: this rank's shard (device memory) -> ``recv_dev`` on root, global hypothesis order.
+    Enqueued on the context's stream."""
+    check(_lib.load().pr_gather_results(int(send_dev) if send_dev else None, n_local, n_total, root, int(recv_dev) if recv_dev else None))
+
+
+def sync():
+    check(_lib.load().pr_sync())
 
 
 def set_option(name: str, value: int):
@@ -273,10 +325,28 @@ class Scene_projective:
         return self
 
     kind = SCENE_PROJ
+    tl_x = tl_y = 0
 
-    def desc(self) -> SceneProjDesc:
-        return SceneProjDesc(self.width, self.height, self.max_dist_diff, (C.c_float * 9)(*self.K),
+    def desc(self):
+        view = SceneProjDesc(self.width, self.height, self.max_dist_diff, (C.c_float * 9)(*self.K),
                              self.pcd_buffer.data(), self.normal_buffer.data())
+        if self.kind == SCENE_PROJ_CROP:
+            return SceneProjCropDesc(view, self.tl_x, self.tl_y)
+        return view
+
+    def crop(self, window: Sequence[int]) -> "Scene_projective":
+        """The same scene restricted to ``window`` = (x, y, width, height): arrays of the window's size and the
+        ``tl_x / tl_y`` offsets of pcd2dep / dep2pcd (common.h:47-73) -- SURVEY 8f rank 3."""
+        x, y, w, h = (int(v) for v in window)
+        out = Scene_projective()
+        out.kind = SCENE_PROJ_CROP
+        out.width, out.height, out.max_dist_diff, out.K = w, h, self.max_dist_diff, self.K
+        out.tl_x, out.tl_y = x, y
+        out.pcd_buffer = DeviceVector(w * h * 3, np.float32)
+        out.normal_buffer = DeviceVector(w * h * 3, np.float32)
+        check(_lib.load().pr_scene_proj_crop_dev(self.pcd_buffer.data(), self.normal_buffer.data(), self.width, self.height,
+                                                 Roi(x, y, w, h), out.pcd_buffer.data(), out.normal_buffer.data()))
+        return out
 
 
 class Scene_nn:
@@ -353,14 +423,23 @@ def ICP_Point2Plane_batch(clouds: DeviceVector, offsets, scene, criteria: ICPCon
 
 
 def refine_batch(tris, poses, width: int, height: int, proj, K, scene,
-                 criteria: ICPConvergenceCriteria = ICPConvergenceCriteria(), results_dev: Optional[int] = None):
+                 criteria: ICPConvergenceCriteria = ICPConvergenceCriteria(), results_dev: Optional[int] = None,
+                 roi: Optional[Sequence[int]] = None):
     """Fused hypothesis refinement (test.cpp:143-172 for a batch): render -> cloud -> ICP on the device.
-    Returns (records[P] of RESULT dtype or None when results_dev is given, cloud sizes[P])."""
+    Returns (records[P] of RESULT dtype or None when results_dev is given, cloud sizes[P]).
+    ``roi`` = (x, y, width, height): render only inside the window (renderer.h:199), clouds with tl = (x, y)."""
     td = _tris_dev(tris)
     poses = _f32(poses, (-1, 16))
     pj, k = _f32(proj, -1), _f32(K, -1)
     sizes = np.zeros(len(poses), np.uint32)
     d = scene.desc()
+    if roi is not None:
+        if results_dev is not None:
+            raise ValueError("roi and results_dev together: use refine_submit")
+        res = np.zeros(len(poses), RESULT)
+        check(_lib.load().pr_refine_batch_roi(td.data(), td.size() // 9, ptr(poses), len(poses), width, height, ptr(pj), ptr(k),
+                                              scene.kind, C.addressof(d), criteria.c(), Roi(*roi), ptr(res), ptr(sizes)))
+        return res, sizes
     if results_dev is None:
         res = np.zeros(len(poses), RESULT)
         check(_lib.load().pr_refine_batch(td.data(), td.size() // 9, ptr(poses), len(poses), width, height, ptr(pj), ptr(k),
@@ -375,7 +454,8 @@ _inflight = {}
 
 
 def refine_submit(slot: int, tris, poses, width: int, height: int, proj, K, scene,
-                  criteria: ICPConvergenceCriteria = ICPConvergenceCriteria(), results_dev: Optional[int] = None):
+                  criteria: ICPConvergenceCriteria = ICPConvergenceCriteria(), results_dev: Optional[int] = None,
+                  roi: Sequence[int] = (0, 0, 0, 0)):
     """Asynchronous ``refine_batch``: enqueue the batch on ``slot`` (0 or 1) and return at once; ``refine_wait(slot)``
     delivers what ``refine_batch`` returns.  With two slots, batch k+1 is enqueued while batch k runs."""
     td = _tris_dev(tris)
@@ -384,9 +464,9 @@ def refine_submit(slot: int, tris, poses, width: int, height: int, proj, K, scen
     sizes = np.zeros(len(poses), np.uint32)
     res = np.zeros(len(poses), RESULT) if results_dev is None else None
     d = scene.desc()
-    check(_lib.load().pr_refine_submit(int(slot), td.data(), td.size() // 9, ptr(poses), len(poses), width, height, ptr(pj), ptr(k),
-                                       scene.kind, C.addressof(d), criteria.c(), ptr(res) if res is not None else None,
-                                       int(results_dev) if results_dev is not None else None, ptr(sizes)))
+    check(_lib.load().pr_refine_submit_roi(int(slot), td.data(), td.size() // 9, ptr(poses), len(poses), width, height, ptr(pj), ptr(k),
+                                           scene.kind, C.addressof(d), criteria.c(), Roi(*roi), ptr(res) if res is not None else None,
+                                           int(results_dev) if results_dev is not None else None, ptr(sizes)))
     _inflight[int(slot)] = (res, sizes, td, scene)              # keep the output arrays (and the inputs' owners) alive
 
 

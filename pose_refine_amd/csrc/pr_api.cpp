@@ -5,6 +5,8 @@
 // cudaMallocs per call: common.cu:27, renderer.cu:39).  No CPU fallback: every device entry point
 // returns PR_ERR_NO_DEVICE when no GPU is usable.
 #include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>          // types and prototypes only: librccl is opened on first use (pr_comm_*), never linked
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cfloat>
@@ -74,18 +76,53 @@ struct PinBuf {                      // grow-only pinned host staging
     template <class T> T *as() const { return static_cast<T *>(p); }
 };
 
-struct Ctx {
-    bool ready = false;
-    int device = -1;
-    hipStream_t stream = nullptr;
-    hipStream_t side[3] = { nullptr, nullptr, nullptr };   // extra lanes of the device-solve loop (pose groups overlap one group's solve tail with another group's pass)
-    hipEvent_t ev_fork = nullptr, ev_join[3] = { nullptr, nullptr, nullptr };
+// ---- which device ranges were written through this library, and when --------------------------------
+// Derived data (the packed projective scene, the kd traversal records, the host copy of a model box) is cached by the address
+// of the caller's buffers.  A cache entry remembers the write generation it was built at and is dropped as soon as a later
+// write through the library (pr_memcpy_*, pr_fill_i32, pr_free, the *_prepare_dev / *_build_dev functions, pr_render) or a
+// pr_invalidate() call overlaps one of its source ranges.  Writes the library cannot see (raw HIP calls, the caller's own
+// kernels) must be announced with pr_invalidate -- include/pose_refine.h states that contract.
+struct WriteLog {
+    std::mutex mu;
+    struct W { uintptr_t lo, hi; };
+    static constexpr uint64_t kRing = 128;
+    W ring[kRing];
+    uint64_t gen = 0;                                            // writes recorded so far; write k (1-based) sits in ring[k % kRing]
+    void note(const void *p, size_t bytes)
+    {
+        if (!p) return;
+        uintptr_t lo = reinterpret_cast<uintptr_t>(p), hi = lo + bytes;
+        if (bytes == 0) {                                        // unknown extent: the whole allocation that contains p
+            void *base = nullptr; size_t size = 0;
+            if (hipMemGetAddressRange(reinterpret_cast<hipDeviceptr_t *>(&base), &size, const_cast<void *>(p)) == hipSuccess && base) { lo = reinterpret_cast<uintptr_t>(base); hi = lo + size; }
+            else { (void)hipGetLastError(); lo = 0; hi = ~(uintptr_t)0; }
+        }
+        std::lock_guard<std::mutex> lk(mu);
+        ++gen;
+        ring[gen % kRing] = W{ lo, hi };
+    }
+    uint64_t now() { std::lock_guard<std::mutex> lk(mu); return gen; }
+    // may [p, p+bytes) have been written after generation `since`?
+    bool written_since(uint64_t since, const void *p, size_t bytes)
+    {
+        const uintptr_t lo = reinterpret_cast<uintptr_t>(p), hi = lo + bytes;
+        std::lock_guard<std::mutex> lk(mu);
+        if (gen - since >= kRing) return true;                   // older writes have left the ring: assume the worst
+        for (uint64_t k = since + 1; k <= gen; ++k) { const W &w = ring[k % kRing]; if (w.lo < hi && lo < w.hi) return true; }
+        return false;
+    }
+};
+WriteLog g_writes;
+
+// ---- process-wide options (pr_set_option): plain ints, shared by every context ---------------------
+constexpr int kSlots = 2;
+struct Options {
     int pose_groups = 2;             // PR_SOLVE_DEVICE: split the batch over this many streams (1..4); 2 measured best (1.31 vs 1.45 ms/step at
                                      // 256 poses); launches of different groups overlap, so timed calls fall back to one group
-    // options
     int solve_mode = PR_SOLVE_HOST;
     int steps = 2;                   // 1024-point steps per workgroup -> 2048 points per workgroup
     int profile = 0;
+    int sample_period = 32;          // profile 2: one timed (synchronous, single-group) call in this many
     int nn_lds_nodes = 1024;
     int nn_lds_records = 0;          // stack traversal: leading 64-byte node records staged in LDS; measured 0/64/128/256/512 -> 42.2/41.6/45.2/45.4/58.2 ms per step (occupancy lost to the extra LDS outweighs the saved L1 lookups)
     int nn_seed = 1;                 // compact kd records: start every search from the previous pass' winner distance
@@ -100,23 +137,38 @@ struct Ctx {
     int use_graph = 1;               // PR_SOLVE_DEVICE, single pose group only (the runtime serialises the branches of a captured multi-stream
                                      // graph, which forfeits the overlap): capture the whole iteration loop in a hipGraph and replay it
     int raster_mode = 0;             // fused path: 0 = global atomicMin inside the per-pose pixel box (reference scheme), 1 = LDS depth bands
-    int n_cus = 256;
-    const void *aabb_key = nullptr; size_t aabb_n = 0;
-    float aabb_host[6] = { 0, 0, 0, 0, 0, 0 }; bool aabb_host_valid = false;
-    const void *mesh_key = nullptr; size_t mesh_n = 0;   // triangle buffer aabb_host belongs to
-    uint32_t cloud_hint = 0;          // largest cloud of the latest finished asynchronous batch: sizes the next batch's grid
-    // workspaces
-    DevBuf aabb, bbox, poses, depth, row_count, row_off, counts, cloud, meta, partial, sums, rec, topo, bmin, bmax, pts, nnrec, nnrec32, nndesc, nn_prev, nndepth, dstate, dresults, vbdesc, flowsync, arrive, conv16, conv8, kd_idx, kd_scratch, kd_child, kd_ctrl, kd_tmp, nn_full;
-    PinBuf h_sums, h_meta, h_counts, h_results, h_dstate, h_flow;
-    // profiling
-    std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
-    struct Span { size_t e0, e1; int kind; };
-    std::vector<Span> spans;
-    double icp_ms = 0, render_ms = 0, cloud_ms = 0; uint64_t icp_launches = 0, icp_points = 0, icp_bytes = 0, sample_clock = 0;
+    int scene_cache = 1;             // keep the packed projective scene / kd traversal records of the latest scene between calls (pr_scene_invalidate)
 };
-Ctx g;
-std::mutex g_mu;
-constexpr uint64_t kSamplePeriod = 32;     // profile 2: one timed (synchronous, single-group) call in this many
+Options opt;
+
+// packed projective scene (one 16-byte record per pixel + the two back-projection tables) of the latest scene it was built for
+struct PackedCache {
+    DevBuf rec;                      // [n] float4, colf[w], rowf[h], exact flag (uint32)
+    const void *pcd = nullptr, *normal = nullptr;
+    uint64_t w = 0, h = 0; float k[4] = { 0, 0, 0, 0 }; uint32_t tl[2] = { 0, 0 };
+    uint64_t gen = 0;
+    bool valid = false, exact = false;
+};
+// everything needed to run a submitted batch again (refine_wait does so when the model box the batch assumed turns out stale)
+struct Resubmit {
+    const pr_triangle *tris = nullptr; size_t n_tris = 0; uint32_t W = 0, H = 0; pr_mat4 proj{}; float K[9] = { 0 };
+    int scene_kind = 0; pr_scene_proj_crop sp{}; pr_scene_nn sn{}; pr_criteria crit{}; pr_roi roi{ 0, 0, 0, 0 };
+    pr_result *results_dev = nullptr;
+};
+struct Slot {
+    DevBuf poses_bbox, depth, row_count, row_off, counts, cloud, meta, partial, dstate, dresults, arrive, aabb_keys;
+    PackedCache packed;
+    PinBuf h_in, h_out;
+    Resubmit again;
+    size_t flag_off = 0;             // offset in h_out of the word the device-side model-box check writes (1 = the assumed box was stale)
+    hipStream_t stream = nullptr, side[3] = { nullptr, nullptr, nullptr };
+    hipEvent_t fork = nullptr, join[3] = { nullptr, nullptr, nullptr }, done = nullptr, scene_ready = nullptr, progress = nullptr;
+    bool progress_valid = false;
+    bool pending = false, delivered = false;
+    uint32_t P = 0;
+    pr_result *user_results_host = nullptr;
+    uint32_t *user_sizes = nullptr;
+};
 
 // ---- hipGraph cache for the device-solve iteration loop ------------------------------------------
 struct GraphKey {                    // every value a captured launch depends on, byte for byte (grows as needed)
@@ -129,8 +181,6 @@ struct CachedGraph {
     std::vector<hipEvent_t> events;      // pairs around every correspondence launch when captured with profiling on
     uint64_t stamp = 0;
 };
-std::vector<CachedGraph> g_graphs;
-uint64_t g_graph_clock = 0;
 void destroy_graph(CachedGraph &c)
 {
     if (c.exec) (void)hipGraphExecDestroy(c.exec);
@@ -138,12 +188,56 @@ void destroy_graph(CachedGraph &c)
     for (hipEvent_t e : c.events) (void)hipEventDestroy(e);
     c = CachedGraph();
 }
-void drop_graphs() { for (auto &c : g_graphs) destroy_graph(c); g_graphs.clear(); }
 
-void drop_graphs();
-int require_ctx()
+struct Ctx {
+    std::mutex mu;                   // one call at a time per context; contexts of different devices / threads run side by side
+    bool ready = false;
+    bool is_private = false;         // pr_thread_context(1): owned by one host thread
+    int device = -1;
+    hipStream_t stream = nullptr;
+    hipStream_t side[3] = { nullptr, nullptr, nullptr };   // extra lanes of the device-solve loop (pose groups overlap one group's solve tail with another group's pass)
+    hipEvent_t ev_fork = nullptr, ev_join[3] = { nullptr, nullptr, nullptr };
+    int n_cus = 256;
+    // host copy of the model box the asynchronous path derives its pixel boxes from: keyed by (pointer, size) and VERIFIED on
+    // the device by every batch that uses it (refine_submit / refine_wait), so a rewritten triangle buffer cannot go unnoticed
+    float aabb_host[6] = { 0, 0, 0, 0, 0, 0 }; bool aabb_host_valid = false;
+    const void *mesh_key = nullptr; size_t mesh_n = 0;   // triangle buffer aabb_host belongs to
+    uint32_t cloud_hint = 0;          // largest cloud of the latest finished asynchronous batch: sizes the next batch's grid
+    // workspaces
+    DevBuf aabb, aabb_keys, bbox, poses, depth, row_count, row_off, counts, cloud, meta, partial, sums, topo, bmin, bmax, pts, nnrec, nnrec32, nndesc, nn_prev, nndepth, dstate, dresults, vbdesc, flowsync, arrive, conv16, conv8, kd_idx, kd_scratch, kd_child, kd_ctrl, kd_tmp, nn_full;
+    PinBuf h_sums, h_meta, h_counts, h_results, h_dstate, h_flow;
+    PackedCache packed;              // synchronous paths (the asynchronous slots keep their own)
+    struct { const void *pcd = nullptr, *normal = nullptr, *nodes = nullptr; uint32_t n_points = 0, n_nodes = 0; uint64_t gen = 0; bool valid = false;
+             uint32_t info[8] = { 0 }; } nn_cache;               // kd traversal records (topo ... nndesc) of the latest kd-tree scene
+    // profiling
+    std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
+    struct Span { size_t e0, e1; int kind; };
+    std::vector<Span> spans;
+    double icp_ms = 0, render_ms = 0, cloud_ms = 0; uint64_t icp_launches = 0, icp_points = 0, icp_bytes = 0, sample_clock = 0;
+    Slot slots[kSlots];
+    std::vector<CachedGraph> graphs;
+    uint64_t graph_clock = 0;
+    // RCCL communicator this context is a rank of (pr_comm_init_rank / pr_comm_init_all), or null
+    ncclComm_t comm = nullptr; int comm_rank = 0, comm_world = 1;
+    DevBuf gather_tmp;
+};
+
+// ---- context registry --------------------------------------------------------------------------------
+// One shared context per device (created by pr_init / pr_set_device / first use) plus optional private contexts of single
+// host threads (pr_thread_context).  `g` is the context the calling thread is bound to; every entry point binds a thread
+// that never chose one to the process default (the device of the first pr_init, else device 0).
+std::mutex g_reg_mu;
+std::vector<Ctx *> g_shared;         // index = device ordinal
+int g_default_device = -1;
+thread_local Ctx *g = nullptr;
+struct PrivateCtx { Ctx *c = nullptr; ~PrivateCtx(); };   // destructor below, once the teardown helpers exist
+thread_local PrivateCtx tl_private;
+
+void drop_graphs() { for (auto &c : g->graphs) destroy_graph(c); g->graphs.clear(); }
+void comm_teardown(Ctx *c);
+
+int device_count_checked(int *n_out)
 {
-    if (g.ready) return PR_OK;
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0) {
@@ -151,41 +245,67 @@ int require_ctx()
                   hipGetErrorString(e), n);
         return PR_ERR_NO_DEVICE;
     }
-    int dev = g.device >= 0 ? g.device : 0;
-    if (dev >= n) { set_error("device %d out of range (%d visible)", dev, n); return PR_ERR_NO_DEVICE; }
-    HIP_TRY(hipSetDevice(dev));
-    HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
-    HIP_TRY(hipEventCreateWithFlags(&g.ev_fork, hipEventDisableTiming));
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) g.n_cus = prop.multiProcessorCount;
-    g.device = dev;
-    g.ready = true;
+    *n_out = n;
     return PR_OK;
 }
+
+// bind the calling thread to the shared context of `device` (-1: the process default), creating it if needed
+int bind_shared(int device)
+{
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    if (device < 0) device = g_default_device >= 0 ? g_default_device : 0;
+    int n = 0;
+    PR_TRY(device_count_checked(&n));
+    if (device >= n) { set_error("device %d out of range (%d visible)", device, n); return PR_ERR_NO_DEVICE; }
+    if ((int)g_shared.size() < n) g_shared.resize((size_t)n, nullptr);
+    if (!g_shared[(size_t)device]) { g_shared[(size_t)device] = new Ctx(); g_shared[(size_t)device]->device = device; }
+    if (g_default_device < 0) g_default_device = device;
+    g = g_shared[(size_t)device];
+    return PR_OK;
+}
+inline int bind_default() { return g ? PR_OK : bind_shared(-1); }
+
+// with g->mu held: make the context's device current for this thread and create its stream on first use
+int require_ctx()
+{
+    HIP_TRY(hipSetDevice(g->device));                            // the current device is per host thread
+    if (g->ready) return PR_OK;
+    HIP_TRY(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming));
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, g->device) == hipSuccess && prop.multiProcessorCount > 0) g->n_cus = prop.multiProcessorCount;
+    g->ready = true;
+    return PR_OK;
+}
+// every device entry point: bind, lock, make current
+#define PR_ENTER()                                   \
+    PR_TRY(bind_default());                          \
+    std::lock_guard<std::mutex> lk(g->mu);           \
+    PR_TRY(require_ctx())
 
 // ---- profiling spans (HIP events on the library stream) ------------------------------------------
 enum { kSpanIcp = 0, kSpanRender = 1, kSpanCloud = 2 };
 size_t take_event()
 {
-    if (g.ev_used == g.ev_pool.size()) { hipEvent_t e; hipEventCreate(&e); g.ev_pool.push_back(e); }
-    return g.ev_used++;
+    if (g->ev_used == g->ev_pool.size()) { hipEvent_t e; hipEventCreate(&e); g->ev_pool.push_back(e); }
+    return g->ev_used++;
 }
 struct SpanGuard {
     bool on; size_t e0 = 0; int kind;
-    explicit SpanGuard(int k) : on(g.profile != 0), kind(k) { if (on) { e0 = take_event(); hipEventRecord(g.ev_pool[e0], g.stream); } }
-    ~SpanGuard() { if (on) { size_t e1 = take_event(); hipEventRecord(g.ev_pool[e1], g.stream); g.spans.push_back({ e0, e1, kind }); } }
+    explicit SpanGuard(int k) : on(opt.profile != 0), kind(k) { if (on) { e0 = take_event(); hipEventRecord(g->ev_pool[e0], g->stream); } }
+    ~SpanGuard() { if (on) { size_t e1 = take_event(); hipEventRecord(g->ev_pool[e1], g->stream); g->spans.push_back({ e0, e1, kind }); } }
 };
 void drain_spans()                   // call after the stream has been synchronised
 {
-    for (const auto &s : g.spans) {
+    for (const auto &s : g->spans) {
         float ms = 0;
-        if (hipEventElapsedTime(&ms, g.ev_pool[s.e0], g.ev_pool[s.e1]) != hipSuccess) continue;
-        if (s.kind == kSpanIcp) { g.icp_ms += ms; g.icp_launches++; }
-        else if (s.kind == kSpanRender) g.render_ms += ms;
-        else g.cloud_ms += ms;
+        if (hipEventElapsedTime(&ms, g->ev_pool[s.e0], g->ev_pool[s.e1]) != hipSuccess) continue;
+        if (s.kind == kSpanIcp) { g->icp_ms += ms; g->icp_launches++; }
+        else if (s.kind == kSpanRender) g->render_ms += ms;
+        else g->cloud_ms += ms;
     }
-    g.spans.clear();
-    g.ev_used = 0;
+    g->spans.clear();
+    g->ev_used = 0;
 }
 
 inline void identity16(float *T) { for (int i = 0; i < 16; ++i) T[i] = (i % 5 == 0) ? 1.0f : 0.0f; }
@@ -199,57 +319,104 @@ struct SceneSel {
     prk::SceneNNDev nn{};
 };
 
-int make_scene(int kind, const void *scene, bool want_packed, SceneSel &out, DevBuf *rec_buf = nullptr, hipStream_t st = nullptr)
+// Packed copy of a projective scene in `pc`: reused while the caller's arrays are unchanged as far as the library can tell
+// (option scene_cache, WriteLog above), rebuilt otherwise.  A rebuild also learns (one 4-byte read-back) whether the pcd array
+// is exactly what dep2pcd produces -- only then may the packed form stand in for it.
+int ensure_packed(PackedCache &pc, const pr_scene_proj &s, uint32_t tl_x, uint32_t tl_y, hipStream_t st)
 {
-    DevBuf &rec = rec_buf ? *rec_buf : g.rec;
-    if (!st) st = g.stream;
+    const size_t n = (size_t)s.width * s.height;
+    const float k[4] = { s.K[0], s.K[4], s.K[2], s.K[5] };
+    const bool same = pc.valid && pc.pcd == s.pcd && pc.normal == s.normal && pc.w == s.width && pc.h == s.height &&
+                      std::memcmp(pc.k, k, sizeof k) == 0 && pc.tl[0] == tl_x && pc.tl[1] == tl_y;
+    if (same && opt.scene_cache && !g_writes.written_since(pc.gen, s.pcd, n * sizeof(pr_vec3)) &&
+        !g_writes.written_since(pc.gen, s.normal, n * sizeof(pr_vec3))) {
+        pc.gen = g_writes.now();
+        return PR_OK;
+    }
+    pc.valid = false;
+    const uint64_t gen = g_writes.now();
+    const size_t tables = ((s.width + s.height) * sizeof(float) + 15) & ~(size_t)15;
+    PR_TRY(pc.rec.ensure(n * sizeof(float4) + tables + 16));
+    float *colf = reinterpret_cast<float *>(pc.rec.as<float4>() + n);
+    float *rowf = colf + s.width;
+    uint32_t *exact_dev = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(colf) + tables);
+    HIP_TRY(prk::launch_pack_proj_scene(s.pcd, s.normal, pc.rec.as<float4>(), n, colf, rowf, (uint32_t)s.width, (uint32_t)s.height,
+                                        k[0], k[1], k[2], k[3], tl_x, tl_y, exact_dev, st));
+    uint32_t exact = 0;
+    HIP_TRY(hipMemcpyAsync(&exact, exact_dev, sizeof exact, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    pc.pcd = s.pcd; pc.normal = s.normal; pc.w = s.width; pc.h = s.height; std::memcpy(pc.k, k, sizeof k); pc.tl[0] = tl_x; pc.tl[1] = tl_y;
+    pc.gen = gen; pc.exact = exact != 0; pc.valid = true;
+    return PR_OK;
+}
+
+int make_scene(int kind, const void *scene, bool want_packed, SceneSel &out, PackedCache *pc_in = nullptr, hipStream_t st = nullptr)
+{
+    PackedCache &pc = pc_in ? *pc_in : g->packed;
+    if (!st) st = g->stream;
     out.kind = kind;
-    if (kind == PR_SCENE_PROJ) {
-        const pr_scene_proj *s = static_cast<const pr_scene_proj *>(scene);
+    if (kind == PR_SCENE_PROJ || kind == PR_SCENE_PROJ_CROP) {
+        const pr_scene_proj *s = static_cast<const pr_scene_proj *>(scene);       // pr_scene_proj_crop starts with the plain view
         if (!s || !s->pcd || !s->normal || s->width == 0 || s->height == 0) { set_error("invalid pr_scene_proj"); return PR_ERR_INVALID; }
-        out.aos = prk::SceneProjAoS{ (uint32_t)s->width, (uint32_t)s->height, s->max_dist_diff, s->K[0], s->K[4], s->K[2], s->K[5], s->pcd, s->normal };
-        out.packed = want_packed;
+        if (s->width > 0x7fffffffull || s->height > 0x7fffffffull) { set_error("pr_scene_proj: frame too large"); return PR_ERR_INVALID; }
+        uint32_t tl_x = 0, tl_y = 0;
+        if (kind == PR_SCENE_PROJ_CROP) { const pr_scene_proj_crop *c = static_cast<const pr_scene_proj_crop *>(scene); tl_x = c->tl_x; tl_y = c->tl_y; }
+        out.kind = PR_SCENE_PROJ;
+        out.aos = prk::SceneProjAoS{ (uint32_t)s->width, (uint32_t)s->height, s->max_dist_diff, s->K[0], s->K[4], s->K[2], s->K[5],
+                                     (float)tl_x, (float)tl_y, s->pcd, s->normal };
+        out.packed = false;
         if (want_packed) {
-            const size_t n = (size_t)s->width * s->height;
-            PR_TRY(rec.ensure(n * sizeof(float4) + (s->width + s->height) * sizeof(float)));
-            float *colf = reinterpret_cast<float *>(rec.as<float4>() + n);
-            float *rowf = colf + s->width;
-            HIP_TRY(prk::launch_pack_proj_scene(s->pcd, s->normal, rec.as<float4>(), n, colf, rowf, (uint32_t)s->width, (uint32_t)s->height,
-                                                s->K[0], s->K[4], s->K[2], s->K[5], st));
-            out.pk = prk::SceneProjPacked{ (uint32_t)s->width, (uint32_t)s->height, s->max_dist_diff, s->K[0], s->K[4], s->K[2], s->K[5],
-                                           rec.as<float4>(), colf, rowf };
+            PR_TRY(ensure_packed(pc, *s, tl_x, tl_y, st));
+            if (pc.exact) {                                         // else: the caller's pcd is not dep2pcd's -- use the arrays as they are
+                const size_t n = (size_t)s->width * s->height;
+                float *colf = reinterpret_cast<float *>(pc.rec.as<float4>() + n);
+                out.packed = true;
+                out.pk = prk::SceneProjPacked{ (uint32_t)s->width, (uint32_t)s->height, s->max_dist_diff, s->K[0], s->K[4], s->K[2], s->K[5],
+                                               (float)tl_x, (float)tl_y, pc.rec.as<float4>(), colf, colf + s->width };
+            }
         }
         return PR_OK;
     }
     if (kind == PR_SCENE_NN) {
         const pr_scene_nn *s = static_cast<const pr_scene_nn *>(scene);
         if (!s || !s->pcd || !s->normal || !s->nodes || s->n_nodes == 0 || s->n_points == 0) { set_error("invalid pr_scene_nn"); return PR_ERR_INVALID; }
-        PR_TRY(g.topo.ensure((size_t)s->n_nodes * sizeof(int4)));
-        PR_TRY(g.bmin.ensure((size_t)s->n_nodes * sizeof(float4)));
-        PR_TRY(g.bmax.ensure((size_t)s->n_nodes * sizeof(float4)));
-        PR_TRY(g.pts.ensure((size_t)s->n_points * sizeof(float4)));
-        PR_TRY(g.nnrec.ensure((size_t)s->n_nodes * 4 * sizeof(float4)));
-        PR_TRY(g.nndepth.ensure(8 * sizeof(uint32_t)));
-        PR_TRY(g.nnrec32.ensure((size_t)s->n_nodes * 2 * sizeof(uint4)));
-        PR_TRY(g.nndesc.ensure((size_t)s->n_nodes * sizeof(uint2)));
-        HIP_TRY(prk::launch_build_nn_accel(s->nodes, s->n_nodes, s->pcd, s->n_points, g.topo.as<int4>(), g.bmin.as<float4>(),
-                                           g.bmax.as<float4>(), g.pts.as<float4>(), g.nnrec.as<float4>(), g.nnrec32.as<uint4>(),
-                                           g.nndesc.as<uint2>(), g.nndepth.as<uint32_t>(), g.stream));
-        uint32_t info[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-        HIP_TRY(hipMemcpyAsync(info, g.nndepth.p, sizeof info, hipMemcpyDeviceToHost, g.stream));
-        HIP_TRY(hipStreamSynchronize(g.stream));
+        auto &nc = g->nn_cache;
+        const bool same = nc.valid && nc.pcd == s->pcd && nc.normal == s->normal && nc.nodes == s->nodes && nc.n_points == s->n_points && nc.n_nodes == s->n_nodes;
+        if (same && opt.scene_cache && !g_writes.written_since(nc.gen, s->pcd, (size_t)s->n_points * sizeof(pr_vec3)) &&
+            !g_writes.written_since(nc.gen, s->nodes, (size_t)s->n_nodes * sizeof(pr_kdnode))) {
+            nc.gen = g_writes.now();                                // (the normals are read through the caller's pointer, never copied)
+        } else {
+            nc.valid = false;
+            const uint64_t gen = g_writes.now();
+            PR_TRY(g->topo.ensure((size_t)s->n_nodes * sizeof(int4)));
+            PR_TRY(g->bmin.ensure((size_t)s->n_nodes * sizeof(float4)));
+            PR_TRY(g->bmax.ensure((size_t)s->n_nodes * sizeof(float4)));
+            PR_TRY(g->pts.ensure((size_t)s->n_points * sizeof(float4)));
+            PR_TRY(g->nnrec.ensure((size_t)s->n_nodes * 4 * sizeof(float4)));
+            PR_TRY(g->nndepth.ensure(8 * sizeof(uint32_t)));
+            PR_TRY(g->nnrec32.ensure((size_t)s->n_nodes * 2 * sizeof(uint4)));
+            PR_TRY(g->nndesc.ensure((size_t)s->n_nodes * sizeof(uint2)));
+            HIP_TRY(prk::launch_build_nn_accel(s->nodes, s->n_nodes, s->pcd, s->n_points, g->topo.as<int4>(), g->bmin.as<float4>(),
+                                               g->bmax.as<float4>(), g->pts.as<float4>(), g->nnrec.as<float4>(), g->nnrec32.as<uint4>(),
+                                               g->nndesc.as<uint2>(), g->nndepth.as<uint32_t>(), g->stream));
+            HIP_TRY(hipMemcpyAsync(nc.info, g->nndepth.p, sizeof nc.info, hipMemcpyDeviceToHost, g->stream));
+            HIP_TRY(hipStreamSynchronize(g->stream));
+            nc.pcd = s->pcd; nc.normal = s->normal; nc.nodes = s->nodes; nc.n_points = s->n_points; nc.n_nodes = s->n_nodes; nc.gen = gen; nc.valid = true;
+        }
+        const uint32_t *info = nc.info;
         const uint32_t depth = info[0];
-        uint32_t lds = (uint32_t)std::max(0, g.nn_lds_nodes);
+        if (depth >= 0x7fffffffu) { nc.valid = false; set_error("pr_scene_nn: the nodes do not form a consistent tree (child / parent links disagree or point outside the array)"); return PR_ERR_INVALID; }
+        uint32_t lds = (uint32_t)std::max(0, opt.nn_lds_nodes);
         lds = std::min(lds, s->n_nodes);
         lds = std::min<uint32_t>(lds, 8192);                      // <= 128 KiB of LDS
         // pending far children on the stack never exceed the tree depth; deeper trees use the stackless walk
         uint32_t stack = 0;
-        if (g.nn_stack) stack = (depth <= 16) ? 16u : ((depth <= 24) ? 24u : 0u);
-        if (stack) lds = std::min<uint32_t>({ (uint32_t)std::max(0, g.nn_lds_records), s->n_nodes, (65536u - stack * 2048u) / 64u });   // stacks + records <= 64 KiB
-        out.nn = prk::SceneNNDev{ s->max_dist_diff, g.topo.as<int4>(), g.bmin.as<float4>(), g.bmax.as<float4>(), g.pts.as<float4>(),
-                                  s->pcd, s->normal, s->n_nodes, lds, g.nnrec.as<float4>(), stack, nullptr, { 0, 0, 0 }, { 0, 0, 0 }, g.nndesc.as<uint2>() };
-        if (stack && g.nn_compact && info[1] == 1u) {
-            out.nn.rec32 = g.nnrec32.as<uint4>();
+        if (opt.nn_stack) stack = (depth <= 16) ? 16u : ((depth <= 24) ? 24u : 0u);
+        if (stack) lds = std::min<uint32_t>({ (uint32_t)std::max(0, opt.nn_lds_records), s->n_nodes, (65536u - stack * 2048u) / 64u });   // stacks + records <= 64 KiB
+        out.nn = prk::SceneNNDev{ s->max_dist_diff, g->topo.as<int4>(), g->bmin.as<float4>(), g->bmax.as<float4>(), g->pts.as<float4>(),
+                                  s->pcd, s->normal, s->n_nodes, lds, g->nnrec.as<float4>(), stack, nullptr, { 0, 0, 0 }, { 0, 0, 0 }, g->nndesc.as<uint2>() };
+        if (stack && opt.nn_compact && info[1] == 1u) {
+            out.nn.rec32 = g->nnrec32.as<uint4>();
             for (int a = 0; a < 3; ++a) { std::memcpy(&out.nn.qmin[a], &info[2 + a], 4); std::memcpy(&out.nn.qscale[a], &info[5 + a], 4); }
         }
         return PR_OK;
@@ -260,7 +427,7 @@ int make_scene(int kind, const void *scene, bool want_packed, SceneSel &out, Dev
 
 hipError_t launch_pass(const prk::IcpBatch &b, const SceneSel &sc, uint32_t P, hipStream_t st = nullptr)
 {
-    if (!st) st = g.stream;
+    if (!st) st = g->stream;
     if (sc.kind == PR_SCENE_NN) return prk::launch_icp_pass_nn(b, sc.nn, P, st);
     if (sc.packed) return prk::launch_icp_pass_proj_packed(b, sc.pk, P, st);
     return prk::launch_icp_pass_proj_aos(b, sc.aos, P, st);
@@ -278,38 +445,38 @@ int ensure_stream(hipStream_t &st, hipEvent_t *ev = nullptr)
 
 // ---- the batched ICP driver -----------------------------------------------------------------------
 // clouds: cloud i = cloud_base[start_h[i] .. start_h[i]+count_h[i]).  start/count must already be in
-// g.start / g.counts on the device when dev_meta_ready, otherwise they are uploaded here.
+// g->start / g->counts on the device when dev_meta_ready, otherwise they are uploaded here.
 int icp_drive(pr_vec3 *cloud_base, const uint32_t *start_h, const uint32_t *count_h, uint32_t P, const SceneSel &sc,
               pr_criteria crit, pr_result *results_host, pr_result *results_dev)
 {
     if (P == 0) return PR_OK;
     if (crit.max_iteration < 0) { set_error("max_iteration must be >= 0"); return PR_ERR_INVALID; }
-    const uint32_t steps = (uint32_t)std::max(1, g.steps);
+    const uint32_t steps = (uint32_t)std::max(1, opt.steps);
     const uint32_t ppb = steps * prk::kPointsPerStep;
     uint32_t max_n = 0; uint64_t sum_n = 0;
     for (uint32_t i = 0; i < P; ++i) { max_n = std::max(max_n, count_h[i]); sum_n += count_h[i]; }
     const uint32_t nblk = (max_n + ppb - 1) / ppb;
 
-    PR_TRY(g.meta.ensure(sizeof(prk::PoseMeta) * P));
-    PR_TRY(g.partial.ensure(sizeof(float) * prk::kAccStride * (size_t)std::max(1u, nblk) * P));
-    PR_TRY(g.sums.ensure(sizeof(float) * prk::kAccStride * P));
-    PR_TRY(g.h_meta.ensure(sizeof(prk::PoseMeta) * P));
-    PR_TRY(g.h_sums.ensure(sizeof(float) * prk::kAccStride * P));
-    PR_TRY(g.h_results.ensure(sizeof(pr_result) * P));
+    PR_TRY(g->meta.ensure(sizeof(prk::PoseMeta) * P));
+    PR_TRY(g->partial.ensure(sizeof(float) * prk::kAccStride * (size_t)std::max(1u, nblk) * P));
+    PR_TRY(g->sums.ensure(sizeof(float) * prk::kAccStride * P));
+    PR_TRY(g->h_meta.ensure(sizeof(prk::PoseMeta) * P));
+    PR_TRY(g->h_sums.ensure(sizeof(float) * prk::kAccStride * P));
+    PR_TRY(g->h_results.ensure(sizeof(pr_result) * P));
 
     prk::IcpBatch b{};
-    b.cloud = cloud_base; b.meta = g.meta.as<prk::PoseMeta>(); b.partial = g.partial.as<float>();
+    b.cloud = cloud_base; b.meta = g->meta.as<prk::PoseMeta>(); b.partial = g->partial.as<float>();
     b.nblk = nblk; b.steps = steps;
-    if (sc.kind == PR_SCENE_NN && sc.nn.rec32 && g.nn_seed) {     // previous winners, indexed like the cloud points
+    if (sc.kind == PR_SCENE_NN && sc.nn.rec32 && opt.nn_seed) {     // previous winners, indexed like the cloud points
         size_t span = 1;
         for (uint32_t i = 0; i < P; ++i) span = std::max(span, (size_t)start_h[i] + count_h[i]);
-        PR_TRY(g.nn_prev.ensure(sizeof(uint32_t) * span));
-        b.nn_prev = g.nn_prev.as<uint32_t>();
+        PR_TRY(g->nn_prev.ensure(sizeof(uint32_t) * span));
+        b.nn_prev = g->nn_prev.as<uint32_t>();
     }
 
-    prk::PoseMeta *h_meta = g.h_meta.as<prk::PoseMeta>();
-    float *h_sums = g.h_sums.as<float>();
-    pr_result *res = g.h_results.as<pr_result>();
+    prk::PoseMeta *h_meta = g->h_meta.as<prk::PoseMeta>();
+    float *h_sums = g->h_sums.as<float>();
+    pr_result *res = g->h_results.as<pr_result>();
     for (uint32_t i = 0; i < P; ++i) {
         identity16(res[i].T); res[i].inlier_rmse = 0.0f; res[i].fitness = 0.0f;   // icp.h:29-31
         std::memset(&h_meta[i], 0, sizeof(prk::PoseMeta));
@@ -317,18 +484,18 @@ int icp_drive(pr_vec3 *cloud_base, const uint32_t *start_h, const uint32_t *coun
         h_meta[i].state = (count_h[i] > 0) ? prk::kRun : prk::kSkip;    // empty cloud: count==0 -> identity result (icp.cu:183)
     }
 
-    if (g.solve_mode == PR_SOLVE_DEVICE) {
-        PR_TRY(g.dstate.ensure(sizeof(prk::DevIcpState) * P));
-        PR_TRY(g.h_dstate.ensure(sizeof(prk::DevIcpState) * P));
-        prk::DevIcpState *init = g.h_dstate.as<prk::DevIcpState>();
+    if (opt.solve_mode == PR_SOLVE_DEVICE) {
+        PR_TRY(g->dstate.ensure(sizeof(prk::DevIcpState) * P));
+        PR_TRY(g->h_dstate.ensure(sizeof(prk::DevIcpState) * P));
+        prk::DevIcpState *init = g->h_dstate.as<prk::DevIcpState>();
         for (uint32_t i = 0; i < P; ++i) { identity16(init[i].T); init[i].fitness = 0; init[i].rmse = 0; init[i].done = (h_meta[i].state == prk::kSkip); init[i].passes = 0; }
         pr_result *dres = results_dev;
-        if (!dres) { PR_TRY(g.dresults.ensure(sizeof(pr_result) * P)); dres = g.dresults.as<pr_result>(); }
+        if (!dres) { PR_TRY(g->dresults.ensure(sizeof(pr_result) * P)); dres = g->dresults.as<pr_result>(); }
         const bool may_exit_early = (crit.relative_fitness > 0.0f && crit.relative_rmse > 0.0f);
-        const bool fused = g.fused_solve != 0;
-        if (fused) PR_TRY(g.arrive.ensure(sizeof(uint32_t) * P));
+        const bool fused = opt.fused_solve != 0;
+        if (fused) PR_TRY(g->arrive.ensure(sizeof(uint32_t) * P));
 
-        if (g.icp_flow) {
+        if (opt.icp_flow) {
             // ---- dataflow path: one persistent launch runs every iteration of every hypothesis ------------------
             std::vector<uint2> desc;
             desc.reserve((size_t)P * std::max(1u, nblk));
@@ -338,153 +505,153 @@ int icp_drive(pr_vec3 *cloud_base, const uint32_t *start_h, const uint32_t *coun
             }
             const uint32_t n_vbs = (uint32_t)desc.size();
             const size_t sync_words = (size_t)2 * P + 1;
-            PR_TRY(g.vbdesc.ensure(sizeof(uint2) * std::max<size_t>(1, n_vbs)));
-            PR_TRY(g.flowsync.ensure(sizeof(uint32_t) * sync_words));
-            PR_TRY(g.h_flow.ensure(sizeof(uint2) * std::max<size_t>(1, n_vbs) + sizeof(uint32_t) * (sync_words + 1)));
-            uint32_t *h_sync = g.h_flow.as<uint32_t>();
+            PR_TRY(g->vbdesc.ensure(sizeof(uint2) * std::max<size_t>(1, n_vbs)));
+            PR_TRY(g->flowsync.ensure(sizeof(uint32_t) * sync_words));
+            PR_TRY(g->h_flow.ensure(sizeof(uint2) * std::max<size_t>(1, n_vbs) + sizeof(uint32_t) * (sync_words + 1)));
+            uint32_t *h_sync = g->h_flow.as<uint32_t>();
             uint2 *h_desc = reinterpret_cast<uint2 *>(h_sync + ((sync_words + 2) & ~(size_t)1));
             for (uint32_t i = 0; i < P; ++i) { h_sync[i] = 0; h_sync[P + i] = (h_meta[i].state == prk::kSkip) ? 0xffffffffu : 0u; }
             h_sync[2 * P] = 0;
             if (n_vbs) std::memcpy(h_desc, desc.data(), sizeof(uint2) * n_vbs);
-            HIP_TRY(hipMemcpyAsync(g.dstate.p, init, sizeof(prk::DevIcpState) * P, hipMemcpyHostToDevice, g.stream));
-            HIP_TRY(hipMemcpyAsync(g.meta.p, h_meta, sizeof(prk::PoseMeta) * P, hipMemcpyHostToDevice, g.stream));
-            HIP_TRY(hipMemcpyAsync(g.flowsync.p, h_sync, sizeof(uint32_t) * sync_words, hipMemcpyHostToDevice, g.stream));
+            HIP_TRY(hipMemcpyAsync(g->dstate.p, init, sizeof(prk::DevIcpState) * P, hipMemcpyHostToDevice, g->stream));
+            HIP_TRY(hipMemcpyAsync(g->meta.p, h_meta, sizeof(prk::PoseMeta) * P, hipMemcpyHostToDevice, g->stream));
+            HIP_TRY(hipMemcpyAsync(g->flowsync.p, h_sync, sizeof(uint32_t) * sync_words, hipMemcpyHostToDevice, g->stream));
             if (n_vbs) {
-                HIP_TRY(hipMemcpyAsync(g.vbdesc.p, h_desc, sizeof(uint2) * n_vbs, hipMemcpyHostToDevice, g.stream));
+                HIP_TRY(hipMemcpyAsync(g->vbdesc.p, h_desc, sizeof(uint2) * n_vbs, hipMemcpyHostToDevice, g->stream));
                 prk::FlowArgs fa{};
-                fa.cloud = cloud_base; fa.meta = g.meta.as<prk::PoseMeta>(); fa.partial = g.partial.as<float>();
-                fa.st = g.dstate.as<prk::DevIcpState>(); fa.vb_desc = g.vbdesc.as<uint2>();
-                fa.arrive = g.flowsync.as<uint32_t>(); fa.ready = fa.arrive + P; fa.abort_flag = fa.arrive + 2 * P;
+                fa.cloud = cloud_base; fa.meta = g->meta.as<prk::PoseMeta>(); fa.partial = g->partial.as<float>();
+                fa.st = g->dstate.as<prk::DevIcpState>(); fa.vb_desc = g->vbdesc.as<uint2>();
+                fa.arrive = g->flowsync.as<uint32_t>(); fa.ready = fa.arrive + P; fa.abort_flag = fa.arrive + 2 * P;
                 fa.n_vbs = n_vbs; fa.nblk = nblk; fa.steps = steps; fa.crit = crit;
                 uint32_t grid = 0;
                 SpanGuard sp(kSpanIcp);
-                if (sc.kind == PR_SCENE_NN) HIP_TRY(prk::launch_icp_flow_nn(fa, sc.nn, (uint32_t)g.n_cus, g.stream, &grid));
-                else if (sc.packed) HIP_TRY(prk::launch_icp_flow_proj_packed(fa, sc.pk, (uint32_t)g.n_cus, g.stream, &grid));
-                else HIP_TRY(prk::launch_icp_flow_proj_aos(fa, sc.aos, (uint32_t)g.n_cus, g.stream, &grid));
-                if (g.profile) {                                  // one launch = all passes: 36 B/point on pass 0, 48 B/point afterwards
-                    g.icp_points += sum_n * (uint64_t)(crit.max_iteration + 1);
-                    g.icp_bytes += sum_n * (36ull + 48ull * (uint64_t)crit.max_iteration);
+                if (sc.kind == PR_SCENE_NN) HIP_TRY(prk::launch_icp_flow_nn(fa, sc.nn, (uint32_t)g->n_cus, g->stream, &grid));
+                else if (sc.packed) HIP_TRY(prk::launch_icp_flow_proj_packed(fa, sc.pk, (uint32_t)g->n_cus, g->stream, &grid));
+                else HIP_TRY(prk::launch_icp_flow_proj_aos(fa, sc.aos, (uint32_t)g->n_cus, g->stream, &grid));
+                if (opt.profile) {                                  // one launch = all passes: 36 B/point on pass 0, 48 B/point afterwards
+                    g->icp_points += sum_n * (uint64_t)(crit.max_iteration + 1);
+                    g->icp_bytes += sum_n * (36ull + 48ull * (uint64_t)crit.max_iteration);
                 }
             }
-            HIP_TRY(prk::launch_pack_results(g.dstate.as<prk::DevIcpState>(), dres, P, g.stream));
-            if (results_host) HIP_TRY(hipMemcpyAsync(res, dres, sizeof(pr_result) * P, hipMemcpyDeviceToHost, g.stream));
-            HIP_TRY(hipMemcpyAsync(h_sync + 2 * P, g.flowsync.as<uint32_t>() + 2 * P, sizeof(uint32_t), hipMemcpyDeviceToHost, g.stream));
-            HIP_TRY(hipStreamSynchronize(g.stream));
+            HIP_TRY(prk::launch_pack_results(g->dstate.as<prk::DevIcpState>(), dres, P, g->stream));
+            if (results_host) HIP_TRY(hipMemcpyAsync(res, dres, sizeof(pr_result) * P, hipMemcpyDeviceToHost, g->stream));
+            HIP_TRY(hipMemcpyAsync(h_sync + 2 * P, g->flowsync.as<uint32_t>() + 2 * P, sizeof(uint32_t), hipMemcpyDeviceToHost, g->stream));
+            HIP_TRY(hipStreamSynchronize(g->stream));
             drain_spans();
             if (h_sync[2 * P] != 0) { set_error("dataflow ICP kernel timed out waiting on a hypothesis (workgroups not co-resident?)"); return PR_ERR_HIP; }
             if (results_host) std::memcpy(results_host, res, sizeof(pr_result) * P);
             return PR_OK;
         }
 
-        // profile==2: every kSamplePeriod-th call is a timed call -- it runs synchronously, as one pose group, with the other slot
+        // profile==2: every sample_period-th call is a timed call -- it runs synchronously, as one pose group, with the other slot
         // drained, and times every correspondence launch of its loop
-        const uint64_t tick = g.sample_clock++;
-        const bool sample_call = (g.profile == 2) && (tick % kSamplePeriod == 0);
+        const uint64_t tick = g->sample_clock++;
+        const bool sample_call = (opt.profile == 2) && (tick % (uint64_t)std::max(1, opt.sample_period) == 0);
         // Pose groups: the batch is split over up to four streams so that one group's serial solve tail (and the ragged end
         // of its pass) overlaps another group's pass.  Timed launches (profile 1, the sampled call of profile 2) run as a
         // single group so that the measured kernel has the chip to itself.
-        const bool timed_call = (g.profile == 1) || sample_call;
-        const uint32_t n_groups = timed_call ? 1u : std::max(1u, std::min({ (uint32_t)std::max(1, g.pose_groups), 4u, P / 32u }));
+        const bool timed_call = (opt.profile == 1) || sample_call;
+        const uint32_t n_groups = timed_call ? 1u : std::max(1u, std::min({ (uint32_t)std::max(1, opt.pose_groups), 4u, P / 32u }));
         // the fixed sequence: state upload, (max_iteration+1) x [correspondence pass, finalize+solve], result pack
         auto enqueue_all = [&](std::vector<hipEvent_t> *, bool host_checks) -> int {
-            HIP_TRY(hipMemcpyAsync(g.dstate.p, init, sizeof(prk::DevIcpState) * P, hipMemcpyHostToDevice, g.stream));
-            HIP_TRY(hipMemcpyAsync(g.meta.p, h_meta, sizeof(prk::PoseMeta) * P, hipMemcpyHostToDevice, g.stream));
-            if (fused) HIP_TRY(hipMemsetAsync(g.arrive.p, 0, sizeof(uint32_t) * P, g.stream));
+            HIP_TRY(hipMemcpyAsync(g->dstate.p, init, sizeof(prk::DevIcpState) * P, hipMemcpyHostToDevice, g->stream));
+            HIP_TRY(hipMemcpyAsync(g->meta.p, h_meta, sizeof(prk::PoseMeta) * P, hipMemcpyHostToDevice, g->stream));
+            if (fused) HIP_TRY(hipMemsetAsync(g->arrive.p, 0, sizeof(uint32_t) * P, g->stream));
             // Two pose groups on two streams: while the (latency-bound, one wavefront per pose) finalize+solve
             // of one group runs, the correspondence pass of the other group keeps the chip busy.
             auto group_begin = [&](uint32_t grp) { return (uint32_t)(((uint64_t)P * grp) / n_groups); };
             if (n_groups > 1) {
-                for (uint32_t k = 1; k < n_groups; ++k) PR_TRY(ensure_stream(g.side[k - 1], &g.ev_join[k - 1]));
-                HIP_TRY(hipEventRecord(g.ev_fork, g.stream));
-                for (uint32_t k = 1; k < n_groups; ++k) HIP_TRY(hipStreamWaitEvent(g.side[k - 1], g.ev_fork, 0));
+                for (uint32_t k = 1; k < n_groups; ++k) PR_TRY(ensure_stream(g->side[k - 1], &g->ev_join[k - 1]));
+                HIP_TRY(hipEventRecord(g->ev_fork, g->stream));
+                for (uint32_t k = 1; k < n_groups; ++k) HIP_TRY(hipStreamWaitEvent(g->side[k - 1], g->ev_fork, 0));
             }
             for (uint32_t it = 0; it <= (uint32_t)crit.max_iteration; ++it) {
                 for (uint32_t grp = 0; grp < n_groups; ++grp) {
                     const uint32_t p0 = group_begin(grp), np = group_begin(grp + 1) - p0;
-                    hipStream_t st = grp ? g.side[grp - 1] : g.stream;
+                    hipStream_t st = grp ? g->side[grp - 1] : g->stream;
                     prk::IcpBatch bb = b;
                     bb.meta += p0; bb.partial += (size_t)p0 * nblk * prk::kAccStride;
-                    if (fused) { bb.fused = 1; bb.iter = it; bb.crit = crit; bb.st = g.dstate.as<prk::DevIcpState>() + p0; bb.arrive = g.arrive.as<uint32_t>() + p0; }
+                    if (fused) { bb.fused = 1; bb.iter = it; bb.crit = crit; bb.st = g->dstate.as<prk::DevIcpState>() + p0; bb.arrive = g->arrive.as<uint32_t>() + p0; }
                     bb.score_only = (it == (uint32_t)crit.max_iteration) ? 1u : 0u;
-                    if (grp == 0 && (g.profile == 1 || sample_call)) {           // a timed call times every launch of its loop
+                    if (grp == 0 && (opt.profile == 1 || sample_call)) {           // a timed call times every launch of its loop
                         SpanGuard sp(kSpanIcp); HIP_TRY(launch_pass(bb, sc, np, st));
                         uint64_t pts = 0; for (uint32_t i = p0; i < p0 + np; ++i) pts += count_h[i];
                         // algorithmic bytes per point: 12 read + 24 gathered, + 12 written back once a transform is
                         // pending; the score-only last pass needs the scene point but not its normal (12 + 12 + 12)
                         const bool first = (it == 0), last = (it == (uint32_t)crit.max_iteration);
-                        g.icp_points += pts; g.icp_bytes += pts * ((first || last) ? 36u : 48u);
+                        g->icp_points += pts; g->icp_bytes += pts * ((first || last) ? 36u : 48u);
                     } else HIP_TRY(launch_pass(bb, sc, np, st));
-                    if (!fused) HIP_TRY(prk::launch_icp_finalize_solve(bb.partial, g.meta.as<prk::PoseMeta>() + p0, nblk, steps,
-                                                                       g.dstate.as<prk::DevIcpState>() + p0, crit, it, np, st));
+                    if (!fused) HIP_TRY(prk::launch_icp_finalize_solve(bb.partial, g->meta.as<prk::PoseMeta>() + p0, nblk, steps,
+                                                                       g->dstate.as<prk::DevIcpState>() + p0, crit, it, np, st));
                 }
                 if (host_checks && may_exit_early && (it & 3) == 3 && it < (uint32_t)crit.max_iteration) {
-                    for (uint32_t k = 1; k < n_groups; ++k) HIP_TRY(hipStreamSynchronize(g.side[k - 1]));
-                    HIP_TRY(hipMemcpyAsync(h_meta, g.meta.p, sizeof(prk::PoseMeta) * P, hipMemcpyDeviceToHost, g.stream));
-                    HIP_TRY(hipStreamSynchronize(g.stream));
+                    for (uint32_t k = 1; k < n_groups; ++k) HIP_TRY(hipStreamSynchronize(g->side[k - 1]));
+                    HIP_TRY(hipMemcpyAsync(h_meta, g->meta.p, sizeof(prk::PoseMeta) * P, hipMemcpyDeviceToHost, g->stream));
+                    HIP_TRY(hipStreamSynchronize(g->stream));
                     bool any = false;
                     for (uint32_t i = 0; i < P; ++i) any |= (h_meta[i].state != prk::kSkip);
                     if (!any) break;
                 }
             }
-            for (uint32_t k = 1; k < n_groups; ++k) { HIP_TRY(hipEventRecord(g.ev_join[k - 1], g.side[k - 1])); HIP_TRY(hipStreamWaitEvent(g.stream, g.ev_join[k - 1], 0)); }
-            HIP_TRY(prk::launch_pack_results(g.dstate.as<prk::DevIcpState>(), dres, P, g.stream));
+            for (uint32_t k = 1; k < n_groups; ++k) { HIP_TRY(hipEventRecord(g->ev_join[k - 1], g->side[k - 1])); HIP_TRY(hipStreamWaitEvent(g->stream, g->ev_join[k - 1], 0)); }
+            HIP_TRY(prk::launch_pack_results(g->dstate.as<prk::DevIcpState>(), dres, P, g->stream));
             // results go to the pinned staging buffer (a pageable destination is not capturable)
-            if (results_host) HIP_TRY(hipMemcpyAsync(res, dres, sizeof(pr_result) * P, hipMemcpyDeviceToHost, g.stream));
+            if (results_host) HIP_TRY(hipMemcpyAsync(res, dres, sizeof(pr_result) * P, hipMemcpyDeviceToHost, g->stream));
             return PR_OK;
         };
 
-        if (g.use_graph && n_groups == 1 && (g.profile == 0 || (g.profile == 2 && !sample_call))) {   // HIP events recorded inside a captured graph cannot be timed
+        if (opt.use_graph && n_groups == 1 && (opt.profile == 0 || (opt.profile == 2 && !sample_call))) {   // HIP events recorded inside a captured graph cannot be timed
             GraphKey key;
-            key.add(P); key.add(nblk); key.add(steps); key.add(crit); key.add(sc); key.add(cloud_base); key.add(g.meta.p); key.add(g.partial.p);
-            key.add(g.dstate.p); key.add(dres); key.add(results_host != nullptr); key.add(res); key.add(h_meta); key.add(init); key.add(g.profile); key.add(g.pose_groups); key.add(g.fused_solve); key.add(g.arrive.p); key.add(b.nn_prev);
+            key.add(P); key.add(nblk); key.add(steps); key.add(crit); key.add(sc); key.add(cloud_base); key.add(g->meta.p); key.add(g->partial.p);
+            key.add(g->dstate.p); key.add(dres); key.add(results_host != nullptr); key.add(res); key.add(h_meta); key.add(init); key.add(opt.profile); key.add(opt.pose_groups); key.add(opt.fused_solve); key.add(g->arrive.p); key.add(b.nn_prev);
             CachedGraph *hit = nullptr;
-            for (auto &c : g_graphs) if (c.exec && c.key == key) { hit = &c; break; }
+            for (auto &c : g->graphs) if (c.exec && c.key == key) { hit = &c; break; }
             if (!hit) {
-                if (g_graphs.size() >= 8) {                         // evict the least recently used entry
+                if (g->graphs.size() >= 8) {                         // evict the least recently used entry
                     size_t lru = 0;
-                    for (size_t i = 1; i < g_graphs.size(); ++i) if (g_graphs[i].stamp < g_graphs[lru].stamp) lru = i;
-                    destroy_graph(g_graphs[lru]);
-                    g_graphs.erase(g_graphs.begin() + lru);
+                    for (size_t i = 1; i < g->graphs.size(); ++i) if (g->graphs[i].stamp < g->graphs[lru].stamp) lru = i;
+                    destroy_graph(g->graphs[lru]);
+                    g->graphs.erase(g->graphs.begin() + lru);
                 }
                 CachedGraph c; c.key = key;
-                HIP_TRY(hipStreamSynchronize(g.stream));
-                HIP_TRY(hipStreamBeginCapture(g.stream, hipStreamCaptureModeThreadLocal));
+                HIP_TRY(hipStreamSynchronize(g->stream));
+                HIP_TRY(hipStreamBeginCapture(g->stream, hipStreamCaptureModeThreadLocal));
                 int rc = enqueue_all(nullptr, /*host_checks=*/false);
-                hipError_t ce = hipStreamEndCapture(g.stream, &c.graph);
+                hipError_t ce = hipStreamEndCapture(g->stream, &c.graph);
                 if (rc != PR_OK || ce != hipSuccess) { destroy_graph(c); if (rc == PR_OK) { set_error("hipStreamEndCapture failed: %s", hipGetErrorString(ce)); rc = PR_ERR_HIP; } return rc; }
                 HIP_TRY(hipGraphInstantiate(&c.exec, c.graph, nullptr, nullptr, 0));
-                g_graphs.push_back(std::move(c));
-                hit = &g_graphs.back();
+                g->graphs.push_back(std::move(c));
+                hit = &g->graphs.back();
             }
-            hit->stamp = ++g_graph_clock;
-            HIP_TRY(hipGraphLaunch(hit->exec, g.stream));
-            HIP_TRY(hipStreamSynchronize(g.stream));
+            hit->stamp = ++g->graph_clock;
+            HIP_TRY(hipGraphLaunch(hit->exec, g->stream));
+            HIP_TRY(hipStreamSynchronize(g->stream));
             if (results_host) std::memcpy(results_host, res, sizeof(pr_result) * P);
             drain_spans();
             return PR_OK;
         }
 
         PR_TRY(enqueue_all(nullptr, /*host_checks=*/true));
-        HIP_TRY(hipStreamSynchronize(g.stream));
+        HIP_TRY(hipStreamSynchronize(g->stream));
         if (results_host) std::memcpy(results_host, res, sizeof(pr_result) * P);
         drain_spans();
         return PR_OK;
     }
 
     // PR_SOLVE_HOST: one launch + one small D2H per iteration, the per-pose logic of icp.cu:178-212 on the host
-    const uint32_t host_sample_it = (uint32_t)((g.sample_clock++ * 5 + 1) % (uint64_t)(crit.max_iteration + 1));
+    const uint32_t host_sample_it = (uint32_t)((g->sample_clock++ * 5 + 1) % (uint64_t)(crit.max_iteration + 1));
     uint32_t active = 0;
     for (uint32_t i = 0; i < P; ++i) active += (h_meta[i].state != prk::kSkip);
     for (uint32_t it = 0; it <= (uint32_t)crit.max_iteration && active > 0; ++it) {
-        HIP_TRY(hipMemcpyAsync(g.meta.p, h_meta, sizeof(prk::PoseMeta) * P, hipMemcpyHostToDevice, g.stream));
-        if (g.profile == 1 || (g.profile == 2 && it == host_sample_it)) {
+        HIP_TRY(hipMemcpyAsync(g->meta.p, h_meta, sizeof(prk::PoseMeta) * P, hipMemcpyHostToDevice, g->stream));
+        if (opt.profile == 1 || (opt.profile == 2 && it == host_sample_it)) {
             SpanGuard sp(kSpanIcp); HIP_TRY(launch_pass(b, sc, P));
-            for (uint32_t i = 0; i < P; ++i) if (h_meta[i].state != prk::kSkip) { g.icp_points += count_h[i]; g.icp_bytes += (uint64_t)count_h[i] * (it == 0 ? 36u : 48u); }
+            for (uint32_t i = 0; i < P; ++i) if (h_meta[i].state != prk::kSkip) { g->icp_points += count_h[i]; g->icp_bytes += (uint64_t)count_h[i] * (it == 0 ? 36u : 48u); }
         } else HIP_TRY(launch_pass(b, sc, P));
-        HIP_TRY(prk::launch_icp_finalize(g.partial.as<float>(), g.meta.as<prk::PoseMeta>(), nblk, steps,
-                                         g.sums.as<float>(), P, g.stream));
-        HIP_TRY(hipMemcpyAsync(h_sums, g.sums.p, sizeof(float) * prk::kAccStride * P, hipMemcpyDeviceToHost, g.stream));
-        HIP_TRY(hipStreamSynchronize(g.stream));
+        HIP_TRY(prk::launch_icp_finalize(g->partial.as<float>(), g->meta.as<prk::PoseMeta>(), nblk, steps,
+                                         g->sums.as<float>(), P, g->stream));
+        HIP_TRY(hipMemcpyAsync(h_sums, g->sums.p, sizeof(float) * prk::kAccStride * P, hipMemcpyDeviceToHost, g->stream));
+        HIP_TRY(hipStreamSynchronize(g->stream));
         active = 0;
         for (uint32_t i = 0; i < P; ++i) {
             if (h_meta[i].state == prk::kSkip) continue;
@@ -511,8 +678,8 @@ int icp_drive(pr_vec3 *cloud_base, const uint32_t *start_h, const uint32_t *coun
     }
     if (results_host) std::memcpy(results_host, res, sizeof(pr_result) * P);
     if (results_dev) {
-        HIP_TRY(hipMemcpyAsync(results_dev, res, sizeof(pr_result) * P, hipMemcpyHostToDevice, g.stream));
-        HIP_TRY(hipStreamSynchronize(g.stream));
+        HIP_TRY(hipMemcpyAsync(results_dev, res, sizeof(pr_result) * P, hipMemcpyHostToDevice, g->stream));
+        HIP_TRY(hipStreamSynchronize(g->stream));
     }
     drain_spans();
     return PR_OK;
@@ -539,13 +706,13 @@ int render_impl(const pr_triangle *tris_dev, size_t n_tris, const pr_mat4 *poses
         rw = (size_t)roi.width; rh = (size_t)roi.height;
     }
     if (P == 0) return PR_OK;
-    PR_TRY(g.poses.ensure(sizeof(pr_mat4) * P));
+    PR_TRY(g->poses.ensure(sizeof(pr_mat4) * P));
     SpanGuard sp(kSpanRender);
-    HIP_TRY(hipMemcpyAsync(g.poses.p, poses_host, sizeof(pr_mat4) * P, hipMemcpyHostToDevice, g.stream));
-    HIP_TRY(prk::launch_fill_i32(depth_dev, P * rw * rh, INT32_MAX, g.stream));
-    HIP_TRY(prk::launch_raster(tris_dev, (uint32_t)n_tris, g.poses.as<pr_mat4>(), (uint32_t)P, depth_dev, (uint32_t)W, (uint32_t)H,
-                               *proj, roi, (uint32_t)rw, (uint32_t)rh, g.stream));
-    if (zero_empty) HIP_TRY(prk::launch_max2zero(depth_dev, P * rw * rh, g.stream));
+    HIP_TRY(hipMemcpyAsync(g->poses.p, poses_host, sizeof(pr_mat4) * P, hipMemcpyHostToDevice, g->stream));
+    HIP_TRY(prk::launch_fill_i32(depth_dev, P * rw * rh, INT32_MAX, g->stream));
+    HIP_TRY(prk::launch_raster(tris_dev, (uint32_t)n_tris, g->poses.as<pr_mat4>(), (uint32_t)P, depth_dev, (uint32_t)W, (uint32_t)H,
+                               *proj, roi, (uint32_t)rw, (uint32_t)rh, g->stream));
+    if (zero_empty) HIP_TRY(prk::launch_max2zero(depth_dev, P * rw * rh, g->stream));
     return PR_OK;
 }
 
@@ -555,32 +722,42 @@ int depth2cloud_impl(const T *depth_dev, uint32_t W, uint32_t H, const float K[9
 {
     if (!depth_dev || !K || !cloud_out || !n_out || W == 0 || H == 0 || stride == 0) { set_error("pr_depth2cloud: bad arguments"); return PR_ERR_INVALID; }
     const uint32_t gh = H / stride;
-    PR_TRY(g.row_count.ensure(sizeof(uint32_t) * std::max(1u, gh)));
-    PR_TRY(g.row_off.ensure(sizeof(uint32_t) * std::max(1u, gh)));
-    PR_TRY(g.counts.ensure(sizeof(uint32_t)));
-    HIP_TRY(prk::launch_depth2cloud<T>(depth_dev, 1, 0, W, H, stride, tl_x, tl_y, K[0], K[4], K[2], K[5], false, g.row_count.as<uint32_t>(),
-                                       g.row_off.as<uint32_t>(), g.counts.as<uint32_t>(), nullptr, 0, false, g.stream));
+    PR_TRY(g->row_count.ensure(sizeof(uint32_t) * std::max(1u, gh)));
+    PR_TRY(g->row_off.ensure(sizeof(uint32_t) * std::max(1u, gh)));
+    PR_TRY(g->counts.ensure(sizeof(uint32_t)));
+    HIP_TRY(prk::launch_depth2cloud<T>(depth_dev, 1, 0, W, H, stride, tl_x, tl_y, K[0], K[4], K[2], K[5], false, g->row_count.as<uint32_t>(),
+                                       g->row_off.as<uint32_t>(), g->counts.as<uint32_t>(), nullptr, 0, false, g->stream));
     uint32_t n = 0;
-    HIP_TRY(hipMemcpyAsync(&n, g.counts.p, sizeof n, hipMemcpyDeviceToHost, g.stream));
-    HIP_TRY(hipStreamSynchronize(g.stream));
+    HIP_TRY(hipMemcpyAsync(&n, g->counts.p, sizeof n, hipMemcpyDeviceToHost, g->stream));
+    HIP_TRY(hipStreamSynchronize(g->stream));
     pr_vec3 *cloud = nullptr;
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&cloud), sizeof(pr_vec3) * std::max(1u, n)));
     if (n > 0) {
-        hipError_t e = prk::launch_depth2cloud<T>(depth_dev, 1, 0, W, H, stride, tl_x, tl_y, K[0], K[4], K[2], K[5], false, g.row_count.as<uint32_t>(),
-                                                  g.row_off.as<uint32_t>(), g.counts.as<uint32_t>(), cloud, 0, true, g.stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(g.stream);
+        hipError_t e = prk::launch_depth2cloud<T>(depth_dev, 1, 0, W, H, stride, tl_x, tl_y, K[0], K[4], K[2], K[5], false, g->row_count.as<uint32_t>(),
+                                                  g->row_off.as<uint32_t>(), g->counts.as<uint32_t>(), cloud, 0, true, g->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
         if (e != hipSuccess) { hipFree(cloud); set_error("depth2cloud emit failed: %s", hipGetErrorString(e)); return PR_ERR_HIP; }
     }
     *cloud_out = cloud; *n_out = n;
     return PR_OK;
 }
 
+bool roi_ok(pr_roi roi, uint32_t W, uint32_t H)
+{
+    if (roi.width <= 0 || roi.height <= 0) return true;            // no ROI
+    if (roi.x < 0 || roi.y < 0 || (size_t)roi.x + (size_t)roi.width > W || (size_t)roi.y + (size_t)roi.height > H) {
+        set_error("roi out of image");                               // renderer.cu:202-203 asserts
+        return false;
+    }
+    return true;
+}
+
 int refine_impl(const pr_triangle *tris_dev, size_t n_tris, const pr_mat4 *poses_host, uint32_t P, uint32_t W, uint32_t H,
-                const pr_mat4 *proj, const float K[9], int scene_kind, const void *scene, pr_criteria crit,
+                const pr_mat4 *proj, const float K[9], int scene_kind, const void *scene, pr_criteria crit, pr_roi roi,
                 pr_result *results_host, pr_result *results_dev, uint32_t *sizes_host)
 {
     if (!K || W == 0 || H == 0) { set_error("pr_refine_batch: bad arguments"); return PR_ERR_INVALID; }
-    if (!frame_size_ok(W, H)) return PR_ERR_INVALID;
+    if (!frame_size_ok(W, H) || !roi_ok(roi, W, H)) return PR_ERR_INVALID;
     if (P == 0) return PR_OK;
     SceneSel sc;
     std::memset(static_cast<void *>(&sc), 0, sizeof sc);           // also zeroes padding: sc is part of the graph-cache key
@@ -590,48 +767,47 @@ int refine_impl(const pr_triangle *tris_dev, size_t n_tris, const pr_mat4 *poses
     const size_t img = (size_t)W * H;
     uint32_t chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(P, ((size_t)4 << 30) / (img * sizeof(int32_t))));
     std::vector<uint32_t> start(chunk), count(chunk);
+    // model box: recomputed from the triangle buffer on every call (one pass over the mesh; nothing is cached by address here)
+    PR_TRY(g->aabb.ensure(6 * sizeof(float)));
+    PR_TRY(g->aabb_keys.ensure(6 * sizeof(uint32_t)));
+    HIP_TRY(prk::launch_model_aabb(tris_dev, (uint32_t)n_tris, g->aabb_keys.as<uint32_t>(), g->aabb.as<float>(), nullptr, nullptr, g->stream));
     for (uint32_t p0 = 0; p0 < P; p0 += chunk) {
         const uint32_t np = std::min(chunk, P - p0);
-        PR_TRY(g.depth.ensure(sizeof(int32_t) * img * np));
-        PR_TRY(g.row_count.ensure(sizeof(uint32_t) * (size_t)H * np));
-        PR_TRY(g.row_off.ensure(sizeof(uint32_t) * (size_t)H * np));
-        PR_TRY(g.counts.ensure(sizeof(uint32_t) * np));
-        PR_TRY(g.h_counts.ensure(sizeof(uint32_t) * np));
-        uint32_t *h_counts = g.h_counts.as<uint32_t>();
-        // model box once per (triangle buffer, size); per-pose pixel boxes; raster + row counts + row scan
-        PR_TRY(g.aabb.ensure(6 * sizeof(float)));
-        PR_TRY(g.bbox.ensure(sizeof(int4) * np));
-        PR_TRY(g.poses.ensure(sizeof(pr_mat4) * np));
-        if (g.aabb_key != tris_dev || g.aabb_n != n_tris) {
-            HIP_TRY(prk::launch_model_aabb(tris_dev, (uint32_t)n_tris, g.aabb.as<float>(), g.stream));
-            g.aabb_key = tris_dev; g.aabb_n = n_tris; g.aabb_host_valid = false;
-        }
+        PR_TRY(g->depth.ensure(sizeof(int32_t) * img * np));
+        PR_TRY(g->row_count.ensure(sizeof(uint32_t) * (size_t)H * np));
+        PR_TRY(g->row_off.ensure(sizeof(uint32_t) * (size_t)H * np));
+        PR_TRY(g->counts.ensure(sizeof(uint32_t) * np));
+        PR_TRY(g->h_counts.ensure(sizeof(uint32_t) * np));
+        uint32_t *h_counts = g->h_counts.as<uint32_t>();
+        // per-pose pixel boxes; raster + row counts + row scan
+        PR_TRY(g->bbox.ensure(sizeof(int4) * np));
+        PR_TRY(g->poses.ensure(sizeof(pr_mat4) * np));
         {
             SpanGuard sp(kSpanRender);
-            HIP_TRY(hipMemcpyAsync(g.poses.p, poses_host + p0, sizeof(pr_mat4) * np, hipMemcpyHostToDevice, g.stream));
-            if (g.raster_mode == 1)
-                HIP_TRY(prk::launch_render_bands(tris_dev, (uint32_t)n_tris, g.poses.as<pr_mat4>(), np, g.aabb.as<float>(), g.bbox.as<int4>(),
-                                                 g.depth.as<int32_t>(), g.row_count.as<uint32_t>(), g.row_off.as<uint32_t>(),
-                                                 g.counts.as<uint32_t>(), W, H, *proj, (uint32_t)g.n_cus, g.stream));
+            HIP_TRY(hipMemcpyAsync(g->poses.p, poses_host + p0, sizeof(pr_mat4) * np, hipMemcpyHostToDevice, g->stream));
+            if (opt.raster_mode == 1)
+                HIP_TRY(prk::launch_render_bands(tris_dev, (uint32_t)n_tris, g->poses.as<pr_mat4>(), np, g->aabb.as<float>(), g->bbox.as<int4>(),
+                                                 g->depth.as<int32_t>(), g->row_count.as<uint32_t>(), g->row_off.as<uint32_t>(),
+                                                 g->counts.as<uint32_t>(), W, H, *proj, roi, (uint32_t)g->n_cus, g->stream));
             else
-                HIP_TRY(prk::launch_render_boxes(tris_dev, (uint32_t)n_tris, g.poses.as<pr_mat4>(), np, g.aabb.as<float>(), g.bbox.as<int4>(),
-                                                 g.depth.as<int32_t>(), g.row_count.as<uint32_t>(), g.row_off.as<uint32_t>(),
-                                                 g.counts.as<uint32_t>(), W, H, *proj, g.stream));
+                HIP_TRY(prk::launch_render_boxes(tris_dev, (uint32_t)n_tris, g->poses.as<pr_mat4>(), np, g->aabb.as<float>(), g->bbox.as<int4>(),
+                                                 g->depth.as<int32_t>(), g->row_count.as<uint32_t>(), g->row_off.as<uint32_t>(),
+                                                 g->counts.as<uint32_t>(), W, H, *proj, roi, g->stream));
         }
-        HIP_TRY(hipMemcpyAsync(h_counts, g.counts.p, sizeof(uint32_t) * np, hipMemcpyDeviceToHost, g.stream));
-        HIP_TRY(hipStreamSynchronize(g.stream));
+        HIP_TRY(hipMemcpyAsync(h_counts, g->counts.p, sizeof(uint32_t) * np, hipMemcpyDeviceToHost, g->stream));
+        HIP_TRY(hipStreamSynchronize(g->stream));
         uint32_t max_n = 0;
         for (uint32_t i = 0; i < np; ++i) max_n = std::max(max_n, h_counts[i]);
         const size_t cstride = ((size_t)max_n + 3) & ~(size_t)3;           // keeps every cloud 16-byte aligned
-        PR_TRY(g.cloud.ensure(sizeof(pr_vec3) * std::max<size_t>(4, cstride) * np));
+        PR_TRY(g->cloud.ensure(sizeof(pr_vec3) * std::max<size_t>(4, cstride) * np));
         if (max_n > 0) {
             SpanGuard sp(kSpanCloud);
-            HIP_TRY(prk::launch_emit_box(g.depth.as<int32_t>(), np, W, H, g.bbox.as<int4>(), K[0], K[4], K[2], K[5],
-                                         g.row_count.as<uint32_t>(), g.row_off.as<uint32_t>(), g.cloud.as<pr_vec3>(), cstride, g.stream));
+            HIP_TRY(prk::launch_emit_box(g->depth.as<int32_t>(), np, W, H, g->bbox.as<int4>(), K[0], K[4], K[2], K[5],
+                                         g->row_count.as<uint32_t>(), g->row_off.as<uint32_t>(), g->cloud.as<pr_vec3>(), cstride, g->stream));
         }
         for (uint32_t i = 0; i < np; ++i) { start[i] = (uint32_t)(i * cstride); count[i] = h_counts[i]; }
         if (sizes_host) std::memcpy(sizes_host + p0, count.data(), sizeof(uint32_t) * np);
-        PR_TRY(icp_drive(g.cloud.as<pr_vec3>(), start.data(), count.data(), np, sc, crit,
+        PR_TRY(icp_drive(g->cloud.as<pr_vec3>(), start.data(), count.data(), np, sc, crit,
                          results_host ? results_host + p0 : nullptr, results_dev ? results_dev + p0 : nullptr));
     }
     return PR_OK;
@@ -643,20 +819,6 @@ int refine_impl(const pr_triangle *tris_dev, size_t n_tris, const pr_mat4 *poses
 // Here the host computes the per-pose pixel boxes itself (same arithmetic as pose_bbox_kernel, 8 corners per pose), which
 // bounds every cloud by its box area, the start state is written by a kernel from the device-side counts, and a batch is
 // only waited for when its results are wanted -- so the next batch can be enqueued while this one runs.
-struct Slot {
-    DevBuf poses_bbox, depth, row_count, row_off, counts, cloud, meta, partial, dstate, dresults, arrive, rec;
-    PinBuf h_in, h_out;
-    hipStream_t stream = nullptr, side[3] = { nullptr, nullptr, nullptr };
-    hipEvent_t fork = nullptr, join[3] = { nullptr, nullptr, nullptr }, done = nullptr, scene_ready = nullptr, progress = nullptr;
-    bool progress_valid = false;
-    bool pending = false, delivered = false;
-    uint32_t P = 0;
-    pr_result *user_results_host = nullptr;
-    uint32_t *user_sizes = nullptr;
-};
-constexpr int kSlots = 2;
-Slot g_slots[kSlots];
-
 int slot_streams(Slot &sl)
 {
     if (sl.stream) return PR_OK;
@@ -667,11 +829,18 @@ int slot_streams(Slot &sl)
     HIP_TRY(hipEventCreateWithFlags(&sl.progress, hipEventDisableTiming));
     return PR_OK;                                                // side streams: ensure_stream, when a batch has pose groups
 }
+// wait for everything a slot has in flight (its stream and side streams)
+void slot_drain(Slot &sl)
+{
+    for (int i = 0; i < 3; ++i) if (sl.side[i]) (void)hipStreamSynchronize(sl.side[i]);
+    if (sl.stream) (void)hipStreamSynchronize(sl.stream);
+}
 void slot_release(Slot &sl)
 {
-    if (sl.stream) hipStreamSynchronize(sl.stream);
+    slot_drain(sl);
     for (DevBuf *b : { &sl.poses_bbox, &sl.depth, &sl.row_count, &sl.row_off, &sl.counts, &sl.cloud, &sl.meta, &sl.partial, &sl.dstate,
-                       &sl.dresults, &sl.arrive, &sl.rec }) b->release();
+                       &sl.dresults, &sl.arrive, &sl.aabb_keys, &sl.packed.rec }) b->release();
+    sl.packed = PackedCache();
     sl.h_in.release(); sl.h_out.release();
     for (int i = 0; i < 3; ++i) {
         if (sl.side[i]) hipStreamDestroy(sl.side[i]);
@@ -687,25 +856,28 @@ void slot_release(Slot &sl)
     sl.fork = sl.done = sl.scene_ready = nullptr; sl.stream = nullptr; sl.pending = false;
 }
 
-// Host-side box of a triangle buffer, once per (pointer, size): it feeds the per-pose pixel boxes computed on the host.
+// Host-side copy of a triangle buffer's box, once per (pointer, size): it feeds the per-pose pixel boxes computed on the host,
+// which size a batch before anything of it has run.  The copy is an ASSUMPTION about memory the caller owns: every batch that
+// uses it re-derives the box on the device (one pass over the mesh, on a stream that is idle at that point) and refine_wait
+// re-runs the batch through the synchronous path if the two differ -- a rewritten mesh costs one repeated batch, never a wrong one.
 // (An indexed form of the soup with a per-pose vertex stage was built and measured as well: three divergent 16-byte gathers
 // per triangle cost the texture addresser more than the 170 saved VALU instructions give back -- 1.27 -> 1.32 ms per step.)
 int ensure_model_box(const pr_triangle *tris_dev, size_t n_tris)
 {
-    if (g.mesh_key == tris_dev && g.mesh_n == n_tris && g.aabb_host_valid) return PR_OK;
+    if (g->mesh_key == tris_dev && g->mesh_n == n_tris && g->aabb_host_valid) return PR_OK;
     std::vector<pr_triangle> h(n_tris);
-    HIP_TRY(hipMemcpy(h.data(), tris_dev, sizeof(pr_triangle) * n_tris, hipMemcpyDeviceToHost));
+    if (n_tris) HIP_TRY(hipMemcpy(h.data(), tris_dev, sizeof(pr_triangle) * n_tris, hipMemcpyDeviceToHost));
     const float *f = reinterpret_cast<const float *>(h.data());
     float lo[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, hi[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
     for (size_t v = 0; v < n_tris * 3; ++v)
         for (int d = 0; d < 3; ++d) { lo[d] = fminf(lo[d], f[3 * v + d]); hi[d] = fmaxf(hi[d], f[3 * v + d]); }
-    for (int d = 0; d < 3; ++d) { g.aabb_host[d] = lo[d]; g.aabb_host[3 + d] = hi[d]; }
-    g.mesh_key = tris_dev; g.mesh_n = n_tris; g.aabb_host_valid = true;
+    for (int d = 0; d < 3; ++d) { g->aabb_host[d] = lo[d]; g->aabb_host[3 + d] = hi[d]; }
+    g->mesh_key = tris_dev; g->mesh_n = n_tris; g->aabb_host_valid = true;
     return PR_OK;
 }
 
 // pose_bbox_kernel on the host (same operations in the same order; any conservative box gives the same images and clouds)
-void pose_bbox_host(const float *aabb, const pr_mat4 &pose, const pr_mat4 &proj, uint32_t width, uint32_t height, int32_t out[4])
+void pose_bbox_host(const float *aabb, const pr_mat4 &pose, const pr_mat4 &proj, uint32_t width, uint32_t height, pr_roi roi, int32_t out[4])
 {
     const float *M = pose.m;
     float mnx = FLT_MAX, mny = FLT_MAX, mxx = -FLT_MAX, mxy = -FLT_MAX;
@@ -728,89 +900,142 @@ void pose_bbox_host(const float *aabb, const pr_mat4 &pose, const pr_mat4 &proj,
         x0 = std::max(0, (int)floorf(mnx) - 2);  x1 = std::min((int)width - 1, (int)ceilf(mxx) + 2);
         y0 = std::max(0, (int)floorf(mny) - 2);  y1 = std::min((int)height - 1, (int)ceilf(mxy) + 2);
     }
+    if (roi.width > 0 && roi.height > 0) {
+        x0 = std::max(x0, roi.x);  x1 = std::min(x1, roi.x + roi.width - 1);
+        y0 = std::max(y0, (int)height - 1 - (roi.y + roi.height - 1));  y1 = std::min(y1, (int)height - 1 - roi.y);
+    }
     out[0] = x0; out[1] = y0; out[2] = x1; out[3] = y1;
 }
 
 int refine_wait(int slot)
 {
     if (slot < 0 || slot >= kSlots) { set_error("slot must be 0..%d", kSlots - 1); return PR_ERR_INVALID; }
-    Slot &sl = g_slots[slot];
+    Slot &sl = g->slots[slot];
     if (!sl.pending) { set_error("pr_refine_wait: nothing was submitted on slot %d", slot); return PR_ERR_INVALID; }
     sl.pending = false;
     if (sl.delivered) return PR_OK;
     HIP_TRY(hipEventSynchronize(sl.done));
+    const unsigned char *h_out = sl.h_out.as<unsigned char>();
+    if (*reinterpret_cast<const volatile uint32_t *>(h_out + sl.flag_off) != 0u) {
+        // the triangle buffer no longer has the box this batch was sized with: forget the host copy and run the batch again,
+        // synchronously (that path derives every box on the device); outputs are overwritten in full
+        g->aabb_host_valid = false; g->mesh_key = nullptr;
+        const Resubmit &r = sl.again;
+        const void *scene = (r.scene_kind == PR_SCENE_NN) ? static_cast<const void *>(&r.sn) : static_cast<const void *>(&r.sp);
+        return refine_impl(r.tris, r.n_tris, sl.h_in.as<pr_mat4>(), sl.P, r.W, r.H, &r.proj, r.K, r.scene_kind, scene, r.crit, r.roi,
+                           sl.user_results_host, r.results_dev, sl.user_sizes);
+    }
     const uint32_t *h_counts = sl.h_out.as<uint32_t>();
     uint32_t largest = 1;
     for (uint32_t i = 0; i < sl.P; ++i) largest = std::max(largest, h_counts[i]);
-    g.cloud_hint = largest;
+    g->cloud_hint = largest;
     if (sl.user_sizes) std::memcpy(sl.user_sizes, h_counts, sizeof(uint32_t) * sl.P);
-    if (sl.user_results_host) std::memcpy(sl.user_results_host, reinterpret_cast<const unsigned char *>(h_counts) + (((size_t)sl.P * 4 + 63) & ~(size_t)63),
-                                          sizeof(pr_result) * sl.P);
+    if (sl.user_results_host) std::memcpy(sl.user_results_host, h_out + (((size_t)sl.P * 4 + 63) & ~(size_t)63), sizeof(pr_result) * sl.P);
     return PR_OK;
 }
 
+int refine_submit_async(Slot &sl, const pr_triangle *tris_dev, size_t n_tris, uint32_t P, uint32_t W, uint32_t H,
+                        const pr_mat4 *proj, const float K[9], int scene_kind, const void *scene, pr_criteria crit, pr_roi roi,
+                        pr_result *results_host, pr_result *results_dev);
+
 int refine_submit(int slot, const pr_triangle *tris_dev, size_t n_tris, const pr_mat4 *poses_host, uint32_t P, uint32_t W, uint32_t H,
-                  const pr_mat4 *proj, const float K[9], int scene_kind, const void *scene, pr_criteria crit,
+                  const pr_mat4 *proj, const float K[9], int scene_kind, const void *scene, pr_criteria crit, pr_roi roi,
                   pr_result *results_host, pr_result *results_dev, uint32_t *sizes_host)
 {
     if (slot < 0 || slot >= kSlots) { set_error("slot must be 0..%d", kSlots - 1); return PR_ERR_INVALID; }
-    Slot &sl = g_slots[slot];
+    Slot &sl = g->slots[slot];
     if (sl.pending) { set_error("pr_refine_submit: slot %d still holds an unfinished batch (call pr_refine_wait)", slot); return PR_ERR_INVALID; }
     if (!tris_dev || !poses_host || !proj || !K || W == 0 || H == 0 || (!results_host && !results_dev)) { set_error("pr_refine_submit: bad arguments"); return PR_ERR_INVALID; }
     if (crit.max_iteration < 0) { set_error("max_iteration must be >= 0"); return PR_ERR_INVALID; }
-    if (!frame_size_ok(W, H)) return PR_ERR_INVALID;
+    if (!frame_size_ok(W, H) || !roi_ok(roi, W, H)) return PR_ERR_INVALID;
     sl.P = P; sl.user_results_host = results_host; sl.user_sizes = sizes_host; sl.delivered = false;
     const size_t img = (size_t)W * H;
-    const bool sample_call = (g.profile == 2) && (g.sample_clock % kSamplePeriod == 0);
-    const bool async_ok = P > 0 && g.solve_mode == PR_SOLVE_DEVICE && !g.icp_flow && g.raster_mode == 0 && scene_kind == PR_SCENE_PROJ
-                          && img * sizeof(int32_t) * std::min<size_t>(P, (size_t)std::max(32, g.sub_batch)) <= ((size_t)4 << 30) && (g.profile == 0 || (g.profile == 2 && !sample_call));
+    const uint64_t period = (uint64_t)std::max(1, opt.sample_period);
+    const bool sample_call = (opt.profile == 2) && (g->sample_clock % period == 0);
+    const bool proj_scene = (scene_kind == PR_SCENE_PROJ || scene_kind == PR_SCENE_PROJ_CROP);
+    const bool async_ok = P > 0 && opt.solve_mode == PR_SOLVE_DEVICE && !opt.icp_flow && opt.raster_mode == 0 && proj_scene
+                          && img * sizeof(int32_t) * std::min<size_t>(P, (size_t)std::max(32, opt.sub_batch)) <= ((size_t)4 << 30) && (opt.profile == 0 || (opt.profile == 2 && !sample_call));
     if (!async_ok) {
         // the synchronous path (host solve, kd-tree scenes, timed calls, oversized batches): let the other slot drain first so
         // that a timed launch has the chip to itself, then run to completion; pr_refine_wait has nothing left to do
-        for (Slot &o : g_slots) if (o.pending && !o.delivered && o.done) HIP_TRY(hipEventSynchronize(o.done));
-        PR_TRY(refine_impl(tris_dev, n_tris, poses_host, P, W, H, proj, K, scene_kind, scene, crit, results_host, results_dev, sizes_host));
+        for (Slot &o : g->slots) if (o.pending && !o.delivered && o.done) HIP_TRY(hipEventSynchronize(o.done));
+        PR_TRY(refine_impl(tris_dev, n_tris, poses_host, P, W, H, proj, K, scene_kind, scene, crit, roi, results_host, results_dev, sizes_host));
         sl.pending = true; sl.delivered = true;
         return PR_OK;
     }
-    g.sample_clock++;
+    g->sample_clock++;
+    // the host copies of this batch's inputs (the poses are staged from here; the rest is what a re-run needs)
+    const size_t in_bytes = (sizeof(pr_mat4) + sizeof(int4)) * (size_t)P;
+    PR_TRY(sl.h_in.ensure(in_bytes + 16));
+    std::memcpy(sl.h_in.p, poses_host, sizeof(pr_mat4) * P);
+    Resubmit &r = sl.again;
+    r.tris = tris_dev; r.n_tris = n_tris; r.W = W; r.H = H; r.proj = *proj; std::memcpy(r.K, K, sizeof r.K);
+    r.scene_kind = scene_kind; r.crit = crit; r.roi = roi; r.results_dev = results_dev;
+    if (scene_kind == PR_SCENE_PROJ_CROP) r.sp = *static_cast<const pr_scene_proj_crop *>(scene);
+    else { r.sp.view = *static_cast<const pr_scene_proj *>(scene); r.sp.tl_x = r.sp.tl_y = 0; }
+    const int rc = refine_submit_async(sl, tris_dev, n_tris, P, W, H, proj, K, scene_kind, scene, crit, roi, results_host, results_dev);
+    if (rc != PR_OK) {                                            // part of the batch may already be queued: do not leave it running
+        slot_drain(sl);                                           // behind the caller's back (its buffers may go away next)
+        sl.pending = false;
+        return rc;
+    }
+    sl.pending = true;
+    return PR_OK;
+}
+
+int refine_submit_async(Slot &sl, const pr_triangle *tris_dev, size_t n_tris, uint32_t P, uint32_t W, uint32_t H,
+                        const pr_mat4 *proj, const float K[9], int scene_kind, const void *scene, pr_criteria crit, pr_roi roi,
+                        pr_result *results_host, pr_result *results_dev)
+{
+    const size_t img = (size_t)W * H;
     PR_TRY(slot_streams(sl));
     SceneSel sc;
     std::memset(static_cast<void *>(&sc), 0, sizeof sc);
-    // the packed copy of the scene does not depend on the render: it is built on the first side stream (idle until the loop
-    // forks), the loop waits for it; batches without pose groups build it in line
-    const uint32_t groups_hint = std::max(1u, std::min({ (uint32_t)std::max(1, g.pose_groups), 4u, std::min<uint32_t>(P, (uint32_t)std::max(32, g.sub_batch)) / 32u }));
+    // the packed copy of the scene does not depend on the render: when it has to be (re)built that happens on the first side
+    // stream (idle until the loop forks), the loop waits for it; batches without pose groups build it in line
+    const uint32_t groups_hint = std::max(1u, std::min({ (uint32_t)std::max(1, opt.pose_groups), 4u, std::min<uint32_t>(P, (uint32_t)std::max(32, opt.sub_batch)) / 32u }));
     for (uint32_t k = 1; k < groups_hint; ++k) PR_TRY(ensure_stream(sl.side[k - 1], &sl.join[k - 1]));
     hipStream_t scene_stream = groups_hint > 1 ? sl.side[0] : sl.stream;
-    PR_TRY(make_scene(scene_kind, scene, /*want_packed=*/true, sc, &sl.rec, scene_stream));
+    PR_TRY(make_scene(scene_kind, scene, /*want_packed=*/true, sc, &sl.packed, scene_stream));
+
+    PR_TRY(ensure_model_box(tris_dev, n_tris));                 // once per triangle buffer ...
+    const size_t res_off = ((size_t)P * 4 + 63) & ~(size_t)63;
+    sl.flag_off = (res_off + sizeof(pr_result) * P + 63) & ~(size_t)63;
+    PR_TRY(sl.h_out.ensure(sl.flag_off + 64));
+    void *h_in_dev = nullptr, *h_out_dev = nullptr;              // the pinned staging buffers as the device sees them
+    HIP_TRY(hipHostGetDevicePointer(&h_in_dev, sl.h_in.p, 0));
+    HIP_TRY(hipHostGetDevicePointer(&h_out_dev, sl.h_out.p, 0));
+    // ... and checked against the buffer's present content by every batch (refine_wait acts on the flag)
+    PR_TRY(sl.aabb_keys.ensure(6 * sizeof(uint32_t)));
+    *reinterpret_cast<volatile uint32_t *>(sl.h_out.as<unsigned char>() + sl.flag_off) = 0u;
+    HIP_TRY(prk::launch_model_aabb(tris_dev, (uint32_t)n_tris, sl.aabb_keys.as<uint32_t>(), nullptr, g->aabb_host,
+                                   reinterpret_cast<uint32_t *>(static_cast<unsigned char *>(h_out_dev) + sl.flag_off), scene_stream));
     HIP_TRY(hipEventRecord(sl.scene_ready, scene_stream));
 
-    PR_TRY(ensure_model_box(tris_dev, n_tris));                 // once per triangle buffer
     // staging: [poses][boxes]; the cloud stride and the grid come from the largest box
     const size_t in_bytes = (sizeof(pr_mat4) + sizeof(int4)) * (size_t)P;
-    PR_TRY(sl.h_in.ensure(in_bytes + 16));
     PR_TRY(sl.poses_bbox.ensure(in_bytes + 16));
     pr_mat4 *h_poses = sl.h_in.as<pr_mat4>();
     int32_t *h_box = reinterpret_cast<int32_t *>(h_poses + P);
-    std::memcpy(h_poses, poses_host, sizeof(pr_mat4) * P);
     size_t max_area = 1;
     for (uint32_t i = 0; i < P; ++i) {
-        pose_bbox_host(g.aabb_host, h_poses[i], *proj, W, H, h_box + 4 * (size_t)i);
+        pose_bbox_host(g->aabb_host, h_poses[i], *proj, W, H, roi, h_box + 4 * (size_t)i);
         const int32_t *b = h_box + 4 * (size_t)i;
         max_area = std::max(max_area, (size_t)std::max(0, b[2] - b[0] + 1) * (size_t)std::max(0, b[3] - b[1] + 1));   // an off-screen pose has an empty box
     }
     const size_t cstride = (max_area + 3) & ~(size_t)3;
-    const uint32_t steps = (uint32_t)std::max(1, g.steps);
+    const uint32_t steps = (uint32_t)std::max(1, opt.steps);
     const uint32_t ppb = steps * prk::kPointsPerStep;
     const uint32_t nblk = (uint32_t)((max_area + ppb - 1) / ppb);       // bound from the pixel boxes: capacity of the partial sums
     // grid: one workgroup per block of the largest cloud of the previous batch (workgroups loop if this batch's clouds are
     // larger, surplus workgroups exit at once); the box bound itself would launch ~60 % empty workgroups (-2.5 % poses/s)
-    const uint32_t grid_x = g.cloud_hint ? std::min(nblk, (g.cloud_hint + ppb - 1) / ppb) : nblk;
-    if (cstride * (size_t)std::min<size_t>(P, (size_t)std::max(32, g.sub_batch)) > 0xffffffffull) { set_error("pr_refine_submit: batch too large for 32-bit cloud offsets"); return PR_ERR_INVALID; }
+    const uint32_t grid_x = g->cloud_hint ? std::min(nblk, (g->cloud_hint + ppb - 1) / ppb) : nblk;
+    if (cstride * (size_t)std::min<size_t>(P, (size_t)std::max(32, opt.sub_batch)) > 0xffffffffull) { set_error("pr_refine_submit: batch too large for 32-bit cloud offsets"); return PR_ERR_INVALID; }
 
     // Large batches run as consecutive sub-batches that reuse the same depth / cloud / partial-sum memory: the clouds of
     // <= 512 hypotheses (~140 MB touched) stay in the 256 MiB Infinity Cache over their 21 passes (1024 poses as one batch:
     // 199 k poses/s, as 2 x 512: see DESIGN.md)
-    const uint32_t sub_cap = (uint32_t)std::max(32, g.sub_batch);
+    const uint32_t sub_cap = (uint32_t)std::max(32, opt.sub_batch);
     const uint32_t n_sub = (P + sub_cap - 1) / sub_cap;
     const uint32_t sub = (P + n_sub - 1) / n_sub;
     PR_TRY(sl.depth.ensure(sizeof(int32_t) * img * sub));
@@ -822,39 +1047,35 @@ int refine_submit(int slot, const pr_triangle *tris_dev, size_t n_tris, const pr
     PR_TRY(sl.partial.ensure(sizeof(float) * prk::kAccStride * (size_t)nblk * sub));
     PR_TRY(sl.dstate.ensure(sizeof(prk::DevIcpState) * P));
     PR_TRY(sl.arrive.ensure(sizeof(uint32_t) * P));
-    const size_t res_off = ((size_t)P * 4 + 63) & ~(size_t)63;
-    PR_TRY(sl.h_out.ensure(res_off + sizeof(pr_result) * P));
     pr_result *dres = results_dev;
     if (!dres) { PR_TRY(sl.dresults.ensure(sizeof(pr_result) * P)); dres = sl.dresults.as<pr_result>(); }
 
     hipStream_t st = sl.stream;
     pr_mat4 *d_poses = sl.poses_bbox.as<pr_mat4>();
     int4 *d_box = reinterpret_cast<int4 *>(d_poses + P);
-    void *h_in_dev = nullptr, *h_out_dev = nullptr;              // the pinned staging buffers as the device sees them
-    HIP_TRY(hipHostGetDevicePointer(&h_in_dev, sl.h_in.p, 0));
-    HIP_TRY(hipHostGetDevicePointer(&h_out_dev, sl.h_out.p, 0));
     // Both phases are bound by the same units, so a batch that renders while the other slot is in the middle of its ICP loop
     // slows that loop by more than it gains; its render is therefore held back until the other slot has issued pass
     // `overlap_pass` of its (last sub-batch's) loop -- late enough to disturb little, early enough that the GPU never idles.
-    for (Slot &o : g_slots)
+    for (Slot &o : g->slots)
         if (&o != &sl && o.pending && !o.delivered && o.progress_valid) HIP_TRY(hipStreamWaitEvent(st, o.progress, 0));
     sl.progress_valid = false;
     HIP_TRY(prk::launch_stage_words(h_in_dev, d_poses, in_bytes, st));
-    const bool fused = g.fused_solve != 0;
+    const bool fused = opt.fused_solve != 0;
+    const pr_roi none{ 0, 0, 0, 0 };                              // the ROI is already part of the host-computed boxes
     for (uint32_t q0 = 0; q0 < P; q0 += sub) {
         const uint32_t nq = std::min(sub, P - q0);
         prk::PoseMeta *meta = sl.meta.as<prk::PoseMeta>() + q0;
         prk::DevIcpState *dstate = sl.dstate.as<prk::DevIcpState>() + q0;
         uint32_t *arrive = sl.arrive.as<uint32_t>() + q0;
         HIP_TRY(prk::launch_render_boxes(tris_dev, (uint32_t)n_tris, d_poses + q0, nq, nullptr, d_box + q0, sl.depth.as<int32_t>(),
-                                         sl.row_count.as<uint32_t>(), sl.row_off.as<uint32_t>(), sl.counts.as<uint32_t>() + q0, W, H, *proj, st,
+                                         sl.row_count.as<uint32_t>(), sl.row_off.as<uint32_t>(), sl.counts.as<uint32_t>() + q0, W, H, *proj, none, st,
                                          /*compute_boxes=*/false, meta, dstate, arrive, (uint32_t)cstride));
         HIP_TRY(prk::launch_emit_box(sl.depth.as<int32_t>(), nq, W, H, d_box + q0, K[0], K[4], K[2], K[5], sl.row_count.as<uint32_t>(),
                                      sl.row_off.as<uint32_t>(), sl.cloud.as<pr_vec3>(), cstride, st));
         if (q0 == 0) HIP_TRY(hipStreamWaitEvent(st, sl.scene_ready, 0));
 
         // the iteration loop: (max_iteration+1) x [pass (+ fused finalize/solve)], pose groups on the slot's side streams
-        const uint32_t n_groups = std::max(1u, std::min({ (uint32_t)std::max(1, g.pose_groups), 4u, nq / 32u }));
+        const uint32_t n_groups = std::max(1u, std::min({ (uint32_t)std::max(1, opt.pose_groups), 4u, nq / 32u }));
         auto group_begin = [&](uint32_t grp) { return (uint32_t)(((uint64_t)nq * grp) / n_groups); };
         if (n_groups > 1) {
             for (uint32_t k = 1; k < n_groups; ++k) PR_TRY(ensure_stream(sl.side[k - 1], &sl.join[k - 1]));
@@ -874,7 +1095,7 @@ int refine_submit(int slot, const pr_triangle *tris_dev, size_t n_tris, const pr
                 HIP_TRY(launch_pass(bb, sc, np, gs));
                 if (!fused) HIP_TRY(prk::launch_icp_finalize_solve(bb.partial, meta + p0, nblk, steps, dstate + p0, crit, it, np, gs));
             }
-            if (q0 + sub >= P && it == std::min<uint32_t>((uint32_t)crit.max_iteration, g.overlap_pass >= 0 ? (uint32_t)g.overlap_pass : (uint32_t)((crit.max_iteration + 1) * 7 / 10))) {
+            if (q0 + sub >= P && it == std::min<uint32_t>((uint32_t)crit.max_iteration, opt.overlap_pass >= 0 ? (uint32_t)opt.overlap_pass : (uint32_t)((crit.max_iteration + 1) * 7 / 10))) {
                 HIP_TRY(hipEventRecord(sl.progress, st));
                 sl.progress_valid = true;
             }
@@ -884,7 +1105,6 @@ int refine_submit(int slot, const pr_triangle *tris_dev, size_t n_tris, const pr
     HIP_TRY(prk::launch_pack_export(sl.dstate.as<prk::DevIcpState>(), dres, sl.counts.as<uint32_t>(), static_cast<uint32_t *>(h_out_dev),
                                     results_host ? reinterpret_cast<pr_result *>(static_cast<unsigned char *>(h_out_dev) + res_off) : nullptr, P, st));
     HIP_TRY(hipEventRecord(sl.done, st));
-    sl.pending = true;
     return PR_OK;
 }
 
@@ -893,28 +1113,28 @@ int kd_build_dev(pr_vec3 *pcd, pr_vec3 *nrm, uint32_t n, int max_leaf, pr_kdnode
 {
     if (n == 0 || cap == 0) { set_error("kd-tree build: no points"); return PR_ERR_INVALID; }
     const uint32_t cap32 = (uint32_t)std::min<size_t>(cap, 0x7fffffff);
-    PR_TRY(g.kd_idx.ensure(sizeof(int) * n));
-    PR_TRY(g.kd_scratch.ensure(sizeof(int) * n));
-    PR_TRY(g.kd_child.ensure(sizeof(int) * cap32));
-    PR_TRY(g.kd_ctrl.ensure(sizeof(uint32_t) * 4));
-    PR_TRY(g.kd_tmp.ensure(sizeof(pr_vec3) * 2 * (size_t)n));
-    HIP_TRY(prk::launch_kd_init(nodes, cap32, g.kd_idx.as<int>(), n, g.kd_ctrl.as<uint32_t>(), g.stream));
+    PR_TRY(g->kd_idx.ensure(sizeof(int) * n));
+    PR_TRY(g->kd_scratch.ensure(sizeof(int) * n));
+    PR_TRY(g->kd_child.ensure(sizeof(int) * cap32));
+    PR_TRY(g->kd_ctrl.ensure(sizeof(uint32_t) * 4));
+    PR_TRY(g->kd_tmp.ensure(sizeof(pr_vec3) * 2 * (size_t)n));
+    HIP_TRY(prk::launch_kd_init(nodes, cap32, g->kd_idx.as<int>(), n, g->kd_ctrl.as<uint32_t>(), g->stream));
     uint32_t ctrl[4] = { 0, 1, 1, 1 };
     for (int level = 0; level < 4096; ++level) {
-        HIP_TRY(prk::launch_kd_level(nodes, g.kd_ctrl.as<uint32_t>(), max_leaf, g.kd_child.as<int>(), cap32, 0, pcd, g.kd_idx.as<int>(),
-                                     g.kd_scratch.as<int>(), /*plan_only=*/true, g.stream));
-        HIP_TRY(hipMemcpyAsync(ctrl, g.kd_ctrl.p, sizeof ctrl, hipMemcpyDeviceToHost, g.stream));
-        HIP_TRY(hipStreamSynchronize(g.stream));
+        HIP_TRY(prk::launch_kd_level(nodes, g->kd_ctrl.as<uint32_t>(), max_leaf, g->kd_child.as<int>(), cap32, 0, pcd, g->kd_idx.as<int>(),
+                                     g->kd_scratch.as<int>(), /*plan_only=*/true, g->stream));
+        HIP_TRY(hipMemcpyAsync(ctrl, g->kd_ctrl.p, sizeof ctrl, hipMemcpyDeviceToHost, g->stream));
+        HIP_TRY(hipStreamSynchronize(g->stream));
         if (ctrl[3] > cap32) { set_error("kd-tree build: node capacity %u too small", cap32); return PR_ERR_NOMEM; }
         if (ctrl[3] == ctrl[2]) break;                             // no node of this level split: done (pcd_scene.cpp:166-168)
-        HIP_TRY(prk::launch_kd_level(nodes, g.kd_ctrl.as<uint32_t>(), max_leaf, g.kd_child.as<int>(), cap32, ctrl[1] - ctrl[0], pcd,
-                                     g.kd_idx.as<int>(), g.kd_scratch.as<int>(), /*plan_only=*/false, g.stream));
+        HIP_TRY(prk::launch_kd_level(nodes, g->kd_ctrl.as<uint32_t>(), max_leaf, g->kd_child.as<int>(), cap32, ctrl[1] - ctrl[0], pcd,
+                                     g->kd_idx.as<int>(), g->kd_scratch.as<int>(), /*plan_only=*/false, g->stream));
     }
-    pr_vec3 *tp = g.kd_tmp.as<pr_vec3>(), *tn = tp + n;
-    HIP_TRY(prk::launch_kd_permute(pcd, nrm, g.kd_idx.as<int>(), n, tp, tn, g.stream));
-    HIP_TRY(hipMemcpyAsync(pcd, tp, sizeof(pr_vec3) * n, hipMemcpyDeviceToDevice, g.stream));
-    HIP_TRY(hipMemcpyAsync(nrm, tn, sizeof(pr_vec3) * n, hipMemcpyDeviceToDevice, g.stream));
-    HIP_TRY(hipStreamSynchronize(g.stream));
+    pr_vec3 *tp = g->kd_tmp.as<pr_vec3>(), *tn = tp + n;
+    HIP_TRY(prk::launch_kd_permute(pcd, nrm, g->kd_idx.as<int>(), n, tp, tn, g->stream));
+    HIP_TRY(hipMemcpyAsync(pcd, tp, sizeof(pr_vec3) * n, hipMemcpyDeviceToDevice, g->stream));
+    HIP_TRY(hipMemcpyAsync(nrm, tn, sizeof(pr_vec3) * n, hipMemcpyDeviceToDevice, g->stream));
+    HIP_TRY(hipStreamSynchronize(g->stream));
     if (n_nodes) *n_nodes = ctrl[2];
     return PR_OK;
 }
@@ -924,23 +1144,100 @@ int scene_nn_prepare_dev_t(const T *depth, const float K[9], uint32_t W, uint32_
                            pr_kdnode *nodes, size_t cap, uint32_t *n_points, uint32_t *n_nodes)
 {
     const size_t px = (size_t)W * H;
-    PR_TRY(g.nn_full.ensure(sizeof(pr_vec3) * 2 * px));
-    PR_TRY(g.row_count.ensure(sizeof(uint32_t) * H));
-    PR_TRY(g.row_off.ensure(sizeof(uint32_t) * H));
-    PR_TRY(g.counts.ensure(sizeof(uint32_t)));
-    pr_vec3 *full_pcd = g.nn_full.as<pr_vec3>(), *full_nrm = full_pcd + px;
+    PR_TRY(g->nn_full.ensure(sizeof(pr_vec3) * 2 * px));
+    PR_TRY(g->row_count.ensure(sizeof(uint32_t) * H));
+    PR_TRY(g->row_off.ensure(sizeof(uint32_t) * H));
+    PR_TRY(g->counts.ensure(sizeof(uint32_t)));
+    pr_vec3 *full_pcd = g->nn_full.as<pr_vec3>(), *full_nrm = full_pcd + px;
     // normals of every pixel (get_normal sees the uint16 image), then the valid pixels in row-major order
-    HIP_TRY(prk::launch_scene_proj_prepare<T>(depth, W, H, K[0], K[4], K[2], K[5], full_pcd, full_nrm, g.stream));
-    HIP_TRY(prk::launch_nn_gather<T>(depth, W, H, K[0], K[4], K[2], K[5], full_nrm, g.row_count.as<uint32_t>(), g.row_off.as<uint32_t>(),
-                                     g.counts.as<uint32_t>(), nullptr, nullptr, false, g.stream));
+    HIP_TRY(prk::launch_scene_proj_prepare<T>(depth, W, H, K[0], K[4], K[2], K[5], full_pcd, full_nrm, g->stream));
+    HIP_TRY(prk::launch_nn_gather<T>(depth, W, H, K[0], K[4], K[2], K[5], full_nrm, g->row_count.as<uint32_t>(), g->row_off.as<uint32_t>(),
+                                     g->counts.as<uint32_t>(), nullptr, nullptr, false, g->stream));
     uint32_t n = 0;
-    HIP_TRY(hipMemcpyAsync(&n, g.counts.p, sizeof n, hipMemcpyDeviceToHost, g.stream));
-    HIP_TRY(hipStreamSynchronize(g.stream));
+    HIP_TRY(hipMemcpyAsync(&n, g->counts.p, sizeof n, hipMemcpyDeviceToHost, g->stream));
+    HIP_TRY(hipStreamSynchronize(g->stream));
     if (n_points) *n_points = n;
     if (n == 0) { if (n_nodes) *n_nodes = 0; return PR_OK; }
-    HIP_TRY(prk::launch_nn_gather<T>(depth, W, H, K[0], K[4], K[2], K[5], full_nrm, g.row_count.as<uint32_t>(), g.row_off.as<uint32_t>(),
-                                     g.counts.as<uint32_t>(), pcd, nrm, true, g.stream));
+    HIP_TRY(prk::launch_nn_gather<T>(depth, W, H, K[0], K[4], K[2], K[5], full_nrm, g->row_count.as<uint32_t>(), g->row_off.as<uint32_t>(),
+                                     g->counts.as<uint32_t>(), pcd, nrm, true, g->stream));
     return kd_build_dev(pcd, nrm, n, max_leaf, nodes, cap, n_nodes);
+}
+
+// ---- RCCL, opened on first use ----------------------------------------------------------------------------
+// The gather of the solved transforms is the job's only collective.  librccl is half a gigabyte of code objects
+// that a single-GPU host never needs, and a Python host usually has one loaded already (PyTorch's): dlopen by soname picks
+// that one up, otherwise the ROCm copy is loaded.
+struct Rccl {
+    void *lib = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+Rccl g_rccl;
+int rccl_load()
+{
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    if (g_rccl.lib) return PR_OK;
+    void *h = nullptr;
+    for (const char *name : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" }) { h = dlopen(name, RTLD_NOW | RTLD_LOCAL); if (h) break; }
+    if (!h) { set_error("cannot open librccl (%s)", dlerror()); return PR_ERR_COMM; }
+    Rccl r; r.lib = h;
+#define PR_SYM(field, name) r.field = reinterpret_cast<decltype(r.field)>(dlsym(h, name)); if (!r.field) { set_error("librccl lacks %s", name); dlclose(h); return PR_ERR_COMM; }
+    PR_SYM(GetUniqueId, "ncclGetUniqueId") PR_SYM(CommInitRank, "ncclCommInitRank") PR_SYM(CommInitAll, "ncclCommInitAll")
+    PR_SYM(CommDestroy, "ncclCommDestroy") PR_SYM(GroupStart, "ncclGroupStart") PR_SYM(GroupEnd, "ncclGroupEnd")
+    PR_SYM(Send, "ncclSend") PR_SYM(Recv, "ncclRecv") PR_SYM(GetErrorString, "ncclGetErrorString")
+#undef PR_SYM
+    g_rccl = r;
+    return PR_OK;
+}
+#define NCCL_TRY(expr)                                                                          \
+    do {                                                                                        \
+        ncclResult_t r_ = (expr);                                                               \
+        if (r_ != ncclSuccess) { set_error("%s failed: %s", #expr, g_rccl.GetErrorString(r_)); return PR_ERR_COMM; } \
+    } while (0)
+
+void comm_teardown(Ctx *c)
+{
+    if (c->comm && g_rccl.CommDestroy) { (void)hipSetDevice(c->device); if (c->stream) (void)hipStreamSynchronize(c->stream); (void)g_rccl.CommDestroy(c->comm); }
+    c->comm = nullptr; c->comm_rank = 0; c->comm_world = 1;
+}
+
+void ctx_teardown(Ctx *c)        // c->mu held (or c unreachable); the calling thread is bound to c
+{
+    if (!c->ready) return;
+    (void)hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    for (Slot &sl : c->slots) slot_release(sl);
+    for (DevBuf *b : { &c->aabb, &c->aabb_keys, &c->bbox, &c->poses, &c->depth, &c->row_count, &c->row_off, &c->counts, &c->cloud, &c->meta, &c->partial,
+                       &c->sums, &c->packed.rec, &c->topo, &c->bmin, &c->bmax, &c->pts, &c->nnrec, &c->nnrec32, &c->nndesc, &c->nn_prev, &c->nndepth, &c->dstate, &c->dresults, &c->vbdesc, &c->flowsync, &c->arrive, &c->conv16, &c->conv8, &c->kd_idx, &c->kd_scratch, &c->kd_child, &c->kd_ctrl, &c->kd_tmp, &c->nn_full, &c->gather_tmp }) b->release();
+    for (PinBuf *b : { &c->h_sums, &c->h_meta, &c->h_counts, &c->h_results, &c->h_dstate, &c->h_flow }) b->release();
+    c->packed = PackedCache(); c->nn_cache.valid = false;
+    for (auto &gr : c->graphs) destroy_graph(gr);
+    c->graphs.clear();
+    for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);
+    c->ev_pool.clear(); c->ev_used = 0; c->spans.clear();
+    hipStreamDestroy(c->stream);
+    if (c->ev_fork) hipEventDestroy(c->ev_fork);
+    c->ev_fork = nullptr;
+    for (int i = 0; i < 3; ++i) {
+        if (c->side[i]) hipStreamDestroy(c->side[i]);
+        if (c->ev_join[i]) hipEventDestroy(c->ev_join[i]);
+        c->side[i] = nullptr; c->ev_join[i] = nullptr;
+    }
+    c->stream = nullptr; c->ready = false; c->mesh_key = nullptr; c->aabb_host_valid = false; c->cloud_hint = 0;
+}
+
+PrivateCtx::~PrivateCtx()               // a thread that ends with a private context releases it
+{
+    if (!c) return;
+    { std::lock_guard<std::mutex> lk(c->mu); comm_teardown(c); ctx_teardown(c); }
+    delete c; c = nullptr;
 }
 
 }  // namespace
@@ -958,85 +1255,99 @@ int pr_device_count(void)
     return n;
 }
 
-int pr_init(int device)
+static void hw_queues_hint()
 {
-    std::lock_guard<std::mutex> lk(g_mu);
-    if (g.ready && g.device == device) return PR_OK;
-    if (g.ready) { set_error("pr_init: already initialised on device %d", g.device); return PR_ERR_INVALID; }
-    g.device = device;
     // The two asynchronous slots and their pose groups need four streams that really run side by side; the runtime maps all
     // streams of a process onto GPU_MAX_HW_QUEUES hardware queues (default 4, shared with every other stream of the process),
     // and streams that share a queue serialise.  This only takes effect if the HIP runtime has not been initialised yet --
     // hosts that initialise it earlier (PyTorch) set the variable themselves, as bench.py does.
     setenv("GPU_MAX_HW_QUEUES", "8", /*overwrite=*/0);
+}
+
+int pr_init(int device)
+{
+    hw_queues_hint();
+    if (device < 0) { set_error("pr_init: device must be >= 0"); return PR_ERR_INVALID; }
+    if (tl_private.c && tl_private.c->device != device) { set_error("pr_init: this thread owns a private context on device %d (pr_thread_context(0) first)", tl_private.c->device); return PR_ERR_INVALID; }
+    if (!tl_private.c) PR_TRY(bind_shared(device));
+    std::lock_guard<std::mutex> lk(g->mu);
     return require_ctx();
 }
+int pr_set_device(int device) { return pr_init(device); }
 
 int pr_shutdown(void)
 {
-    std::lock_guard<std::mutex> lk(g_mu);
-    if (!g.ready) return PR_OK;
-    hipStreamSynchronize(g.stream);
-    for (Slot &sl : g_slots) slot_release(sl);
-    for (DevBuf *b : { &g.aabb, &g.bbox, &g.poses, &g.depth, &g.row_count, &g.row_off, &g.counts, &g.cloud, &g.meta, &g.partial,
-                       &g.sums, &g.rec, &g.topo, &g.bmin, &g.bmax, &g.pts, &g.nnrec, &g.nnrec32, &g.nndesc, &g.nn_prev, &g.nndepth, &g.dstate, &g.dresults, &g.vbdesc, &g.flowsync, &g.arrive, &g.conv16, &g.conv8, &g.kd_idx, &g.kd_scratch, &g.kd_child, &g.kd_ctrl, &g.kd_tmp, &g.nn_full }) b->release();
-    for (PinBuf *b : { &g.h_sums, &g.h_meta, &g.h_counts, &g.h_results, &g.h_dstate, &g.h_flow }) b->release();
-    drop_graphs();
-    for (hipEvent_t e : g.ev_pool) hipEventDestroy(e);
-    g.ev_pool.clear(); g.ev_used = 0; g.spans.clear();
-    hipStreamDestroy(g.stream);
-    if (g.ev_fork) hipEventDestroy(g.ev_fork);
-    g.ev_fork = nullptr;
-    for (int i = 0; i < 3; ++i) {
-        if (g.side[i]) hipStreamDestroy(g.side[i]);
-        if (g.ev_join[i]) hipEventDestroy(g.ev_join[i]);
-        g.side[i] = nullptr; g.ev_join[i] = nullptr;
-    }
-    g.stream = nullptr; g.ready = false; g.device = -1; g.aabb_key = nullptr; g.aabb_n = 0;
+    if (!g) return PR_OK;
+    std::lock_guard<std::mutex> lk(g->mu);
+    comm_teardown(g);
+    ctx_teardown(g);
     return PR_OK;
+}
+
+// A private context for the calling thread on its current device: own stream, workspaces, slots and caches, so that host threads
+// that each drive their own hypotheses (the reference's usage: icp.cu:170,178 cudaStreamPerThread, README.md:15) do not
+// serialise on the device's shared context.  pr_thread_context(0) (or thread exit) releases it and re-binds to the shared one.
+int pr_thread_context(int enable)
+{
+    PR_TRY(bind_default());
+    if (enable) {
+        if (tl_private.c) return PR_OK;
+        Ctx *c = new Ctx();
+        c->device = g->device; c->is_private = true;
+        tl_private.c = c; g = c;
+        std::lock_guard<std::mutex> lk(g->mu);
+        return require_ctx();
+    }
+    if (!tl_private.c) return PR_OK;
+    const int dev = tl_private.c->device;
+    { std::lock_guard<std::mutex> lk(tl_private.c->mu); comm_teardown(tl_private.c); ctx_teardown(tl_private.c); }
+    delete tl_private.c; tl_private.c = nullptr; g = nullptr;
+    return bind_shared(dev);
 }
 
 int pr_sync(void)
 {
-    std::lock_guard<std::mutex> lk(g_mu);
-    PR_TRY(require_ctx());
-    HIP_TRY(hipStreamSynchronize(g.stream));
+    PR_ENTER();
+    HIP_TRY(hipStreamSynchronize(g->stream));
     return PR_OK;
 }
 
 int pr_malloc(void **dev_ptr, size_t bytes)
 {
-    std::lock_guard<std::mutex> lk(g_mu);
-    PR_TRY(require_ctx());
+    PR_ENTER();
     if (!dev_ptr) { set_error("pr_malloc: null out pointer"); return PR_ERR_INVALID; }
     HIP_TRY(hipMalloc(dev_ptr, bytes ? bytes : 1));
     return PR_OK;
 }
-// the per-model boxes are keyed by the triangle buffer's address: writing to or freeing that buffer through this library
-// drops them
-static void forget_model(const void *dev_ptr)
+int pr_invalidate(const void *dev_ptr, size_t bytes)
 {
-    if (dev_ptr == g.mesh_key) { g.mesh_key = nullptr; g.aabb_host_valid = false; }
-    if (dev_ptr == g.aabb_key) g.aabb_key = nullptr;
+    if (!dev_ptr) return PR_OK;
+    g_writes.note(dev_ptr, bytes);
+    return PR_OK;
 }
 int pr_free(void *dev_ptr)
 {
-    std::lock_guard<std::mutex> lk(g_mu);
     if (!dev_ptr) return PR_OK;
-    PR_TRY(require_ctx());
-    HIP_TRY(hipStreamSynchronize(g.stream));
-    forget_model(dev_ptr);
+    PR_ENTER();
+    // nothing this context still has in flight may outlive the buffer: the library stream and every slot with an unfinished batch
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    for (Slot &sl : g->slots) if (sl.pending && !sl.delivered) slot_drain(sl);
+    g_writes.note(dev_ptr, 0);                                     // the address may come back with other content
+    if (dev_ptr == g->mesh_key) { g->mesh_key = nullptr; g->aabb_host_valid = false; }
     HIP_TRY(hipFree(dev_ptr));
     return PR_OK;
 }
 static int copy_sync(void *dst, const void *src, size_t bytes, hipMemcpyKind kind)
 {
-    std::lock_guard<std::mutex> lk(g_mu);
-    PR_TRY(require_ctx());
-    if (kind != hipMemcpyDeviceToHost) forget_model(dst);
+    PR_ENTER();
     if (bytes == 0) return PR_OK;
-    HIP_TRY(hipMemcpyAsync(dst, src, bytes, kind, g.stream));
-    HIP_TRY(hipStreamSynchronize(g.stream));
+    if (kind != hipMemcpyDeviceToHost) {
+        g_writes.note(dst, bytes);
+        if (g->mesh_key && reinterpret_cast<uintptr_t>(dst) < reinterpret_cast<uintptr_t>(g->mesh_key) + g->mesh_n * sizeof(pr_triangle) &&
+            reinterpret_cast<uintptr_t>(g->mesh_key) < reinterpret_cast<uintptr_t>(dst) + bytes) { g->mesh_key = nullptr; g->aabb_host_valid = false; }
+    }
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, kind, g->stream));
+    HIP_TRY(hipStreamSynchronize(g->stream));
     return PR_OK;
 }
 int pr_memcpy_h2d(void *d, const void *s, size_t n) { return copy_sync(d, s, n, hipMemcpyHostToDevice); }
@@ -1045,20 +1356,20 @@ int pr_memcpy_d2d(void *d, const void *s, size_t n) { return copy_sync(d, s, n, 
 
 int pr_fill_i32(int32_t *dev_dst, size_t count, int32_t value)
 {
-    std::lock_guard<std::mutex> lk(g_mu);
-    PR_TRY(require_ctx());
-    HIP_TRY(prk::launch_fill_i32(dev_dst, count, value, g.stream));
-    HIP_TRY(hipStreamSynchronize(g.stream));
+    PR_ENTER();
+    g_writes.note(dev_dst, count * sizeof(int32_t));
+    HIP_TRY(prk::launch_fill_i32(dev_dst, count, value, g->stream));
+    HIP_TRY(hipStreamSynchronize(g->stream));
     return PR_OK;
 }
 
 int pr_render(const pr_triangle *tris_dev, size_t n_tris, const pr_mat4 *poses_host, size_t n_poses, size_t width, size_t height,
               const pr_mat4 *proj, pr_roi roi, int32_t *depth_dev_out)
 {
-    std::lock_guard<std::mutex> lk(g_mu);
-    PR_TRY(require_ctx());
+    PR_ENTER();
+    if (depth_dev_out) g_writes.note(depth_dev_out, sizeof(int32_t) * n_poses * ((roi.width > 0 && roi.height > 0) ? (size_t)roi.width * roi.height : width * height));
     PR_TRY(render_impl(tris_dev, n_tris, poses_host, n_poses, width, height, proj, roi, depth_dev_out, true));
-    HIP_TRY(hipStreamSynchronize(g.stream));            // renderer.cu:295 cudaDeviceSynchronize
+    HIP_TRY(hipStreamSynchronize(g->stream));            // renderer.cu:295 cudaDeviceSynchronize
     drain_spans();
     return PR_OK;
 }
@@ -1066,14 +1377,13 @@ int pr_render(const pr_triangle *tris_dev, size_t n_tris, const pr_mat4 *poses_h
 int pr_render_to_host(const pr_triangle *tris_dev, size_t n_tris, const pr_mat4 *poses_host, size_t n_poses, size_t width, size_t height,
                       const pr_mat4 *proj, pr_roi roi, int32_t *depth_host_out)
 {
-    std::lock_guard<std::mutex> lk(g_mu);
-    PR_TRY(require_ctx());
+    PR_ENTER();
     size_t rw = width, rh = height;
     if (roi.width > 0 && roi.height > 0) { rw = (size_t)roi.width; rh = (size_t)roi.height; }
-    PR_TRY(g.depth.ensure(sizeof(int32_t) * std::max<size_t>(1, n_poses * rw * rh)));
-    PR_TRY(render_impl(tris_dev, n_tris, poses_host, n_poses, width, height, proj, roi, g.depth.as<int32_t>(), true));
-    HIP_TRY(hipMemcpyAsync(depth_host_out, g.depth.p, sizeof(int32_t) * n_poses * rw * rh, hipMemcpyDeviceToHost, g.stream));
-    HIP_TRY(hipStreamSynchronize(g.stream));
+    PR_TRY(g->depth.ensure(sizeof(int32_t) * std::max<size_t>(1, n_poses * rw * rh)));
+    PR_TRY(render_impl(tris_dev, n_tris, poses_host, n_poses, width, height, proj, roi, g->depth.as<int32_t>(), true));
+    HIP_TRY(hipMemcpyAsync(depth_host_out, g->depth.p, sizeof(int32_t) * n_poses * rw * rh, hipMemcpyDeviceToHost, g->stream));
+    HIP_TRY(hipStreamSynchronize(g->stream));
     drain_spans();
     return PR_OK;
 }
@@ -1081,35 +1391,33 @@ int pr_render_to_host(const pr_triangle *tris_dev, size_t n_tris, const pr_mat4 
 int pr_depth2cloud_i32(const int32_t *depth_dev, uint32_t width, uint32_t height, const float K[9], uint32_t stride, uint32_t tl_x,
                        uint32_t tl_y, pr_vec3 **cloud_dev_out, uint32_t *n_points)
 {
-    std::lock_guard<std::mutex> lk(g_mu);
-    PR_TRY(require_ctx());
+    PR_ENTER();
     return depth2cloud_impl<int32_t>(depth_dev, width, height, K, stride, tl_x, tl_y, cloud_dev_out, n_points);
 }
 int pr_depth2cloud_u16(const uint16_t *depth_dev, uint32_t width, uint32_t height, const float K[9], uint32_t stride, uint32_t tl_x,
                        uint32_t tl_y, pr_vec3 **cloud_dev_out, uint32_t *n_points)
 {
-    std::lock_guard<std::mutex> lk(g_mu);
-    PR_TRY(require_ctx());
+    PR_ENTER();
     return depth2cloud_impl<uint16_t>(depth_dev, width, height, K, stride, tl_x, tl_y, cloud_dev_out, n_points);
 }
 
 int pr_scene_proj_prepare_dev(const void *depth_dev, int depth_is_i32, const float K[9], size_t width, size_t height,
                               pr_vec3 *pcd_dev_out, pr_vec3 *normal_dev_out)
 {
-    std::lock_guard<std::mutex> lk(g_mu);
-    PR_TRY(require_ctx());
+    PR_ENTER();
     if (!depth_dev || !K || !pcd_dev_out || !normal_dev_out || width == 0 || height == 0) { set_error("pr_scene_proj_prepare_dev: bad arguments"); return PR_ERR_INVALID; }
-    if (depth_is_i32) HIP_TRY(prk::launch_scene_proj_prepare<int32_t>(static_cast<const int32_t *>(depth_dev), (uint32_t)width, (uint32_t)height, K[0], K[4], K[2], K[5], pcd_dev_out, normal_dev_out, g.stream));
-    else HIP_TRY(prk::launch_scene_proj_prepare<uint16_t>(static_cast<const uint16_t *>(depth_dev), (uint32_t)width, (uint32_t)height, K[0], K[4], K[2], K[5], pcd_dev_out, normal_dev_out, g.stream));
-    HIP_TRY(hipStreamSynchronize(g.stream));
+    g_writes.note(pcd_dev_out, width * height * sizeof(pr_vec3)); g_writes.note(normal_dev_out, width * height * sizeof(pr_vec3));
+    if (depth_is_i32) HIP_TRY(prk::launch_scene_proj_prepare<int32_t>(static_cast<const int32_t *>(depth_dev), (uint32_t)width, (uint32_t)height, K[0], K[4], K[2], K[5], pcd_dev_out, normal_dev_out, g->stream));
+    else HIP_TRY(prk::launch_scene_proj_prepare<uint16_t>(static_cast<const uint16_t *>(depth_dev), (uint32_t)width, (uint32_t)height, K[0], K[4], K[2], K[5], pcd_dev_out, normal_dev_out, g->stream));
+    HIP_TRY(hipStreamSynchronize(g->stream));
     return PR_OK;
 }
 
 int pr_kdtree_build_dev(pr_vec3 *pcd_dev, pr_vec3 *normal_dev, size_t n_points, int max_leaf, pr_kdnode *nodes_dev_out, size_t cap_nodes, uint32_t *n_nodes)
 {
-    std::lock_guard<std::mutex> lk(g_mu);
-    PR_TRY(require_ctx());
+    PR_ENTER();
     if (!pcd_dev || !normal_dev || !nodes_dev_out) { set_error("pr_kdtree_build_dev: bad arguments"); return PR_ERR_INVALID; }
+    g_writes.note(pcd_dev, n_points * sizeof(pr_vec3)); g_writes.note(normal_dev, n_points * sizeof(pr_vec3)); g_writes.note(nodes_dev_out, cap_nodes * sizeof(pr_kdnode));
     return kd_build_dev(pcd_dev, normal_dev, (uint32_t)n_points, max_leaf, nodes_dev_out, cap_nodes, n_nodes);
 }
 
@@ -1117,9 +1425,9 @@ int pr_scene_nn_prepare_dev(const void *depth_dev, int depth_is_i32, const float
                             pr_vec3 *pcd_dev_out, pr_vec3 *normal_dev_out, pr_kdnode *nodes_dev_out, size_t cap_nodes,
                             uint32_t *n_points, uint32_t *n_nodes)
 {
-    std::lock_guard<std::mutex> lk(g_mu);
-    PR_TRY(require_ctx());
+    PR_ENTER();
     if (!depth_dev || !K || !pcd_dev_out || !normal_dev_out || !nodes_dev_out || width <= 0 || height <= 0) { set_error("pr_scene_nn_prepare_dev: bad arguments"); return PR_ERR_INVALID; }
+    g_writes.note(pcd_dev_out, (size_t)width * height * sizeof(pr_vec3)); g_writes.note(normal_dev_out, (size_t)width * height * sizeof(pr_vec3)); g_writes.note(nodes_dev_out, cap_nodes * sizeof(pr_kdnode));
     if (depth_is_i32) return scene_nn_prepare_dev_t<int32_t>(static_cast<const int32_t *>(depth_dev), K, (uint32_t)width, (uint32_t)height, max_leaf,
                                                              pcd_dev_out, normal_dev_out, nodes_dev_out, cap_nodes, n_points, n_nodes);
     return scene_nn_prepare_dev_t<uint16_t>(static_cast<const uint16_t *>(depth_dev), K, (uint32_t)width, (uint32_t)height, max_leaf,
@@ -1128,25 +1436,23 @@ int pr_scene_nn_prepare_dev(const void *depth_dev, int depth_is_i32, const float
 
 int pr_raw2depth_mask(const int32_t *raw_dev, size_t count, uint16_t *depth_host_out, uint8_t *mask_host_out)
 {
-    std::lock_guard<std::mutex> lk(g_mu);
-    PR_TRY(require_ctx());
+    PR_ENTER();
     if (!raw_dev || (!depth_host_out && !mask_host_out)) { set_error("pr_raw2depth_mask: bad arguments"); return PR_ERR_INVALID; }
     if (count == 0) return PR_OK;
-    if (depth_host_out) PR_TRY(g.conv16.ensure(count * sizeof(uint16_t) + 16));
-    if (mask_host_out) PR_TRY(g.conv8.ensure(count + 16));
-    HIP_TRY(prk::launch_raw2depth_mask(raw_dev, count, depth_host_out ? g.conv16.as<uint16_t>() : nullptr, mask_host_out ? g.conv8.as<uint8_t>() : nullptr, g.stream));
+    if (depth_host_out) PR_TRY(g->conv16.ensure(count * sizeof(uint16_t) + 16));
+    if (mask_host_out) PR_TRY(g->conv8.ensure(count + 16));
+    HIP_TRY(prk::launch_raw2depth_mask(raw_dev, count, depth_host_out ? g->conv16.as<uint16_t>() : nullptr, mask_host_out ? g->conv8.as<uint8_t>() : nullptr, g->stream));
     // ONE copy per output for the whole stack (the reference issues one thrust::copy per pose, renderer.cu:370-373)
-    if (depth_host_out) HIP_TRY(hipMemcpyAsync(depth_host_out, g.conv16.p, count * sizeof(uint16_t), hipMemcpyDeviceToHost, g.stream));
-    if (mask_host_out) HIP_TRY(hipMemcpyAsync(mask_host_out, g.conv8.p, count, hipMemcpyDeviceToHost, g.stream));
-    HIP_TRY(hipStreamSynchronize(g.stream));
+    if (depth_host_out) HIP_TRY(hipMemcpyAsync(depth_host_out, g->conv16.p, count * sizeof(uint16_t), hipMemcpyDeviceToHost, g->stream));
+    if (mask_host_out) HIP_TRY(hipMemcpyAsync(mask_host_out, g->conv8.p, count, hipMemcpyDeviceToHost, g->stream));
+    HIP_TRY(hipStreamSynchronize(g->stream));
     return PR_OK;
 }
 
 int pr_icp_batch(pr_vec3 *clouds_dev, const uint32_t *offsets_host, uint32_t n_clouds, int scene_kind, const void *scene,
                  pr_criteria crit, pr_result *results_host)
 {
-    std::lock_guard<std::mutex> lk(g_mu);
-    PR_TRY(require_ctx());
+    PR_ENTER();
     if (!clouds_dev || !offsets_host || !results_host) { set_error("pr_icp_batch: bad arguments"); return PR_ERR_INVALID; }
     SceneSel sc;
     std::memset(static_cast<void *>(&sc), 0, sizeof sc);
@@ -1170,105 +1476,225 @@ int pr_icp_nn(pr_vec3 *cloud_dev, uint32_t n_points, const pr_scene_nn *scene, p
     return pr_icp_batch(cloud_dev, off, 1, PR_SCENE_NN, scene, crit, result_out);
 }
 
+int pr_refine_batch_roi(const pr_triangle *tris_dev, size_t n_tris, const pr_mat4 *poses_host, uint32_t n_poses, uint32_t width, uint32_t height,
+                        const pr_mat4 *proj, const float K[9], int scene_kind, const void *scene, pr_criteria crit, pr_roi roi,
+                        pr_result *results_host, uint32_t *cloud_sizes_host)
+{
+    PR_ENTER();
+    if (!results_host) { set_error("pr_refine_batch: results_host is null"); return PR_ERR_INVALID; }
+    if (n_poses == 0) return PR_OK;
+    PR_TRY(refine_submit(0, tris_dev, n_tris, poses_host, n_poses, width, height, proj, K, scene_kind, scene, crit, roi, results_host, nullptr, cloud_sizes_host));
+    return refine_wait(0);
+}
 int pr_refine_batch(const pr_triangle *tris_dev, size_t n_tris, const pr_mat4 *poses_host, uint32_t n_poses, uint32_t width, uint32_t height,
                     const pr_mat4 *proj, const float K[9], int scene_kind, const void *scene, pr_criteria crit,
                     pr_result *results_host, uint32_t *cloud_sizes_host)
 {
-    std::lock_guard<std::mutex> lk(g_mu);
-    PR_TRY(require_ctx());
-    if (!results_host) { set_error("pr_refine_batch: results_host is null"); return PR_ERR_INVALID; }
-    if (n_poses == 0) return PR_OK;
-    PR_TRY(refine_submit(0, tris_dev, n_tris, poses_host, n_poses, width, height, proj, K, scene_kind, scene, crit, results_host, nullptr, cloud_sizes_host));
-    return refine_wait(0);
+    return pr_refine_batch_roi(tris_dev, n_tris, poses_host, n_poses, width, height, proj, K, scene_kind, scene, crit, pr_roi{ 0, 0, 0, 0 }, results_host, cloud_sizes_host);
 }
 int pr_refine_batch_dev(const pr_triangle *tris_dev, size_t n_tris, const pr_mat4 *poses_host, uint32_t n_poses, uint32_t width, uint32_t height,
                         const pr_mat4 *proj, const float K[9], int scene_kind, const void *scene, pr_criteria crit,
                         pr_result *results_dev, uint32_t *cloud_sizes_host)
 {
-    std::lock_guard<std::mutex> lk(g_mu);
-    PR_TRY(require_ctx());
+    PR_ENTER();
     if (!results_dev) { set_error("pr_refine_batch_dev: results_dev is null"); return PR_ERR_INVALID; }
     if (n_poses == 0) return PR_OK;
-    PR_TRY(refine_submit(0, tris_dev, n_tris, poses_host, n_poses, width, height, proj, K, scene_kind, scene, crit, nullptr, results_dev, cloud_sizes_host));
+    PR_TRY(refine_submit(0, tris_dev, n_tris, poses_host, n_poses, width, height, proj, K, scene_kind, scene, crit, pr_roi{ 0, 0, 0, 0 }, nullptr, results_dev, cloud_sizes_host));
     return refine_wait(0);
+}
+int pr_refine_submit_roi(int slot, const pr_triangle *tris_dev, size_t n_tris, const pr_mat4 *poses_host, uint32_t n_poses, uint32_t width, uint32_t height,
+                         const pr_mat4 *proj, const float K[9], int scene_kind, const void *scene, pr_criteria crit, pr_roi roi,
+                         pr_result *results_host, pr_result *results_dev, uint32_t *cloud_sizes_host)
+{
+    PR_ENTER();
+    return refine_submit(slot, tris_dev, n_tris, poses_host, n_poses, width, height, proj, K, scene_kind, scene, crit, roi, results_host, results_dev, cloud_sizes_host);
 }
 int pr_refine_submit(int slot, const pr_triangle *tris_dev, size_t n_tris, const pr_mat4 *poses_host, uint32_t n_poses, uint32_t width, uint32_t height,
                      const pr_mat4 *proj, const float K[9], int scene_kind, const void *scene, pr_criteria crit,
                      pr_result *results_host, pr_result *results_dev, uint32_t *cloud_sizes_host)
 {
-    std::lock_guard<std::mutex> lk(g_mu);
-    PR_TRY(require_ctx());
-    return refine_submit(slot, tris_dev, n_tris, poses_host, n_poses, width, height, proj, K, scene_kind, scene, crit, results_host, results_dev, cloud_sizes_host);
+    return pr_refine_submit_roi(slot, tris_dev, n_tris, poses_host, n_poses, width, height, proj, K, scene_kind, scene, crit, pr_roi{ 0, 0, 0, 0 }, results_host, results_dev, cloud_sizes_host);
 }
 int pr_refine_wait(int slot)
 {
-    std::lock_guard<std::mutex> lk(g_mu);
-    PR_TRY(require_ctx());
+    PR_ENTER();
     return refine_wait(slot);
+}
+
+// Scene_projective restricted to a window of the frame: copies the window's rows of the full-frame arrays
+int pr_scene_proj_crop_dev(const pr_vec3 *pcd_full_dev, const pr_vec3 *normal_full_dev, size_t width, size_t height, pr_roi window,
+                           pr_vec3 *pcd_out_dev, pr_vec3 *normal_out_dev)
+{
+    PR_ENTER();
+    if (!pcd_full_dev || !normal_full_dev || !pcd_out_dev || !normal_out_dev || window.width <= 0 || window.height <= 0 || window.x < 0 || window.y < 0 ||
+        (size_t)window.x + (size_t)window.width > width || (size_t)window.y + (size_t)window.height > height) { set_error("pr_scene_proj_crop_dev: bad arguments"); return PR_ERR_INVALID; }
+    const size_t cw = (size_t)window.width, ch = (size_t)window.height;
+    g_writes.note(pcd_out_dev, cw * ch * sizeof(pr_vec3)); g_writes.note(normal_out_dev, cw * ch * sizeof(pr_vec3));
+    const size_t off = (size_t)window.y * width + (size_t)window.x;
+    HIP_TRY(hipMemcpy2DAsync(pcd_out_dev, cw * sizeof(pr_vec3), pcd_full_dev + off, width * sizeof(pr_vec3), cw * sizeof(pr_vec3), ch, hipMemcpyDeviceToDevice, g->stream));
+    HIP_TRY(hipMemcpy2DAsync(normal_out_dev, cw * sizeof(pr_vec3), normal_full_dev + off, width * sizeof(pr_vec3), cw * sizeof(pr_vec3), ch, hipMemcpyDeviceToDevice, g->stream));
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    return PR_OK;
+}
+
+// ---- the job's one collective -----------------------------------------------------------------------------------------
+int pr_comm_id(unsigned char id_out[PR_COMM_ID_BYTES])
+{
+    static_assert(PR_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "id size");
+    if (!id_out) { set_error("pr_comm_id: null argument"); return PR_ERR_INVALID; }
+    PR_TRY(rccl_load());
+    ncclUniqueId id;
+    NCCL_TRY(g_rccl.GetUniqueId(&id));
+    std::memcpy(id_out, id.internal, PR_COMM_ID_BYTES);
+    return PR_OK;
+}
+int pr_comm_init_rank(const unsigned char id_in[PR_COMM_ID_BYTES], int rank, int world)
+{
+    if (!id_in || world < 1 || rank < 0 || rank >= world) { set_error("pr_comm_init_rank: bad arguments"); return PR_ERR_INVALID; }
+    PR_TRY(rccl_load());
+    PR_ENTER();
+    comm_teardown(g);
+    ncclUniqueId id;
+    std::memcpy(id.internal, id_in, PR_COMM_ID_BYTES);
+    NCCL_TRY(g_rccl.CommInitRank(&g->comm, world, id, rank));
+    g->comm_rank = rank; g->comm_world = world;
+    return PR_OK;
+}
+int pr_comm_init_all(int n_devices)
+{
+    if (n_devices < 1) { set_error("pr_comm_init_all: n_devices must be >= 1"); return PR_ERR_INVALID; }
+    PR_TRY(rccl_load());
+    Ctx *mine = g;
+    std::vector<Ctx *> cs((size_t)n_devices);
+    std::vector<int> devs((size_t)n_devices);
+    for (int d = 0; d < n_devices; ++d) {                          // the shared context of every device, initialised
+        PR_TRY(bind_shared(d));
+        std::lock_guard<std::mutex> lk(g->mu);
+        PR_TRY(require_ctx());
+        comm_teardown(g);
+        cs[(size_t)d] = g; devs[(size_t)d] = d;
+    }
+    std::vector<ncclComm_t> comms((size_t)n_devices, nullptr);
+    NCCL_TRY(g_rccl.CommInitAll(comms.data(), n_devices, devs.data()));
+    for (int d = 0; d < n_devices; ++d) { cs[(size_t)d]->comm = comms[(size_t)d]; cs[(size_t)d]->comm_rank = d; cs[(size_t)d]->comm_world = n_devices; }
+    g = mine;                                                       // the calling thread keeps the context it had (or none)
+    if (g) (void)hipSetDevice(g->device);
+    return PR_OK;
+}
+int pr_comm_destroy(void)
+{
+    if (!g) return PR_OK;
+    std::lock_guard<std::mutex> lk(g->mu);
+    comm_teardown(g);
+    return PR_OK;
+}
+int pr_comm_rank(int *rank, int *world)
+{
+    PR_TRY(bind_default());
+    if (rank) *rank = g->comm_rank;
+    if (world) *world = g->comm_world;
+    return PR_OK;
+}
+// Gather of the sharded results to `root`, in global hypothesis order: rank r contributes the pr_pr_shard_range(n_total, r, world)
+// block.  Grouped ncclSend / ncclRecv of exactly the bytes each rank owns (72 B per hypothesis; 36.9 KB per rank at 4096
+// hypotheses on 8 GPUs -- one hop over xGMI, latency-bound).  Enqueued on the context's stream; pr_sync / pr_memcpy_d2h order after it.
+int pr_gather_results(const pr_result *send_dev, uint32_t n_local, uint32_t n_total, int root, pr_result *recv_dev)
+{
+    PR_ENTER();
+    const int world = g->comm_world, rank = g->comm_rank;
+    if (root < 0 || root >= world) { set_error("pr_gather_results: root %d outside 0..%d", root, world - 1); return PR_ERR_INVALID; }
+    uint32_t first = 0, count = 0;
+    pr_shard_range(n_total, (uint32_t)rank, (uint32_t)world, &first, &count);
+    if (count != n_local) { set_error("pr_gather_results: rank %d holds %u results, its shard of %u over %d ranks has %u", rank, n_local, n_total, world, count); return PR_ERR_INVALID; }
+    if ((n_local && !send_dev) || (rank == root && n_total && !recv_dev)) { set_error("pr_gather_results: null buffer"); return PR_ERR_INVALID; }
+    if (world == 1 || !g->comm) {
+        if (world != 1) { set_error("pr_gather_results: no communicator (pr_comm_init_rank / pr_comm_init_all)"); return PR_ERR_COMM; }
+        if (n_local && recv_dev != send_dev) HIP_TRY(hipMemcpyAsync(recv_dev, send_dev, sizeof(pr_result) * n_local, hipMemcpyDeviceToDevice, g->stream));
+        if (n_local) g_writes.note(recv_dev, sizeof(pr_result) * n_local);
+        return PR_OK;
+    }
+    NCCL_TRY(g_rccl.GroupStart());
+    if (n_local) NCCL_TRY(g_rccl.Send(send_dev, (size_t)n_local * sizeof(pr_result), ncclChar, root, g->comm, g->stream));
+    if (rank == root) {
+        for (int r = 0; r < world; ++r) {
+            uint32_t f = 0, c = 0;
+            pr_shard_range(n_total, (uint32_t)r, (uint32_t)world, &f, &c);
+            if (c) NCCL_TRY(g_rccl.Recv(recv_dev + f, (size_t)c * sizeof(pr_result), ncclChar, r, g->comm, g->stream));
+        }
+        g_writes.note(recv_dev, sizeof(pr_result) * n_total);
+    }
+    NCCL_TRY(g_rccl.GroupEnd());
+    return PR_OK;
 }
 
 int pr_set_option(const char *name, int value)
 {
-    std::lock_guard<std::mutex> lk(g_mu);
+    std::lock_guard<std::mutex> lk(g_reg_mu);
     if (!name) { set_error("pr_set_option: null name"); return PR_ERR_INVALID; }
     const std::string n(name);
-    if (n == "solve") { if (value != PR_SOLVE_HOST && value != PR_SOLVE_DEVICE) { set_error("solve must be 0 or 1"); return PR_ERR_INVALID; } g.solve_mode = value; }
-    else if (n == "points_per_block") { if (value < 1024 || value % 1024) { set_error("points_per_block must be a multiple of 1024"); return PR_ERR_INVALID; } g.steps = value / 1024; }
-    else if (n == "profile") { if (value < 0 || value > 2) { set_error("profile must be 0, 1 (every launch) or 2 (every launch of one call in 32)"); return PR_ERR_INVALID; } g.profile = value; }
-    else if (n == "nn_lds_nodes") g.nn_lds_nodes = std::max(0, value);
-    else if (n == "nn_lds_records") g.nn_lds_records = std::max(0, value);
-    else if (n == "nn_compact") g.nn_compact = value ? 1 : 0;
-    else if (n == "nn_seed") g.nn_seed = value ? 1 : 0;
-    else if (n == "nn_stack") g.nn_stack = value ? 1 : 0;
-    else if (n == "graph") g.use_graph = value ? 1 : 0;
-    else if (n == "icp_flow") g.icp_flow = value ? 1 : 0;
-    else if (n == "fused_solve") g.fused_solve = value ? 1 : 0;
-    else if (n == "sub_batch") g.sub_batch = std::max(32, value);
-    else if (n == "overlap_pass") g.overlap_pass = std::max(-1, value);
-    else if (n == "pose_groups") g.pose_groups = std::min(4, std::max(1, value));
-    else if (n == "raster_mode") { if (value != 0 && value != 1) { set_error("raster_mode must be 0 or 1"); return PR_ERR_INVALID; } g.raster_mode = value; }
+    if (n == "solve") { if (value != PR_SOLVE_HOST && value != PR_SOLVE_DEVICE) { set_error("solve must be 0 or 1"); return PR_ERR_INVALID; } opt.solve_mode = value; }
+    else if (n == "points_per_block") { if (value < 1024 || value % 1024) { set_error("points_per_block must be a multiple of 1024"); return PR_ERR_INVALID; } opt.steps = value / 1024; }
+    else if (n == "profile") { if (value < 0 || value > 2) { set_error("profile must be 0, 1 (every launch) or 2 (every launch of one call in sample_period)"); return PR_ERR_INVALID; } opt.profile = value; }
+    else if (n == "sample_period") opt.sample_period = std::max(1, value);
+    else if (n == "scene_cache") opt.scene_cache = value ? 1 : 0;
+    else if (n == "nn_lds_nodes") opt.nn_lds_nodes = std::max(0, value);
+    else if (n == "nn_lds_records") opt.nn_lds_records = std::max(0, value);
+    else if (n == "nn_compact") opt.nn_compact = value ? 1 : 0;
+    else if (n == "nn_seed") opt.nn_seed = value ? 1 : 0;
+    else if (n == "nn_stack") opt.nn_stack = value ? 1 : 0;
+    else if (n == "graph") opt.use_graph = value ? 1 : 0;
+    else if (n == "icp_flow") opt.icp_flow = value ? 1 : 0;
+    else if (n == "fused_solve") opt.fused_solve = value ? 1 : 0;
+    else if (n == "sub_batch") opt.sub_batch = std::max(32, value);
+    else if (n == "overlap_pass") opt.overlap_pass = std::max(-1, value);
+    else if (n == "pose_groups") opt.pose_groups = std::min(4, std::max(1, value));
+    else if (n == "raster_mode") { if (value != 0 && value != 1) { set_error("raster_mode must be 0 or 1"); return PR_ERR_INVALID; } opt.raster_mode = value; }
     else { set_error("unknown option %s", name); return PR_ERR_INVALID; }
     return PR_OK;
 }
 int pr_get_option(const char *name, int *value)
 {
-    std::lock_guard<std::mutex> lk(g_mu);
+    std::lock_guard<std::mutex> lk(g_reg_mu);
     if (!name || !value) { set_error("pr_get_option: null argument"); return PR_ERR_INVALID; }
     const std::string n(name);
-    if (n == "solve") *value = g.solve_mode;
-    else if (n == "points_per_block") *value = g.steps * 1024;
-    else if (n == "profile") *value = g.profile;
-    else if (n == "nn_lds_nodes") *value = g.nn_lds_nodes;
-    else if (n == "nn_lds_records") *value = g.nn_lds_records;
-    else if (n == "nn_compact") *value = g.nn_compact;
-    else if (n == "nn_seed") *value = g.nn_seed;
-    else if (n == "nn_stack") *value = g.nn_stack;
-    else if (n == "raster_mode") *value = g.raster_mode;
-    else if (n == "graph") *value = g.use_graph;
-    else if (n == "icp_flow") *value = g.icp_flow;
-    else if (n == "fused_solve") *value = g.fused_solve;
-    else if (n == "sub_batch") *value = g.sub_batch;
-    else if (n == "overlap_pass") *value = g.overlap_pass;
-    else if (n == "pose_groups") *value = g.pose_groups;
+    if (n == "solve") *value = opt.solve_mode;
+    else if (n == "points_per_block") *value = opt.steps * 1024;
+    else if (n == "profile") *value = opt.profile;
+    else if (n == "sample_period") *value = opt.sample_period;
+    else if (n == "scene_cache") *value = opt.scene_cache;
+    else if (n == "nn_lds_nodes") *value = opt.nn_lds_nodes;
+    else if (n == "nn_lds_records") *value = opt.nn_lds_records;
+    else if (n == "nn_compact") *value = opt.nn_compact;
+    else if (n == "nn_seed") *value = opt.nn_seed;
+    else if (n == "nn_stack") *value = opt.nn_stack;
+    else if (n == "raster_mode") *value = opt.raster_mode;
+    else if (n == "graph") *value = opt.use_graph;
+    else if (n == "icp_flow") *value = opt.icp_flow;
+    else if (n == "fused_solve") *value = opt.fused_solve;
+    else if (n == "sub_batch") *value = opt.sub_batch;
+    else if (n == "overlap_pass") *value = opt.overlap_pass;
+    else if (n == "pose_groups") *value = opt.pose_groups;
     else { set_error("unknown option %s", name); return PR_ERR_INVALID; }
     return PR_OK;
 }
 
 int pr_profile_reset(void)
 {
-    std::lock_guard<std::mutex> lk(g_mu);
-    g.icp_ms = g.render_ms = g.cloud_ms = 0; g.icp_launches = g.icp_points = g.icp_bytes = 0; g.sample_clock = 0;
+    PR_TRY(bind_default());
+    std::lock_guard<std::mutex> lk(g->mu);
+    g->icp_ms = g->render_ms = g->cloud_ms = 0; g->icp_launches = g->icp_points = g->icp_bytes = 0; g->sample_clock = 0;
     return PR_OK;
 }
 int pr_profile_read(double *kernel_ms, uint64_t *launches, uint64_t *points, uint64_t *algorithmic_bytes, double *render_ms, double *cloud_ms)
 {
-    std::lock_guard<std::mutex> lk(g_mu);
-    if (kernel_ms) *kernel_ms = g.icp_ms;
-    if (launches) *launches = g.icp_launches;
-    if (points) *points = g.icp_points;
-    if (algorithmic_bytes) *algorithmic_bytes = g.icp_bytes;
-    if (render_ms) *render_ms = g.render_ms;
-    if (cloud_ms) *cloud_ms = g.cloud_ms;
+    PR_TRY(bind_default());
+    std::lock_guard<std::mutex> lk(g->mu);
+    if (kernel_ms) *kernel_ms = g->icp_ms;
+    if (launches) *launches = g->icp_launches;
+    if (points) *points = g->icp_points;
+    if (algorithmic_bytes) *algorithmic_bytes = g->icp_bytes;
+    if (render_ms) *render_ms = g->render_ms;
+    if (cloud_ms) *cloud_ms = g->cloud_ms;
     return PR_OK;
 }
 

@@ -54,14 +54,16 @@ struct IcpBatch {
 struct SceneProjAoS {
     uint32_t width, height;
     float max_dist_diff, fx, fy, cx, cy;
+    float tlx, tly;             // (float)tl_x, (float)tl_y of pcd2dep (common.h:64-67): 0 unless the scene buffers cover a crop of the frame
     const pr_vec3 *pcd, *normal;
 };
 // projective scene repacked by the fused pipeline: one 16-byte record {nx,ny,nz,z} per pixel
 struct SceneProjPacked {
     uint32_t width, height;
     float max_dist_diff, fx, fy, cx, cy;
+    float tlx, tly;
     const float4 *rec;
-    const float *colf, *rowf;   // colf[x] = ((float)x - cx)/fx, rowf[y] = ((float)y - cy)/fy
+    const float *colf, *rowf;   // colf[x] = ((float)(x + tl_x) - cx)/fx, rowf[y] = ((float)(y + tl_y) - cy)/fy
 };
 // kd-tree scene: reference arrays + the traversal structure derived from them (build_nn_accel)
 struct SceneNNDev {
@@ -120,13 +122,13 @@ hipError_t launch_depth2cloud(const T *depth, uint32_t n_img, size_t img_stride,
                               bool empty_intmax, uint32_t *row_count, uint32_t *row_off, uint32_t *counts,
                               pr_vec3 *cloud, size_t cloud_stride, bool emit, hipStream_t s);
 
-hipError_t launch_model_aabb(const pr_triangle *tris, uint32_t n_tris, float *aabb, hipStream_t s);
+hipError_t launch_model_aabb(const pr_triangle *tris, uint32_t n_tris, uint32_t *keys, float *aabb_out, const float *expect, uint32_t *flag_out, hipStream_t s);
 hipError_t launch_render_bands(const pr_triangle *tris, uint32_t n_tris, const pr_mat4 *poses_dev, uint32_t n_poses, const float *aabb,
                                int4 *bbox, int32_t *depth, uint32_t *row_count, uint32_t *row_off, uint32_t *counts,
-                               uint32_t width, uint32_t height, const pr_mat4 &proj, uint32_t n_cus, hipStream_t s);
+                               uint32_t width, uint32_t height, const pr_mat4 &proj, pr_roi roi, uint32_t n_cus, hipStream_t s);
 hipError_t launch_render_boxes(const pr_triangle *tris, uint32_t n_tris, const pr_mat4 *poses_dev, uint32_t n_poses, const float *aabb,
                                int4 *bbox, int32_t *depth, uint32_t *row_count, uint32_t *row_off, uint32_t *counts,
-                               uint32_t width, uint32_t height, const pr_mat4 &proj, hipStream_t s, bool compute_boxes = true,
+                               uint32_t width, uint32_t height, const pr_mat4 &proj, pr_roi roi, hipStream_t s, bool compute_boxes = true,
                                PoseMeta *meta = nullptr, DevIcpState *st = nullptr, uint32_t *arrive = nullptr, uint32_t cloud_stride = 0);
 hipError_t launch_pack_export(const DevIcpState *st, pr_result *out, const uint32_t *counts, uint32_t *host_counts, pr_result *host_results,
                               uint32_t n, hipStream_t s);
@@ -160,7 +162,8 @@ template <typename T>
 hipError_t launch_scene_proj_prepare(const T *depth, uint32_t W, uint32_t H, float fx, float fy, float cx, float cy, pr_vec3 *pcd, pr_vec3 *normal, hipStream_t s);
 hipError_t launch_raw2depth_mask(const int32_t *raw, size_t n, uint16_t *depth16, uint8_t *mask8, hipStream_t s);
 hipError_t launch_pack_proj_scene(const pr_vec3 *pcd, const pr_vec3 *normal, float4 *rec, size_t n, float *colf, float *rowf,
-                                  uint32_t width, uint32_t height, float fx, float fy, float cx, float cy, hipStream_t s);
+                                  uint32_t width, uint32_t height, float fx, float fy, float cx, float cy, uint32_t tl_x, uint32_t tl_y,
+                                  uint32_t *exact, hipStream_t s);
 // info[0] = tree depth, info[1] = 1 when the 32-byte records are valid, info[2..7] = qmin[3], qscale[3] (float bits)
 hipError_t launch_build_nn_accel(const pr_kdnode *nodes, uint32_t n_nodes, const pr_vec3 *pcd, uint32_t n_points,
                                  int4 *topo, float4 *bmin, float4 *bmax, float4 *pts, float4 *rec, uint4 *rec32, uint2 *desc, uint32_t *info, hipStream_t s);

@@ -227,7 +227,10 @@ __global__ __launch_bounds__(256) void raster_kernel(const pr_triangle *__restri
         cmax0 = (float)((roi.x + roi.width) - 1);
         cmax1 = (float)((unsigned long long)(height - 1) - (unsigned long long)(long long)roi.y);
     }
-    (void)boxes;
+    if (boxes) {                                                 // fused path: the hypothesis' pixel box (already intersected with the caller's ROI,
+        const int4 bb = boxes[blockIdx.y];                       // if any); a conservative box clips nothing, an ROI clips like renderer.cu:106-113
+        cmin0 = (float)bb.x; cmin1 = (float)bb.y; cmax0 = (float)bb.z; cmax1 = (float)bb.w;
+    }
 
     TriSetup t;
     int n = 0;
@@ -250,13 +253,17 @@ __global__ __launch_bounds__(256) void raster_kernel(const pr_triangle *__restri
 //  touched (the conservative box of the object instead of the whole frame) differ.
 // ================================================================================================
 
-// axis-aligned box of the mesh: {minx,miny,minz,maxx,maxy,maxz}.  One workgroup.
-__global__ __launch_bounds__(1024) void model_aabb_kernel(const pr_triangle *__restrict__ tris, uint32_t n_tris, float *__restrict__ aabb)
+// axis-aligned box of the mesh: {minx,miny,minz,maxx,maxy,maxz}.  Any number of workgroups: each reduces a slice and merges it
+// into six 32-bit keys with atomicMin -- a float maps to a key that orders like the float (sign bit flipped for positives, all
+// bits for negatives); minima store the key, maxima its complement, so all six start from 0xffffffff (one memset).
+__device__ __forceinline__ uint32_t f32_key(float v) { const uint32_t b = __float_as_uint(v); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
+__device__ __forceinline__ float key_f32(uint32_t k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+__global__ __launch_bounds__(256) void model_aabb_kernel(const pr_triangle *__restrict__ tris, uint32_t n_tris, uint32_t *__restrict__ keys)
 {
-    __shared__ float red[16][6];
+    __shared__ float red[4][6];
     float lo[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, hi[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
     const float *v = reinterpret_cast<const float *>(tris);
-    for (uint32_t i = threadIdx.x; i < n_tris * 3u; i += 1024) {
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n_tris * 3u; i += gridDim.x * 256) {
 #pragma unroll
         for (int a = 0; a < 3; ++a) { const float c = v[(size_t)i * 3 + a]; lo[a] = fminf(lo[a], c); hi[a] = fmaxf(hi[a], c); }
     }
@@ -268,9 +275,25 @@ __global__ __launch_bounds__(1024) void model_aabb_kernel(const pr_triangle *__r
     __syncthreads();
     if (threadIdx.x < 6) {
         float r = red[0][threadIdx.x];
-        for (int w = 1; w < 16; ++w) r = (threadIdx.x < 3) ? fminf(r, red[w][threadIdx.x]) : fmaxf(r, red[w][threadIdx.x]);
-        aabb[threadIdx.x] = r;
+        for (int w = 1; w < 4; ++w) r = (threadIdx.x < 3) ? fminf(r, red[w][threadIdx.x]) : fmaxf(r, red[w][threadIdx.x]);
+        atomicMin(&keys[threadIdx.x], (threadIdx.x < 3) ? f32_key(r) : ~f32_key(r));
     }
+}
+// keys -> floats (aabb_out, optional) and/or a check against the box the host assumed (flag_out, optional: 1 = differs).
+// An empty mesh leaves the keys untouched: +FLT_MAX / -FLT_MAX like the single-pass form.
+struct AabbExpected { float v[6]; };
+__global__ void model_aabb_finish_kernel(const uint32_t *__restrict__ keys, float *__restrict__ aabb_out, AabbExpected expect, uint32_t *__restrict__ flag_out)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    bool differs = false;
+    for (int a = 0; a < 6; ++a) {
+        const uint32_t k = keys[a];
+        float v = (a < 3) ? key_f32(k) : key_f32(~k);
+        if (k == 0xffffffffu) v = (a < 3) ? FLT_MAX : -FLT_MAX;
+        if (aabb_out) aabb_out[a] = v;
+        if (!(v == expect.v[a])) differs = true;
+    }
+    if (flag_out) *flag_out = differs ? 1u : 0u;
 }
 
 // Conservative pixel box {x0,y0,x1,y1} (raster coordinates, y not yet flipped) of the mesh under
@@ -279,7 +302,7 @@ __global__ __launch_bounds__(1024) void model_aabb_kernel(const pr_triangle *__r
 // as long as all of them are in front of the camera, and 2 pixels of padding cover float rounding.
 // Any corner at or behind the camera plane -> the whole frame.
 __global__ __launch_bounds__(256) void pose_bbox_kernel(const float *__restrict__ aabb, const pr_mat4 *__restrict__ poses, uint32_t n_poses,
-                                                        pr_mat4 proj, uint32_t width, uint32_t height, int4 *__restrict__ bbox)
+                                                        pr_mat4 proj, uint32_t width, uint32_t height, pr_roi roi, int4 *__restrict__ bbox)
 {
     const uint32_t p = blockIdx.x * 256 + threadIdx.x;
     if (p >= n_poses) return;
@@ -303,6 +326,10 @@ __global__ __launch_bounds__(256) void pose_bbox_kernel(const float *__restrict_
     if (all_front && finite) {
         x0 = max(0, (int)floorf(mnx) - 2);  x1 = min((int)width - 1, (int)ceilf(mxx) + 2);
         y0 = max(0, (int)floorf(mny) - 2);  y1 = min((int)height - 1, (int)ceilf(mxy) + 2);
+    }
+    if (roi.width > 0 && roi.height > 0) {                       // renderer.cu:106-113: the ROI is given in image rows, the raster runs flipped
+        x0 = max(x0, roi.x);  x1 = min(x1, roi.x + roi.width - 1);
+        y0 = max(y0, (int)height - 1 - (roi.y + roi.height - 1));  y1 = min(y1, (int)height - 1 - roi.y);
     }
     bbox[p] = make_int4(x0, y0, x1, y1);
 }
@@ -626,11 +653,13 @@ __device__ __forceinline__ float div_normal_range(float a, float b)
 // values end up as INT_MIN on x86 (rejected).  The same decision is taken here on the float before converting: valid iff
 // -1 < v < width.  Whenever the quotient is outside the normal range (z = 0, denormal, inf, NaN) the point is rejected on
 // both sides -- by this range test or by the |src.z - dst.z| test -- so the cheaper division above cannot change a result.
-__device__ __forceinline__ bool proj_pixel(float sx, float sy, float sz, float fx, float fy, float cx, float cy,
+__device__ __forceinline__ bool proj_pixel(float sx, float sy, float sz, float fx, float fy, float cx, float cy, float tlx, float tly,
                                            uint32_t width, uint32_t height, uint32_t &idx, int &px, int &py)
 {
-    const float vx = div_normal_range(sx, sz) * fx + cx - 0.0f + 0.5f;
-    const float vy = div_normal_range(sy, sz) * fy + cy - 0.0f + 0.5f;
+    // common.h:64-67: int(x/z*fx + cx - tl_x + 0.5f); tl_* are size_t in the reference and enter the float expression converted
+    // to float (0.0f for a scene that covers the whole frame -- subtracting it is exact)
+    const float vx = div_normal_range(sx, sz) * fx + cx - tlx + 0.5f;
+    const float vy = div_normal_range(sy, sz) * fy + cy - tly + 0.5f;
     if (!(vx > -1.0f && vx < (float)width && vy > -1.0f && vy < (float)height)) return false;
     px = (int)vx; py = (int)vy;
     idx = (uint32_t)px + (uint32_t)py * width;
@@ -640,7 +669,7 @@ __device__ __forceinline__ bool proj_pixel(float sx, float sy, float sz, float f
 __device__ __forceinline__ bool query(const SceneProjAoS &s, float sx, float sy, float sz, Corr &c)
 {
     uint32_t idx; int px, py;
-    if (!proj_pixel(sx, sy, sz, s.fx, s.fy, s.cx, s.cy, s.width, s.height, idx, px, py)) return false;
+    if (!proj_pixel(sx, sy, sz, s.fx, s.fy, s.cx, s.cy, s.tlx, s.tly, s.width, s.height, idx, px, py)) return false;
     const float *d = reinterpret_cast<const float *>(s.pcd + idx);
     const float dz = d[2];
     const float diff = sz - dz;
@@ -654,7 +683,7 @@ __device__ __forceinline__ bool query(const SceneProjAoS &s, float sx, float sy,
 __device__ __forceinline__ bool query(const SceneProjPacked &s, float sx, float sy, float sz, Corr &c)
 {
     uint32_t idx; int px, py;
-    if (!proj_pixel(sx, sy, sz, s.fx, s.fy, s.cx, s.cy, s.width, s.height, idx, px, py)) return false;
+    if (!proj_pixel(sx, sy, sz, s.fx, s.fy, s.cx, s.cy, s.tlx, s.tly, s.width, s.height, idx, px, py)) return false;
     const float4 r = s.rec[idx];                                 // one 16-byte gather: {nx, ny, nz, z}
     const float dz = r.w;
     const float diff = sz - dz;
@@ -678,7 +707,7 @@ struct Gathered { float a0, a1, a2, a3, b0, b1, b2; };
 __device__ __forceinline__ bool gather_issue(const SceneProjAoS &s, float sx, float sy, float sz, bool live, Gathered &g)
 {
     uint32_t idx; int px, py;
-    const bool in_img = live && proj_pixel(sx, sy, sz, s.fx, s.fy, s.cx, s.cy, s.width, s.height, idx, px, py);
+    const bool in_img = live && proj_pixel(sx, sy, sz, s.fx, s.fy, s.cx, s.cy, s.tlx, s.tly, s.width, s.height, idx, px, py);
     const uint32_t at = in_img ? idx : 0u;
     const float *d = reinterpret_cast<const float *>(s.pcd + at);
     const float *n = reinterpret_cast<const float *>(s.normal + at);
@@ -697,7 +726,7 @@ __device__ __forceinline__ bool gather_finish(const SceneProjAoS &s, bool in_img
 __device__ __forceinline__ bool gather_issue(const SceneProjPacked &s, float sx, float sy, float sz, bool live, Gathered &g)
 {
     uint32_t idx; int px, py;
-    const bool in_img = live && proj_pixel(sx, sy, sz, s.fx, s.fy, s.cx, s.cy, s.width, s.height, idx, px, py);
+    const bool in_img = live && proj_pixel(sx, sy, sz, s.fx, s.fy, s.cx, s.cy, s.tlx, s.tly, s.width, s.height, idx, px, py);
     const float4 r = s.rec[in_img ? idx : 0u];                    // {nx, ny, nz, z}
     g.a0 = r.x; g.a1 = r.y; g.a2 = r.z; g.a3 = r.w;
     g.b0 = s.colf[in_img ? px : 0]; g.b1 = s.rowf[in_img ? py : 0]; g.b2 = 0.0f;
@@ -2001,16 +2030,27 @@ __global__ __launch_bounds__(256) void nn_gather_emit_kernel(const T *__restrict
 // ================================================================================================
 //  scene repacking
 // ================================================================================================
+// colf[x] = ((float)(x + tl_x) - cx)/fx, rowf[y] = ((float)(y + tl_y) - cy)/fy: the factors dep2pcd (common.h:47-61) multiplies z with.
+// The packed record drops pcd.x / pcd.y and the query rebuilds them as colf*z, rowf*z -- exact only for a pcd buffer that WAS
+// built by dep2pcd with this K and offset.  The buffers are the caller's (public members in the reference), so every pixel that
+// can take part in a match (z > 0) is checked here; a single deviation clears *exact and the caller's arrays are used as they are.
 __global__ __launch_bounds__(256) void pack_proj_scene_kernel(const pr_vec3 *__restrict__ pcd, const pr_vec3 *__restrict__ normal,
                                                               float4 *__restrict__ rec, size_t n, float *__restrict__ colf,
                                                               float *__restrict__ rowf, uint32_t width, uint32_t height,
-                                                              float fx, float fy, float cx, float cy)
+                                                              float fx, float fy, float cx, float cy, uint32_t tl_x, uint32_t tl_y,
+                                                              uint32_t *__restrict__ exact)
 {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < width) colf[i] = ((float)i - cx) / fx;
-    if (i < height) rowf[i] = ((float)i - cy) / fy;
+    if (i < width) colf[i] = ((float)(i + tl_x) - cx) / fx;
+    if (i < height) rowf[i] = ((float)(i + tl_y) - cy) / fy;
     if (i >= n) return;
-    rec[i] = make_float4(normal[i].x, normal[i].y, normal[i].z, pcd[i].z);
+    const pr_vec3 p = pcd[i];
+    rec[i] = make_float4(normal[i].x, normal[i].y, normal[i].z, p.z);
+    if (p.z > 0) {
+        const uint32_t x = (uint32_t)(i % width), y = (uint32_t)(i / width);
+        const float ex = ((float)((size_t)x + tl_x) - cx) / fx * p.z, ey = ((float)((size_t)y + tl_y) - cy) / fy * p.z;
+        if (!(__float_as_uint(ex) == __float_as_uint(p.x) && __float_as_uint(ey) == __float_as_uint(p.y))) *exact = 0u;
+    }
 }
 
 __global__ __launch_bounds__(256) void nn_accel_kernel(const pr_kdnode *__restrict__ nodes, uint32_t n_nodes,
@@ -2053,7 +2093,8 @@ __global__ __launch_bounds__(256) void nn_records_kernel(const int4 *__restrict_
     else {
         const int dim = (int)((uint32_t)t.w >> 30);
         r0 = make_float4(__int_as_float(t.x), __int_as_float(t.y), __int_as_float(t.z), __int_as_float(dim));
-        const float4 a0 = bmin[t.y], a1 = bmax[t.y], c0 = bmin[t.z], c1 = bmax[t.z];
+        const int y = ((uint32_t)t.y < n_nodes) ? t.y : 0, z = ((uint32_t)t.z < n_nodes) ? t.z : 0;   // malformed links are reported below
+        const float4 a0 = bmin[y], a1 = bmax[y], c0 = bmin[z], c1 = bmax[z];
         r1 = make_float4(a0.x, a0.y, a0.z, a1.x);
         r2 = make_float4(a1.y, a1.z, c0.x, c0.y);
         r3 = make_float4(c0.z, c1.x, c1.y, c1.z);
@@ -2061,6 +2102,13 @@ __global__ __launch_bounds__(256) void nn_records_kernel(const int4 *__restrict_
     rec[(size_t)i * 4] = r0; rec[(size_t)i * 4 + 1] = r1; rec[(size_t)i * 4 + 2] = r2; rec[(size_t)i * 4 + 3] = r3;
     uint32_t depth = 0;
     for (int p = (t.w & 0x3fffffff) - 1; p >= 0 && depth < 4096; p = (topo[p].w & 0x3fffffff) - 1) ++depth;
+    // The stack size is derived from this depth, which follows the PARENT links, while the search follows the CHILD links: the
+    // nodes are the caller's, so the two are cross-checked.  Any disagreement reports an impossible depth and the scene is
+    // searched with the reference's stackless walk instead (which uses both kinds of link exactly like pcd_scene.h:60-136).
+    if (t.z >= 0) {
+        const bool in_range = (uint32_t)t.y < n_nodes && (uint32_t)t.z < n_nodes && t.y > (int)i && t.z > (int)i;
+        if (!in_range || (topo[t.y].w & 0x3fffffff) - 1 != (int)i || (topo[t.z].w & 0x3fffffff) - 1 != (int)i) depth = 0x7fffffffu;
+    }
     atomicMax(max_depth, depth);
 }
 
@@ -2096,10 +2144,18 @@ __global__ __launch_bounds__(256) void nn_records32_kernel(const int4 *__restric
     else {
         const uint32_t dim = (uint32_t)t.w >> 30;
         w[0] = (uint32_t)t.x; w[1] = (uint32_t)t.y | (dim << 30);
-        ok = (t.z == t.y + 1) && ((uint32_t)t.y < (1u << 30)) && dim < 3;
+        ok = (t.z == t.y + 1) && ((uint32_t)t.y < (1u << 30)) && dim < 3 && (uint32_t)t.z < n_nodes;
+        // the 8-byte descent skips a far side on (q - split)^2 alone, which needs left_max <= split <= right_min
+        // (pcd_scene.cpp:135 builds trees that way; other trees take the exact 64-byte records)
+        if (ok) {
+            const float lmax = (dim == 0) ? bmax[t.y].x : ((dim == 1) ? bmax[t.y].y : bmax[t.y].z);
+            const float rmin = (dim == 0) ? bmin[t.z].x : ((dim == 1) ? bmin[t.z].y : bmin[t.z].z);
+            const float split = __int_as_float(t.x);
+            if (!(lmax <= split && split <= rmin)) ok = false;
+        }
         uint32_t q[12];
         for (int c = 0; c < 2; ++c) {
-            const int ch = c ? t.z : t.y;
+            const int ch = ok ? (c ? t.z : t.y) : 0;
             const float lo[3] = { bmin[ch].x, bmin[ch].y, bmin[ch].z }, hi[3] = { bmax[ch].x, bmax[ch].y, bmax[ch].z };
             for (int a = 0; a < 3; ++a) {
                 const float qmin = __uint_as_float(info[2 + a]), qs = __uint_as_float(info[5 + a]);
@@ -2155,9 +2211,18 @@ hipError_t launch_raster(const pr_triangle *tris, uint32_t n_tris, const pr_mat4
     return hipGetLastError();
 }
 
-hipError_t launch_model_aabb(const pr_triangle *tris, uint32_t n_tris, float *aabb, hipStream_t s)
+// keys: 6 x uint32 scratch; aabb_out (device, 6 floats) and/or flag_out (device-visible word: 1 when the box differs from `expect`)
+hipError_t launch_model_aabb(const pr_triangle *tris, uint32_t n_tris, uint32_t *keys, float *aabb_out, const float *expect, uint32_t *flag_out, hipStream_t s)
 {
-    hipLaunchKernelGGL(model_aabb_kernel, dim3(1), dim3(1024), 0, s, tris, n_tris, aabb);
+    hipError_t e = hipMemsetAsync(keys, 0xff, 6 * sizeof(uint32_t), s);
+    if (e != hipSuccess) return e;
+    if (n_tris > 0) {
+        const uint32_t blocks = (n_tris * 3u + 2047u) / 2048u;           // >= 8 vertices per lane
+        hipLaunchKernelGGL(model_aabb_kernel, dim3(blocks < 1 ? 1 : (blocks > 512 ? 512 : blocks)), dim3(256), 0, s, tris, n_tris, keys);
+    }
+    AabbExpected ex{};
+    if (expect) for (int a = 0; a < 6; ++a) ex.v[a] = expect[a];
+    hipLaunchKernelGGL(model_aabb_finish_kernel, dim3(1), dim3(64), 0, s, keys, aabb_out, ex, flag_out);
     return hipGetLastError();
 }
 
@@ -2165,7 +2230,7 @@ hipError_t launch_model_aabb(const pr_triangle *tris, uint32_t n_tris, float *aa
 // inside each hypothesis' box; row_count/row_off/counts as launch_depth2cloud(emit=false) would.
 hipError_t launch_render_bands(const pr_triangle *tris, uint32_t n_tris, const pr_mat4 *poses_dev, uint32_t n_poses, const float *aabb,
                                int4 *bbox, int32_t *depth, uint32_t *row_count, uint32_t *row_off, uint32_t *counts,
-                               uint32_t width, uint32_t height, const pr_mat4 &proj, uint32_t n_cus, hipStream_t s)
+                               uint32_t width, uint32_t height, const pr_mat4 &proj, pr_roi roi, uint32_t n_cus, hipStream_t s)
 {
     if (n_poses == 0) return hipSuccess;
     static bool attr_set = false;
@@ -2176,7 +2241,7 @@ hipError_t launch_render_bands(const pr_triangle *tris, uint32_t n_tris, const p
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(pose_bbox_kernel, dim3((n_poses + 255) / 256), dim3(256), 0, s, aabb, poses_dev, n_poses, proj, width, height, bbox);
+    hipLaunchKernelGGL(pose_bbox_kernel, dim3((n_poses + 255) / 256), dim3(256), 0, s, aabb, poses_dev, n_poses, proj, width, height, roi, bbox);
     hipError_t e = hipMemsetAsync(row_count, 0, sizeof(uint32_t) * (size_t)n_poses * height, s);
     if (e != hipSuccess) return e;
     const uint32_t rows_min = cap_px / width > 0 ? cap_px / width : 1;
@@ -2192,12 +2257,12 @@ hipError_t launch_render_bands(const pr_triangle *tris, uint32_t n_tris, const p
 // fused-path render, reference scheme (global int32 atomicMin) but only inside each hypothesis' box
 hipError_t launch_render_boxes(const pr_triangle *tris, uint32_t n_tris, const pr_mat4 *poses_dev, uint32_t n_poses, const float *aabb,
                                int4 *bbox, int32_t *depth, uint32_t *row_count, uint32_t *row_off, uint32_t *counts,
-                               uint32_t width, uint32_t height, const pr_mat4 &proj, hipStream_t s, bool compute_boxes,
+                               uint32_t width, uint32_t height, const pr_mat4 &proj, pr_roi roi, hipStream_t s, bool compute_boxes,
                                PoseMeta *meta, DevIcpState *st, uint32_t *arrive, uint32_t cloud_stride)
 {
     if (n_poses == 0) return hipSuccess;
     if (compute_boxes)
-        hipLaunchKernelGGL(pose_bbox_kernel, dim3((n_poses + 255) / 256), dim3(256), 0, s, aabb, poses_dev, n_poses, proj, width, height, bbox);
+        hipLaunchKernelGGL(pose_bbox_kernel, dim3((n_poses + 255) / 256), dim3(256), 0, s, aabb, poses_dev, n_poses, proj, width, height, roi, bbox);
     const pr_roi none{ 0, 0, 0, 0 };
     for (uint32_t p0 = 0; p0 < n_poses; p0 += 32768) {
         const uint32_t np = (n_poses - p0 < 32768) ? (n_poses - p0) : 32768;
@@ -2403,12 +2468,16 @@ hipError_t launch_raw2depth_mask(const int32_t *raw, size_t n, uint16_t *depth16
     return hipGetLastError();
 }
 
+// *exact (device word) is set non-zero and cleared by the kernel when the pcd buffer is not what dep2pcd would have produced
 hipError_t launch_pack_proj_scene(const pr_vec3 *pcd, const pr_vec3 *normal, float4 *rec, size_t n, float *colf, float *rowf,
-                                  uint32_t width, uint32_t height, float fx, float fy, float cx, float cy, hipStream_t s)
+                                  uint32_t width, uint32_t height, float fx, float fy, float cx, float cy, uint32_t tl_x, uint32_t tl_y,
+                                  uint32_t *exact, hipStream_t s)
 {
     if (n == 0) return hipSuccess;
+    hipError_t e = hipMemsetAsync(exact, 1, sizeof(uint32_t), s);          // non-zero = exact so far
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(pack_proj_scene_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, pcd, normal, rec, n, colf, rowf,
-                       width, height, fx, fy, cx, cy);
+                       width, height, fx, fy, cx, cy, tl_x, tl_y, exact);
     return hipGetLastError();
 }
 hipError_t launch_build_nn_accel(const pr_kdnode *nodes, uint32_t n_nodes, const pr_vec3 *pcd, uint32_t n_points,

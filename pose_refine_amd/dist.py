@@ -44,7 +44,16 @@ def gather_results(local, world: int, rank: int, dst: int = 0, max_count: Option
     if world == 1:
         return GatherWork(None, [local]) if async_op else [local]
     n_local = local.numel() // RESULT_FLOATS
-    cap = max_count if max_count is not None else n_local
+    if max_count is None:
+        # shards of a batch differ by at most one record (shard_bounds): every rank must send the same number of elements, so
+        # agree on the largest shard first (one 8-byte all-reduce; pass max_count = ceil(n_items / world) to skip it)
+        cap_t = torch.tensor([n_local], dtype=torch.int64, device=local.device)
+        dist.all_reduce(cap_t, op=dist.ReduceOp.MAX)
+        cap = int(cap_t.item())
+    else:
+        cap = max_count
+        if cap < n_local:
+            raise ValueError(f"max_count {cap} is smaller than this rank's {n_local} records")
     buf = local.reshape(-1)
     if cap != n_local:
         buf = torch.zeros(cap * RESULT_FLOATS, dtype=local.dtype, device=local.device)
