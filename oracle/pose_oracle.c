@@ -432,8 +432,8 @@ size_t po_kd_build(po_vec3 *pcd, po_vec3 *nrm, size_t n, int max_leaf, po_kdnode
 int po_query_proj(const po_scene_proj *s, po_vec3 src, po_vec3 *dst, po_vec3 *nrm)
 {
     const float *K = s->K;
-    int x = f2i_x86(src.x / src.z * K[0] + K[2] - 0.0f + 0.5f);
-    int y = f2i_x86(src.y / src.z * K[4] + K[5] - 0.0f + 0.5f);
+    int x = f2i_x86(src.x / src.z * K[0] + K[2] - (float)s->tl_x + 0.5f);   /* size_t tl_x enters the float expression as float */
+    int y = f2i_x86(src.y / src.z * K[4] + K[5] - (float)s->tl_y + 0.5f);
     if (x < 0 || y < 0 || (size_t)x >= s->width || (size_t)y >= s->height) return 0;
     size_t i = (size_t)x + (size_t)y * s->width;
     po_vec3 d = s->pcd[i];
@@ -717,20 +717,23 @@ int po_icp(po_vec3 *cloud, size_t n, int kind, const void *scene, po_criteria cr
  * (the per-pose loop of BASELINE.md section 3), OpenMP across hypotheses. */
 int po_refine_batch(const po_tri *tris, size_t n_tris, const float *poses16, size_t n_poses,
                     size_t width, size_t height, const float proj[16], const float K[9],
-                    int kind, const void *scene, po_criteria crit, int sum_mode, uint32_t ppb,
+                    int kind, const void *scene, po_criteria crit, int sum_mode, uint32_t ppb, po_roi roi,
                     po_result *results, uint32_t *cloud_sizes)
 {
     int threads = 1;
 #ifdef _OPENMP
     threads = omp_get_max_threads();
 #endif
-    po_roi none = { 0, 0, 0, 0 };
+    /* with an ROI (renderer.h:199): the hypothesis is rendered into a roi.width x roi.height image and the cloud is
+       extracted with tl = (roi.x, roi.y) (icp.h:57-60), which restores full-frame coordinates */
+    const int has_roi = roi.width > 0 && roi.height > 0;
+    const size_t rw = has_roi ? (size_t)roi.width : width, rh = has_roi ? (size_t)roi.height : height;
 #pragma omp parallel for schedule(dynamic, 1)
     for (long ip = 0; ip < (long)n_poses; ip++) {
         int32_t *depth = (int32_t *)malloc(width * height * sizeof(int32_t));
         po_vec3 *cloud = (po_vec3 *)malloc(width * height * sizeof(po_vec3));
-        po_render(tris, n_tris, poses16 + 16 * (size_t)ip, 1, width, height, proj, none, depth);
-        size_t n = po_depth2cloud_i32(depth, (uint32_t)width, (uint32_t)height, K, 1, 0, 0, cloud);
+        po_render(tris, n_tris, poses16 + 16 * (size_t)ip, 1, width, height, proj, roi, depth);
+        size_t n = po_depth2cloud_i32(depth, (uint32_t)rw, (uint32_t)rh, K, 1, has_roi ? (uint32_t)roi.x : 0u, has_roi ? (uint32_t)roi.y : 0u, cloud);
         po_icp(cloud, n, kind, scene, crit, sum_mode, ppb, &results[ip], NULL);
         if (cloud_sizes) cloud_sizes[ip] = (uint32_t)n;
         free(cloud); free(depth);

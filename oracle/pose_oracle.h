@@ -58,6 +58,8 @@ typedef struct {
     float K[9];
     const po_vec3 *pcd;
     const po_vec3 *normal;
+    size_t tl_x, tl_y;           /* pcd2dep's offsets (common.h:63-73): 0 for a full-frame scene; the arrays of a cropped scene
+                                    start at frame pixel (tl_x, tl_y) -- the reference declares the parameters, never passes them */
 } po_scene_proj;
 
 typedef struct {
@@ -118,7 +120,7 @@ void po_sum29(const po_vec3 *cloud, size_t n, int scene_kind, const void *scene,
 int po_refine_batch(const po_tri *tris, size_t n_tris, const float *poses16, size_t n_poses,
                     size_t width, size_t height, const float proj[16], const float K[9],
                     int scene_kind, const void *scene, po_criteria crit,
-                    int sum_mode, uint32_t points_per_block, po_result *results, uint32_t *cloud_sizes);
+                    int sum_mode, uint32_t points_per_block, po_roi roi /* width<=0: none */, po_result *results, uint32_t *cloud_sizes);
 
 #ifdef __cplusplus
 }

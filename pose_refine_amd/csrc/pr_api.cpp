@@ -1607,8 +1607,7 @@ int pr_gather_results(const pr_result *send_dev, uint32_t n_local, uint32_t n_to
     pr_shard_range(n_total, (uint32_t)rank, (uint32_t)world, &first, &count);
     if (count != n_local) { set_error("pr_gather_results: rank %d holds %u results, its shard of %u over %d ranks has %u", rank, n_local, n_total, world, count); return PR_ERR_INVALID; }
     if ((n_local && !send_dev) || (rank == root && n_total && !recv_dev)) { set_error("pr_gather_results: null buffer"); return PR_ERR_INVALID; }
-    if (world == 1 || !g->comm) {
-        if (world != 1) { set_error("pr_gather_results: no communicator (pr_comm_init_rank / pr_comm_init_all)"); return PR_ERR_COMM; }
+    if (!g->comm) {                                               // no communicator: a single-rank job gathers by copying
         if (n_local && recv_dev != send_dev) HIP_TRY(hipMemcpyAsync(recv_dev, send_dev, sizeof(pr_result) * n_local, hipMemcpyDeviceToDevice, g->stream));
         if (n_local) g_writes.note(recv_dev, sizeof(pr_result) * n_local);
         return PR_OK;

@@ -44,7 +44,7 @@ class Criteria(C.Structure):
 
 class SceneProj(C.Structure):
     _fields_ = [("width", C.c_size_t), ("height", C.c_size_t), ("max_dist_diff", C.c_float),
-                ("K", C.c_float * 9), ("pcd", C.c_void_p), ("normal", C.c_void_p)]
+                ("K", C.c_float * 9), ("pcd", C.c_void_p), ("normal", C.c_void_p), ("tl_x", C.c_size_t), ("tl_y", C.c_size_t)]
 
 
 class SceneNN(C.Structure):
@@ -86,7 +86,7 @@ def lib():
         L.po_sum29.argtypes = [f32p, C.c_size_t, C.c_int, C.c_void_p, C.c_int, C.c_uint32, f32p]
         L.po_refine_batch.restype = C.c_int
         L.po_refine_batch.argtypes = [f32p, C.c_size_t, f32p, C.c_size_t, C.c_size_t, C.c_size_t, f32p, f32p,
-                                      C.c_int, C.c_void_p, Criteria, C.c_int, C.c_uint32, C.c_void_p, u32p]
+                                      C.c_int, C.c_void_p, Criteria, C.c_int, C.c_uint32, Roi, C.c_void_p, u32p]
         L.po_ply_count.restype = C.c_size_t
         L.po_ply_count.argtypes = [C.c_char_p, C.c_void_p]
         L.po_ply_load.restype = C.c_int
@@ -155,8 +155,18 @@ class ProjScene:
         d = np.ascontiguousarray(depth, np.int32 if is32 else np.uint16)
         lib().po_scene_proj_init(d.ctypes.data, int(is32), self.K, w, h, self.pcd.reshape(-1), self.normal.reshape(-1))
         self.max_dist_diff = max_dist_diff
-        self.desc = SceneProj(w, h, max_dist_diff, (C.c_float * 9)(*self.K), self.pcd.ctypes.data, self.normal.ctypes.data)
+        self.desc = SceneProj(w, h, max_dist_diff, (C.c_float * 9)(*self.K), self.pcd.ctypes.data, self.normal.ctypes.data, 0, 0)
         self.kind = SCENE_PROJ
+
+    def crop(self, window):
+        """The scene restricted to window = (x, y, width, height): arrays of the window, pcd2dep offsets tl = (x, y)."""
+        x, y, w, h = (int(v) for v in window)
+        out = object.__new__(ProjScene)
+        out.width, out.height, out.K, out.max_dist_diff, out.kind = w, h, self.K, self.max_dist_diff, SCENE_PROJ
+        out.pcd = np.ascontiguousarray(self.pcd.reshape(self.height, self.width, 3)[y:y + h, x:x + w]).reshape(-1, 3)
+        out.normal = np.ascontiguousarray(self.normal.reshape(self.height, self.width, 3)[y:y + h, x:x + w]).reshape(-1, 3)
+        out.desc = SceneProj(w, h, self.max_dist_diff, (C.c_float * 9)(*self.K), out.pcd.ctypes.data, out.normal.ctypes.data, x, y)
+        return out
 
     def ptr(self):
         return C.addressof(self.desc)
@@ -217,12 +227,12 @@ def solve666(A, b):
 
 
 def refine_batch(tris, poses, width, height, proj, K, scene, criteria=(0.0, 0.0, 20),
-                 sum_mode=SUM_SEQUENTIAL, ppb=2048):
+                 sum_mode=SUM_SEQUENTIAL, ppb=2048, roi=(0, 0, 0, 0)):
     tris = _f32(tris).reshape(-1, 9)
     poses = _f32(poses).reshape(-1, 16)
     res = np.zeros(len(poses), RESULT)
     sizes = np.zeros(len(poses), np.uint32)
     threads = lib().po_refine_batch(tris.reshape(-1), len(tris), poses.reshape(-1), len(poses), width, height,
                                     _f32(proj).reshape(-1), _f32(K).reshape(-1), scene.kind, scene.ptr(),
-                                    Criteria(*criteria), sum_mode, ppb, res.ctypes.data, sizes)
+                                    Criteria(*criteria), sum_mode, ppb, Roi(*roi), res.ctypes.data, sizes)
     return res, sizes, threads
