@@ -13,7 +13,9 @@ round trips (PR_SOLVE_HOST) or the device solve, and the result gather.
 
 Multi-GPU (weak scaling): rank r refines hypotheses [r*P, (r+1)*P) of the seeded stream -- no
 data-path collective -- then ONE RCCL gather of the P x 72-byte RegistrationResult records to
-rank 0 over xGMI (torch.distributed backend "nccl" == RCCL).
+rank 0 over xGMI: pr_gather_results of the C ABI (grouped ncclSend/ncclRecv on the library's
+stream; the communicator's 128-byte id travels over torch.distributed, which also provides the
+barrier and the max-over-ranks clock).  PR_BENCH_GATHER=torch uses torch.distributed.gather instead.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) including `roofline` for the
 dominant kernel (the correspondence kernel, HIP-event timed on the library's own stream) and
@@ -39,9 +41,13 @@ HBM_PEAK = 8.0e12                       # MI355X_MICROARCH.md: 8 TB/s spec
 # N*(21*36 + 20*12) = 996 N bytes per pose over 21 launches.
 BYTES_PER_POINT_PASS0, BYTES_PER_POINT_PASSK = 36.0, 48.0
 # HBM-side traffic of the correspondence kernel measured with rocprofv3 PMC passes (FETCH_SIZE x2 per the
-# gfx950 correction of MI355X_MICROARCH.md + WRITE_SIZE), profiles/r01/README.md: 24.7 B/point at P=256
-# (24.2 at P=1024).  bench.py cannot collect PMCs itself; it scales the committed measurement.
-PMC_TRAFFIC_BYTES_PER_POINT = {"proj": 25.0, "nn": None}
+# gfx950 correction of MI355X_MICROARCH.md + WRITE_SIZE; both calibrated on max2zero_kernel, which moves a known
+# number of bytes): profiles/r01/README.md (projective: 25.0 B/point at P=256) and profiles/r02/README.md (kd-tree).
+# bench.py cannot collect PMCs itself (they need their own rocprofv3 passes): `traffic` is the committed per-point
+# measurement x the points of a launch, and `frac_hbm_counter` is that traffic over the launch time measured here.
+PMC_TRAFFIC_BYTES_PER_POINT = {"proj": 25.0, "nn": 37.0}
+PMC_TRAFFIC_SOURCE = {"proj": "profiles/r01/pmc_p256_FETCH_SIZE.md + pmc_p256_WRITE_SIZE_TCC.md",
+                      "nn": "profiles/r02/nn_baseline/pmc_nn_FETCH_SIZE.md + pmc_nn_WRITE_SIZE.md"}
 
 
 def main():
@@ -89,6 +95,20 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     api.init(local_rank)
+    # the gather of the solved transforms: C ABI (RCCL directly) unless told otherwise or the communicator cannot be formed
+    gather_mode = "torch" if (share_device or os.environ.get("PR_BENCH_GATHER", "cabi") == "torch") else "cabi"
+    if world > 1 and gather_mode == "cabi":
+        try:
+            ident = [api.comm_id() if rank == 0 else None]
+            dist.broadcast_object_list(ident, src=0)               # 128 bytes, once
+            api.comm_init_rank(ident[0], rank, world)
+        except Exception as e:                                     # noqa: BLE001 -- a failed bootstrap must not cost the measurement
+            print(f"[bench] rank {rank}: C-ABI communicator unavailable ({e}); falling back to torch.distributed.gather", file=sys.stderr)
+            gather_mode = "torch"
+        flags = [gather_mode == "cabi"] * world
+        dist.all_gather_object(flags, gather_mode == "cabi")
+        if not all(flags):
+            gather_mode = "torch"
     api.set_option("solve", api.SOLVE_DEVICE if args.solve == "device" else api.SOLVE_HOST)
     api.set_option("pose_groups", args.pose_groups)
     api.set_option("fused_solve", args.fused_solve)
@@ -109,6 +129,7 @@ def main():
     # host round trip) and only then is step k-1 waited for and its results handed to the gather -- the GPU always has the
     # next batch queued, and the gather of step k-1 (RCCL's stream) overlaps step k.
     results = [torch.zeros(P * 18, dtype=torch.float32, device="cuda") for _ in range(2)]
+    gathered = [torch.zeros(P * world * 18, dtype=torch.float32, device="cuda") for _ in range(2)] if (world > 1 and rank == 0 and gather_mode == "cabi") else [None, None]
     pending = [None, None]                                       # gather handle per buffer
     inflight = [False, False]                                    # submitted, not yet waited for
     step_no = [0]
@@ -120,8 +141,11 @@ def main():
         _, sizes = api.refine_wait(b)
         inflight[b] = False
         last_sizes[0] = sizes
-        if world > 1:                                           # the single RCCL exchange of the job: P x 72 B per rank to rank 0
-            pending[b] = prd.gather_results(results[b].cpu() if share_device else results[b], world, rank, dst=0, async_op=True)
+        if world > 1 and gather_mode == "cabi":                 # the single RCCL exchange of the job: P x 72 B per rank to rank 0,
+            api.gather_results(results[b].data_ptr(), P, P * world, 0,      # enqueued on the library's stream behind this batch
+                               gathered[b].data_ptr() if rank == 0 else None)
+        elif world > 1:
+            pending[b] = prd.gather_results(results[b].cpu() if share_device else results[b], world, rank, dst=0, max_count=P, async_op=True)
 
     def step():
         b = step_no[0] & 1
@@ -141,13 +165,18 @@ def main():
             if pending[b] is not None:
                 pending[b].wait()
                 pending[b] = None
+        if world > 1 and gather_mode == "cabi":
+            api.sync()                                           # the library stream carries the gathers
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
-    api.set_option("profile", 1 if args.sequential else 2)   # 2: HIP events around every launch of one step in 32
+    # profile 2: HIP events around every launch of one step in `period`; at least four timed steps per run
+    period = min(32, max(1, args.steps // 4))
+    api.set_option("sample_period", period)
+    api.set_option("profile", 1 if args.sequential else 2)
     api.profile_reset()
     fence()
     t0 = time.perf_counter()
@@ -171,6 +200,7 @@ def main():
         bytes_per_launch = prof["icp_bytes"] / launches          # 36 B/point on pass 0, 48 B/point afterwards
         avg_launch_s = prof["icp_kernel_ms"] * 1e-3 / launches
         achieved = bytes_per_launch / avg_launch_s if avg_launch_s > 0 else 0.0
+        traffic = PMC_TRAFFIC_BYTES_PER_POINT[args.scene] * pts_per_launch if PMC_TRAFFIC_BYTES_PER_POINT[args.scene] else None
         out = {
             "metric": "refined poses/sec (640x480, 20 ICP iters)",
             "value": total_poses / elapsed,
@@ -185,7 +215,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"obj_06.ply, {P}-pose batch per GPU, 640x480 synthetic depth, "
-                                   f"{'projective' if args.scene == 'proj' else 'stackless kd-tree NN'} association, "
+                                   f"{'projective' if args.scene == 'proj' else 'kd-tree NN (near-first depth-first search, per-lane LDS stack on compact 32-byte node records)'} association, "
                                    f"{args.iters} ICP iterations (21 passes), solve on {args.solve}"
                                    + (f", {args.pose_groups} pose groups" if args.solve == "device" else ""),
                        "poses_per_gpu": P, "global_batch": P * world, "points_per_pose_mean": float(np.mean(sizes)),
@@ -193,14 +223,21 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "icp_pass_kernel (correspondence + 29-term reduce" + (" + finalize/solve tail)" if args.fused_solve and args.solve == "device" else ")"),
                          "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK,
-                         "traffic": (PMC_TRAFFIC_BYTES_PER_POINT[args.scene] * pts_per_launch
-                                     if PMC_TRAFFIC_BYTES_PER_POINT[args.scene] else None),
-                         "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/r01/README.md",
+                         # two readings of the same launches: SURVEY 8d's ALGORITHMIC bytes (what `frac` is), and the HBM bytes the
+                         # PMC counters saw for this kernel.  At <= 512 hypotheses per sub-batch the clouds are Infinity-Cache
+                         # resident by design and the 16-byte scene records hit L2, so the counter figure is the lower one.
+                         "frac_algorithmic": achieved / HBM_PEAK,
+                         "frac_hbm_counter": (traffic / avg_launch_s / HBM_PEAK) if (traffic and avg_launch_s > 0) else None,
+                         "traffic": traffic,
+                         "traffic_source": ("committed rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE passes, "
+                                            + PMC_TRAFFIC_SOURCE[args.scene] + f": {PMC_TRAFFIC_BYTES_PER_POINT[args.scene]} B/point x points of a launch"),
+                         "residency": "clouds of a sub-batch (<= 512 hypotheses) stay in the 256 MiB Infinity Cache over the 21 passes; scene records are L2-resident",
                          "avg_launch_us": avg_launch_s * 1e6, "launches": int(launches),
                          "algorithmic_bytes_per_launch": bytes_per_launch, "points_per_launch": pts_per_launch,
                          "timing": ("HIP events on the library stream around every launch (--sequential: synchronous single-group steps)" if args.sequential else
-                                    "HIP events on the library stream around every launch of one step in 32; "
+                                    f"HIP events on the library stream around every launch of one step in {period}; "
                                     "a timed step runs synchronously as one pose group (other slot drained) so the launch has the chip to itself")},
+            "gather": ("none (1 rank)" if world == 1 else ("pr_gather_results: grouped ncclSend/ncclRecv on the library stream (C ABI over RCCL)" if gather_mode == "cabi" else "torch.distributed.gather")),
             "phase_ms_per_timed_step": {"render": prof["render_ms"] / max(1, launches // (args.iters + 1)),
                                         "cloud": prof["cloud_ms"] / max(1, launches // (args.iters + 1))},
         }
@@ -218,6 +255,7 @@ def cpu_baseline(args, tris, poses, scene_depth, K, W, H):
     the same workload: per-pose render_cpu -> depth2cloud_cpu -> ICP_Point2Plane_cpu with the same
     fixed 20 iterations, OpenMP across hypotheses on all host cores."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["PR_ORACLE_BUILD"] = "o3"                          # the restatement with the reference's flags (-O3 -fopenmp)
     import oracle_lib as O
     cores = os.cpu_count() or 1
     per_pose_s = 0.06 if args.scene == "proj" else 1.5             # single-thread estimates (BASELINE.md section 2)
@@ -230,7 +268,9 @@ def cpu_baseline(args, tris, poses, scene_depth, K, W, H):
     _, _, threads = O.refine_batch(tris, poses[:n], W, H, proj, K, oscene, (0.0, 0.0, args.iters), O.SUM_SEQUENTIAL)
     dt = time.perf_counter() - t0
     return {"value": n / dt, "unit": "poses/s", "cores": int(threads), "kind": "port",
-            "sample": f"first {n} hypotheses of the same seeded stream, {dt:.1f} s wall, OpenMP over poses"}
+            "sample": f"first {n} hypotheses of the same seeded stream, {dt:.1f} s wall, OpenMP over poses",
+            "build": "oracle/pose_oracle.c at the reference's flags (-O3 -fopenmp); per-row check against the verbatim "
+                     "reference timings: profiles/r02/cpu_fairness.md"}
 
 
 if __name__ == "__main__":

@@ -255,6 +255,11 @@ int pr_gather_results(const pr_result *send_dev, uint32_t n_local, uint32_t n_to
  *   "nn_stack"         [1]     kd-tree query: per-lane LDS stack (1) or the reference's stackless walk (0)
  *   "nn_compact"       [1]     stack query on 32-byte node records with 16-bit outward-rounded boxes (0: exact 64-byte records)
  *   "nn_seed"          [1]     compact records: start every search from the previous pass' / previous point's winner distance
+ *   "nn_split"         [1]     compact records: the search runs in a kernel of its own (a lane walks "nn_run" [16] consecutive cloud
+ *                              points, each query bounded by the previous one's winner) and the pass gathers its winners
+ *   "nn_count"         [0]     instrumented runs: the search kernel counts its work (pr_nn_counters)
+ *   "nn_grid"          [1]     fused refinement with a kd-tree scene made from a depth image: scene points are also indexed by pixel
+ *                              (first bounds, and an exact window scan once the bound is a few pixels wide)
  *   "nn_lds_nodes"     [1024]  stackless query: leading nodes staged in LDS;  "nn_lds_records" [0]: the same for 64-byte records
  *   "profile"          [0]     see below;  "sample_period" [32]: profile 2 times one call in this many
  *   "scene_cache"      [1]     keep derived scene data between calls (see "Caches" at the top) */
@@ -264,6 +269,10 @@ int  pr_get_option(const char *name, int *value);
  * synchronously as one pose group), 2 does so for one call in `sample_period` (the other calls are unaffected).
  * Accumulated since the last reset: launches timed, model points they processed, and their algorithmic bytes (36 B/point on
  * the first pass of a cloud and on the score-only last pass, 48 B/point in between). */
+/* Work counters of the kd-tree search kernel, collected while option "nn_count" is 1 (instrumented runs; SURVEY 8d "count its own
+ * visits"): out[pass * 8 + k] for ICP passes 0..passes-1 (<= 64), k = 0 queries, 1 settled by the pixel window, 2 handed to the tree,
+ * 3 pyramid descents, 4 tree nodes visited, 5 leaves scanned, 6 leaf points tested, 7 spare.  Reading resets the counters. */
+int  pr_nn_counters(uint64_t *out, uint32_t passes);
 int  pr_profile_reset(void);
 int  pr_profile_read(double *kernel_ms, uint64_t *launches, uint64_t *points, uint64_t *algorithmic_bytes,
                      double *render_ms, double *cloud_ms);

@@ -107,6 +107,7 @@ SIGNATURES = {
     "pr_shard_range": (None, [_u32, _u32, _u32, C.POINTER(_u32), C.POINTER(_u32)]),
     "pr_set_option": (_i32, [C.c_char_p, _i32]),
     "pr_get_option": (_i32, [C.c_char_p, C.POINTER(_i32)]),
+    "pr_nn_counters": (_i32, [_vp, _u32]),
     "pr_profile_reset": (_i32, []),
     "pr_profile_read": (_i32, [C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
                                 C.POINTER(C.c_double), C.POINTER(C.c_double)]),

@@ -117,6 +117,14 @@ def profile_read():
                 render_ms=rms.value, cloud_ms=cms.value)
 
 
+def nn_counters(passes: int = 21) -> np.ndarray:
+    """Per-pass work counters of the kd-tree search kernel (option ``nn_count``): (passes, 8) uint64 --
+    queries, settled by window, tree searches, pyramid descents, tree nodes, leaves, leaf points, spare."""
+    out = np.zeros((passes, 8), np.uint64)
+    check(_lib.load().pr_nn_counters(ptr(out), passes))
+    return out
+
+
 def shard_range(n_items: int, rank: int, world: int):
     first, count = C.c_uint32(), C.c_uint32()
     _lib.load().pr_shard_range(n_items, rank, world, C.byref(first), C.byref(count))
@@ -408,6 +416,10 @@ def ICP_Point2Plane(model_pcd: DeviceVector, scene, criteria: ICPConvergenceCrit
     """``cuda_icp::ICP_Point2Plane_cuda<Scene>`` (icp.cu:156-223).  Mutates ``model_pcd`` in place."""
     res = np.zeros(1, RESULT)
     d = scene.desc()
+    if scene.kind == SCENE_PROJ_CROP:                            # no single-cloud entry point of its own: a batch of one
+        off = np.array([0, model_pcd.size() // 3], np.uint32)
+        check(_lib.load().pr_icp_batch(model_pcd.data(), ptr(off), 1, scene.kind, C.addressof(d), criteria.c(), ptr(res)))
+        return RegistrationResult.from_record(res[0])
     fn = _lib.load().pr_icp_nn if scene.kind == SCENE_NN else _lib.load().pr_icp_proj
     check(fn(model_pcd.data(), model_pcd.size() // 3, C.addressof(d), criteria.c(), ptr(res)))
     return RegistrationResult.from_record(res[0])

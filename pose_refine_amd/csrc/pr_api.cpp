@@ -128,6 +128,10 @@ struct Options {
     int nn_seed = 1;                 // compact kd records: start every search from the previous pass' winner distance
     int nn_compact = 1;              // stack traversal: 32-byte node records with 16-bit outward-rounded child boxes (half the L1 traffic)
     int nn_stack = 1;                // kd-tree query: per-lane LDS stack (1) or the reference's stackless walk (0)
+    int nn_split = 1;                // kd-tree scenes on compact records: search kernel (runs of consecutive points, grid window) + winners pass
+    int nn_run = 1;                  // consecutive cloud points a lane of the search kernel walks
+    int nn_grid = 1;                 // fused path: pixel grid of the scene points (seeds + window search); 0 = tree only
+    int nn_count = 0;                // instrumented runs: the search kernel counts its work per pass (pr_nn_counters)
     int overlap_pass = -1;           // asynchronous path: the other slot's render may start once this slot has issued this pass of its loop
                                      // (-1: 70 % of the passes -- measured best of 6/10/14/17 at 256 and 512 poses per batch)
     int sub_batch = 512;             // asynchronous fused path: hypotheses per sub-batch (cache residency of the clouds)
@@ -208,7 +212,9 @@ struct Ctx {
     PinBuf h_sums, h_meta, h_counts, h_results, h_dstate, h_flow;
     PackedCache packed;              // synchronous paths (the asynchronous slots keep their own)
     struct { const void *pcd = nullptr, *normal = nullptr, *nodes = nullptr; uint32_t n_points = 0, n_nodes = 0; uint64_t gen = 0; bool valid = false;
-             uint32_t info[8] = { 0 }; } nn_cache;               // kd traversal records (topo ... nndesc) of the latest kd-tree scene
+             uint32_t info[8] = { 0 };
+             bool grid_valid = false, grid_usable = false; uint32_t gw = 0, gh = 0; float gk[4] = { 0, 0, 0, 0 }; } nn_cache;   // kd traversal records (topo ... nndesc) + pixel grid of the latest kd-tree scene
+    DevBuf nn_cells, nn_grid, nn_counters;
     // profiling
     std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
     struct Span { size_t e0, e1; int kind; };
@@ -317,7 +323,12 @@ struct SceneSel {
     prk::SceneProjAoS aos{};
     prk::SceneProjPacked pk{};
     prk::SceneNNDev nn{};
+    uint32_t nn_split = 0;           // kd-tree scene: search kernel + winners pass instead of the fused search pass
+    uint32_t nn_max_points = 0;      // largest cloud of the batch (grid of the search kernel)
 };
+constexpr uint32_t kCounterPasses = 64;
+// camera of the hypotheses (fused paths): lets a kd-tree scene be indexed by pixel as well
+struct Camera { uint32_t w = 0, h = 0; float fx = 0, fy = 0, cx = 0, cy = 0; };
 
 // Packed copy of a projective scene in `pc`: reused while the caller's arrays are unchanged as far as the library can tell
 // (option scene_cache, WriteLog above), rebuilt otherwise.  A rebuild also learns (one 4-byte read-back) whether the pcd array
@@ -350,7 +361,7 @@ int ensure_packed(PackedCache &pc, const pr_scene_proj &s, uint32_t tl_x, uint32
     return PR_OK;
 }
 
-int make_scene(int kind, const void *scene, bool want_packed, SceneSel &out, PackedCache *pc_in = nullptr, hipStream_t st = nullptr)
+int make_scene(int kind, const void *scene, bool want_packed, SceneSel &out, PackedCache *pc_in = nullptr, hipStream_t st = nullptr, const Camera *cam = nullptr)
 {
     PackedCache &pc = pc_in ? *pc_in : g->packed;
     if (!st) st = g->stream;
@@ -386,7 +397,7 @@ int make_scene(int kind, const void *scene, bool want_packed, SceneSel &out, Pac
             !g_writes.written_since(nc.gen, s->nodes, (size_t)s->n_nodes * sizeof(pr_kdnode))) {
             nc.gen = g_writes.now();                                // (the normals are read through the caller's pointer, never copied)
         } else {
-            nc.valid = false;
+            nc.valid = false; nc.grid_valid = false;
             const uint64_t gen = g_writes.now();
             PR_TRY(g->topo.ensure((size_t)s->n_nodes * sizeof(int4)));
             PR_TRY(g->bmin.ensure((size_t)s->n_nodes * sizeof(float4)));
@@ -419,6 +430,28 @@ int make_scene(int kind, const void *scene, bool want_packed, SceneSel &out, Pac
             out.nn.rec32 = g->nnrec32.as<uint4>();
             for (int a = 0; a < 3; ++a) { std::memcpy(&out.nn.qmin[a], &info[2 + a], 4); std::memcpy(&out.nn.qscale[a], &info[5 + a], 4); }
         }
+        // pixel grid of the scene points under the hypotheses' camera (fused paths only: a bare ICP call has no camera).  Usable
+        // when every scene point owns a cell -- a Scene_nn made from a depth image with these intrinsics -- else the tree alone.
+        if (cam && opt.nn_grid && out.nn.rec32 && (size_t)cam->w * cam->h <= ((size_t)1 << 24)) {
+            const float gk[4] = { cam->fx, cam->fy, cam->cx, cam->cy };
+            if (!(nc.grid_valid && nc.gw == cam->w && nc.gh == cam->h && std::memcmp(nc.gk, gk, sizeof gk) == 0)) {
+                const size_t cells = (size_t)cam->w * cam->h;
+                PR_TRY(g->nn_cells.ensure(cells * sizeof(int32_t) + 16));
+                PR_TRY(g->nn_grid.ensure(prk::nn_grid_cells(cam->w, cam->h) * sizeof(float4)));
+                uint32_t *flag = reinterpret_cast<uint32_t *>(g->nn_cells.as<int32_t>() + cells);
+                HIP_TRY(prk::launch_build_nn_grid(s->pcd, s->n_points, cam->w, cam->h, gk[0], gk[1], gk[2], gk[3], g->nn_cells.as<int32_t>(),
+                                                  g->nn_grid.as<float4>(), flag, g->stream));
+                uint32_t usable = 0;
+                HIP_TRY(hipMemcpyAsync(&usable, flag, sizeof usable, hipMemcpyDeviceToHost, g->stream));
+                HIP_TRY(hipStreamSynchronize(g->stream));
+                nc.grid_valid = true; nc.grid_usable = usable != 0; nc.gw = cam->w; nc.gh = cam->h; std::memcpy(nc.gk, gk, sizeof gk);
+            }
+            if (nc.grid_usable) {
+                out.nn.grid = g->nn_grid.as<float4>(); out.nn.gw = cam->w; out.nn.gh = cam->h; out.nn.gfx = gk[0]; out.nn.gfy = gk[1]; out.nn.gcx = gk[2]; out.nn.gcy = gk[3];
+                const size_t w4 = (cam->w + 3) / 4, h4 = (cam->h + 3) / 4, w16 = (w4 + 3) / 4, h16 = (h4 + 3) / 4;
+                out.nn.pyr4 = out.nn.grid + (size_t)cam->w * cam->h; out.nn.pyr16 = out.nn.pyr4 + w4 * h4; out.nn.pyr64 = out.nn.pyr16 + w16 * h16;
+            }
+        }
         return PR_OK;
     }
     set_error("unknown scene kind %d", kind);
@@ -428,7 +461,17 @@ int make_scene(int kind, const void *scene, bool want_packed, SceneSel &out, Pac
 hipError_t launch_pass(const prk::IcpBatch &b, const SceneSel &sc, uint32_t P, hipStream_t st = nullptr)
 {
     if (!st) st = g->stream;
-    if (sc.kind == PR_SCENE_NN) return prk::launch_icp_pass_nn(b, sc.nn, P, st);
+    if (sc.kind == PR_SCENE_NN) {
+        if (sc.nn_split && b.nn_prev) {                            // search (applies the pending update, leaves the winners in nn_prev) ...
+            hipError_t e = prk::launch_nn_search(b, sc.nn, P, sc.nn_max_points, (uint32_t)std::max(1, opt.nn_run), st);
+            if (e != hipSuccess) return e;
+            prk::IcpBatch bb = b;                                   // ... then the canonical-order pass over the winners
+            bb.pre_transformed = 1;
+            const prk::SceneNNWinners w{ sc.nn.max_dist_diff, sc.nn.pts, sc.nn.normal, b.nn_prev };
+            return prk::launch_icp_pass_nn_winners(bb, w, P, st);
+        }
+        return prk::launch_icp_pass_nn(b, sc.nn, P, st);
+    }
     if (sc.packed) return prk::launch_icp_pass_proj_packed(b, sc.pk, P, st);
     return prk::launch_icp_pass_proj_aos(b, sc.aos, P, st);
 }
@@ -446,10 +489,11 @@ int ensure_stream(hipStream_t &st, hipEvent_t *ev = nullptr)
 // ---- the batched ICP driver -----------------------------------------------------------------------
 // clouds: cloud i = cloud_base[start_h[i] .. start_h[i]+count_h[i]).  start/count must already be in
 // g->start / g->counts on the device when dev_meta_ready, otherwise they are uploaded here.
-int icp_drive(pr_vec3 *cloud_base, const uint32_t *start_h, const uint32_t *count_h, uint32_t P, const SceneSel &sc,
+int icp_drive(pr_vec3 *cloud_base, const uint32_t *start_h, const uint32_t *count_h, uint32_t P, const SceneSel &sc_in,
               pr_criteria crit, pr_result *results_host, pr_result *results_dev)
 {
     if (P == 0) return PR_OK;
+    SceneSel sc = sc_in;
     if (crit.max_iteration < 0) { set_error("max_iteration must be >= 0"); return PR_ERR_INVALID; }
     const uint32_t steps = (uint32_t)std::max(1, opt.steps);
     const uint32_t ppb = steps * prk::kPointsPerStep;
@@ -467,7 +511,15 @@ int icp_drive(pr_vec3 *cloud_base, const uint32_t *start_h, const uint32_t *coun
     prk::IcpBatch b{};
     b.cloud = cloud_base; b.meta = g->meta.as<prk::PoseMeta>(); b.partial = g->partial.as<float>();
     b.nblk = nblk; b.steps = steps;
-    if (sc.kind == PR_SCENE_NN && sc.nn.rec32 && opt.nn_seed) {     // previous winners, indexed like the cloud points
+    sc.nn_split = (sc.kind == PR_SCENE_NN && sc.nn.rec32 && opt.nn_split && !opt.icp_flow) ? 1u : 0u;
+    sc.nn_max_points = max_n;
+    if (sc.nn_split && opt.nn_count) {                            // instrumented run: kCounterPasses x 8 counters, accumulated until read
+        const bool fresh = g->nn_counters.p == nullptr;
+        PR_TRY(g->nn_counters.ensure(sizeof(unsigned long long) * 8 * kCounterPasses));
+        if (fresh) HIP_TRY(hipMemsetAsync(g->nn_counters.p, 0, sizeof(unsigned long long) * 8 * kCounterPasses, g->stream));
+        if ((uint32_t)crit.max_iteration + 1 <= kCounterPasses) sc.nn.counters = g->nn_counters.as<unsigned long long>();
+    }
+    if (sc.kind == PR_SCENE_NN && sc.nn.rec32 && (opt.nn_seed || sc.nn_split)) {     // winners, indexed like the cloud points
         size_t span = 1;
         for (uint32_t i = 0; i < P; ++i) span = std::max(span, (size_t)start_h[i] + count_h[i]);
         PR_TRY(g->nn_prev.ensure(sizeof(uint32_t) * span));
@@ -571,7 +623,8 @@ int icp_drive(pr_vec3 *cloud_base, const uint32_t *start_h, const uint32_t *coun
                     hipStream_t st = grp ? g->side[grp - 1] : g->stream;
                     prk::IcpBatch bb = b;
                     bb.meta += p0; bb.partial += (size_t)p0 * nblk * prk::kAccStride;
-                    if (fused) { bb.fused = 1; bb.iter = it; bb.crit = crit; bb.st = g->dstate.as<prk::DevIcpState>() + p0; bb.arrive = g->arrive.as<uint32_t>() + p0; }
+                    bb.iter = it;
+                    if (fused) { bb.fused = 1; bb.crit = crit; bb.st = g->dstate.as<prk::DevIcpState>() + p0; bb.arrive = g->arrive.as<uint32_t>() + p0; }
                     bb.score_only = (it == (uint32_t)crit.max_iteration) ? 1u : 0u;
                     if (grp == 0 && (opt.profile == 1 || sample_call)) {           // a timed call times every launch of its loop
                         SpanGuard sp(kSpanIcp); HIP_TRY(launch_pass(bb, sc, np, st));
@@ -644,6 +697,7 @@ int icp_drive(pr_vec3 *cloud_base, const uint32_t *start_h, const uint32_t *coun
     for (uint32_t i = 0; i < P; ++i) active += (h_meta[i].state != prk::kSkip);
     for (uint32_t it = 0; it <= (uint32_t)crit.max_iteration && active > 0; ++it) {
         HIP_TRY(hipMemcpyAsync(g->meta.p, h_meta, sizeof(prk::PoseMeta) * P, hipMemcpyHostToDevice, g->stream));
+        b.iter = it;
         if (opt.profile == 1 || (opt.profile == 2 && it == host_sample_it)) {
             SpanGuard sp(kSpanIcp); HIP_TRY(launch_pass(b, sc, P));
             for (uint32_t i = 0; i < P; ++i) if (h_meta[i].state != prk::kSkip) { g->icp_points += count_h[i]; g->icp_bytes += (uint64_t)count_h[i] * (it == 0 ? 36u : 48u); }
@@ -761,7 +815,8 @@ int refine_impl(const pr_triangle *tris_dev, size_t n_tris, const pr_mat4 *poses
     if (P == 0) return PR_OK;
     SceneSel sc;
     std::memset(static_cast<void *>(&sc), 0, sizeof sc);           // also zeroes padding: sc is part of the graph-cache key
-    PR_TRY(make_scene(scene_kind, scene, /*want_packed=*/true, sc));
+    const Camera cam{ W, H, K[0], K[4], K[2], K[5] };
+    PR_TRY(make_scene(scene_kind, scene, /*want_packed=*/true, sc, nullptr, nullptr, &cam));
     // bound the depth workspace to ~4 GiB per chunk (288 GB of HBM would allow far more; this keeps
     // first-touch cost and the 2^32 element index space comfortable)
     const size_t img = (size_t)W * H;
@@ -1090,7 +1145,8 @@ int refine_submit_async(Slot &sl, const pr_triangle *tris_dev, size_t n_tris, ui
                 hipStream_t gs = grp ? sl.side[grp - 1] : st;
                 prk::IcpBatch bb = b;
                 bb.meta = meta + p0; bb.partial = sl.partial.as<float>() + (size_t)p0 * nblk * prk::kAccStride;
-                if (fused) { bb.fused = 1; bb.iter = it; bb.crit = crit; bb.st = dstate + p0; bb.arrive = arrive + p0; }
+                bb.iter = it;
+                if (fused) { bb.fused = 1; bb.crit = crit; bb.st = dstate + p0; bb.arrive = arrive + p0; }
                 bb.score_only = (it == (uint32_t)crit.max_iteration) ? 1u : 0u;
                 HIP_TRY(launch_pass(bb, sc, np, gs));
                 if (!fused) HIP_TRY(prk::launch_icp_finalize_solve(bb.partial, meta + p0, nblk, steps, dstate + p0, crit, it, np, gs));
@@ -1215,7 +1271,7 @@ void ctx_teardown(Ctx *c)        // c->mu held (or c unreachable); the calling t
     hipStreamSynchronize(c->stream);
     for (Slot &sl : c->slots) slot_release(sl);
     for (DevBuf *b : { &c->aabb, &c->aabb_keys, &c->bbox, &c->poses, &c->depth, &c->row_count, &c->row_off, &c->counts, &c->cloud, &c->meta, &c->partial,
-                       &c->sums, &c->packed.rec, &c->topo, &c->bmin, &c->bmax, &c->pts, &c->nnrec, &c->nnrec32, &c->nndesc, &c->nn_prev, &c->nndepth, &c->dstate, &c->dresults, &c->vbdesc, &c->flowsync, &c->arrive, &c->conv16, &c->conv8, &c->kd_idx, &c->kd_scratch, &c->kd_child, &c->kd_ctrl, &c->kd_tmp, &c->nn_full, &c->gather_tmp }) b->release();
+                       &c->sums, &c->packed.rec, &c->topo, &c->bmin, &c->bmax, &c->pts, &c->nnrec, &c->nnrec32, &c->nndesc, &c->nn_prev, &c->nndepth, &c->dstate, &c->dresults, &c->vbdesc, &c->flowsync, &c->arrive, &c->conv16, &c->conv8, &c->kd_idx, &c->kd_scratch, &c->kd_child, &c->kd_ctrl, &c->kd_tmp, &c->nn_full, &c->gather_tmp, &c->nn_cells, &c->nn_grid, &c->nn_counters }) b->release();
     for (PinBuf *b : { &c->h_sums, &c->h_meta, &c->h_counts, &c->h_results, &c->h_dstate, &c->h_flow }) b->release();
     c->packed = PackedCache(); c->nn_cache.valid = false;
     for (auto &gr : c->graphs) destroy_graph(gr);
@@ -1641,6 +1697,10 @@ int pr_set_option(const char *name, int value)
     else if (n == "nn_compact") opt.nn_compact = value ? 1 : 0;
     else if (n == "nn_seed") opt.nn_seed = value ? 1 : 0;
     else if (n == "nn_stack") opt.nn_stack = value ? 1 : 0;
+    else if (n == "nn_split") opt.nn_split = value ? 1 : 0;
+    else if (n == "nn_run") opt.nn_run = std::min(256, std::max(1, value));
+    else if (n == "nn_grid") opt.nn_grid = value ? 1 : 0;
+    else if (n == "nn_count") opt.nn_count = value ? 1 : 0;
     else if (n == "graph") opt.use_graph = value ? 1 : 0;
     else if (n == "icp_flow") opt.icp_flow = value ? 1 : 0;
     else if (n == "fused_solve") opt.fused_solve = value ? 1 : 0;
@@ -1666,6 +1726,10 @@ int pr_get_option(const char *name, int *value)
     else if (n == "nn_compact") *value = opt.nn_compact;
     else if (n == "nn_seed") *value = opt.nn_seed;
     else if (n == "nn_stack") *value = opt.nn_stack;
+    else if (n == "nn_split") *value = opt.nn_split;
+    else if (n == "nn_run") *value = opt.nn_run;
+    else if (n == "nn_grid") *value = opt.nn_grid;
+    else if (n == "nn_count") *value = opt.nn_count;
     else if (n == "raster_mode") *value = opt.raster_mode;
     else if (n == "graph") *value = opt.use_graph;
     else if (n == "icp_flow") *value = opt.icp_flow;
@@ -1674,6 +1738,20 @@ int pr_get_option(const char *name, int *value)
     else if (n == "overlap_pass") *value = opt.overlap_pass;
     else if (n == "pose_groups") *value = opt.pose_groups;
     else { set_error("unknown option %s", name); return PR_ERR_INVALID; }
+    return PR_OK;
+}
+
+// work counters of the kd-tree search kernel (option "nn_count"): out[pass * 8 + k], k = queries, settled by the pixel window,
+// handed to the tree, pyramid descents, tree nodes visited, leaves scanned, leaf points tested, spare; reading resets them
+int pr_nn_counters(uint64_t *out, uint32_t passes)
+{
+    PR_ENTER();
+    if (!out || passes == 0 || passes > kCounterPasses) { set_error("pr_nn_counters: bad arguments"); return PR_ERR_INVALID; }
+    std::memset(out, 0, sizeof(uint64_t) * 8 * passes);
+    if (!g->nn_counters.p) return PR_OK;
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    HIP_TRY(hipMemcpy(out, g->nn_counters.p, sizeof(uint64_t) * 8 * passes, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(g->nn_counters.p, 0, sizeof(unsigned long long) * 8 * kCounterPasses));
     return PR_OK;
 }
 

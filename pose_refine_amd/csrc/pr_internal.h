@@ -47,6 +47,7 @@ struct IcpBatch {
     DevIcpState    *st;         // [P]
     uint32_t       *arrive;     // [P] zero before the first pass; the solving workgroup re-zeroes its entry
     uint32_t       *nn_prev;    // kd-tree scenes: per cloud point (same indexing as `cloud`) the scene index of the previous pass' winner, or null
+    uint32_t        pre_transformed;   // 1: the pending update has already been applied to the cloud (nn_search_kernel): the pass must not apply it again
     pr_criteria     crit;
 };
 
@@ -82,6 +83,25 @@ struct SceneNNDev {
     float qmin[3], qscale[3];   // dequantisation: qmin[a] + (float)q * qscale[a]
     const uint2 *desc;          // first 8 bytes of every compact record on their own (split | child | dim): all a descent needs when the
                                 // split plane alone already rules the far side out
+    // Pixel grid of the scene points (build_nn_grid): cell (px, py) of a gw x gh image holds the scene point that projects into
+    // it under (gfx, gfy, gcx, gcy) as {x, y, z, index}, or {huge, huge, huge, -1}.  Null unless every scene point owns a cell of
+    // its own (always the case for a Scene_nn made from a depth image with the same intrinsics, pcd_scene.cpp:10-29).
+    const float4 *grid;
+    uint32_t gw, gh;
+    float gfx, gfy, gcx, gcy;
+    // three coarser levels of the same grid: one representative scene point per 4 x 4, 16 x 16 and 64 x 64 pixel block
+    // (the occupied sub-block nearest the block's centre, recursively), same {x, y, z, index} cells
+    const float4 *pyr4, *pyr16, *pyr64;
+    // instrumented runs (option "nn_count"): per ICP pass (IcpBatch::iter) eight 64-bit counters -- queries, settled by the pixel
+    // window, handed to the tree, pyramid descents, tree nodes visited, leaves scanned, leaf points tested, (spare); else null
+    unsigned long long *counters;
+};
+// kd-tree scene after the search kernel has run: the correspondence pass only gathers the winners (no search, no transform)
+struct SceneNNWinners {
+    float max_dist_diff;
+    const float4 *pts;          // {x,y,z,0} per scene point
+    const pr_vec3 *normal;
+    const uint32_t *winner;     // per cloud point (same indexing as IcpBatch::cloud): scene index or 0xffffffff
 };
 
 // device-side solver state for PR_SOLVE_DEVICE (one record per hypothesis)
@@ -140,6 +160,14 @@ hipError_t launch_emit_box(const int32_t *depth, uint32_t n_poses, uint32_t widt
 hipError_t launch_icp_pass_proj_aos(const IcpBatch &b, const SceneProjAoS &sc, uint32_t n_poses, hipStream_t s);
 hipError_t launch_icp_pass_proj_packed(const IcpBatch &b, const SceneProjPacked &sc, uint32_t n_poses, hipStream_t s);
 hipError_t launch_icp_pass_nn(const IcpBatch &b, const SceneNNDev &sc, uint32_t n_poses, hipStream_t s);
+// split form of the kd-tree pass: search (pending transform applied, winners written to b.nn_prev) + gather/accumulate pass
+hipError_t launch_nn_search(const IcpBatch &b, const SceneNNDev &sc, uint32_t n_poses, uint32_t max_points, uint32_t run, hipStream_t s);
+hipError_t launch_icp_pass_nn_winners(const IcpBatch &b, const SceneNNWinners &sc, uint32_t n_poses, hipStream_t s);
+// info[0] = 1 when every scene point owns a grid cell (the grid may be used), 0 otherwise
+// grid: gw*gh cells followed by the three pyramid levels (nn_grid_cells(gw, gh) cells in all)
+size_t nn_grid_cells(uint32_t gw, uint32_t gh);
+hipError_t launch_build_nn_grid(const pr_vec3 *pcd, uint32_t n_points, uint32_t gw, uint32_t gh, float fx, float fy, float cx, float cy,
+                                int32_t *cell_idx, float4 *grid, uint32_t *info, hipStream_t s);
 hipError_t launch_icp_flow_proj_aos(const FlowArgs &a, const SceneProjAoS &sc, uint32_t n_cus, hipStream_t s, uint32_t *grid_out);
 hipError_t launch_icp_flow_proj_packed(const FlowArgs &a, const SceneProjPacked &sc, uint32_t n_cus, hipStream_t s, uint32_t *grid_out);
 hipError_t launch_icp_flow_nn(const FlowArgs &a, const SceneNNDev &sc, uint32_t n_cus, hipStream_t s, uint32_t *grid_out);

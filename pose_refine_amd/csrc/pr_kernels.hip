@@ -741,9 +741,11 @@ __device__ __forceinline__ bool gather_finish(const SceneProjPacked &s, bool in_
     c.dx = g.b0 * dz; c.dy = g.b1 * dz; c.dz = dz; c.nx = g.a0; c.ny = g.a1; c.nz = g.a2;
     return true;
 }
-// never instantiated for the kd-tree scene (it has its own query loop)
+// never instantiated for the kd-tree scenes (they have their own loops)
 __device__ __forceinline__ bool gather_issue(const SceneNNDev &, float, float, float, bool, Gathered &) { return false; }
 __device__ __forceinline__ bool gather_finish(const SceneNNDev &, bool, float, const Gathered &, Corr &) { return false; }
+__device__ __forceinline__ bool gather_issue(const SceneNNWinners &, float, float, float, bool, Gathered &) { return false; }
+__device__ __forceinline__ bool gather_finish(const SceneNNWinners &, bool, float, const Gathered &, Corr &) { return false; }
 
 // Scene_nn::query pcd_scene.h:60-136 -- same stackless near-first traversal, same strict '<' on
 // leaf points and '<=' on the bound, but the bound is the FAR CHILD's own tight box instead of
@@ -823,47 +825,40 @@ constexpr int kLeafBatch = PR_LEAF_BATCH;
 #define PR_NN_WIDE_BOUND 4.0e-6f                                // (2 mm)^2: above it a node's whole record is fetched at once
 #endif
 constexpr uint32_t kNoPrev = 0xffffffffu;
+#ifndef PR_NN_STILL
+#define PR_NN_STILL 2.5e-7f                                     // (0.5 mm)^2: below this step a point's previous winner is taken as a tight seed
+#endif
 
-// kCode = stack entries per lane (16 / 24), + 0x100 when the scene's compact 32-byte records are used
-template <int kCode>
-__device__ __forceinline__ bool query_nn_stack(const SceneNNDev &s, const float4 *lds_rec, int *stk_node, float *stk_lb, float sx, float sy, float sz, Corr &c,
-                                               uint32_t seed, uint32_t seed2, uint32_t &winner)
+// Bound a search may start from when scene point `seed` is known to exist: its distance, inflated by one part in a million so
+// that the point itself -- or an equal one visited earlier -- is still found by the strict '<' of the search.  The bound only
+// removes subtrees and points that are strictly farther than an existing point; winner, distance and tie-break are those of the
+// unseeded search.
+__device__ __forceinline__ void nn_seed_bound(const SceneNNDev &s, float sx, float sy, float sz, uint32_t seed, float &best)
+{
+    const pr_vec3 p = s.pcd[seed != kNoPrev ? seed : 0u];
+    if (seed != kNoPrev) {
+        const float d2 = (sx - p.x) * (sx - p.x) + (sy - p.y) * (sy - p.y) + (sz - p.z) * (sz - p.z);
+        const float b = d2 * 1.000001f + 1e-30f;
+        if (b < best) best = b;
+    }
+}
+
+// kCode = stack entries per lane (16 / 24), + 0x100 when the scene's compact 32-byte records are used.
+// best_init: the bound the search starts from (<= max_dist_diff^2, see PR_NN_BOUNDED; tightened by nn_seed_bound).
+// work counters of the search (SURVEY 8d "count its own visits"): per lane, summed into SceneNNDev::counters when that is set
+struct NNCount { uint32_t nodes = 0, leaves = 0, leaf_points = 0; };
+template <int kCode, bool kWantCorr = true>
+__device__ __forceinline__ bool query_nn_stack_from(const SceneNNDev &s, const float4 *lds_rec, int *stk_node, float *stk_lb, float sx, float sy, float sz, Corr &c,
+                                                    float best_init, uint32_t &winner, NNCount *cnt = nullptr)
 {
     constexpr int kDepth = kCode & 0xff;
     constexpr bool kCompact = (kCode & 0x100) != 0;
     int cur = 0, sp = 0, best_i = -1;                            // -1: no point below the starting bound yet
-#if PR_NN_BOUNDED
-    // a winner is only accepted below max_dist_diff^2 (pcd_scene.h query tail), so the search can start from that bound:
-    // subtrees and points at or beyond it could only produce a neighbour the final test rejects
-    const float accept = s.max_dist_diff * s.max_dist_diff;
-    float best = accept;
-#else
-    float best = FLT_MAX;
-#endif
-    if constexpr (kCompact) {
-        // Temporal seed: the previous pass' winner for this cloud point is still a scene point, so its distance (inflated by one
-        // part in a million, so that the point itself -- or an equal one visited earlier -- is still found by the search) bounds
-        // the answer from the start.  The bound only removes subtrees and points that are strictly farther than an existing
-        // point; winner, distance and tie-break are those of the unseeded search.
-        // seed  = the previous pass' winner of this cloud point (temporal),
-        // seed2 = the winner of the cloud point this lane handled just before (its neighbour in the image, 1-2 mm away): on
-        //         the first passes, when the cloud is still centimetres off the surface, that neighbour's answer is a far
-        //         tighter bound than anything the descent finds early
-        const pr_vec3 pa = s.pcd[seed != kNoPrev ? seed : 0u], pb = s.pcd[seed2 != kNoPrev ? seed2 : 0u];
-        if (seed != kNoPrev) {
-            const float d2 = (sx - pa.x) * (sx - pa.x) + (sy - pa.y) * (sy - pa.y) + (sz - pa.z) * (sz - pa.z);
-            const float b = d2 * 1.000001f + 1e-30f;
-            if (b < best) best = b;
-        }
-        if (seed2 != kNoPrev) {
-            const float d2 = (sx - pb.x) * (sx - pb.x) + (sy - pb.y) * (sy - pb.y) + (sz - pb.z) * (sz - pb.z);
-            const float b = d2 * 1.000001f + 1e-30f;
-            if (b < best) best = b;
-        }
-    }
+    float best = best_init;
     winner = kNoPrev;
     for (;;) {
         float4 h, b0, b1, b2;
+        if (cnt) cnt->nodes++;
         if constexpr (kCompact) {
             // compact records: half the bytes through the L1 (the kernel is bound by the texture-addresser / L1 rate of its
             // divergent loads, not by latency or HBM); only the far child's box is decoded
@@ -928,6 +923,7 @@ __device__ __forceinline__ bool query_nn_stack(const SceneNNDev &s, const float4
         const int hz = __float_as_int(h.z);
         if (hz < 0) {                                            // leaf: points [left, right)
             const int lo = __float_as_int(h.x), hi = __float_as_int(h.y);
+            if (cnt) { cnt->leaves++; cnt->leaf_points += (uint32_t)(hi - lo); }
             // four point loads are issued before the first compare (one memory round trip per batch); indices past
             // the end are clamped to the last point, whose repeated distance can never pass the strict '<' again,
             // so the in-order compares keep the reference's first-occurrence winner
@@ -971,10 +967,149 @@ __device__ __forceinline__ bool query_nn_stack(const SceneNNDev &s, const float4
     }
     if (!(best < s.max_dist_diff * s.max_dist_diff) || best_i < 0) return false;
     winner = (uint32_t)best_i;
-    const float4 d = s.pts[best_i];                              // {x,y,z,0} copy of pcd[best_i]
-    const float *n = reinterpret_cast<const float *>(s.normal + best_i);
-    c.dx = d.x; c.dy = d.y; c.dz = d.z; c.nx = n[0]; c.ny = n[1]; c.nz = n[2];
+    if constexpr (kWantCorr) {
+        const float4 d = s.pts[best_i];                          // {x,y,z,0} copy of pcd[best_i]
+        const float *n = reinterpret_cast<const float *>(s.normal + best_i);
+        c.dx = d.x; c.dy = d.y; c.dz = d.z; c.nx = n[0]; c.ny = n[1]; c.nz = n[2];
+    }
     return true;
+}
+
+// the search started from the acceptance bound and, for compact records, from up to two known scene points:
+//   seed  = the previous pass' winner of this cloud point (temporal),
+//   seed2 = the winner of the cloud point this lane handled just before (its neighbour in the image, 1-2 mm away): on
+//           the first passes, when the cloud is still centimetres off the surface, that neighbour's answer is a far
+//           tighter bound than anything the descent finds early
+template <int kCode>
+__device__ __forceinline__ bool query_nn_stack(const SceneNNDev &s, const float4 *lds_rec, int *stk_node, float *stk_lb, float sx, float sy, float sz, Corr &c,
+                                               uint32_t seed, uint32_t seed2, uint32_t &winner)
+{
+#if PR_NN_BOUNDED
+    // a winner is only accepted below max_dist_diff^2 (pcd_scene.h query tail), so the search can start from that bound:
+    // subtrees and points at or beyond it could only produce a neighbour the final test rejects
+    float best = s.max_dist_diff * s.max_dist_diff;
+#else
+    float best = FLT_MAX;
+#endif
+    if constexpr ((kCode & 0x100) != 0) { nn_seed_bound(s, sx, sy, sz, seed, best); nn_seed_bound(s, sx, sy, sz, seed2, best); }
+    return query_nn_stack_from<kCode>(s, lds_rec, stk_node, stk_lb, sx, sy, sz, c, best, winner);
+}
+
+// ---- pixel grid of a kd-tree scene ---------------------------------------------------------------------------------------
+// A Scene_nn is made from a depth image (pcd_scene.cpp:10-29), so its points are the pixels of that image: cell (px, py) of the
+// grid holds the point that projects into it.  With a valid upper bound B on the squared nearest-neighbour distance (from a
+// seed: an existing scene point), every scene point closer than sqrt(B) projects into a small pixel window around the query's
+// own pixel, and scanning that window IS the exact search -- except for the tie-break between equidistant points, which the
+// reference resolves by traversal order: a tie (or an empty window, or a window too large to pay) hands the query to the
+// kd-tree search.  A unique strict minimum is the reference's winner under any visiting order.
+//   window: u = x/z*fx + cx.  For |p - q| <= r and z_q - r > 0:  |u_p - u_q| <= fx * r * (z_q + |x_q|) / (z_q * (z_q - r)),
+//   and |floor(a) - floor(b)| <= ceil(|a - b|); r carries a 1e-4 relative margin and the window another 1e-3 px for rounding.
+__device__ __forceinline__ void grid_project(const SceneNNDev &s, float x, float y, float z, float &u, float &v)
+{
+    u = x / z * s.gfx + s.gcx + 0.5f;
+    v = y / z * s.gfy + s.gcy + 0.5f;
+}
+constexpr int kGridMaxW = 2;                                     // windows up to 5 x 5 cells; larger ones go to the tree
+// half-widths of the pixel window that holds every scene point closer than sqrt(bound); false when it exceeds kGridMaxW
+__device__ __forceinline__ bool grid_window(const SceneNNDev &s, float sx, float sy, float sz, float bound, int &wx, int &wy)
+{
+    const float r = sqrtf(bound) * 1.0001f;
+    if (!(sz - r > 0.25f * sz)) return false;                    // also NaN and points at or behind the camera
+    const float k = r / (sz * (sz - r));
+    const float du = s.gfx * k * (sz + fabsf(sx)), dv = s.gfy * k * (sz + fabsf(sy));
+    if (!(du <= (float)kGridMaxW - 1e-3f && dv <= (float)kGridMaxW - 1e-3f)) return false;
+    wx = (int)ceilf(du + 1e-3f); wy = (int)ceilf(dv + 1e-3f);
+    return true;
+}
+// Coarse-to-fine descent through the representative points: the nearest of ALL 64 x 64-block representatives, then the nearest
+// 16 x 16-block representative in and around that block (the block's 4 x 4 children plus one ring), then 4 x 4 blocks, then pixels.
+// Every point met is an existing scene point, so its distance is a valid bound (nn_seed_bound's argument); the descent itself
+// decides nothing.  On the test.cpp scene it lands on the true nearest neighbour for 70-85 % of the queries of a hypothesis that
+// starts centimetres off the surface and within a few points of it for the rest (188 distance evaluations at 640 x 480) -- which
+// turns the tree search that follows from "find the neighbour" into "confirm it".
+__device__ __forceinline__ void grid_ring_min(const float4 *__restrict__ level, int lw, int lh, int x0, int y0, int nb, float sx, float sy, float sz,
+                                              float &dmin, int &bx, int &by)
+{
+    dmin = FLT_MAX; bx = min(max(x0, 0), lw - 1); by = min(max(y0, 0), lh - 1);
+    for (int dy = 0; dy < nb; ++dy) {
+        const int y = min(max(y0 + dy, 0), lh - 1);
+        float4 c[6];
+#pragma unroll
+        for (int dx = 0; dx < 6; ++dx) c[dx] = level[(size_t)y * lw + min(max(x0 + dx, 0), lw - 1)];
+#pragma unroll
+        for (int dx = 0; dx < 6; ++dx) {
+            const float d2 = (sx - c[dx].x) * (sx - c[dx].x) + (sy - c[dx].y) * (sy - c[dx].y) + (sz - c[dx].z) * (sz - c[dx].z);
+            if (d2 < dmin) { dmin = d2; bx = min(max(x0 + dx, 0), lw - 1); by = y; }
+        }
+    }
+}
+__device__ __forceinline__ void grid_pyramid_bound(const SceneNNDev &s, float sx, float sy, float sz, float &best)
+{
+    const int w4 = ((int)s.gw + 3) / 4, h4 = ((int)s.gh + 3) / 4, w16 = (w4 + 3) / 4, h16 = (h4 + 3) / 4, w64 = (w16 + 3) / 4, h64 = (h16 + 3) / 4;
+    float dmin = FLT_MAX, dall;
+    int bx = 0, by = 0;
+    for (int i = 0; i < w64 * h64; ++i) {                          // wave-uniform addresses: every lane reads the same few cache lines
+        const float4 c = s.pyr64[i];
+        const float d2 = (sx - c.x) * (sx - c.x) + (sy - c.y) * (sy - c.y) + (sz - c.z) * (sz - c.z);
+        if (d2 < dmin) { dmin = d2; bx = i % w64; by = i / w64; }
+    }
+    dall = dmin;
+    float d;
+    grid_ring_min(s.pyr16, w16, h16, bx * 4 - 1, by * 4 - 1, 6, sx, sy, sz, d, bx, by);   dall = fminf(dall, d);
+    grid_ring_min(s.pyr4, w4, h4, bx * 4 - 1, by * 4 - 1, 6, sx, sy, sz, d, bx, by);       dall = fminf(dall, d);
+    grid_ring_min(s.grid, (int)s.gw, (int)s.gh, bx * 4 - 1, by * 4 - 1, 6, sx, sy, sz, d, bx, by);   dall = fminf(dall, d);
+    const float b = dall * 1.000001f + 1e-30f;                       // empty cells hold huge coordinates: inf
+    if (b < best) best = b;
+}
+__device__ __forceinline__ bool grid_search(const SceneNNDev &s, float sx, float sy, float sz, float bound, uint32_t &winner)
+{
+    int wx, wy;
+    if (!grid_window(s, sx, sy, sz, bound, wx, wy)) return false;
+    float u, v;
+    grid_project(s, sx, sy, sz, u, v);
+    if (!(u > -1e6f && u < 1e6f && v > -1e6f && v < 1e6f)) return false;
+    const int cx0 = (int)floorf(u), cy0 = (int)floorf(v);
+    const int x0 = max(cx0 - wx, 0), x1 = min(cx0 + wx, (int)s.gw - 1);
+    const int y0 = max(cy0 - wy, 0), y1 = min(cy0 + wy, (int)s.gh - 1);
+    if (x0 > x1 || y0 > y1) return false;
+    float best = bound;
+    int best_i = -1, ties = 0;
+    for (int y = y0; y <= y1; ++y) {
+        const float4 *row = s.grid + (size_t)y * s.gw;
+        float4 c[2 * kGridMaxW + 1];
+#pragma unroll
+        for (int i = 0; i < 2 * kGridMaxW + 1; ++i) c[i] = row[min(x0 + i, x1)];          // one round trip per row
+#pragma unroll
+        for (int i = 0; i < 2 * kGridMaxW + 1; ++i) {
+            if (x0 + i > x1) continue;                           // (clamped repeats must not count as ties)
+            const float d2 = (sx - c[i].x) * (sx - c[i].x) + (sy - c[i].y) * (sy - c[i].y) + (sz - c[i].z) * (sz - c[i].z);
+            if (d2 < best) { best = d2; best_i = __float_as_int(c[i].w); ties = 0; }
+            else if (d2 == best && best_i >= 0) ++ties;
+        }
+    }
+    if (best_i < 0 || ties != 0) return false;
+    winner = (uint32_t)best_i;
+    return true;
+}
+// a first bound for a query nothing is known about yet: the nearest of the scene points in the 3 x 3 cells around its own pixel
+__device__ __forceinline__ void grid_seed_bound(const SceneNNDev &s, float sx, float sy, float sz, float &best)
+{
+    float u, v;
+    grid_project(s, sx, sy, sz, u, v);
+    if (!(u > -1e6f && u < 1e6f && v > -1e6f && v < 1e6f)) return;
+    const int cx0 = (int)floorf(u), cy0 = (int)floorf(v);
+    float4 c[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const int x = min(max(cx0 + (i % 3) - 1, 0), (int)s.gw - 1), y = min(max(cy0 + (i / 3) - 1, 0), (int)s.gh - 1);
+        c[i] = s.grid[(size_t)y * s.gw + x];
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const float d2 = (sx - c[i].x) * (sx - c[i].x) + (sy - c[i].y) * (sy - c[i].y) + (sz - c[i].z) * (sz - c[i].z);
+        const float b = d2 * 1.000001f + 1e-30f;                  // empty cells hold huge coordinates: b = inf
+        if (b < best) best = b;
+    }
 }
 
 // ================================================================================================
@@ -1299,7 +1434,27 @@ __device__ __forceinline__ void vb_accumulate(float (&acc_out)[29], float *cl, u
                 for (uint32_t i = 0; i < 12; ++i) if (i < cnt * 3) cl[(size_t)j0 * 3 + i] = p[i];
             }
         }
-        if constexpr (kNN) {
+        if constexpr (kNN && kStack == -1) {
+            // winners of the search kernel: four indices, then the four (point, normal) pairs, all in flight before the first use
+            uint32_t w[4];
+#pragma unroll
+            for (uint32_t i = 0; i < 4; ++i) w[i] = (i < cnt) ? scene.winner[j0 + i] : kNoPrev;
+            float4 d[4]; float nx[4], ny[4], nz[4];
+#pragma unroll
+            for (uint32_t i = 0; i < 4; ++i) {
+                const uint32_t at = (w[i] != kNoPrev) ? w[i] : 0u;
+                d[i] = scene.pts[at];
+                const float *n = reinterpret_cast<const float *>(scene.normal + at);
+                nx[i] = n[0]; ny[i] = n[1]; nz[i] = n[2];
+            }
+#pragma unroll
+            for (uint32_t i = 0; i < 4; ++i) {
+                if (w[i] != kNoPrev) {
+                    Corr c; c.dx = d[i].x; c.dy = d[i].y; c.dz = d[i].z; c.nx = nx[i]; c.ny = ny[i]; c.nz = nz[i];
+                    if constexpr (kScoreOnly) accumulate_score(acc, p[3 * i], p[3 * i + 1], p[3 * i + 2], c); else accumulate(acc, p[3 * i], p[3 * i + 1], p[3 * i + 2], c);
+                }
+            }
+        } else if constexpr (kNN) {
 #pragma unroll
             for (uint32_t i = 0; i < 4; ++i) {
                 if (i < cnt) {
@@ -1468,10 +1623,12 @@ __global__ __launch_bounds__(256, PR_PASS_WAVES) void icp_pass_kernel(IcpBatch b
         __syncthreads();
         lds_topo = reinterpret_cast<const int4 *>(recs);
     }
+    if constexpr (kNN && kStack == -1) scene.winner += pm.start;  // winners are indexed like the cloud
 
     float *cl = reinterpret_cast<float *>(b.cloud + pm.start);
-    const bool xf = (st == kRunWithTransform);                   // also: not the first pass of this cloud (a seed exists)
-    uint32_t *nn_prev = (kNN && b.nn_prev) ? b.nn_prev + pm.start : nullptr;
+    // a pending update that nn_search_kernel has already applied to the cloud must not be applied again
+    const bool xf = (st == kRunWithTransform) && !b.pre_transformed;   // also: not the first pass of this cloud (a seed exists)
+    uint32_t *nn_prev = (kNN && kStack >= 0 && b.nn_prev) ? b.nn_prev + pm.start : nullptr;
     float M[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) M[i] = xf ? pm.xform[i] : 0.0f;
@@ -1527,6 +1684,131 @@ __global__ __launch_bounds__(256, PR_PASS_WAVES) void icp_pass_kernel(IcpBatch b
         b.st[pose] = s;
         return;
     }
+}
+
+// ================================================================================================
+//  kd-tree scenes, split form: the SEARCH on its own.
+//
+//  The fused pass ties the search to the canonical reduction tree: lane t owns points 4t..4t+3 of a 1024-point step, so only
+//  three of four queries can start from their neighbour's answer, and the unseeded ones -- a hundred node visits each while the
+//  hypothesis is still centimetres off the surface -- set the pace of the first passes.  The winner of a query does not depend
+//  on how the search is organised, so the search runs here in whatever order suits it and leaves the winners in `nn_prev`;
+//  the pass that follows (icp_pass_kernel<SceneNNWinners>) gathers them in canonical order -- bit-identical sums.
+//    * a lane walks a RUN of consecutive cloud points (image neighbours): every query but the first of a run starts from the
+//      previous one's winner, whose distance is within microns of the answer (the step between neighbours is lateral);
+//    * the previous pass' winner of the same point bounds the search as before;
+//    * the first query of a run takes a bound from the scene points around its own pixel (grid_seed_bound);
+//    * with a bound that tight the candidates are the handful of scene pixels around the query's pixel: grid_search settles the
+//      query without touching the tree unless there is a tie (the tree's visiting order then decides, as in the reference).
+//  The pending rigid update is applied (and written back) here, so the pass reads the cloud as it is.
+// ================================================================================================
+template <int kCode>
+__global__ __launch_bounds__(256) void nn_search_kernel(IcpBatch b, SceneNNDev scene, uint32_t run)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const uint32_t pose = blockIdx.y;
+    const PoseMeta &pm = b.meta[pose];
+    const int32_t st = pm.state;
+    if (st == kSkip) return;
+    const uint32_t n = pm.count;
+    const uint32_t first = blockIdx.x * kBlockThreads * run;
+    if (first >= n) return;
+    int *stk_node = reinterpret_cast<int *>(lds_raw) + threadIdx.x;
+    float *stk_lb = reinterpret_cast<float *>(lds_raw) + (size_t)(kCode & 0xff) * kBlockThreads + threadIdx.x;
+
+    float *cl = reinterpret_cast<float *>(b.cloud + pm.start);
+    uint32_t *win = b.nn_prev + pm.start;
+    const bool xf = (st == kRunWithTransform);                   // also: the previous pass left winners for this cloud
+    float M[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) M[i] = xf ? pm.xform[i] : 0.0f;
+    const float accept = scene.max_dist_diff * scene.max_dist_diff;
+
+    uint32_t chain = kNoPrev;                                    // winner of this lane's previous query of this pass
+    const uint32_t j0 = first + threadIdx.x * run;
+    NNCount cnt;
+    uint32_t n_query = 0, n_window = 0, n_tree = 0, n_pyramid = 0;
+    for (uint32_t k = 0; k < run; ++k) {
+        const uint32_t j = j0 + k;
+        if (j >= n) break;
+        float x = cl[(size_t)j * 3], y = cl[(size_t)j * 3 + 1], z = cl[(size_t)j * 3 + 2];
+        float moved = FLT_MAX;                                   // squared step of this point since the pass its winner is from
+        if (xf) {                                                // icp.cu:142-153 transform_pcd_cuda
+            const float tx = M[0] * x + M[1] * y + M[2]  * z + M[3];
+            const float ty = M[4] * x + M[5] * y + M[6]  * z + M[7];
+            const float tz = M[8] * x + M[9] * y + M[10] * z + M[11];
+            moved = (tx - x) * (tx - x) + (ty - y) * (ty - y) + (tz - z) * (tz - z);
+            x = tx; y = ty; z = tz;
+            cl[(size_t)j * 3] = x; cl[(size_t)j * 3 + 1] = y; cl[(size_t)j * 3 + 2] = z;
+        }
+        float best = accept;
+        nn_seed_bound(scene, x, y, z, xf ? win[j] : kNoPrev, best);
+        nn_seed_bound(scene, x, y, z, chain, best);
+        // A point that has hardly moved still has (nearly) its true neighbour as temporal seed: d_old - step <= d_new <= d_old + step.
+        // Only queries without such a seed -- the first passes, while the updates are still millimetres -- pay for the descent
+        // through the representative points.
+        { int wx, wy; if (scene.grid && moved > PR_NN_STILL && !grid_window(scene, x, y, z, best, wx, wy)) { grid_pyramid_bound(scene, x, y, z, best); ++n_pyramid; } }
+        uint32_t w = kNoPrev;
+        bool settled = scene.grid && best < accept && grid_search(scene, x, y, z, best, w);
+        ++n_query;
+        if (settled) ++n_window;
+        else {
+            Corr c;
+            ++n_tree;
+            if (!query_nn_stack_from<kCode, false>(scene, nullptr, stk_node, stk_lb, x, y, z, c, best, w, &cnt)) w = kNoPrev;
+        }
+        win[j] = w;
+        if (w != kNoPrev) chain = w;
+    }
+    if (scene.counters) {                                        // instrumented runs only (option "nn_count")
+        const uint32_t v[7] = { n_query, n_window, n_tree, n_pyramid, cnt.nodes, cnt.leaves, cnt.leaf_points };
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            uint32_t t = v[i];
+            for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
+            if ((threadIdx.x & 63u) == 0u) atomicAdd(&scene.counters[(size_t)b.iter * 8 + i], (unsigned long long)t);
+        }
+    }
+}
+
+// scene points -> grid cells.  cell_idx starts at -1; a second claim on a cell, or a point outside the image, clears info[0].
+__global__ __launch_bounds__(256) void nn_grid_claim_kernel(const pr_vec3 *__restrict__ pcd, uint32_t n_points, SceneNNDev g, int32_t *__restrict__ cell_idx,
+                                                            uint32_t *__restrict__ info)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_points) return;
+    const pr_vec3 p = pcd[i];
+    float u, v;
+    grid_project(g, p.x, p.y, p.z, u, v);
+    if (!(p.z > 0 && u >= 0.0f && u < (float)g.gw && v >= 0.0f && v < (float)g.gh)) { info[0] = 0u; return; }
+    const int cell = (int)floorf(v) * (int)g.gw + (int)floorf(u);
+    if (atomicCAS(&cell_idx[cell], -1, (int)i) != -1) info[0] = 0u;
+}
+// one coarser level: cell (bx, by) takes the occupied child cell nearest its centre (children = 4 x 4 cells of the finer level)
+__global__ __launch_bounds__(256) void nn_grid_coarsen_kernel(const float4 *__restrict__ fine, int fw, int fh, float4 *__restrict__ coarse, int cw, int ch)
+{
+    const int c = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (c >= cw * ch) return;
+    const int bx = c % cw, by = c / cw;
+    float4 pick = make_float4(1e30f, 1e30f, 1e30f, __int_as_float(-1));
+    int pick_d = 1 << 30;
+    for (int dy = 0; dy < 4; ++dy)
+        for (int dx = 0; dx < 4; ++dx) {
+            const int x = bx * 4 + dx, y = by * 4 + dy;
+            if (x >= fw || y >= fh) continue;
+            const float4 v = fine[(size_t)y * fw + x];
+            const int dist = (2 * dx - 3) * (2 * dx - 3) + (2 * dy - 3) * (2 * dy - 3);      // squared distance to the block centre, in half cells
+            if (__float_as_int(v.w) >= 0 && dist < pick_d) { pick = v; pick_d = dist; }
+        }
+    coarse[c] = pick;
+}
+__global__ __launch_bounds__(256) void nn_grid_fill_kernel(const pr_vec3 *__restrict__ pcd, const int32_t *__restrict__ cell_idx, uint32_t n_cells,
+                                                           float4 *__restrict__ grid)
+{
+    const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= n_cells) return;
+    const int i = cell_idx[c];
+    grid[c] = (i >= 0) ? make_float4(pcd[i].x, pcd[i].y, pcd[i].z, __int_as_float(i)) : make_float4(1e30f, 1e30f, 1e30f, __int_as_float(-1));
 }
 
 // second stage: workgroup sums added sequentially in workgroup order, starting from 0
@@ -2350,6 +2632,56 @@ hipError_t launch_icp_pass_nn(const IcpBatch &b, const SceneNNDev &sc, uint32_t 
     if (sc.stack_depth == 16) return launch_pass<SceneNNDev, true, 16>(b, sc, n_poses, (size_t)16 * kBlockThreads * 8 + (size_t)sc.lds_nodes * 64, s);
     if (sc.stack_depth == 24) return launch_pass<SceneNNDev, true, 24>(b, sc, n_poses, (size_t)24 * kBlockThreads * 8 + (size_t)sc.lds_nodes * 64, s);
     return launch_pass<SceneNNDev, true, 0>(b, sc, n_poses, (size_t)sc.lds_nodes * sizeof(int4), s);
+}
+
+hipError_t launch_icp_pass_nn_winners(const IcpBatch &b, const SceneNNWinners &sc, uint32_t n_poses, hipStream_t s)
+{ return launch_pass<SceneNNWinners, true, -1>(b, sc, n_poses, 0, s); }
+
+hipError_t launch_nn_search(const IcpBatch &b, const SceneNNDev &sc, uint32_t n_poses, uint32_t max_points, uint32_t run, hipStream_t s)
+{
+    if (n_poses == 0 || max_points == 0) return hipSuccess;
+    if (!sc.rec32 || (sc.stack_depth != 16 && sc.stack_depth != 24) || !b.nn_prev) return hipErrorInvalidValue;
+    if (run == 0) run = 1;
+    const uint32_t per_block = kBlockThreads * run;
+    const uint32_t gx = (max_points + per_block - 1) / per_block;
+    for (uint32_t p0 = 0; p0 < n_poses; p0 += 32768) {
+        const uint32_t np = (n_poses - p0 < 32768) ? (n_poses - p0) : 32768;
+        IcpBatch bb = b;
+        bb.meta += p0;
+        if (sc.stack_depth == 16) hipLaunchKernelGGL(HIP_KERNEL_NAME(nn_search_kernel<16 + 0x100>), dim3(gx, np), dim3(kBlockThreads), (size_t)16 * kBlockThreads * 8, s, bb, sc, run);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(nn_search_kernel<24 + 0x100>), dim3(gx, np), dim3(kBlockThreads), (size_t)24 * kBlockThreads * 8, s, bb, sc, run);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_build_nn_grid(const pr_vec3 *pcd, uint32_t n_points, uint32_t gw, uint32_t gh, float fx, float fy, float cx, float cy,
+                                int32_t *cell_idx, float4 *grid, uint32_t *info, hipStream_t s)
+{
+    const uint32_t cells = gw * gh;
+    if (cells == 0 || n_points == 0) return hipSuccess;
+    hipError_t e = hipMemsetAsync(cell_idx, 0xff, sizeof(int32_t) * cells, s);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(info, 1, sizeof(uint32_t), s);                 // non-zero: usable so far
+    if (e != hipSuccess) return e;
+    SceneNNDev g{};
+    g.gw = gw; g.gh = gh; g.gfx = fx; g.gfy = fy; g.gcx = cx; g.gcy = cy;
+    hipLaunchKernelGGL(nn_grid_claim_kernel, dim3((n_points + 255) / 256), dim3(256), 0, s, pcd, n_points, g, cell_idx, info);
+    hipLaunchKernelGGL(nn_grid_fill_kernel, dim3((cells + 255) / 256), dim3(256), 0, s, pcd, cell_idx, cells, grid);
+    int fw = (int)gw, fh = (int)gh;
+    float4 *fine = grid;
+    for (int level = 0; level < 3; ++level) {
+        const int cw = (fw + 3) / 4, ch = (fh + 3) / 4;
+        float4 *coarse = fine + (size_t)fw * fh;
+        hipLaunchKernelGGL(nn_grid_coarsen_kernel, dim3((uint32_t)((cw * ch + 255) / 256)), dim3(256), 0, s, fine, fw, fh, coarse, cw, ch);
+        fine = coarse; fw = cw; fh = ch;
+    }
+    return hipGetLastError();
+}
+size_t nn_grid_cells(uint32_t gw, uint32_t gh)
+{
+    size_t total = (size_t)gw * gh, w = gw, h = gh;
+    for (int level = 0; level < 3; ++level) { w = (w + 3) / 4; h = (h + 3) / 4; total += w * h; }
+    return total;
 }
 
 template <class Scene, bool kNN, int kStack>

@@ -13,7 +13,9 @@ import numpy as np
 
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _ORACLE_DIR = os.path.join(_ROOT, "oracle")
-_SO = os.path.join(_ORACLE_DIR, "liboracle.so")
+# PR_ORACLE_BUILD=o3 selects the build with the reference's optimisation flags (oracle/Makefile): bench.py's cpu_baseline uses
+# it; every parity test uses the default build (-O2 -ffp-contract=off: bit-reproducible sums)
+_SO = os.path.join(_ORACLE_DIR, "liboracle_o3.so" if os.environ.get("PR_ORACLE_BUILD") == "o3" else "liboracle.so")
 
 SCENE_PROJ, SCENE_NN = 0, 1
 SUM_SEQUENTIAL, SUM_CANONICAL = 0, 1

@@ -8,6 +8,8 @@ from pose_refine_amd import api, synth
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 scene_kind = sys.argv[2] if len(sys.argv) > 2 else "proj"
 api.init(0); api.set_option("solve", 1); api.set_option("raster_mode", int(os.environ.get("PR_RASTER_MODE", "1")))
+for kv in filter(None, os.environ.get("PR_OPTS", "").split(",")):      # e.g. PR_OPTS=nn_run=8,nn_grid=0,pose_groups=1
+    k, v = kv.split("="); api.set_option(k, int(v))
 model = api.Model(os.path.join(ROOT, "tests/golden/obj_06.ply"))
 K = synth.K_TEST; proj = api.compute_proj(K, 640, 480)
 sd = api.render_host(model, synth.scene_pose()[None], 640, 480, proj)[0]
