@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--sequential", action="store_true",
                     help="every step through the synchronous single-group path with HIP events around EVERY correspondence launch "
                          "(profile 1): the mode in which rocprofv3's per-launch average and the event average measure the same thing")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="library option (pr_set_option), repeatable -- tuning runs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-poses", type=int, default=0, help="CPU baseline sample size (0 = auto)")
     args = ap.parse_args()
@@ -114,6 +115,9 @@ def main():
     api.set_option("fused_solve", args.fused_solve)
     if args.overlap_pass >= 0:
         api.set_option("overlap_pass", args.overlap_pass)
+    for kv in args.opt:
+        name, value = kv.split("=")
+        api.set_option(name, int(value))
 
     W, H, K = synth.WIDTH, synth.HEIGHT, synth.K_TEST
     P = args.poses

@@ -9,6 +9,7 @@
 #include "../geometry.h"
 #include "pose_refine.h"
 #include "pose_refine/cv_compat.h"
+#include "pose_refine/thrust_compat.h"
 
 namespace pose_refine_detail {
 inline void must(int rc, const char *what)
@@ -37,6 +38,11 @@ public:
     T *begin() { return __gpu_memory; }
     T *end() { return __gpu_memory + __size; }
     size_t size() const { return __size; }
+#ifdef POSE_REFINE_HAVE_THRUST                                   // common.h:30-33; hipcc + rocThrust only (pose_refine/thrust_compat.h)
+    thrust::device_ptr<T> data_thr() { return thrust::device_ptr<T>(__gpu_memory); }
+    thrust::device_ptr<T> begin_thr() { return thrust::device_ptr<T>(__gpu_memory); }
+    thrust::device_ptr<T> end_thr() { return thrust::device_ptr<T>(__gpu_memory + __size); }
+#endif
     void __malloc(size_t n)
     {
         if (valid) __free();

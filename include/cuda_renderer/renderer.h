@@ -11,6 +11,7 @@
 
 #include "pose_refine.h"
 #include "pose_refine/cv_compat.h"
+#include "pose_refine/thrust_compat.h"
 
 namespace cuda_renderer {
 
@@ -31,37 +32,64 @@ public:
     Model() {}
     ~Model() {}
     explicit Model(const std::string &fileName) { LoadModel(fileName); }
-    void LoadModel(const std::string &fileName)
+    void LoadModel(const std::string &fileName)              // renderer.cpp:16-58 (PLY / OBJ through pr_mesh_load instead of assimp)
     {
         size_t nt = 0, nv = 0;
-        if (pr_ply_count(fileName.c_str(), &nt, &nv) != PR_OK) { std::cerr << pr_last_error() << std::endl; std::exit(1); }
-        tris.resize(nt);
-        if (pr_ply_load(fileName.c_str(), reinterpret_cast<pr_triangle *>(tris.data()), nt, &nt) != PR_OK) { std::cerr << pr_last_error() << std::endl; std::exit(1); }
-        tris.resize(nt);
-        std::cout << "load model success\nface(triangles) nums: " << tris.size() << std::endl;
+        if (pr_mesh_count(fileName.c_str(), &nt, &nv) != PR_OK) { std::cerr << pr_last_error() << std::endl; std::exit(1); }
+        tris.resize(nt); faces.resize(nt); vertices.resize(nv);
+        if (pr_mesh_load(fileName.c_str(), reinterpret_cast<pr_triangle *>(tris.data()), nt, &nt, reinterpret_cast<pr_vec3 *>(vertices.data()), nv, &nv,
+                         reinterpret_cast<int32_t *>(faces.data()), &bbox_min.x, &bbox_max.x) != PR_OK) { std::cerr << pr_last_error() << std::endl; std::exit(1); }
+        std::cout << "load model success    " << std::endl;
+        std::cout << "face(triangles) nums: " << faces.size() << std::endl;
+        std::cout << "       vertices nums: " << vertices.size() << std::endl;
+        if (faces.size() > 10000) std::cout << "you may want tools like meshlab to simplify models to speed up rendering" << std::endl;
+        std::cout << "------------------------------------\n" << std::endl;
     }
+    // wanted data (renderer.h:143-147); bbox_* are aiVector3D in the reference: same .x / .y / .z access
     std::vector<Triangle> tris;
     std::vector<float3> vertices;
     std::vector<int3> faces;
+    float3 bbox_min{ 0, 0, 0 }, bbox_max{ 0, 0, 0 };
 };
+static_assert(sizeof(Model::int3) == 12 && sizeof(Model::float3) == sizeof(pr_vec3), "POD layouts");
 static_assert(sizeof(Model::Triangle) == sizeof(pr_triangle) && sizeof(Model::mat4x4) == sizeof(pr_mat4) && sizeof(Model::ROI) == sizeof(pr_roi), "POD layouts");
 
-template <typename T> class device_vector_holder {           // renderer.h:161-187, move-only
+// renderer.h:161-187 / renderer.cu:15-50.  Move-only (the reference returns it by value relying on copy elision).
+// begin_thr() / end_thr() (renderer.h:175-177) return thrust::device_ptr<T>: they exist when this header is compiled by hipcc with
+// rocThrust on the include path, so `thrust::copy(h.begin_thr(), h.end_thr(), host.begin())` (cuda_renderer/test.cpp:90,135,
+// pose_renderer.cpp:12) builds unchanged there; a plain host compiler has no Thrust and uses upload() / download(), which are the
+// same two copies.
+template <typename T> class device_vector_holder {
 public:
     T *__gpu_memory = nullptr; size_t __size = 0; bool valid = false;
     device_vector_holder() {}
     explicit device_vector_holder(size_t n) { __malloc(n); }
+    device_vector_holder(size_t n, T init) { __malloc(n); fill(init); }               // renderer.h:169, renderer.cu:29-34 thrust::fill
     device_vector_holder(const device_vector_holder &) = delete;
+    device_vector_holder &operator=(const device_vector_holder &) = delete;
     device_vector_holder(device_vector_holder &&o) noexcept : __gpu_memory(o.__gpu_memory), __size(o.__size), valid(o.valid) { o.__gpu_memory = nullptr; o.valid = false; o.__size = 0; }
+    device_vector_holder &operator=(device_vector_holder &&o) noexcept
+    { if (this != &o) { __free(); __gpu_memory = o.__gpu_memory; __size = o.__size; valid = o.valid; o.__gpu_memory = nullptr; o.__size = 0; o.valid = false; } return *this; }
     ~device_vector_holder() { __free(); }
     T *data() { return __gpu_memory; }
     T *begin() { return __gpu_memory; }
     T *end() { return __gpu_memory + __size; }
     size_t size() const { return __size; }
+#ifdef POSE_REFINE_HAVE_THRUST
+    thrust::device_ptr<T> data_thr() { return thrust::device_ptr<T>(__gpu_memory); }
+    thrust::device_ptr<T> begin_thr() { return thrust::device_ptr<T>(__gpu_memory); }
+    thrust::device_ptr<T> end_thr() { return thrust::device_ptr<T>(__gpu_memory + __size); }
+#endif
     void __malloc(size_t n) { if (valid) __free(); void *p = nullptr; if (pr_malloc(&p, n * sizeof(T)) != PR_OK) { std::cerr << pr_last_error() << std::endl; std::exit(1); } __gpu_memory = static_cast<T *>(p); __size = n; valid = true; }
     void __free() { if (valid) { pr_free(__gpu_memory); valid = false; __size = 0; __gpu_memory = nullptr; } }
     void upload(const std::vector<T> &h) { if (__size != h.size()) __malloc(h.size()); if (!h.empty()) pr_memcpy_h2d(__gpu_memory, h.data(), h.size() * sizeof(T)); }
     std::vector<T> download() const { std::vector<T> h(__size); if (__size) pr_memcpy_d2h(h.data(), __gpu_memory, __size * sizeof(T)); return h; }
+private:
+    void fill(T init)
+    {
+        if (sizeof(T) == 4) { int32_t bits; std::memcpy(&bits, &init, 4); if (pr_fill_i32(reinterpret_cast<int32_t *>(__gpu_memory), __size, bits) != PR_OK) { std::cerr << pr_last_error() << std::endl; std::exit(1); } }
+        else { std::vector<T> h(__size, init); upload(h); }
+    }
 };
 using Int_holder = device_vector_holder<int>;
 

@@ -119,7 +119,16 @@ int pr_fill_i32(int32_t *dev_dst, size_t count, int32_t value);   /* holder(size
 int pr_invalidate(const void *dev_ptr, size_t bytes);
 
 /* ---- host-side model / scene preparation (CPU in the reference too) --------------------------- */
-/* Model::Model(fileName) renderer.cpp:11-58: ASCII PLY -> triangle list (only tris feed this path). */
+/* Model::Model(fileName) / LoadModel renderer.cpp:11-104 + get_bounding_box :106-150.  The reference imports through assimp; here:
+ * PLY (ASCII, binary little / big endian, typed properties) and Wavefront OBJ, single mesh, identity node transform.
+ * Faces with < 3 indices are dropped (renderer.cpp:78), polygons are fanned into triangles (assimp's aiProcess_Triangulate).
+ * Any output pointer may be NULL; faces_out receives 3 vertex indices per triangle (Model::faces), vertices_out the file's vertex
+ * list (Model::vertices), bbox_min / bbox_max the component-wise extremes of the vertices (Model::bbox_min / bbox_max). */
+int pr_mesh_count(const char *path, size_t *n_triangles, size_t *n_vertices);
+int pr_mesh_load(const char *path, pr_triangle *tris_out, size_t cap_triangles, size_t *n_triangles,
+                 pr_vec3 *vertices_out, size_t cap_vertices, size_t *n_vertices, int32_t *faces_out,
+                 float bbox_min[3], float bbox_max[3]);
+/* triangles only (the hot path consumes nothing else) */
 int pr_ply_count(const char *path, size_t *n_triangles, size_t *n_vertices);
 int pr_ply_load(const char *path, pr_triangle *tris_out, size_t cap_triangles, size_t *n_triangles);
 /* compute_proj renderer.cpp:161-185 */
@@ -155,6 +164,9 @@ int pr_scene_nn_prepare_dev(const void *depth_dev, int depth_is_i32, const float
                             uint32_t *n_points, uint32_t *n_nodes);
 /* eigen_slover_666 icp.cpp:29-45 (public in icp.h:54) */
 void pr_solve_666(const float A[36], const float b[6], pr_mat4 *T_out);
+/* Mat4x4f * Mat4x4f geometry.h:292-298 (entries summed over k = 3,2,1,0): what `result.transformation_ = extrinsic * result.transformation_`
+ * (icp.cu:212) evaluates; C_out may alias A or B */
+void pr_mat4_mul(const pr_mat4 *A, const pr_mat4 *B, pr_mat4 *C_out);
 
 /* ---- renderer (cuda_renderer/renderer.cu) ------------------------------------------------------ */
 /* render_cuda_keep_in_gpu renderer.cu:269-336: depth_dev_out[n_poses*rw*rh] int32 mm, 0 = empty.

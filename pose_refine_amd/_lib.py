@@ -73,6 +73,8 @@ SIGNATURES = {
     "pr_fill_i32": (_i32, [_vp, _sz, C.c_int32]),
     "pr_invalidate": (_i32, [_vp, _sz]),
     "pr_scene_proj_crop_dev": (_i32, [_vp, _vp, _sz, _sz, Roi, _vp, _vp]),
+    "pr_mesh_count": (_i32, [C.c_char_p, C.POINTER(_sz), C.POINTER(_sz)]),
+    "pr_mesh_load": (_i32, [C.c_char_p, _vp, _sz, C.POINTER(_sz), _vp, _sz, C.POINTER(_sz), _vp, _vp, _vp]),
     "pr_ply_count": (_i32, [C.c_char_p, C.POINTER(_sz), C.POINTER(_sz)]),
     "pr_ply_load": (_i32, [C.c_char_p, _vp, _sz, C.POINTER(_sz)]),
     "pr_compute_proj": (None, [_vp, _i32, _i32, C.c_float, C.c_float, _vp]),
@@ -85,6 +87,7 @@ SIGNATURES = {
     "pr_scene_nn_prepare_dev": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _sz, C.POINTER(_u32), C.POINTER(_u32)]),
     "pr_kdtree_build": (_i32, [_vp, _vp, _sz, _i32, _vp, _sz, C.POINTER(_u32)]),
     "pr_solve_666": (None, [_vp, _vp, _vp]),
+    "pr_mat4_mul": (None, [_vp, _vp, _vp]),
     "pr_render": (_i32, [_vp, _sz, _vp, _sz, _sz, _sz, _vp, Roi, _vp]),
     "pr_render_to_host": (_i32, [_vp, _sz, _vp, _sz, _sz, _sz, _vp, Roi, _vp]),
     "pr_depth2cloud_i32": (_i32, [_vp, _u32, _u32, _vp, _u32, _u32, _u32, C.POINTER(_vp), C.POINTER(_u32)]),

@@ -185,19 +185,26 @@ class DeviceVector:
 # cuda_renderer
 # ------------------------------------------------------------------------------------------------
 class Model:
-    """``cuda_renderer::Model(fileName)`` -- only ``tris`` feeds this path (renderer.cpp:11-58)."""
+    """``cuda_renderer::Model(fileName)`` (renderer.cpp:11-104): ``tris`` feeds the path; ``vertices``, ``faces``,
+    ``bbox_min`` / ``bbox_max`` are the reference's other public members (renderer.h:143-147)."""
 
     def __init__(self, file_name: Optional[str] = None, tris: Optional[np.ndarray] = None):
         if tris is not None:
             self.tris = _f32(tris, (-1, 3, 3))
+            self.vertices = self.tris.reshape(-1, 3)
+            self.faces = np.arange(len(self.vertices), dtype=np.int32).reshape(-1, 3)
+            self.bbox_min, self.bbox_max = (self.vertices.min(0), self.vertices.max(0)) if len(self.vertices) else (np.zeros(3, np.float32),) * 2
         else:
             lib = _lib.load()
             nt, nv = C.c_size_t(), C.c_size_t()
-            check(lib.pr_ply_count(file_name.encode(), C.byref(nt), C.byref(nv)))
+            check(lib.pr_mesh_count(file_name.encode(), C.byref(nt), C.byref(nv)))
             buf = np.zeros((nt.value, 3, 3), np.float32)
-            got = C.c_size_t()
-            check(lib.pr_ply_load(file_name.encode(), ptr(buf), nt.value, C.byref(got)))
-            self.tris = np.ascontiguousarray(buf[:got.value])
+            self.vertices = np.zeros((nv.value, 3), np.float32)
+            self.faces = np.zeros((nt.value, 3), np.int32)
+            self.bbox_min, self.bbox_max = np.zeros(3, np.float32), np.zeros(3, np.float32)
+            check(lib.pr_mesh_load(file_name.encode(), ptr(buf), nt.value, C.byref(nt), ptr(self.vertices), nv.value, C.byref(nv),
+                                   ptr(self.faces), ptr(self.bbox_min), ptr(self.bbox_max)))
+            self.tris = buf
         self._dev: Optional[DeviceVector] = None
 
     def device_tris(self) -> DeviceVector:

@@ -2,6 +2,7 @@
 // preparation (normals, back-projection, kd-tree build) and the 6x6 update solver.
 // These run on the CPU in the reference as well (init_Scene_*_cuda = CPU preparation + H2D copy,
 // depth_scene.cu:3-20, pcd_scene.cu:3-20; eigen_slover_666 is host code called from icp.cu:207).
+#include <algorithm>
 #include <cfloat>
 #include <climits>
 #include <cmath>
@@ -25,33 +26,149 @@ void set_error(const char *fmt, ...);   // pr_api.cpp
 
 namespace {
 
-struct PlyHeader {
-    size_t n_vertices = 0, n_faces = 0;
-    int vertex_props = 0;
-    bool ascii = false, ok = false;
+// ---- mesh import: what Model::LoadModel takes from assimp (cuda_renderer/renderer.cpp:16-104) ----------------------------
+// The reference hands the file to assimp (aiProcessPreset_TargetRealtime_Quality, which triangulates) and walks the scene graph,
+// multiplying node transforms into the vertices (recursive_render).  The formats this path is fed are single-mesh files without
+// a node hierarchy, so the graph walk reduces to the identity transform; what remains is the file parsing, done here for PLY
+// (ASCII, binary little / big endian, any scalar property types, extra vertex properties skipped) and Wavefront OBJ:
+//   tris      every face as triangles (faces with < 3 indices dropped, renderer.cpp:78; polygons fanned like aiProcess_Triangulate)
+//   vertices  the file's vertex list, faces the index triples (renderer.cpp:87-100)
+//   bbox      component-wise min / max over the vertices (get_bounding_box, renderer.cpp:106-150)
+struct Mesh {
+    std::vector<pr_vec3> vertices;
+    std::vector<int32_t> faces;          // 3 per triangle
+    std::string error;
 };
 
-PlyHeader read_ply_header(std::ifstream &in)
+enum PlyType { kI8, kU8, kI16, kU16, kI32, kU32, kF32, kF64, kBad };
+PlyType ply_type(const std::string &t)
 {
-    PlyHeader h;
+    if (t == "char" || t == "int8") return kI8;       if (t == "uchar" || t == "uint8") return kU8;
+    if (t == "short" || t == "int16") return kI16;    if (t == "ushort" || t == "uint16") return kU16;
+    if (t == "int" || t == "int32") return kI32;      if (t == "uint" || t == "uint32") return kU32;
+    if (t == "float" || t == "float32") return kF32;  if (t == "double" || t == "float64") return kF64;
+    return kBad;
+}
+size_t ply_size(PlyType t) { static const size_t sz[] = { 1, 1, 2, 2, 4, 4, 4, 8, 0 }; return sz[t]; }
+struct PlyProp { std::string name; bool is_list = false; PlyType count_type = kBad, type = kBad; };
+struct PlyElement { std::string name; size_t count = 0; std::vector<PlyProp> props; };
+
+double ply_read_binary(std::istream &in, PlyType t, bool swap, bool &ok)
+{
+    unsigned char b[8] = { 0 };
+    const size_t n = ply_size(t);
+    if (!in.read(reinterpret_cast<char *>(b), (std::streamsize)n)) { ok = false; return 0; }
+    if (swap) for (size_t i = 0; i < n / 2; ++i) std::swap(b[i], b[n - 1 - i]);
+    switch (t) {
+    case kI8: return (double)*reinterpret_cast<int8_t *>(b);     case kU8: return (double)b[0];
+    case kI16: { int16_t v; std::memcpy(&v, b, 2); return v; }   case kU16: { uint16_t v; std::memcpy(&v, b, 2); return v; }
+    case kI32: { int32_t v; std::memcpy(&v, b, 4); return v; }   case kU32: { uint32_t v; std::memcpy(&v, b, 4); return v; }
+    case kF32: { float v; std::memcpy(&v, b, 4); return v; }     case kF64: { double v; std::memcpy(&v, b, 8); return v; }
+    default: ok = false; return 0;
+    }
+}
+
+void add_polygon(Mesh &m, const std::vector<long> &idx, size_t n_vertices)
+{
+    if (idx.size() < 3) return;                                   // renderer.cpp:78
+    for (long i : idx) if (i < 0 || (size_t)i >= n_vertices) { m.error = "face refers to a vertex that does not exist"; return; }
+    for (size_t k = 1; k + 1 < idx.size(); ++k) { m.faces.push_back((int32_t)idx[0]); m.faces.push_back((int32_t)idx[k]); m.faces.push_back((int32_t)idx[k + 1]); }
+}
+
+bool load_ply(const char *path, Mesh &m)
+{
+    std::ifstream in(path, std::ios::binary);
+    if (!in) { m.error = std::string("cannot open ") + path; return false; }
     std::string line;
-    if (!std::getline(in, line) || line.compare(0, 3, "ply") != 0) return h;
-    enum { kNone, kVertex, kFace, kOther } section = kNone;
+    if (!std::getline(in, line) || line.compare(0, 3, "ply") != 0) { m.error = "not a PLY file"; return false; }
+    bool ascii = false, big = false, header_ok = false;
+    std::vector<PlyElement> elems;
+    while (std::getline(in, line)) {
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        std::istringstream ss(line);
+        std::string tok;
+        ss >> tok;
+        if (tok == "end_header") { header_ok = true; break; }
+        if (tok == "format") { std::string f; ss >> f; ascii = (f == "ascii"); big = (f == "binary_big_endian"); if (!ascii && !big && f != "binary_little_endian") { m.error = "unknown PLY format " + f; return false; } }
+        else if (tok == "element") { PlyElement e; ss >> e.name >> e.count; elems.push_back(e); }
+        else if (tok == "property" && !elems.empty()) {
+            PlyProp p; std::string t; ss >> t;
+            if (t == "list") { std::string ct, it; ss >> ct >> it >> p.name; p.is_list = true; p.count_type = ply_type(ct); p.type = ply_type(it); if (p.count_type == kBad) { m.error = "unknown PLY type " + ct; return false; } }
+            else { ss >> p.name; p.type = ply_type(t); }
+            if (p.type == kBad) { m.error = "unknown PLY property type in: " + line; return false; }
+            elems.back().props.push_back(p);
+        }
+    }
+    if (!header_ok) { m.error = "PLY header without end_header"; return false; }
+    const uint16_t probe = 1;
+    const bool host_little = *reinterpret_cast<const unsigned char *>(&probe) == 1;
+    const bool swap = !ascii && (big == host_little);
+    size_t n_vertices = 0;
+    for (const PlyElement &e : elems) {
+        const bool is_vertex = (e.name == "vertex"), is_face = (e.name == "face");
+        int ix = -1, iy = -1, iz = -1, ilist = -1;
+        for (size_t k = 0; k < e.props.size(); ++k) {
+            if (is_vertex && !e.props[k].is_list) { if (e.props[k].name == "x") ix = (int)k; else if (e.props[k].name == "y") iy = (int)k; else if (e.props[k].name == "z") iz = (int)k; }
+            if (is_face && e.props[k].is_list && ilist < 0 && (e.props[k].name == "vertex_indices" || e.props[k].name == "vertex_index")) ilist = (int)k;
+        }
+        if (is_vertex && (ix < 0 || iy < 0 || iz < 0)) { m.error = "PLY vertex element without x / y / z"; return false; }
+        if (is_vertex) { n_vertices = e.count; m.vertices.resize(e.count); }
+        std::vector<long> poly;
+        for (size_t i = 0; i < e.count; ++i) {
+            std::istringstream ls;
+            if (ascii) { do { if (!std::getline(in, line)) { m.error = "truncated PLY body"; return false; } } while (line.find_first_not_of(" \t\r") == std::string::npos); ls.str(line); }
+            for (size_t k = 0; k < e.props.size(); ++k) {
+                const PlyProp &p = e.props[k];
+                bool ok = true;
+                auto next = [&](PlyType t) { double v = 0; if (ascii) { if (!(ls >> v)) ok = false; } else v = ply_read_binary(in, t, swap, ok); return v; };
+                if (!p.is_list) {
+                    const double v = next(p.type);
+                    if (!ok) { m.error = "truncated PLY body"; return false; }
+                    if (is_vertex) { if ((int)k == ix) m.vertices[i].x = (float)v; else if ((int)k == iy) m.vertices[i].y = (float)v; else if ((int)k == iz) m.vertices[i].z = (float)v; }
+                } else {
+                    const double cnt = next(p.count_type);
+                    if (!ok || cnt < 0 || cnt > 1e6) { m.error = "bad PLY list"; return false; }
+                    poly.clear();
+                    for (long j = 0; j < (long)cnt; ++j) { const double v = next(p.type); if (!ok) { m.error = "truncated PLY body"; return false; } poly.push_back((long)v); }
+                    if (is_face && (int)k == ilist) { add_polygon(m, poly, n_vertices); if (!m.error.empty()) return false; }
+                }
+            }
+        }
+    }
+    return true;
+}
+
+bool load_obj(const char *path, Mesh &m)
+{
+    std::ifstream in(path);
+    if (!in) { m.error = std::string("cannot open ") + path; return false; }
+    std::string line;
+    struct Pending { std::vector<long> idx; };
+    std::vector<Pending> polys;
     while (std::getline(in, line)) {
         std::istringstream ss(line);
         std::string tok;
         ss >> tok;
-        if (tok == "end_header") { h.ok = true; break; }
-        if (tok == "format") { std::string f; ss >> f; h.ascii = (f == "ascii"); }
-        else if (tok == "element") {
-            std::string name; size_t n = 0;
-            ss >> name >> n;
-            if (name == "vertex") { h.n_vertices = n; section = kVertex; }
-            else if (name == "face") { h.n_faces = n; section = kFace; }
-            else section = kOther;
-        } else if (tok == "property" && section == kVertex) h.vertex_props++;
+        if (tok == "v") { pr_vec3 v{ 0, 0, 0 }; ss >> v.x >> v.y >> v.z; m.vertices.push_back(v); }
+        else if (tok == "f") {
+            Pending p; std::string ref;
+            while (ss >> ref) { long i = strtol(ref.c_str(), nullptr, 10); p.idx.push_back(i < 0 ? (long)m.vertices.size() + i : i - 1); }   // v, v/vt, v/vt/vn, v//vn; negative = relative
+            polys.push_back(std::move(p));
+        }
     }
-    return h;
+    for (const Pending &p : polys) { add_polygon(m, p.idx, m.vertices.size()); if (!m.error.empty()) return false; }
+    return true;
+}
+
+bool load_mesh(const char *path, Mesh &m)
+{
+    if (!path) { m.error = "null path"; return false; }
+    const std::string s(path);
+    const size_t dot = s.rfind('.');
+    std::string ext = dot == std::string::npos ? "" : s.substr(dot + 1);
+    for (char &c : ext) c = (char)tolower((unsigned char)c);
+    if (ext == "obj") return load_obj(path, m);
+    return load_ply(path, m);                                     // .ply and anything that starts with the PLY magic
 }
 
 inline uint16_t saturate_u16(int32_t v) { return (uint16_t)(v < 0 ? 0 : (v > 65535 ? 65535 : v)); }
@@ -68,50 +185,45 @@ inline pr_vec3 back_project(size_t col, size_t row, float depth_mm, bool zero, c
 
 extern "C" {
 
-int pr_ply_count(const char *path, size_t *n_triangles, size_t *n_vertices)
+// Model::Model(fileName) / LoadModel (cuda_renderer/renderer.cpp:11-58)
+int pr_mesh_count(const char *path, size_t *n_triangles, size_t *n_vertices)
 {
-    std::ifstream in(path);
-    if (!in) { prh::set_error("pr_ply_count: cannot open %s", path); return PR_ERR_IO; }
-    PlyHeader h = read_ply_header(in);
-    if (!h.ok || !h.ascii) { prh::set_error("pr_ply_count: %s is not an ASCII PLY", path); return PR_ERR_IO; }
-    if (n_triangles) *n_triangles = h.n_faces;
-    if (n_vertices) *n_vertices = h.n_vertices;
+    Mesh m;
+    if (!load_mesh(path, m)) { prh::set_error("pr_mesh_count: %s", m.error.c_str()); return PR_ERR_IO; }
+    if (n_triangles) *n_triangles = m.faces.size() / 3;
+    if (n_vertices) *n_vertices = m.vertices.size();
     return PR_OK;
 }
-
-// Replaces Model::LoadModel/recursive_render (cuda_renderer/renderer.cpp:16-104) for plain PLY files:
-// the path only consumes `tris`; faces with < 3 indices are dropped (:78), others must be triangles (:79).
+int pr_mesh_load(const char *path, pr_triangle *tris_out, size_t cap_triangles, size_t *n_triangles,
+                 pr_vec3 *vertices_out, size_t cap_vertices, size_t *n_vertices, int32_t *faces_out,
+                 float bbox_min[3], float bbox_max[3])
+{
+    Mesh m;
+    if (!load_mesh(path, m)) { prh::set_error("pr_mesh_load: %s", m.error.c_str()); return PR_ERR_IO; }
+    const size_t nt = m.faces.size() / 3;
+    for (size_t t = 0; t < nt && t < cap_triangles; ++t) {
+        const int32_t *f = &m.faces[3 * t];
+        if (tris_out) tris_out[t] = pr_triangle{ m.vertices[(size_t)f[0]], m.vertices[(size_t)f[1]], m.vertices[(size_t)f[2]] };
+        if (faces_out) { faces_out[3 * t] = f[0]; faces_out[3 * t + 1] = f[1]; faces_out[3 * t + 2] = f[2]; }
+    }
+    if (vertices_out) for (size_t v = 0; v < m.vertices.size() && v < cap_vertices; ++v) vertices_out[v] = m.vertices[v];
+    if (n_triangles) *n_triangles = nt;
+    if (n_vertices) *n_vertices = m.vertices.size();
+    // get_bounding_box (renderer.cpp:143-150) starts from +-1e10 and folds every vertex in
+    float lo[3] = { 1e10f, 1e10f, 1e10f }, hi[3] = { -1e10f, -1e10f, -1e10f };
+    for (const pr_vec3 &v : m.vertices) {
+        lo[0] = std::min(lo[0], v.x); lo[1] = std::min(lo[1], v.y); lo[2] = std::min(lo[2], v.z);
+        hi[0] = std::max(hi[0], v.x); hi[1] = std::max(hi[1], v.y); hi[2] = std::max(hi[2], v.z);
+    }
+    if (bbox_min) for (int a = 0; a < 3; ++a) bbox_min[a] = lo[a];
+    if (bbox_max) for (int a = 0; a < 3; ++a) bbox_max[a] = hi[a];
+    return PR_OK;
+}
+// the two original entry points (triangles only)
+int pr_ply_count(const char *path, size_t *n_triangles, size_t *n_vertices) { return pr_mesh_count(path, n_triangles, n_vertices); }
 int pr_ply_load(const char *path, pr_triangle *tris_out, size_t cap, size_t *n_triangles)
 {
-    std::ifstream in(path);
-    if (!in) { prh::set_error("pr_ply_load: cannot open %s", path); return PR_ERR_IO; }
-    PlyHeader h = read_ply_header(in);
-    if (!h.ok || !h.ascii || h.vertex_props < 3) { prh::set_error("pr_ply_load: unsupported PLY %s", path); return PR_ERR_IO; }
-    std::vector<pr_vec3> verts(h.n_vertices);
-    std::string line;
-    for (size_t i = 0; i < h.n_vertices; ++i) {
-        if (!std::getline(in, line)) { prh::set_error("pr_ply_load: truncated vertex list"); return PR_ERR_IO; }
-        const char *p = line.c_str(); char *e = nullptr;
-        verts[i].x = strtof(p, &e); p = e;
-        verts[i].y = strtof(p, &e); p = e;
-        verts[i].z = strtof(p, &e);
-    }
-    size_t n = 0;
-    for (size_t f = 0; f < h.n_faces; ++f) {
-        if (!std::getline(in, line)) break;
-        const char *p = line.c_str(); char *e = nullptr;
-        long k = strtol(p, &e, 10); p = e;
-        if (k < 3) continue;
-        if (k != 3) { prh::set_error("pr_ply_load: face %zu is not a triangle", f); return PR_ERR_INVALID; }
-        long idx[3];
-        for (int j = 0; j < 3; ++j) { idx[j] = strtol(p, &e, 10); p = e; }
-        for (int j = 0; j < 3; ++j)
-            if (idx[j] < 0 || (size_t)idx[j] >= h.n_vertices) { prh::set_error("pr_ply_load: bad vertex index"); return PR_ERR_INVALID; }
-        if (n < cap && tris_out) tris_out[n] = pr_triangle{ verts[idx[0]], verts[idx[1]], verts[idx[2]] };
-        ++n;
-    }
-    if (n_triangles) *n_triangles = n;
-    return PR_OK;
+    return pr_mesh_load(path, tris_out, cap, n_triangles, nullptr, 0, nullptr, nullptr, nullptr, nullptr);
 }
 
 // compute_proj (cuda_renderer/renderer.cpp:161-185), including its sign flips
@@ -280,6 +392,9 @@ int pr_scene_nn_prepare(const void *depth, int is_i32, const float K[9], int W, 
 }
 
 void pr_solve_666(const float A[36], const float b[6], pr_mat4 *T_out) { prs::solve_666_impl(A, b, T_out->m); }
+// mat<4,4,float> * mat<4,4,float> (cuda_icp/geometry.h:292-298): the product the ICP loop accumulates its result with (icp.cu:212);
+// the same source (pr_solver.inl) is compiled for the device-side loop
+void pr_mat4_mul(const pr_mat4 *A, const pr_mat4 *B, pr_mat4 *C_out) { prs::mat4_mul_impl(A->m, B->m, C_out->m); }
 
 void pr_shard_range(uint32_t n_items, uint32_t rank, uint32_t world, uint32_t *first, uint32_t *count)
 {

@@ -116,7 +116,7 @@ def test_icp_single_cloud(gpu, scenario, gscenes, kind, crit, solve):
         assert res.inlier_rmse_ == pytest.approx(float(ores["inlier_rmse"]), rel=1e-6)
         assert np.allclose(res.transformation_, ores["T"].reshape(4, 4), rtol=0, atol=TOL_T)
         # the reference mutates the caller's cloud (test.cpp:129 comment)
-        assert np.allclose(dev.to_host().reshape(-1, 3), ocloud, rtol=0, atol=1e-5)
+        assert np.array_equal(dev.to_host().reshape(-1, 3), ocloud)              # bit for bit: same updates, same order
         if solve == api.SOLVE_HOST:
             assert np.array_equal(res.transformation_, ores["T"].reshape(4, 4)) or \
                 np.allclose(res.transformation_, ores["T"].reshape(4, 4), rtol=0, atol=1e-6)
