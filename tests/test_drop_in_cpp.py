@@ -93,3 +93,29 @@ def test_thrust_copy_through_holders_runs():
     exe = compile_thrust_driver()
     out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
     assert out.strip().endswith("OK")
+
+
+def compile_shard_driver():
+    lib_dir = os.path.join(ROOT, "pose_refine_amd", "lib")
+    exe = os.path.join(ROOT, "tests", "cpp", "shard_test")
+    subprocess.run(["g++", "-std=c++14", "-O2", "-Wall", "-pthread", "-I" + os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "cpp", "shard_test.cpp"), "-o", exe,
+                    "-L" + lib_dir, "-lpose_refine_hip", "-Wl,-rpath," + lib_dir], check=True)
+    return exe
+
+
+def test_cpp_shard_driver_compiles():
+    from pose_refine_amd import build
+    build.build()
+    assert os.path.exists(compile_shard_driver())
+
+
+@pytest.mark.gpu
+def test_cpp_host_shards_over_all_visible_gpus(golden_dir):
+    """tests/cpp/shard_test.cpp: one host thread per visible GPU, pr_comm_init_all + pr_gather_results (RCCL), virtual ranks and
+    private-context threads -- all bit-identical to the unsharded batch (no Python on that side)."""
+    exe = compile_shard_driver()
+    r = subprocess.run([exe, golden_dir + "/"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    got = json.loads(r.stdout[r.stdout.rindex("{"):])
+    assert got["failures"] == 0 and got["devices"] >= 1 and got["mean_fitness"] > 0.3
