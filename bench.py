@@ -42,12 +42,12 @@ HBM_PEAK = 8.0e12                       # MI355X_MICROARCH.md: 8 TB/s spec
 BYTES_PER_POINT_PASS0, BYTES_PER_POINT_PASSK = 36.0, 48.0
 # HBM-side traffic of the correspondence kernel measured with rocprofv3 PMC passes (FETCH_SIZE x2 per the
 # gfx950 correction of MI355X_MICROARCH.md + WRITE_SIZE; both calibrated on max2zero_kernel, which moves a known
-# number of bytes): profiles/r01/README.md (projective: 25.0 B/point at P=256) and profiles/r02/README.md (kd-tree).
+# number of bytes): profiles/r02/README.md (projective 24.9 B/point, kd-tree 51.5 B/point over its two kernels).
 # bench.py cannot collect PMCs itself (they need their own rocprofv3 passes): `traffic` is the committed per-point
 # measurement x the points of a launch, and `frac_hbm_counter` is that traffic over the launch time measured here.
-PMC_TRAFFIC_BYTES_PER_POINT = {"proj": 25.0, "nn": 37.0}
-PMC_TRAFFIC_SOURCE = {"proj": "profiles/r01/pmc_p256_FETCH_SIZE.md + pmc_p256_WRITE_SIZE_TCC.md",
-                      "nn": "profiles/r02/nn_baseline/pmc_nn_FETCH_SIZE.md + pmc_nn_WRITE_SIZE.md"}
+PMC_TRAFFIC_BYTES_PER_POINT = {"proj": 24.9, "nn": 51.5}
+PMC_TRAFFIC_SOURCE = {"proj": "profiles/r02/pmc_proj_FETCH_SIZE.md + pmc_proj_WRITE_SIZE.md (icp_pass_kernel<SceneProjPacked>)",
+                      "nn": "profiles/r02/pmc_nn_FETCH_SIZE.md + pmc_nn_WRITE_SIZE.md (nn_search_kernel 33.9 + winners pass 17.6 B/point)"}
 
 
 def main():
@@ -67,6 +67,7 @@ def main():
                          "(profile 1): the mode in which rocprofv3's per-launch average and the event average measure the same thing")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="library option (pr_set_option), repeatable -- tuning runs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kdtree-extra", action="store_true", help="skip the short configs[2] (kd-tree association) measurement appended to the line")
     ap.add_argument("--cpu-poses", type=int, default=0, help="CPU baseline sample size (0 = auto)")
     args = ap.parse_args()
 
@@ -177,8 +178,12 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    # profile 2: HIP events around every launch of one step in `period`; at least four timed steps per run
-    period = min(32, max(1, args.steps // 4))
+    # profile 2: HIP events around every launch of one step in `period`.  A sampled step runs synchronously as one pose group with
+    # the other slot drained (so that the timed launches have the chip to themselves) and costs ~0.6 ms more than a pipelined
+    # one -- inside the timed region, where it counts against `value`.  Four sampled steps (84 launches) from 40 steps up, two
+    # (42 launches) below that: at the driver's --steps 20 four would cost 10 % of the reported throughput.
+    n_samples = 4 if args.steps >= 40 else 2
+    period = min(32, max(1, -(-args.steps // n_samples)))
     api.set_option("sample_period", period)
     api.set_option("profile", 1 if args.sequential else 2)
     api.profile_reset()
@@ -245,6 +250,8 @@ def main():
             "phase_ms_per_timed_step": {"render": prof["render_ms"] / max(1, launches // (args.iters + 1)),
                                         "cloud": prof["cloud_ms"] / max(1, launches // (args.iters + 1))},
         }
+        if world == 1 and args.scene == "proj" and not args.no_kdtree_extra and not args.sequential:
+            out["config2_kdtree"] = kdtree_extra(args, api, model, poses, scene_depth, W, H, proj, K)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, model.tris, poses, scene_depth, K, W, H)
         print(json.dumps(out), flush=True)
@@ -252,6 +259,40 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def kdtree_extra(args, api, model, poses, scene_depth, W, H, proj, K, steps=8):
+    """BASELINE.json configs[2] next to the headline: the same 256-hypothesis batch against the kd-tree scene (Scene_nn), a
+    few steps through the synchronous path, plus one instrumented batch whose work counters give the LOGICAL bytes of the
+    search (nodes x 32 B + leaf points x 12 B + window cells x 16 B + 28 B per query for cloud and winner)."""
+    import numpy as np
+    crit = api.ICPConvergenceCriteria(0.0, 0.0, args.iters)
+    scene = api.Scene_nn().init_Scene_nn_cuda(scene_depth, K)
+    for _ in range(2):
+        api.refine_batch(model, poses, W, H, proj, K, scene, crit)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        _, sizes = api.refine_batch(model, poses, W, H, proj, K, scene, crit)
+    dt = (time.perf_counter() - t0) / steps
+    api.set_option("nn_count", 1)
+    api.nn_counters(args.iters + 1)
+    api.refine_batch(model, poses, W, H, proj, K, scene, crit)
+    c = api.nn_counters(args.iters + 1).astype(np.float64)
+    api.set_option("nn_count", 0)
+    tot = c.sum(0)
+    logical = tot[4] * 32 + tot[6] * 12 + tot[7] * 16 + tot[0] * 28
+    hbm = PMC_TRAFFIC_BYTES_PER_POINT["nn"] * tot[0] if PMC_TRAFFIC_BYTES_PER_POINT["nn"] else None
+    return {"workload": f"obj_06.ply, {len(poses)}-pose batch, 640x480, kd-tree nearest-neighbour association (Scene_nn: exact search, "
+                        "reference tie-breaks; search kernel = pixel-window scan where the bound allows it, near-first tree search "
+                        f"on compact 32-byte node records otherwise), {args.iters} ICP iterations, synchronous path",
+            "value": len(poses) / dt, "unit": "poses/s", "ms_per_step": dt * 1e3, "steps": steps,
+            "queries_per_step": tot[0], "settled_by_pixel_window_frac": tot[1] / max(tot[0], 1.0), "tree_searches_frac": tot[2] / max(tot[0], 1.0),
+            "tree_nodes_per_tree_search": tot[4] / max(tot[2], 1.0), "leaf_points_per_tree_search": tot[6] / max(tot[2], 1.0),
+            "logical_bytes_per_step": logical, "logical_GBps_over_step": logical / dt / 1e9,
+            "hbm_bytes_per_step_counter": hbm, "hbm_GBps_counter_over_step": (hbm / dt / 1e9) if hbm else None,
+            "hbm_frac_of_peak": (hbm / dt / HBM_PEAK) if hbm else None,
+            "note": "the kd-tree kernels are cache- and latency-bound by design (SURVEY 8d): their working set (0.85 MB tree + 4.9 MB grid) "
+                    "lives in L2, so HBM carries only the clouds and winners; `logical` counts every byte the search asks the caches for"}
 
 
 def cpu_baseline(args, tris, poses, scene_depth, K, W, H):

@@ -283,7 +283,7 @@ int  pr_get_option(const char *name, int *value);
  * the first pass of a cloud and on the score-only last pass, 48 B/point in between). */
 /* Work counters of the kd-tree search kernel, collected while option "nn_count" is 1 (instrumented runs; SURVEY 8d "count its own
  * visits"): out[pass * 8 + k] for ICP passes 0..passes-1 (<= 64), k = 0 queries, 1 settled by the pixel window, 2 handed to the tree,
- * 3 pyramid descents, 4 tree nodes visited, 5 leaves scanned, 6 leaf points tested, 7 spare.  Reading resets the counters. */
+ * 3 pyramid descents, 4 tree nodes visited, 5 leaves scanned, 6 leaf points tested, 7 window cells read.  Reading resets the counters. */
 int  pr_nn_counters(uint64_t *out, uint32_t passes);
 int  pr_profile_reset(void);
 int  pr_profile_read(double *kernel_ms, uint64_t *launches, uint64_t *points, uint64_t *algorithmic_bytes,

@@ -119,7 +119,7 @@ def profile_read():
 
 def nn_counters(passes: int = 21) -> np.ndarray:
     """Per-pass work counters of the kd-tree search kernel (option ``nn_count``): (passes, 8) uint64 --
-    queries, settled by window, tree searches, pyramid descents, tree nodes, leaves, leaf points, spare."""
+    queries, settled by window, tree searches, pyramid descents, tree nodes, leaves, leaf points, window cells."""
     out = np.zeros((passes, 8), np.uint64)
     check(_lib.load().pr_nn_counters(ptr(out), passes))
     return out

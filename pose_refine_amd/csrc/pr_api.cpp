@@ -140,7 +140,8 @@ struct Options {
                                      // 256 poses and 35 % slower at 1024), 0 = one launch per pass + per solve
     int use_graph = 1;               // PR_SOLVE_DEVICE, single pose group only (the runtime serialises the branches of a captured multi-stream
                                      // graph, which forfeits the overlap): capture the whole iteration loop in a hipGraph and replay it
-    int raster_mode = 0;             // fused path: 0 = global atomicMin inside the per-pose pixel box (reference scheme), 1 = LDS depth bands
+    int raster_mode = 0;             // fused path: 0 = global atomicMin inside the per-pose pixel box (reference scheme), 1 = LDS depth bands (int32),
+                                     // 2 = one workgroup per hypothesis with its whole box in LDS as 16-bit depth offsets (global path for boxes that do not fit)
     int scene_cache = 1;             // keep the packed projective scene / kd traversal records of the latest scene between calls (pr_scene_invalidate)
 };
 Options opt;
@@ -160,7 +161,7 @@ struct Resubmit {
     pr_result *results_dev = nullptr;
 };
 struct Slot {
-    DevBuf poses_bbox, depth, row_count, row_off, counts, cloud, meta, partial, dstate, dresults, arrive, aabb_keys;
+    DevBuf poses_bbox, depth, row_count, row_off, counts, cloud, meta, partial, dstate, dresults, arrive, aabb_keys, overflow;
     PackedCache packed;
     PinBuf h_in, h_out;
     Resubmit again;
@@ -214,7 +215,7 @@ struct Ctx {
     struct { const void *pcd = nullptr, *normal = nullptr, *nodes = nullptr; uint32_t n_points = 0, n_nodes = 0; uint64_t gen = 0; bool valid = false;
              uint32_t info[8] = { 0 };
              bool grid_valid = false, grid_usable = false; uint32_t gw = 0, gh = 0; float gk[4] = { 0, 0, 0, 0 }; } nn_cache;   // kd traversal records (topo ... nndesc) + pixel grid of the latest kd-tree scene
-    DevBuf nn_cells, nn_grid, nn_counters;
+    DevBuf nn_cells, nn_grid, nn_counters, tile_info, overflow;
     // profiling
     std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
     struct Span { size_t e0, e1; int kind; };
@@ -826,6 +827,7 @@ int refine_impl(const pr_triangle *tris_dev, size_t n_tris, const pr_mat4 *poses
     PR_TRY(g->aabb.ensure(6 * sizeof(float)));
     PR_TRY(g->aabb_keys.ensure(6 * sizeof(uint32_t)));
     HIP_TRY(prk::launch_model_aabb(tris_dev, (uint32_t)n_tris, g->aabb_keys.as<uint32_t>(), g->aabb.as<float>(), nullptr, nullptr, g->stream));
+    bool tile_off = false;
     for (uint32_t p0 = 0; p0 < P; p0 += chunk) {
         const uint32_t np = std::min(chunk, P - p0);
         PR_TRY(g->depth.ensure(sizeof(int32_t) * img * np));
@@ -844,13 +846,24 @@ int refine_impl(const pr_triangle *tris_dev, size_t n_tris, const pr_mat4 *poses
                 HIP_TRY(prk::launch_render_bands(tris_dev, (uint32_t)n_tris, g->poses.as<pr_mat4>(), np, g->aabb.as<float>(), g->bbox.as<int4>(),
                                                  g->depth.as<int32_t>(), g->row_count.as<uint32_t>(), g->row_off.as<uint32_t>(),
                                                  g->counts.as<uint32_t>(), W, H, *proj, roi, (uint32_t)g->n_cus, g->stream));
-            else
+            else if (opt.raster_mode == 2 && !tile_off) {
+                PR_TRY(g->tile_info.ensure(sizeof(int2) * np));
+                PR_TRY(g->overflow.ensure(sizeof(uint32_t)));
+                HIP_TRY(hipMemsetAsync(g->overflow.p, 0, sizeof(uint32_t), g->stream));
+                HIP_TRY(prk::launch_render_boxes(tris_dev, (uint32_t)n_tris, g->poses.as<pr_mat4>(), np, g->aabb.as<float>(), g->bbox.as<int4>(),
+                                                 g->depth.as<int32_t>(), g->row_count.as<uint32_t>(), g->row_off.as<uint32_t>(),
+                                                 g->counts.as<uint32_t>(), W, H, *proj, roi, g->stream, true, nullptr, nullptr, nullptr, 0,
+                                                 g->tile_info.as<int2>(), g->overflow.as<uint32_t>(), false));
+            } else
                 HIP_TRY(prk::launch_render_boxes(tris_dev, (uint32_t)n_tris, g->poses.as<pr_mat4>(), np, g->aabb.as<float>(), g->bbox.as<int4>(),
                                                  g->depth.as<int32_t>(), g->row_count.as<uint32_t>(), g->row_off.as<uint32_t>(),
                                                  g->counts.as<uint32_t>(), W, H, *proj, roi, g->stream));
         }
         HIP_TRY(hipMemcpyAsync(h_counts, g->counts.p, sizeof(uint32_t) * np, hipMemcpyDeviceToHost, g->stream));
+        uint32_t overflowed = 0;
+        if (opt.raster_mode == 2 && !tile_off) HIP_TRY(hipMemcpyAsync(&overflowed, g->overflow.p, sizeof overflowed, hipMemcpyDeviceToHost, g->stream));
         HIP_TRY(hipStreamSynchronize(g->stream));
+        if (overflowed) { tile_off = true; p0 -= chunk; continue; }    // a fragment left the 16-bit range (tile_record's bound failed): draw this chunk again through the global path
         uint32_t max_n = 0;
         for (uint32_t i = 0; i < np; ++i) max_n = std::max(max_n, h_counts[i]);
         const size_t cstride = ((size_t)max_n + 3) & ~(size_t)3;           // keeps every cloud 16-byte aligned
@@ -894,7 +907,7 @@ void slot_release(Slot &sl)
 {
     slot_drain(sl);
     for (DevBuf *b : { &sl.poses_bbox, &sl.depth, &sl.row_count, &sl.row_off, &sl.counts, &sl.cloud, &sl.meta, &sl.partial, &sl.dstate,
-                       &sl.dresults, &sl.arrive, &sl.aabb_keys, &sl.packed.rec }) b->release();
+                       &sl.dresults, &sl.arrive, &sl.aabb_keys, &sl.overflow, &sl.packed.rec }) b->release();
     sl.packed = PackedCache();
     sl.h_in.release(); sl.h_out.release();
     for (int i = 0; i < 3; ++i) {
@@ -1271,7 +1284,7 @@ void ctx_teardown(Ctx *c)        // c->mu held (or c unreachable); the calling t
     hipStreamSynchronize(c->stream);
     for (Slot &sl : c->slots) slot_release(sl);
     for (DevBuf *b : { &c->aabb, &c->aabb_keys, &c->bbox, &c->poses, &c->depth, &c->row_count, &c->row_off, &c->counts, &c->cloud, &c->meta, &c->partial,
-                       &c->sums, &c->packed.rec, &c->topo, &c->bmin, &c->bmax, &c->pts, &c->nnrec, &c->nnrec32, &c->nndesc, &c->nn_prev, &c->nndepth, &c->dstate, &c->dresults, &c->vbdesc, &c->flowsync, &c->arrive, &c->conv16, &c->conv8, &c->kd_idx, &c->kd_scratch, &c->kd_child, &c->kd_ctrl, &c->kd_tmp, &c->nn_full, &c->gather_tmp, &c->nn_cells, &c->nn_grid, &c->nn_counters }) b->release();
+                       &c->sums, &c->packed.rec, &c->topo, &c->bmin, &c->bmax, &c->pts, &c->nnrec, &c->nnrec32, &c->nndesc, &c->nn_prev, &c->nndepth, &c->dstate, &c->dresults, &c->vbdesc, &c->flowsync, &c->arrive, &c->conv16, &c->conv8, &c->kd_idx, &c->kd_scratch, &c->kd_child, &c->kd_ctrl, &c->kd_tmp, &c->nn_full, &c->gather_tmp, &c->nn_cells, &c->nn_grid, &c->nn_counters, &c->tile_info, &c->overflow }) b->release();
     for (PinBuf *b : { &c->h_sums, &c->h_meta, &c->h_counts, &c->h_results, &c->h_dstate, &c->h_flow }) b->release();
     c->packed = PackedCache(); c->nn_cache.valid = false;
     for (auto &gr : c->graphs) destroy_graph(gr);
@@ -1707,7 +1720,7 @@ int pr_set_option(const char *name, int value)
     else if (n == "sub_batch") opt.sub_batch = std::max(32, value);
     else if (n == "overlap_pass") opt.overlap_pass = std::max(-1, value);
     else if (n == "pose_groups") opt.pose_groups = std::min(4, std::max(1, value));
-    else if (n == "raster_mode") { if (value != 0 && value != 1) { set_error("raster_mode must be 0 or 1"); return PR_ERR_INVALID; } opt.raster_mode = value; }
+    else if (n == "raster_mode") { if (value < 0 || value > 2) { set_error("raster_mode must be 0, 1 or 2"); return PR_ERR_INVALID; } opt.raster_mode = value; }
     else { set_error("unknown option %s", name); return PR_ERR_INVALID; }
     return PR_OK;
 }
@@ -1742,7 +1755,7 @@ int pr_get_option(const char *name, int *value)
 }
 
 // work counters of the kd-tree search kernel (option "nn_count"): out[pass * 8 + k], k = queries, settled by the pixel window,
-// handed to the tree, pyramid descents, tree nodes visited, leaves scanned, leaf points tested, spare; reading resets them
+// handed to the tree, pyramid descents, tree nodes visited, leaves scanned, leaf points tested, window cells read; reading resets them
 int pr_nn_counters(uint64_t *out, uint32_t passes)
 {
     PR_ENTER();

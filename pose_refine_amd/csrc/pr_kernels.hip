@@ -211,10 +211,11 @@ __device__ __forceinline__ void wave_raster(const TriSetup &t, int n, float (*w)
 __global__ __launch_bounds__(256) void raster_kernel(const pr_triangle *__restrict__ tris, uint32_t n_tris,
                                                      const pr_mat4 *__restrict__ poses, int32_t *__restrict__ depth,
                                                      uint32_t width, uint32_t height, pr_mat4 proj, pr_roi roi,
-                                                     uint32_t rw, uint32_t rh, const int4 *__restrict__ boxes)
+                                                     uint32_t rw, uint32_t rh, const int4 *__restrict__ boxes, const int2 *__restrict__ tile_info)
 {
     __shared__ float sh[4][kSetupWords][64];
     __shared__ uint32_t shq[4][128];
+    if (tile_info && tile_info[blockIdx.y].y) return;            // drawn by raster_tile_kernel
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t ti = blockIdx.x * 256 + threadIdx.x;
     const float *M = poses[blockIdx.y].m;                        // wave-uniform -> scalar loads
@@ -302,12 +303,13 @@ __global__ void model_aabb_finish_kernel(const uint32_t *__restrict__ keys, floa
 // as long as all of them are in front of the camera, and 2 pixels of padding cover float rounding.
 // Any corner at or behind the camera plane -> the whole frame.
 __global__ __launch_bounds__(256) void pose_bbox_kernel(const float *__restrict__ aabb, const pr_mat4 *__restrict__ poses, uint32_t n_poses,
-                                                        pr_mat4 proj, uint32_t width, uint32_t height, pr_roi roi, int4 *__restrict__ bbox)
+                                                        pr_mat4 proj, uint32_t width, uint32_t height, pr_roi roi, int4 *__restrict__ bbox,
+                                                        int2 *__restrict__ tile_info, uint32_t tile_cap_px)
 {
     const uint32_t p = blockIdx.x * 256 + threadIdx.x;
     if (p >= n_poses) return;
     const float *M = poses[p].m;
-    float mnx = FLT_MAX, mny = FLT_MAX, mxx = -FLT_MAX, mxy = -FLT_MAX;
+    float mnx = FLT_MAX, mny = FLT_MAX, mxx = -FLT_MAX, mxy = -FLT_MAX, mnz = FLT_MAX, mxz = -FLT_MAX;
     bool all_front = true;
     for (int c = 0; c < 8; ++c) {
         const float x = aabb[(c & 1) ? 3 : 0], y = aabb[(c & 2) ? 4 : 1], z = aabb[(c & 4) ? 5 : 2];
@@ -320,6 +322,7 @@ __global__ __launch_bounds__(256) void pose_bbox_kernel(const float *__restrict_
         const float sx = cxp / lz * (float)width / 2.0f + (float)width / 2.0f;
         const float sy = cyp / lz * (float)height / 2.0f + (float)height / 2.0f;
         mnx = fminf(mnx, sx); mxx = fmaxf(mxx, sx); mny = fminf(mny, sy); mxy = fmaxf(mxy, sy);
+        mnz = fminf(mnz, lz); mxz = fmaxf(mxz, lz);
     }
     int x0 = 0, y0 = 0, x1 = (int)width - 1, y1 = (int)height - 1;
     const bool finite = (mnx > -1e8f) && (mxx < 1e8f) && (mny > -1e8f) && (mxy < 1e8f);
@@ -332,14 +335,17 @@ __global__ __launch_bounds__(256) void pose_bbox_kernel(const float *__restrict_
         y0 = max(y0, (int)height - 1 - (roi.y + roi.height - 1));  y1 = min(y1, (int)height - 1 - roi.y);
     }
     bbox[p] = make_int4(x0, y0, x1, y1);
+    if (tile_info) tile_info[p] = tile_record(all_front && finite, mnz, mxz, x0, y0, x1, y1, tile_cap_px);
 }
 
 // INT_MAX-fill and per-row valid counts restricted to each hypothesis' pixel box (image rows are
 // the flipped raster rows).  One wavefront per image row; rows outside the box only write count 0.
 constexpr uint32_t kBoxRowsPerBlock = 16;                        // 4 wavefronts x 4 rows: few, fatter workgroups (dispatch-bound otherwise)
-__global__ __launch_bounds__(256) void fill_box_kernel(int32_t *__restrict__ depth, const int4 *__restrict__ bbox, uint32_t width, uint32_t height)
+__global__ __launch_bounds__(256) void fill_box_kernel(int32_t *__restrict__ depth, const int4 *__restrict__ bbox, uint32_t width, uint32_t height,
+                                                       const int2 *__restrict__ tile_info)
 {
     const uint32_t lane = threadIdx.x & 63;
+    if (tile_info && tile_info[blockIdx.y].y) return;            // drawn by raster_tile_kernel
     const int4 bb = bbox[blockIdx.y];
     for (uint32_t r = 0; r < 4; ++r) {
         const uint32_t row = blockIdx.x * kBoxRowsPerBlock + (threadIdx.x >> 6) * 4 + r;
@@ -351,10 +357,11 @@ __global__ __launch_bounds__(256) void fill_box_kernel(int32_t *__restrict__ dep
     }
 }
 __global__ __launch_bounds__(256) void count_box_kernel(const int32_t *__restrict__ depth, const int4 *__restrict__ bbox, uint32_t width,
-                                                        uint32_t height, uint32_t *__restrict__ row_count)
+                                                        uint32_t height, uint32_t *__restrict__ row_count, const int2 *__restrict__ tile_info)
 {
     // latency-bound, not bandwidth-bound: every lane keeps 4 rows x 4 column chunks = 16 loads in flight before the first ballot
     const uint32_t lane = threadIdx.x & 63;
+    if (tile_info && tile_info[blockIdx.y].y) return;            // counted by raster_tile_kernel
     const int4 bb = bbox[blockIdx.y];
     const uint32_t row0 = blockIdx.x * kBoxRowsPerBlock + (threadIdx.x >> 6) * 4;
     uint32_t cnt[4] = { 0, 0, 0, 0 };
@@ -463,6 +470,97 @@ __global__ __launch_bounds__(1024) void raster_band_kernel(const pr_triangle *__
             if (lane == 0) row_count[(size_t)pose * height + yw] = cnt;
         }
         __syncthreads();
+    }
+}
+
+// ================================================================================================
+//  Tile raster: ONE workgroup per hypothesis keeps the hypothesis' whole pixel box in LDS as 16-bit depth offsets (an object
+//  at the usual distance covers ~220 x 224 px: 98 KB as uint16, twice that as int32 -- which is what made the int32 band variant
+//  rasterise every triangle twice).  Triangles are walked wave-cooperatively exactly like raster_kernel (same wave_raster, same
+//  per-candidate arithmetic); only the depth test differs: a compare-and-swap on the 32-bit LDS word that holds the pixel's 16
+//  bits instead of a returnless global atomicMin (170 of the global variant's ~400 us per 256 hypotheses are that atomic backing
+//  up the memory pipeline).  The box is then written out once -- INT_MAX where nothing was drawn, like the cleared frame -- with
+//  its per-row valid counts, so these hypotheses need neither the box clear nor the row-count pass.
+//  Hypotheses whose box does not fit, or whose depth range is not safely 16 bits wide (tile_record), are left to the global path.
+// ================================================================================================
+constexpr uint32_t kTileThreads = 512;                           // 8 wavefronts: their raster scratch (35 KB) + the tile must fit 160 KB
+constexpr uint32_t kTileCapPx = 61440;                           // 120 KB of uint16
+__global__ __launch_bounds__(kTileThreads) void raster_tile_kernel(const pr_triangle *__restrict__ tris, uint32_t n_tris,
+                                                                   const pr_mat4 *__restrict__ poses, const int4 *__restrict__ bbox,
+                                                                   const int2 *__restrict__ tile_info, int32_t *__restrict__ depth,
+                                                                   uint32_t *__restrict__ row_count, uint32_t width, uint32_t height,
+                                                                   pr_mat4 proj, uint32_t *__restrict__ overflow)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char tile_raw[];
+    const uint32_t pose = blockIdx.x;
+    const int2 ti = tile_info[pose];
+    if (!ti.y) return;
+    const int4 bb = bbox[pose];
+    const int bw = bb.z - bb.x + 1, bh = bb.w - bb.y + 1;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t *rc = row_count + (size_t)pose * height;
+    if (bw <= 0 || bh <= 0) {                                    // nothing can be drawn: all rows empty
+        for (uint32_t r = threadIdx.x; r < height; r += kTileThreads) rc[r] = 0u;
+        return;
+    }
+    const uint32_t n_px = (uint32_t)bw * (uint32_t)bh;
+    uint32_t *tile32 = reinterpret_cast<uint32_t *>(tile_raw);
+    const uint32_t tile_words = (n_px + 1u) / 2u;
+    float (*scratch)[64] = reinterpret_cast<float (*)[64]>(tile_raw + (size_t)((tile_words * 4u + 15u) & ~15u)) + (size_t)wave * (kSetupWords + 2);
+    uint32_t *queue = reinterpret_cast<uint32_t *>(scratch + kSetupWords);                  // 128 words
+    for (uint32_t i = threadIdx.x; i < tile_words; i += kTileThreads) tile32[i] = 0xffffffffu;
+    __syncthreads();
+
+    const float *M = poses[pose].m;
+    const float cmin0 = (float)bb.x, cmin1 = (float)bb.y, cmax0 = (float)bb.z, cmax1 = (float)bb.w;
+    const int dbase = ti.x;
+    bool bad = false;
+    for (uint32_t base = wave * 64u; base < n_tris; base += (kTileThreads / 64u) * 64u) {
+        const uint32_t t_i = base + lane;
+        TriSetup t;
+        int n = 0;
+        if (t_i < n_tris) {
+            tri_setup(reinterpret_cast<const float *>(tris + t_i), M, proj, width, height, cmin0, cmin1, cmax0, cmax1, t);
+            n = t.nx * t.ny;
+        } else { t.nx = t.ny = 0; t.x0 = t.y0 = 0; t.base_inv = 0; for (int k = 0; k < 3; ++k) t.px[k] = t.py[k] = t.w3[k] = 0; }
+        wave_raster(t, n, scratch, queue, [&](int x, int y, int d) {
+            const uint32_t off = (uint32_t)(y - bb.y) * (uint32_t)bw + (uint32_t)(x - bb.x);
+            const long long rel = (long long)d - (long long)dbase;
+            if (rel < 0 || rel > 65534) { bad = true; return; }   // cannot happen for an eligible hypothesis (tile_record); reported, never hidden
+            const uint32_t v = (uint32_t)rel, shift = (off & 1u) * 16u;
+            uint32_t *word = tile32 + (off >> 1);
+            uint32_t seen = *word;
+            for (;;) {
+                if (v >= ((seen >> shift) & 0xffffu)) break;
+                const uint32_t want = (seen & ~(0xffffu << shift)) | (v << shift);
+                const uint32_t prev = atomicCAS(word, seen, want);
+                if (prev == seen) break;
+                seen = prev;
+            }
+        });
+    }
+    if (__ballot(bad) != 0ull && lane == 0) atomicOr(overflow, 1u);
+    __syncthreads();
+
+    // write the box out (raster row y lands on image row height-1-y, renderer.cu:142) with its per-row counts; rows outside: count 0
+    int32_t *img = depth + (size_t)pose * width * height;
+    const uint16_t *tile16 = reinterpret_cast<const uint16_t *>(tile_raw);
+    for (uint32_t row = wave; row < height; row += kTileThreads / 64u) {
+        const int ry = (int)height - 1 - (int)row;
+        if (ry < bb.y || ry > bb.w) { if (lane == 0) rc[row] = 0u; continue; }
+        const uint32_t r = (uint32_t)(ry - bb.y);
+        uint32_t cnt = 0;
+        for (int c0 = 0; c0 < bw; c0 += 64) {
+            const int c = c0 + (int)lane;
+            int32_t dv = INT_MAX;
+            if (c < bw) {
+                const uint32_t v = tile16[r * (uint32_t)bw + (uint32_t)c];
+                dv = (v == 0xffffu) ? INT_MAX : dbase + (int32_t)v;
+                img[(size_t)row * width + (uint32_t)(bb.x + c)] = dv;
+            }
+            cnt += (uint32_t)__popcll(__ballot(c < bw && dv > 0 && dv != INT_MAX));
+        }
+        if (lane == 0) rc[row] = cnt;
     }
 }
 
@@ -1061,7 +1159,7 @@ __device__ __forceinline__ void grid_pyramid_bound(const SceneNNDev &s, float sx
     const float b = dall * 1.000001f + 1e-30f;                       // empty cells hold huge coordinates: inf
     if (b < best) best = b;
 }
-__device__ __forceinline__ bool grid_search(const SceneNNDev &s, float sx, float sy, float sz, float bound, uint32_t &winner)
+__device__ __forceinline__ bool grid_search(const SceneNNDev &s, float sx, float sy, float sz, float bound, uint32_t &winner, uint32_t *cells = nullptr)
 {
     int wx, wy;
     if (!grid_window(s, sx, sy, sz, bound, wx, wy)) return false;
@@ -1072,6 +1170,7 @@ __device__ __forceinline__ bool grid_search(const SceneNNDev &s, float sx, float
     const int x0 = max(cx0 - wx, 0), x1 = min(cx0 + wx, (int)s.gw - 1);
     const int y0 = max(cy0 - wy, 0), y1 = min(cy0 + wy, (int)s.gh - 1);
     if (x0 > x1 || y0 > y1) return false;
+    if (cells) *cells += (uint32_t)((x1 - x0 + 1) * (y1 - y0 + 1));
     float best = bound;
     int best_i = -1, ties = 0;
     for (int y = y0; y <= y1; ++y) {
@@ -1727,7 +1826,7 @@ __global__ __launch_bounds__(256) void nn_search_kernel(IcpBatch b, SceneNNDev s
     uint32_t chain = kNoPrev;                                    // winner of this lane's previous query of this pass
     const uint32_t j0 = first + threadIdx.x * run;
     NNCount cnt;
-    uint32_t n_query = 0, n_window = 0, n_tree = 0, n_pyramid = 0;
+    uint32_t n_query = 0, n_window = 0, n_tree = 0, n_pyramid = 0, n_cells = 0;
     for (uint32_t k = 0; k < run; ++k) {
         const uint32_t j = j0 + k;
         if (j >= n) break;
@@ -1749,7 +1848,7 @@ __global__ __launch_bounds__(256) void nn_search_kernel(IcpBatch b, SceneNNDev s
         // through the representative points.
         { int wx, wy; if (scene.grid && moved > PR_NN_STILL && !grid_window(scene, x, y, z, best, wx, wy)) { grid_pyramid_bound(scene, x, y, z, best); ++n_pyramid; } }
         uint32_t w = kNoPrev;
-        bool settled = scene.grid && best < accept && grid_search(scene, x, y, z, best, w);
+        bool settled = scene.grid && best < accept && grid_search(scene, x, y, z, best, w, &n_cells);
         ++n_query;
         if (settled) ++n_window;
         else {
@@ -1761,9 +1860,9 @@ __global__ __launch_bounds__(256) void nn_search_kernel(IcpBatch b, SceneNNDev s
         if (w != kNoPrev) chain = w;
     }
     if (scene.counters) {                                        // instrumented runs only (option "nn_count")
-        const uint32_t v[7] = { n_query, n_window, n_tree, n_pyramid, cnt.nodes, cnt.leaves, cnt.leaf_points };
+        const uint32_t v[8] = { n_query, n_window, n_tree, n_pyramid, cnt.nodes, cnt.leaves, cnt.leaf_points, n_cells };
 #pragma unroll
-        for (int i = 0; i < 7; ++i) {
+        for (int i = 0; i < 8; ++i) {
             uint32_t t = v[i];
             for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
             if ((threadIdx.x & 63u) == 0u) atomicAdd(&scene.counters[(size_t)b.iter * 8 + i], (unsigned long long)t);
@@ -2463,6 +2562,7 @@ __global__ __launch_bounds__(256) void nn_records32_kernel(const int4 *__restric
 // ================================================================================================
 //  launchers
 // ================================================================================================
+uint32_t tile_cap_px() { return kTileCapPx; }
 static inline uint32_t cap_grid(size_t want) { return (uint32_t)(want < 1 ? 1 : (want > 8192 ? 8192 : want)); }
 
 hipError_t launch_fill_i32(int32_t *dst, size_t n, int32_t v, hipStream_t s)
@@ -2488,7 +2588,7 @@ hipError_t launch_raster(const pr_triangle *tris, uint32_t n_tris, const pr_mat4
     for (uint32_t p0 = 0; p0 < n_poses; p0 += 32768) {
         const uint32_t np = (n_poses - p0 < 32768) ? (n_poses - p0) : 32768;
         hipLaunchKernelGGL(raster_kernel, dim3((n_tris + 255) / 256, np), dim3(256), 0, s, tris, n_tris, poses_dev + p0,
-                           depth + (size_t)p0 * rw * rh, width, height, proj, roi, rw, rh, (const int4 *)nullptr);
+                           depth + (size_t)p0 * rw * rh, width, height, proj, roi, rw, rh, (const int4 *)nullptr, (const int2 *)nullptr);
     }
     return hipGetLastError();
 }
@@ -2523,7 +2623,7 @@ hipError_t launch_render_bands(const pr_triangle *tris, uint32_t n_tris, const p
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(pose_bbox_kernel, dim3((n_poses + 255) / 256), dim3(256), 0, s, aabb, poses_dev, n_poses, proj, width, height, roi, bbox);
+    hipLaunchKernelGGL(pose_bbox_kernel, dim3((n_poses + 255) / 256), dim3(256), 0, s, aabb, poses_dev, n_poses, proj, width, height, roi, bbox, (int2 *)nullptr, 0u);
     hipError_t e = hipMemsetAsync(row_count, 0, sizeof(uint32_t) * (size_t)n_poses * height, s);
     if (e != hipSuccess) return e;
     const uint32_t rows_min = cap_px / width > 0 ? cap_px / width : 1;
@@ -2540,21 +2640,38 @@ hipError_t launch_render_bands(const pr_triangle *tris, uint32_t n_tris, const p
 hipError_t launch_render_boxes(const pr_triangle *tris, uint32_t n_tris, const pr_mat4 *poses_dev, uint32_t n_poses, const float *aabb,
                                int4 *bbox, int32_t *depth, uint32_t *row_count, uint32_t *row_off, uint32_t *counts,
                                uint32_t width, uint32_t height, const pr_mat4 &proj, pr_roi roi, hipStream_t s, bool compute_boxes,
-                               PoseMeta *meta, DevIcpState *st, uint32_t *arrive, uint32_t cloud_stride)
+                               PoseMeta *meta, DevIcpState *st, uint32_t *arrive, uint32_t cloud_stride,
+                               int2 *tile_info, uint32_t *overflow, bool all_tiled)
 {
     if (n_poses == 0) return hipSuccess;
     if (compute_boxes)
-        hipLaunchKernelGGL(pose_bbox_kernel, dim3((n_poses + 255) / 256), dim3(256), 0, s, aabb, poses_dev, n_poses, proj, width, height, roi, bbox);
+        hipLaunchKernelGGL(pose_bbox_kernel, dim3((n_poses + 255) / 256), dim3(256), 0, s, aabb, poses_dev, n_poses, proj, width, height, roi, bbox,
+                           tile_info, kTileCapPx);
     const pr_roi none{ 0, 0, 0, 0 };
-    for (uint32_t p0 = 0; p0 < n_poses; p0 += 32768) {
+    if (tile_info && n_tris > 0) {                               // hypotheses whose pixel box fits the LDS tile (see raster_tile_kernel)
+        static bool attr_set = false;
+        const size_t lds = (size_t)kTileCapPx * 2 + 16 + (size_t)(kTileThreads / 64) * (kSetupWords + 2) * 64 * sizeof(float);
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(raster_tile_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            attr_set = true;
+        }
+        for (uint32_t p0 = 0; p0 < n_poses; p0 += 32768) {
+            const uint32_t np = (n_poses - p0 < 32768) ? (n_poses - p0) : 32768;
+            hipLaunchKernelGGL(raster_tile_kernel, dim3(np), dim3(kTileThreads), lds, s, tris, n_tris, poses_dev + p0, bbox + p0, tile_info + p0,
+                               depth + (size_t)p0 * width * height, row_count + (size_t)p0 * height, width, height, proj, overflow);
+        }
+    }
+    const int2 *skip = (tile_info && n_tris > 0) ? tile_info : nullptr;
+    for (uint32_t p0 = 0; p0 < n_poses && !(skip && all_tiled); p0 += 32768) {
         const uint32_t np = (n_poses - p0 < 32768) ? (n_poses - p0) : 32768;
         const size_t off = (size_t)p0 * width * height;
-        hipLaunchKernelGGL(fill_box_kernel, dim3((height + kBoxRowsPerBlock - 1) / kBoxRowsPerBlock, np), dim3(256), 0, s, depth + off, bbox + p0, width, height);
+        hipLaunchKernelGGL(fill_box_kernel, dim3((height + kBoxRowsPerBlock - 1) / kBoxRowsPerBlock, np), dim3(256), 0, s, depth + off, bbox + p0, width, height, skip ? skip + p0 : nullptr);
         if (n_tris > 0)                                          // an empty mesh renders nothing: every cloud is empty
         hipLaunchKernelGGL(raster_kernel, dim3((n_tris + 255) / 256, np), dim3(256), 0, s, tris, n_tris, poses_dev + p0, depth + off,
-                           width, height, proj, none, width, height, (const int4 *)(bbox + p0));
+                           width, height, proj, none, width, height, (const int4 *)(bbox + p0), skip ? skip + p0 : nullptr);
         hipLaunchKernelGGL(count_box_kernel, dim3((height + kBoxRowsPerBlock - 1) / kBoxRowsPerBlock, np), dim3(256), 0, s, depth + off, bbox + p0, width, height,
-                           row_count + (size_t)p0 * height);
+                           row_count + (size_t)p0 * height, skip ? skip + p0 : nullptr);
     }
     if (meta) hipLaunchKernelGGL(d2c_scan_init_kernel, dim3(n_poses), dim3(256), 0, s, row_count, height, row_off, counts, meta, st, arrive, cloud_stride);
     else hipLaunchKernelGGL(d2c_scan_kernel, dim3(n_poses), dim3(256), 0, s, row_count, height, row_off, counts);

@@ -1,27 +1,53 @@
 #!/bin/bash
-# One GPU-box session that produces everything the round's evidence needs (run through gpurun):
-#   tests, smoke, bench lines (P=256 proj default, host solve, P=1024, NN), rocprofv3 kernel stats, PMC passes.
+# One GPU-box session that produces the round's evidence (run through gpurun): tests, smoke, bench lines, rocprofv3 kernel
+# stats, PMC passes, BASELINE configs[4], the 2-rank share-device run, the C++ shard driver.  Output: gpurun_out/round/
 set -u
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/round; mkdir -p $OUT
+B="timeout 600 python bench.py"
+summ() { python tools/rocpd_summary.py "$1"; }
 python -m pytest tests -m gpu -q 2>&1 | tail -3 > $OUT/pytest_gpu.txt; cat $OUT/pytest_gpu.txt
 python __graft_entry__.py --smoke 2>&1 | tail -2 > $OUT/smoke.txt; cat $OUT/smoke.txt
-python bench.py 2>/dev/null | tail -1 > $OUT/bench_p256_proj.json
-python bench.py --steps 40 --warmup 5 --solve host --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_p256_proj_hostsolve.json
-python bench.py --sequential --fused-solve 0 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_p256_proj_sequential_unfused.json
-python bench.py --steps 60 --poses 1024 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_p1024_proj.json
-python bench.py --steps 60 --poses 512 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_p512_proj.json
-python bench.py --steps 5 --warmup 2 --scene nn --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_p256_nn.json
-rocprofv3 --kernel-trace --stats -d $OUT/stats -o bench -- python bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.json 2>/dev/null
-python tools/rocpd_summary.py $OUT/stats/bench_results.db > $OUT/kernel_stats_bench.md
+$B 2>/dev/null | tail -1 > $OUT/bench_p256_proj.json
+$B --steps 20 --warmup 5 2>/dev/null | tail -1 > $OUT/bench_p256_proj_steps20.json
+$B --steps 40 --warmup 5 --solve host --no-cpu-baseline --no-kdtree-extra 2>/dev/null | tail -1 > $OUT/bench_p256_proj_hostsolve.json
+$B --sequential --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_p256_proj_sequential.json
+$B --sequential --fused-solve 0 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_p256_proj_sequential_unfused.json
+$B --steps 60 --poses 1024 --no-cpu-baseline --no-kdtree-extra 2>/dev/null | tail -1 > $OUT/bench_p1024_proj.json
+$B --steps 60 --poses 512 --no-cpu-baseline --no-kdtree-extra 2>/dev/null | tail -1 > $OUT/bench_p512_proj.json
+$B --steps 20 --warmup 3 --scene nn 2>/dev/null | tail -1 > $OUT/bench_p256_nn.json
+# rocprofv3 kernel stats of the same commands
+rocprofv3 --kernel-trace --stats -d $OUT/stats -o bench -- python bench.py --no-cpu-baseline --no-kdtree-extra > $OUT/bench_under_rocprof.json 2>/dev/null
+summ $OUT/stats/bench_results.db > $OUT/kernel_stats_bench_p256.md
 rocprofv3 --kernel-trace --stats -d $OUT/stats1 -o bench -- python bench.py --sequential --no-cpu-baseline > $OUT/bench_under_rocprof_sequential.json 2>/dev/null
-python tools/rocpd_summary.py $OUT/stats1/bench_results.db > $OUT/kernel_stats_bench_sequential.md
-python bench.py --sequential --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_p256_proj_sequential.json
-for c in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"; do n=$(echo $c | tr " " "_"); rocprofv3 --kernel-trace --pmc $c -d $OUT/pmc -o pmc_$n -- python tools/pmc_workload.py 256 > /dev/null 2>&1; python tools/rocpd_summary.py $OUT/pmc/pmc_${n}_results.db | sed -n '/PMC counters/,$p' > $OUT/pmc_$n.md; done
-for c in "FETCH_SIZE" "WRITE_SIZE"; do rocprofv3 --kernel-trace --pmc $c -d $OUT/pmc -o pmc1024_$c -- python tools/pmc_workload.py 1024 > /dev/null 2>&1; python tools/rocpd_summary.py $OUT/pmc/pmc1024_${c}_results.db | sed -n '/PMC counters/,$p' > $OUT/pmc1024_$c.md; done
-rm -rf $OUT/stats $OUT/stats1 $OUT/pmc
+summ $OUT/stats1/bench_results.db > $OUT/kernel_stats_bench_p256_sequential.md
+rocprofv3 --kernel-trace --stats -d $OUT/stats2 -o bench -- python bench.py --steps 20 --warmup 3 --scene nn --no-cpu-baseline > $OUT/bench_nn_under_rocprof.json 2>/dev/null
+summ $OUT/stats2/bench_results.db > $OUT/kernel_stats_bench_p256_nn.md
+# PMC passes (each counter set in a run of its own): HBM bytes of the correspondence kernels, projective and kd-tree
+for c in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"; do n=$(echo $c | tr " " "_")
+  PR_RASTER_MODE=0 timeout 300 rocprofv3 --kernel-trace --pmc $c -d $OUT/pmc -o p_$n -- python tools/pmc_workload.py 256 > /dev/null 2>&1
+  summ $OUT/pmc/p_${n}_results.db | sed -n '/PMC counters/,$p' | grep -E "counter|---|icp_pass|max2zero|fill_i32|raster_kernel" > $OUT/pmc_proj_$n.md
+  PR_RASTER_MODE=0 timeout 300 rocprofv3 --kernel-trace --pmc $c -d $OUT/pmc -o n_$n -- python tools/pmc_workload.py 256 nn > /dev/null 2>&1
+  summ $OUT/pmc/n_${n}_results.db | sed -n '/PMC counters/,$p' | grep -E "counter|---|icp_pass|nn_search|max2zero|fill_i32" > $OUT/pmc_nn_$n.md
+done
+for c in "SQ_INSTS_VALU SQ_INSTS_VMEM SQ_INSTS_LDS" "SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TOTAL_ACCESSES_sum" "TA_BUSY_avr TA_TA_BUSY_sum GRBM_GUI_ACTIVE"; do n=$(echo $c | tr " " "_")
+  PR_RASTER_MODE=0 timeout 300 rocprofv3 --kernel-trace --pmc $c -d $OUT/pmc -o s_$n -- python tools/pmc_workload.py 256 nn > /dev/null 2>&1
+  summ $OUT/pmc/s_${n}_results.db | sed -n '/PMC counters/,$p' | grep -E "counter|---|nn_search|icp_pass" > $OUT/sq_nn_$n.md
+done
+python tools/nn_counters.py > $OUT/nn_work_counters.md 2>/dev/null
+bash tools/nn_passes.sh "nn_split=1" "nn_split=0" 2>/dev/null | grep -E "==|us:" > $OUT/nn_per_pass_us.txt
+# BASELINE configs[4]: 1M triangles, 1280x720, 128 hypotheses (the per-GPU share of 1024 over 8)
+timeout 600 python tools/config5.py 128 --check > $OUT/config5.txt 2>&1; tail -4 $OUT/config5.txt
+rocprofv3 --kernel-trace --stats -d $OUT/stats3 -o c5 -- python tools/config5.py 128 > /dev/null 2>&1
+summ $OUT/stats3/c5_results.db > $OUT/kernel_stats_config5.md
+# two ranks on the one GPU of this box (gloo gather on host copies; everything else is the N > 1 code path)
+PR_BENCH_SHARE_DEVICE=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 40 --warmup 5 2>/dev/null | tail -1 > $OUT/bench_2ranks_share_device.json
+# C++ host: shard driver
+g++ -std=c++14 -O2 -pthread -Iinclude tests/cpp/shard_test.cpp -o tests/cpp/shard_test -Lpose_refine_amd/lib -lpose_refine_hip -Wl,-rpath,$PWD/pose_refine_amd/lib && ./tests/cpp/shard_test tests/golden/ 4096 2>&1 | tail -1 > $OUT/shard_test_4096.json; cat $OUT/shard_test_4096.json
+rm -rf $OUT/stats $OUT/stats1 $OUT/stats2 $OUT/stats3 $OUT/pmc
 lscpu | grep -E 'Model name|^CPU\(s\)|Socket|Core' > $OUT/host_cpu.txt
 for f in $OUT/bench_*.json; do echo "== $f"; python -c "
-import json,sys
+import json
 d=json.loads(open('$f').read().strip().splitlines()[-1])
-print('%.0f poses/s  %.3f ms/step  frac %.3f  launch %.1f us' % (d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['avg_launch_us']), d.get('cpu_baseline',''))"; done
+r=d['roofline']
+print('%.0f poses/s  %.3f ms/step  frac %.3f  launch %.1f us' % (d['value'], d['ms_per_step'], r['frac'], r['avg_launch_us']), d.get('cpu_baseline',{}).get('value',''), d.get('config2_kdtree',{}).get('value',''))"; done
