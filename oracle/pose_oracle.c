@@ -624,8 +624,8 @@ static inline void point29(const po_vec3 *cloud, size_t j, int kind, const void 
 
 /* The canonical tree the HIP kernels implement:
  *   workgroup = 256 lanes = 4 wavefronts; workgroup g owns points [g*PPB, (g+1)*PPB), PPB = 1024*S;
- *   lane t accumulates, starting from 0, points g*PPB + s*1024 + 4*t + i for s=0..S-1, i=0..3 in
- *   that order; each wavefront is reduced by a balanced pairwise tree over its 64 lanes in lane
+ *   lane t accumulates, starting from 0, points g*PPB + s*1024 + 256*i + t for s=0..S-1, i=0..3 in
+ *   that order (adjacent lanes hold adjacent points); each wavefront is reduced by a balanced pairwise tree over its 64 lanes in lane
  *   order (adjacent pairs first); the 4 wavefront sums are added as ((w0+w1)+w2)+w3; workgroup
  *   sums are added sequentially in workgroup order starting from 0. */
 static void sum29_canonical(const po_vec3 *cloud, size_t n, int kind, const void *scene,
@@ -642,7 +642,7 @@ static void sum29_canonical(const po_vec3 *cloud, size_t n, int kind, const void
             for (int c = 0; c < 29; c++) acc[c] = 0;
             for (uint32_t s = 0; s < steps; s++)
                 for (int i = 0; i < 4; i++) {
-                    size_t j = g * (size_t)ppb + (size_t)s * 1024 + (size_t)t * 4 + i;
+                    size_t j = g * (size_t)ppb + (size_t)s * 1024 + (size_t)i * 256 + (size_t)t;
                     if (j >= n) continue;
                     float c29[29];
                     point29(cloud, j, kind, scene, c29);

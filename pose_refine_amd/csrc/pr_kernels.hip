@@ -729,6 +729,7 @@ __global__ __launch_bounds__(256) void d2c_emit_kernel(const T *__restrict__ dep
 // ================================================================================================
 //  scene queries
 // ================================================================================================
+typedef float float2v __attribute__((ext_vector_type(2)));
 struct Corr { float dx, dy, dz, nx, ny, nz; };   // destination point and its normal
 
 // Correctly rounded a / b for every operand pair whose quotient is in the normal range: the Newton/FMA sequence the
@@ -755,9 +756,21 @@ __device__ __forceinline__ bool proj_pixel(float sx, float sy, float sz, float f
                                            uint32_t width, uint32_t height, uint32_t &idx, int &px, int &py)
 {
     // common.h:64-67: int(x/z*fx + cx - tl_x + 0.5f); tl_* are size_t in the reference and enter the float expression converted
-    // to float (0.0f for a scene that covers the whole frame -- subtracting it is exact)
-    const float vx = div_normal_range(sx, sz) * fx + cx - tlx + 0.5f;
-    const float vy = div_normal_range(sy, sz) * fy + cy - tly + 0.5f;
+    // to float (0.0f for a scene that covers the whole frame -- subtracting it is exact).
+    // Both coordinates go through div_normal_range's sequence side by side in packed instructions (v_pk_mul_f32 / v_pk_fma_f32 /
+    // v_pk_add_f32: two IEEE operations per issue slot, each element rounded exactly like the scalar form); the reciprocal of z and
+    // its first refinement are shared.
+    float r = __builtin_amdgcn_rcpf(sz);
+    const float e0 = __builtin_fmaf(-sz, r, 1.0f);
+    r = __builtin_fmaf(e0, r, r);
+    const float2v a{ sx, sy }, rr{ r, r }, nz{ -sz, -sz };
+    float2v q = a * rr;
+    const float2v e1 = __builtin_elementwise_fma(nz, q, a);
+    q = __builtin_elementwise_fma(e1, rr, q);
+    const float2v e2 = __builtin_elementwise_fma(nz, q, a);
+    q = __builtin_elementwise_fma(e2, rr, q);
+    const float2v v = q * float2v{ fx, fy } + float2v{ cx, cy } - float2v{ tlx, tly } + float2v{ 0.5f, 0.5f };
+    const float vx = v.x, vy = v.y;
     if (!(vx > -1.0f && vx < (float)width && vy > -1.0f && vy < (float)height)) return false;
     px = (int)vx; py = (int)vy;
     idx = (uint32_t)px + (uint32_t)py * width;
@@ -1217,46 +1230,57 @@ __device__ __forceinline__ void grid_seed_bound(const SceneNNDev &s, float sx, f
 // The 29 running sums of a lane are kept as 15 register pairs: v_pk_mul_f32 / v_pk_add_f32 do two IEEE single-precision
 // operations per issue slot (separate multiply and add, no contraction), so every sum sees exactly the operations of the
 // scalar form (pcd2Ab functor, icp.h:86-136) at roughly half the instruction count.
-typedef float float2v __attribute__((ext_vector_type(2)));
 #ifndef PR_PACKED_ACC
 #define PR_PACKED_ACC 1
 #endif
 #if PR_PACKED_ACC
-struct Acc29 { float2v pk[15]; };
+// 16 register pairs.  The four natural pairs of a correspondence -- C01 = (J0, J1) and C2R = (J2, r) computed here, N01 = (J3, J4) =
+// (nx, ny) and N2Z = (J5, z) = (nz, dz) as the scene record delivers them -- are multiplied pair by pair: a packed instruction may
+// take either half of each operand for each of its two results (op_sel), so every instruction below forms two of the 27 products
+// without a single register move (the previous pairing needed 11 v_mov per point to line its operands up).  Three result halves
+// are surplus (a repeated J1*J0, J4*J3 and dz*J5) and accumulate in halves that are never exported.
+//   pair k holds the sums kAccLo[k], kAccHi[k] (icp.h:138-206 numbering; -1 = surplus)
+struct Acc29 { float2v pk[16]; };
+__device__ constexpr int kAccLo[16] = { 0, 6, 2, 7, 3, 8, 5, 11, 12, 24, 14, 15, 18, 17, 20, 27 };
+__device__ constexpr int kAccHi[16] = { 1, -1, 21, 22, 4, 9, 10, 23, 13, 25, 26, 16, -1, 19, -1, 28 };
 __device__ __forceinline__ void acc_clear(Acc29 &a) {
 #pragma unroll
-    for (int i = 0; i < 15; ++i) a.pk[i] = float2v{ 0.0f, 0.0f };
+    for (int i = 0; i < 16; ++i) a.pk[i] = float2v{ 0.0f, 0.0f };
 }
 __device__ __forceinline__ void acc_export(const Acc29 &a, float (&out)[29]) {
 #pragma unroll
-    for (int i = 0; i < 29; ++i) out[i] = (i & 1) ? a.pk[i >> 1].y : a.pk[i >> 1].x;
+    for (int i = 0; i < 16; ++i) { if (kAccLo[i] >= 0) out[kAccLo[i]] = a.pk[i].x; if (kAccHi[i] >= 0) out[kAccHi[i]] = a.pk[i].y; }
 }
+#define PR_SEL(v, i, j) __builtin_shufflevector(v, v, i, j)
 __device__ __forceinline__ void accumulate(Acc29 &acc, float sx, float sy, float sz, const Corr &c)
 {
     const float ex = c.dx - sx, ey = c.dy - sy, ez = c.dz - sz;
     const float r = ex * c.nx + ey * c.ny + ez * c.nz;
-    const float J0 = c.nz * sy - c.ny * sz;
-    const float J1 = c.nx * sz - c.nz * sx;
-    const float J2 = c.ny * sx - c.nx * sy;
-    const float J3 = c.nx, J4 = c.ny, J5 = c.nz;
+    const float2v C01{ c.nz * sy - c.ny * sz, c.nx * sz - c.nz * sx };
+    const float2v C2R{ c.ny * sx - c.nx * sy, r };
+    const float2v N01{ c.nx, c.ny };
+    const float2v N2Z{ c.nz, c.dz };
     const float e2 = ex * ex + ey * ey + ez * ez;
-    // sums 0..20: J[a]*J[b] for a <= b, row-major; 21..26: J[a]*r; 27: squared distance; 28: count
-    acc.pk[0]  += float2v{ J0, J0 } * float2v{ J0, J1 };
-    acc.pk[1]  += float2v{ J0, J0 } * float2v{ J2, J3 };
-    acc.pk[2]  += float2v{ J0, J0 } * float2v{ J4, J5 };
-    acc.pk[3]  += float2v{ J1, J1 } * float2v{ J1, J2 };
-    acc.pk[4]  += float2v{ J1, J1 } * float2v{ J3, J4 };
-    acc.pk[5]  += float2v{ J1, J2 } * float2v{ J5, J2 };
-    acc.pk[6]  += float2v{ J2, J2 } * float2v{ J3, J4 };
-    acc.pk[7]  += float2v{ J2, J3 } * float2v{ J5, J3 };
-    acc.pk[8]  += float2v{ J3, J3 } * float2v{ J4, J5 };
-    acc.pk[9]  += float2v{ J4, J4 } * float2v{ J4, J5 };
-    acc.pk[10] += float2v{ J5, J0 } * float2v{ J5, r };
-    acc.pk[11] += float2v{ J1, J2 } * float2v{ r, r };
-    acc.pk[12] += float2v{ J3, J4 } * float2v{ r, r };
-    acc.pk[13] += float2v{ J5 * r, e2 };
-    acc.pk[14] += float2v{ 1.0f, 0.0f };
+    // sums 0..20: J[a]*J[b] for a <= b, row-major; 21..26: J[a]*r; 27: squared distance; 28: count.  IEEE multiplication
+    // commutes, so r*J[a] and J[a]*r are the same float.
+    acc.pk[0]  += PR_SEL(C01, 0, 0) * C01;                        // J0J0, J0J1
+    acc.pk[1]  += PR_SEL(C01, 1, 1) * PR_SEL(C01, 1, 0);          // J1J1, (J1J0)
+    acc.pk[2]  += PR_SEL(C01, 0, 0) * C2R;                        // J0J2, J0r
+    acc.pk[3]  += PR_SEL(C01, 1, 1) * C2R;                        // J1J2, J1r
+    acc.pk[4]  += PR_SEL(C01, 0, 0) * N01;                        // J0J3, J0J4
+    acc.pk[5]  += PR_SEL(C01, 1, 1) * N01;                        // J1J3, J1J4
+    acc.pk[6]  += C01 * PR_SEL(N2Z, 0, 0);                        // J0J5, J1J5
+    acc.pk[7]  += PR_SEL(C2R, 0, 0) * C2R;                        // J2J2, J2r
+    acc.pk[8]  += PR_SEL(C2R, 0, 0) * N01;                        // J2J3, J2J4
+    acc.pk[9]  += PR_SEL(C2R, 1, 1) * N01;                        // J3r,  J4r
+    acc.pk[10] += C2R * PR_SEL(N2Z, 0, 0);                        // J2J5, J5r
+    acc.pk[11] += PR_SEL(N01, 0, 0) * N01;                        // J3J3, J3J4
+    acc.pk[12] += PR_SEL(N01, 1, 1) * PR_SEL(N01, 1, 0);          // J4J4, (J4J3)
+    acc.pk[13] += N01 * PR_SEL(N2Z, 0, 0);                        // J3J5, J4J5
+    acc.pk[14] += PR_SEL(N2Z, 0, 0) * N2Z;                        // J5J5, (J5 dz)
+    acc.pk[15] += float2v{ e2, 1.0f };
 }
+#undef PR_SEL
 #else
 struct Acc29 { float v[29]; };
 __device__ __forceinline__ void acc_clear(Acc29 &a) {
@@ -1296,8 +1320,7 @@ __device__ __forceinline__ void accumulate_score(Acc29 &acc, float sx, float sy,
     const float ex = c.dx - sx, ey = c.dy - sy, ez = c.dz - sz;
     const float e2 = ex * ex + ey * ey + ez * ez;
 #if PR_PACKED_ACC
-    acc.pk[13].y += e2;
-    acc.pk[14].x += 1.0f;
+    acc.pk[15] += float2v{ e2, 1.0f };
 #else
     acc.v[27] += e2;
     acc.v[28] += 1.0f;
@@ -1491,53 +1514,54 @@ __device__ __forceinline__ void vb_accumulate(float (&acc_out)[29], float *cl, u
                                               uint32_t *nn_prev = nullptr, bool nn_seeded = false)
 {
     (void)nn_prev; (void)nn_seeded;
-    const bool vec_ok = ((reinterpret_cast<uintptr_t>(cl) & 15u) == 0);
     struct { uint32_t steps; } b{ steps };
     Acc29 acc;                                                   // the caller's sums start at zero
     acc_clear(acc);
     uint32_t lane_winner = kNoPrev;                              // kd-tree scenes: the last neighbour this lane found (spatial seed)
     (void)lane_winner;
     (void)lds_topo; (void)stk_node; (void)stk_lb;
-    // one 1024-point step of this lane: 4 consecutive points = 48 contiguous bytes
-    auto load_step = [&](uint32_t s, float (&p)[12], uint32_t &j0, uint32_t &cnt, bool &full) {
-        j0 = first + s * kPointsPerStep + threadIdx.x * kPointsPerLane;
-        cnt = (j0 >= n) ? 0u : ((n - j0 < kPointsPerLane) ? (n - j0) : kPointsPerLane);
-        full = vec_ok && cnt == kPointsPerLane;
-        if (full) {
-            const float4 *src = reinterpret_cast<const float4 *>(cl + (size_t)j0 * 3);
-            const float4 a0 = src[0], a1 = src[1], a2 = src[2];
-            p[0] = a0.x; p[1] = a0.y; p[2] = a0.z; p[3] = a0.w; p[4] = a1.x; p[5] = a1.y;
-            p[6] = a1.z; p[7] = a1.w; p[8] = a2.x; p[9] = a2.y; p[10] = a2.z; p[11] = a2.w;
-        } else {
+    // One 1024-point step: lane t takes points first + s*1024 + i*256 + t, i = 0..3 -- ADJACENT LANES HOLD ADJACENT CLOUD POINTS,
+    // i.e. neighbouring pixels of the rendered hypothesis.  The cloud moves as 12-byte loads / stores that are contiguous across
+    // the wavefront (768 B per instruction), and -- what matters -- the 64 scene gathers of an instruction land on neighbouring
+    // scene pixels: 8-10 cache lines instead of the 32+ of a stride-4 mapping.  The pass is bound by the texture addresser / L1
+    // rate of exactly those gathers (TA busy 64 %, VALU 54 %: profiles/r02/sq_proj_*.md), not by issue slots or HBM.
+    auto point_of = [&](uint32_t j0, uint32_t i) { return j0 + i * kBlockThreads; };
+    auto load_step = [&](uint32_t s, float (&p)[12], uint32_t &j0, uint32_t &cnt) {
+        j0 = first + s * kPointsPerStep + threadIdx.x;
+        cnt = (j0 >= n) ? 0u : (((n - j0 + kBlockThreads - 1u) / kBlockThreads < kPointsPerLane) ? (n - j0 + kBlockThreads - 1u) / kBlockThreads : kPointsPerLane);
 #pragma unroll
-            for (uint32_t i = 0; i < 12; ++i) p[i] = (i < cnt * 3) ? cl[(size_t)j0 * 3 + i] : 0.0f;
+        for (uint32_t i = 0; i < 4; ++i) {
+            pr_vec3 v{ 0.0f, 0.0f, 0.0f };
+            if (i < cnt) v = reinterpret_cast<const pr_vec3 *>(cl)[point_of(j0, i)];
+            p[3 * i] = v.x; p[3 * i + 1] = v.y; p[3 * i + 2] = v.z;
         }
     };
-    auto process_step = [&](float (&p)[12], uint32_t j0, uint32_t cnt, bool full) {
+    auto process_step = [&](float (&p)[12], uint32_t j0, uint32_t cnt) {
         if (cnt == 0) return;
         if (xf) {                                                // icp.cu:142-153 transform_pcd_cuda, fused
+            // rows 0 and 1 of the update side by side in packed instructions (same per-element operations, same order:
+            // ((m0*x + m1*y) + m2*z) + m3), row 2 scalar
+            const float2v Mx{ M[0], M[4] }, My{ M[1], M[5] }, Mz{ M[2], M[6] }, Mt{ M[3], M[7] };
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float x = p[3 * i], y = p[3 * i + 1], z = p[3 * i + 2];
-                p[3 * i]     = M[0] * x + M[1] * y + M[2]  * z + M[3];
-                p[3 * i + 1] = M[4] * x + M[5] * y + M[6]  * z + M[7];
+                float2v t = Mx * float2v{ x, x };
+                t = t + My * float2v{ y, y };
+                t = t + Mz * float2v{ z, z };
+                t = t + Mt;
+                p[3 * i]     = t.x;
+                p[3 * i + 1] = t.y;
                 p[3 * i + 2] = M[8] * x + M[9] * y + M[10] * z + M[11];
             }
-            if (full) {
-                float4 *dst = reinterpret_cast<float4 *>(cl + (size_t)j0 * 3);
-                dst[0] = make_float4(p[0], p[1], p[2], p[3]);
-                dst[1] = make_float4(p[4], p[5], p[6], p[7]);
-                dst[2] = make_float4(p[8], p[9], p[10], p[11]);
-            } else {
 #pragma unroll
-                for (uint32_t i = 0; i < 12; ++i) if (i < cnt * 3) cl[(size_t)j0 * 3 + i] = p[i];
-            }
+            for (uint32_t i = 0; i < 4; ++i)
+                if (i < cnt) reinterpret_cast<pr_vec3 *>(cl)[point_of(j0, i)] = pr_vec3{ p[3 * i], p[3 * i + 1], p[3 * i + 2] };
         }
         if constexpr (kNN && kStack == -1) {
             // winners of the search kernel: four indices, then the four (point, normal) pairs, all in flight before the first use
             uint32_t w[4];
 #pragma unroll
-            for (uint32_t i = 0; i < 4; ++i) w[i] = (i < cnt) ? scene.winner[j0 + i] : kNoPrev;
+            for (uint32_t i = 0; i < 4; ++i) w[i] = (i < cnt) ? scene.winner[point_of(j0, i)] : kNoPrev;
             float4 d[4]; float nx[4], ny[4], nz[4];
 #pragma unroll
             for (uint32_t i = 0; i < 4; ++i) {
@@ -1560,11 +1584,11 @@ __device__ __forceinline__ void vb_accumulate(float (&acc_out)[29], float *cl, u
                     Corr c;
                     bool ok;
                     if constexpr (kStack > 0) {
-                        const uint32_t seed = (nn_prev && nn_seeded) ? nn_prev[j0 + i] : kNoPrev;
+                        const uint32_t seed = (nn_prev && nn_seeded) ? nn_prev[point_of(j0, i)] : kNoPrev;
                         uint32_t winner;
                         ok = query_nn_stack<kStack>(scene, reinterpret_cast<const float4 *>(lds_topo), stk_node, stk_lb, p[3 * i], p[3 * i + 1], p[3 * i + 2], c,
                                                     seed, nn_prev ? lane_winner : kNoPrev, winner);
-                        if (nn_prev) nn_prev[j0 + i] = ok ? winner : kNoPrev;
+                        if (nn_prev) nn_prev[point_of(j0, i)] = ok ? winner : kNoPrev;
                         if (ok) lane_winner = winner;
                     } else ok = query_nn<true>(scene, lds_topo, p[3 * i], p[3 * i + 1], p[3 * i + 2], c);
                     if (ok) { if constexpr (kScoreOnly) accumulate_score(acc, p[3 * i], p[3 * i + 1], p[3 * i + 2], c); else accumulate(acc, p[3 * i], p[3 * i + 1], p[3 * i + 2], c); }
@@ -1601,10 +1625,10 @@ __device__ __forceinline__ void vb_accumulate(float (&acc_out)[29], float *cl, u
 
     for (uint32_t s = 0; s < b.steps; ++s) {
         float p[12];
-        uint32_t j0, cnt; bool full;
-        load_step(s, p, j0, cnt, full);
+        uint32_t j0, cnt;
+        load_step(s, p, j0, cnt);
         if (cnt == 0) break;
-        process_step(p, j0, cnt, full);
+        process_step(p, j0, cnt);
     }
     acc_export(acc, acc_out);
 }
