@@ -771,10 +771,22 @@ __device__ __forceinline__ bool proj_pixel(float sx, float sy, float sz, float f
     q = __builtin_elementwise_fma(e2, rr, q);
     const float2v v = q * float2v{ fx, fy } + float2v{ cx, cy } - float2v{ tlx, tly } + float2v{ 0.5f, 0.5f };
     const float vx = v.x, vy = v.y;
+    // no early exit: the conversions of an out-of-range value saturate harmlessly and the caller only uses px / py / idx when
+    // the test passed (straight-line code keeps the packed values out of merge copies)
+#ifndef PR_BRANCHLESS_PROJ
+#define PR_BRANCHLESS_PROJ 0                                   // measured (tools/ab_flags.sh, same box): the straight-line form is 1.8 % slower
+#endif
+#if PR_BRANCHLESS_PROJ
+    const bool in_img = (vx > -1.0f) & (vx < (float)width) & (vy > -1.0f) & (vy < (float)height);
+    px = (int)vx; py = (int)vy;
+    idx = (uint32_t)px + (uint32_t)py * width;
+    return in_img;
+#else
     if (!(vx > -1.0f && vx < (float)width && vy > -1.0f && vy < (float)height)) return false;
     px = (int)vx; py = (int)vy;
     idx = (uint32_t)px + (uint32_t)py * width;
     return true;
+#endif
 }
 
 __device__ __forceinline__ bool query(const SceneProjAoS &s, float sx, float sy, float sz, Corr &c)
@@ -837,7 +849,7 @@ __device__ __forceinline__ bool gather_finish(const SceneProjAoS &s, bool in_img
 __device__ __forceinline__ bool gather_issue(const SceneProjPacked &s, float sx, float sy, float sz, bool live, Gathered &g)
 {
     uint32_t idx; int px, py;
-    const bool in_img = live && proj_pixel(sx, sy, sz, s.fx, s.fy, s.cx, s.cy, s.tlx, s.tly, s.width, s.height, idx, px, py);
+    const bool in_img = proj_pixel(sx, sy, sz, s.fx, s.fy, s.cx, s.cy, s.tlx, s.tly, s.width, s.height, idx, px, py) & live;
     const float4 r = s.rec[in_img ? idx : 0u];                    // {nx, ny, nz, z}
     g.a0 = r.x; g.a1 = r.y; g.a2 = r.z; g.a3 = r.w;
     g.b0 = s.colf[in_img ? px : 0]; g.b1 = s.rowf[in_img ? py : 0]; g.b2 = 0.0f;
@@ -1529,10 +1541,12 @@ __device__ __forceinline__ void vb_accumulate(float (&acc_out)[29], float *cl, u
     auto load_step = [&](uint32_t s, float (&p)[12], uint32_t &j0, uint32_t &cnt) {
         j0 = first + s * kPointsPerStep + threadIdx.x;
         cnt = (j0 >= n) ? 0u : (((n - j0 + kBlockThreads - 1u) / kBlockThreads < kPointsPerLane) ? (n - j0 + kBlockThreads - 1u) / kBlockThreads : kPointsPerLane);
+        // unconditional loads (a lane past the end re-reads the cloud's last point and never uses it: `i < cnt` gates every use)
+        const uint32_t last = n - 1u;                                // n >= 1 here: the workgroup has points
 #pragma unroll
         for (uint32_t i = 0; i < 4; ++i) {
-            pr_vec3 v{ 0.0f, 0.0f, 0.0f };
-            if (i < cnt) v = reinterpret_cast<const pr_vec3 *>(cl)[point_of(j0, i)];
+            const uint32_t j = point_of(j0, i);
+            const pr_vec3 v = reinterpret_cast<const pr_vec3 *>(cl)[j < last ? j : last];
             p[3 * i] = v.x; p[3 * i + 1] = v.y; p[3 * i + 2] = v.z;
         }
     };
