@@ -267,8 +267,8 @@ int pr_gather_results(const pr_result *send_dev, uint32_t n_local, uint32_t n_to
  *   "nn_stack"         [1]     kd-tree query: per-lane LDS stack (1) or the reference's stackless walk (0)
  *   "nn_compact"       [1]     stack query on 32-byte node records with 16-bit outward-rounded boxes (0: exact 64-byte records)
  *   "nn_seed"          [1]     compact records: start every search from the previous pass' / previous point's winner distance
- *   "nn_split"         [1]     compact records: the search runs in a kernel of its own (a lane walks "nn_run" [16] consecutive cloud
- *                              points, each query bounded by the previous one's winner) and the pass gathers its winners
+ *   "nn_split"         [1]     compact records: the search runs in a kernel of its own (adjacent lanes = adjacent cloud points, a workgroup
+ *                              takes "nn_run" [1] chunks of 256 points) and the pass gathers its winners in canonical order
  *   "nn_count"         [0]     instrumented runs: the search kernel counts its work (pr_nn_counters)
  *   "nn_grid"          [1]     fused refinement with a kd-tree scene made from a depth image: scene points are also indexed by pixel
  *                              (first bounds, and an exact window scan once the bound is a few pixels wide)

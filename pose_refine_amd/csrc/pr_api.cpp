@@ -129,7 +129,7 @@ struct Options {
     int nn_compact = 1;              // stack traversal: 32-byte node records with 16-bit outward-rounded child boxes (half the L1 traffic)
     int nn_stack = 1;                // kd-tree query: per-lane LDS stack (1) or the reference's stackless walk (0)
     int nn_split = 1;                // kd-tree scenes on compact records: search kernel (runs of consecutive points, grid window) + winners pass
-    int nn_run = 1;                  // consecutive cloud points a lane of the search kernel walks
+    int nn_run = 1;                  // 256-point chunks a workgroup of the search kernel takes (lane t of chunk k: point 256 k + t)
     int nn_grid = 1;                 // fused path: pixel grid of the scene points (seeds + window search); 0 = tree only
     int nn_count = 0;                // instrumented runs: the search kernel counts its work per pass (pr_nn_counters)
     int overlap_pass = -1;           // asynchronous path: the other slot's render may start once this slot has issued this pass of its loop
@@ -523,8 +523,13 @@ int icp_drive(pr_vec3 *cloud_base, const uint32_t *start_h, const uint32_t *coun
     if (sc.kind == PR_SCENE_NN && sc.nn.rec32 && (opt.nn_seed || sc.nn_split)) {     // winners, indexed like the cloud points
         size_t span = 1;
         for (uint32_t i = 0; i < P; ++i) span = std::max(span, (size_t)start_h[i] + count_h[i]);
-        PR_TRY(g->nn_prev.ensure(sizeof(uint32_t) * span));
+        // winners | slack of the keep-the-winner test | queue of unsettled queries (8 B each) | two queue counters per hypothesis
+        PR_TRY(g->nn_prev.ensure(sizeof(uint32_t) * (span * 4 + 2 * (size_t)P) + 64));
         b.nn_prev = g->nn_prev.as<uint32_t>();
+        b.nn_slack = reinterpret_cast<float *>(b.nn_prev + span);
+        b.nn_queue = reinterpret_cast<uint2 *>(b.nn_prev + 2 * span);
+        b.nn_qcount = b.nn_prev + 4 * span;
+        HIP_TRY(hipMemsetAsync(b.nn_qcount, 0, sizeof(uint32_t) * 2 * P, g->stream));
     }
 
     prk::PoseMeta *h_meta = g->h_meta.as<prk::PoseMeta>();
@@ -623,7 +628,7 @@ int icp_drive(pr_vec3 *cloud_base, const uint32_t *start_h, const uint32_t *coun
                     const uint32_t p0 = group_begin(grp), np = group_begin(grp + 1) - p0;
                     hipStream_t st = grp ? g->side[grp - 1] : g->stream;
                     prk::IcpBatch bb = b;
-                    bb.meta += p0; bb.partial += (size_t)p0 * nblk * prk::kAccStride;
+                    bb.meta += p0; bb.partial += (size_t)p0 * nblk * prk::kAccStride; if (bb.nn_qcount) bb.nn_qcount += 2 * (size_t)p0;
                     bb.iter = it;
                     if (fused) { bb.fused = 1; bb.crit = crit; bb.st = g->dstate.as<prk::DevIcpState>() + p0; bb.arrive = g->arrive.as<uint32_t>() + p0; }
                     bb.score_only = (it == (uint32_t)crit.max_iteration) ? 1u : 0u;

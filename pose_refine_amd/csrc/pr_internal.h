@@ -47,6 +47,11 @@ struct IcpBatch {
     DevIcpState    *st;         // [P]
     uint32_t       *arrive;     // [P] zero before the first pass; the solving workgroup re-zeroes its entry
     uint32_t       *nn_prev;    // kd-tree scenes: per cloud point (same indexing as `cloud`) the scene index of the previous pass' winner, or null
+    float          *nn_slack;   // kd-tree scenes, search kernel: per cloud point, a lower bound on the distance of every scene point OTHER than the
+                                // winner, minus the distance the point has travelled since that bound was established (<= 0: none)
+    uint2          *nn_queue;   // search kernel -> tree kernel: per hypothesis (same indexing as the cloud) the (point, bound) of every query the first
+                                // half could not settle;  nn_qcount: two counters per hypothesis (same pose indexing as `meta`), alternating per pass
+    uint32_t       *nn_qcount;
     uint32_t        pre_transformed;   // 1: the pending update has already been applied to the cloud (nn_search_kernel): the pass must not apply it again
     pr_criteria     crit;
 };

@@ -730,6 +730,12 @@ __global__ __launch_bounds__(256) void d2c_emit_kernel(const T *__restrict__ dep
 //  scene queries
 // ================================================================================================
 typedef float float2v __attribute__((ext_vector_type(2)));
+// base + 32-bit byte offset: lets the compiler address with a scalar base and one 32-bit VGPR (global_load ... v_off, s[base])
+// instead of building a 64-bit address per lane (v_lshl_add_u64 / v_mad_u64_u32 plus the copies that come with 64-bit values)
+template <class T> __device__ __forceinline__ T ld_off(const void *base, uint32_t byte_off)
+{ return *reinterpret_cast<const T *>(static_cast<const char *>(base) + byte_off); }
+template <class T> __device__ __forceinline__ void st_off(void *base, uint32_t byte_off, const T &v)
+{ *reinterpret_cast<T *>(static_cast<char *>(base) + byte_off) = v; }
 struct Corr { float dx, dy, dz, nx, ny, nz; };   // destination point and its normal
 
 // Correctly rounded a / b for every operand pair whose quotient is in the normal range: the Newton/FMA sequence the
@@ -848,11 +854,12 @@ __device__ __forceinline__ bool gather_finish(const SceneProjAoS &s, bool in_img
 }
 __device__ __forceinline__ bool gather_issue(const SceneProjPacked &s, float sx, float sy, float sz, bool live, Gathered &g)
 {
-    uint32_t idx; int px, py;
-    const bool in_img = proj_pixel(sx, sy, sz, s.fx, s.fy, s.cx, s.cy, s.tlx, s.tly, s.width, s.height, idx, px, py) & live;
-    const float4 r = s.rec[in_img ? idx : 0u];                    // {nx, ny, nz, z}
+    // pixel 0 stands in for points that do not project into the image (the three values keep their zeros on that path)
+    uint32_t idx = 0u; int px = 0, py = 0;
+    const bool in_img = live && proj_pixel(sx, sy, sz, s.fx, s.fy, s.cx, s.cy, s.tlx, s.tly, s.width, s.height, idx, px, py);
+    const float4 r = ld_off<float4>(s.rec, idx * 16u);                                 // {nx, ny, nz, z}
     g.a0 = r.x; g.a1 = r.y; g.a2 = r.z; g.a3 = r.w;
-    g.b0 = s.colf[in_img ? px : 0]; g.b1 = s.rowf[in_img ? py : 0]; g.b2 = 0.0f;
+    g.b0 = ld_off<float>(s.colf, (uint32_t)px * 4u); g.b1 = ld_off<float>(s.rowf, (uint32_t)py * 4u); g.b2 = 0.0f;
     return in_img;
 }
 __device__ __forceinline__ bool gather_finish(const SceneProjPacked &s, bool in_img, float sz, const Gathered &g, Corr &c)
@@ -948,6 +955,9 @@ constexpr int kLeafBatch = PR_LEAF_BATCH;
 #define PR_NN_WIDE_BOUND 4.0e-6f                                // (2 mm)^2: above it a node's whole record is fetched at once
 #endif
 constexpr uint32_t kNoPrev = 0xffffffffu;
+#ifndef PR_NN_COVER_PAD
+#define PR_NN_COVER_PAD 5.0e-4f                                 // metres a window search looks beyond its bound for the runner-up (about one pixel at 300 mm)
+#endif
 #ifndef PR_NN_STILL
 #define PR_NN_STILL 2.5e-7f                                     // (0.5 mm)^2: below this step a point's previous winner is taken as a tight seed
 #endif
@@ -1184,10 +1194,19 @@ __device__ __forceinline__ void grid_pyramid_bound(const SceneNNDev &s, float sx
     const float b = dall * 1.000001f + 1e-30f;                       // empty cells hold huge coordinates: inf
     if (b < best) best = b;
 }
-__device__ __forceinline__ bool grid_search(const SceneNNDev &s, float sx, float sy, float sz, float bound, uint32_t &winner, uint32_t *cells = nullptr)
+__device__ __forceinline__ bool grid_search(const SceneNNDev &s, float sx, float sy, float sz, float bound, uint32_t &winner, uint32_t *cells = nullptr,
+                                            float *best_sq = nullptr, float *other_sq = nullptr)
 {
     int wx, wy;
-    if (!grid_window(s, sx, sy, sz, bound, wx, wy)) return false;
+    // The window has to hold every point closer than sqrt(bound) for the search to be exact.  When a slightly larger window still
+    // fits it is taken instead: the extra ring costs a few cells and tells how far the RUNNER-UP is (other_sq), which is what lets
+    // the following passes keep this winner without searching (nn_search_kernel).
+    float cover = bound;
+    if (other_sq) {
+        const float rc = sqrtf(bound) + PR_NN_COVER_PAD;
+        if (grid_window(s, sx, sy, sz, rc * rc, wx, wy)) cover = rc * rc;
+    }
+    if (cover == bound && !grid_window(s, sx, sy, sz, bound, wx, wy)) return false;
     float u, v;
     grid_project(s, sx, sy, sz, u, v);
     if (!(u > -1e6f && u < 1e6f && v > -1e6f && v < 1e6f)) return false;
@@ -1196,8 +1215,27 @@ __device__ __forceinline__ bool grid_search(const SceneNNDev &s, float sx, float
     const int y0 = max(cy0 - wy, 0), y1 = min(cy0 + wy, (int)s.gh - 1);
     if (x0 > x1 || y0 > y1) return false;
     if (cells) *cells += (uint32_t)((x1 - x0 + 1) * (y1 - y0 + 1));
-    float best = bound;
-    int best_i = -1, ties = 0;
+    float best = bound, second = cover;                           // `second`: smallest squared distance of any scene point other than the winner,
+    int best_i = -1, ties = 0;                                    // capped at what the window covers (points outside it are at least that far)
+    if (wx <= 1 && wy <= 1) {
+        // the common case once aligned (a bound below one pixel): the 3 x 3 cells in ONE round trip instead of one per row
+        float4 c[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) c[i] = s.grid[(size_t)min(y0 + i / 3, y1) * s.gw + min(x0 + i % 3, x1)];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            if (x0 + i % 3 > x1 || y0 + i / 3 > y1) continue;    // (clamped repeats must not count as ties)
+            const float d2 = (sx - c[i].x) * (sx - c[i].x) + (sy - c[i].y) * (sy - c[i].y) + (sz - c[i].z) * (sz - c[i].z);
+            if (d2 < best) { if (best_i >= 0) second = best; best = d2; best_i = __float_as_int(c[i].w); ties = 0; }
+            else if (d2 == best && best_i >= 0) ++ties;
+            else if (d2 < second) second = d2;
+        }
+        if (best_i < 0 || ties != 0) return false;
+        winner = (uint32_t)best_i;
+        if (best_sq) *best_sq = best;
+        if (other_sq) *other_sq = second;
+        return true;
+    }
     for (int y = y0; y <= y1; ++y) {
         const float4 *row = s.grid + (size_t)y * s.gw;
         float4 c[2 * kGridMaxW + 1];
@@ -1207,12 +1245,15 @@ __device__ __forceinline__ bool grid_search(const SceneNNDev &s, float sx, float
         for (int i = 0; i < 2 * kGridMaxW + 1; ++i) {
             if (x0 + i > x1) continue;                           // (clamped repeats must not count as ties)
             const float d2 = (sx - c[i].x) * (sx - c[i].x) + (sy - c[i].y) * (sy - c[i].y) + (sz - c[i].z) * (sz - c[i].z);
-            if (d2 < best) { best = d2; best_i = __float_as_int(c[i].w); ties = 0; }
+            if (d2 < best) { if (best_i >= 0) second = best; best = d2; best_i = __float_as_int(c[i].w); ties = 0; }
             else if (d2 == best && best_i >= 0) ++ties;
+            else if (d2 < second) second = d2;
         }
     }
     if (best_i < 0 || ties != 0) return false;
     winner = (uint32_t)best_i;
+    if (best_sq) *best_sq = best;
+    if (other_sq) *other_sq = second;
     return true;
 }
 // a first bound for a query nothing is known about yet: the nearest of the scene points in the 3 x 3 cells around its own pixel
@@ -1546,7 +1587,7 @@ __device__ __forceinline__ void vb_accumulate(float (&acc_out)[29], float *cl, u
 #pragma unroll
         for (uint32_t i = 0; i < 4; ++i) {
             const uint32_t j = point_of(j0, i);
-            const pr_vec3 v = reinterpret_cast<const pr_vec3 *>(cl)[j < last ? j : last];
+            const pr_vec3 v = ld_off<pr_vec3>(cl, (j < last ? j : last) * 12u);
             p[3 * i] = v.x; p[3 * i + 1] = v.y; p[3 * i + 2] = v.z;
         }
     };
@@ -1569,7 +1610,7 @@ __device__ __forceinline__ void vb_accumulate(float (&acc_out)[29], float *cl, u
             }
 #pragma unroll
             for (uint32_t i = 0; i < 4; ++i)
-                if (i < cnt) reinterpret_cast<pr_vec3 *>(cl)[point_of(j0, i)] = pr_vec3{ p[3 * i], p[3 * i + 1], p[3 * i + 2] };
+                if (i < cnt) st_off<pr_vec3>(cl, point_of(j0, i) * 12u, pr_vec3{ p[3 * i], p[3 * i + 1], p[3 * i + 2] });
         }
         if constexpr (kNN && kStack == -1) {
             // winners of the search kernel: four indices, then the four (point, normal) pairs, all in flight before the first use
@@ -1839,10 +1880,8 @@ __global__ __launch_bounds__(256, PR_PASS_WAVES) void icp_pass_kernel(IcpBatch b
 //      query without touching the tree unless there is a tie (the tree's visiting order then decides, as in the reference).
 //  The pending rigid update is applied (and written back) here, so the pass reads the cloud as it is.
 // ================================================================================================
-template <int kCode>
 __global__ __launch_bounds__(256) void nn_search_kernel(IcpBatch b, SceneNNDev scene, uint32_t run)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const uint32_t pose = blockIdx.y;
     const PoseMeta &pm = b.meta[pose];
     const int32_t st = pm.state;
@@ -1850,8 +1889,6 @@ __global__ __launch_bounds__(256) void nn_search_kernel(IcpBatch b, SceneNNDev s
     const uint32_t n = pm.count;
     const uint32_t first = blockIdx.x * kBlockThreads * run;
     if (first >= n) return;
-    int *stk_node = reinterpret_cast<int *>(lds_raw) + threadIdx.x;
-    float *stk_lb = reinterpret_cast<float *>(lds_raw) + (size_t)(kCode & 0xff) * kBlockThreads + threadIdx.x;
 
     float *cl = reinterpret_cast<float *>(b.cloud + pm.start);
     uint32_t *win = b.nn_prev + pm.start;
@@ -1861,33 +1898,139 @@ __global__ __launch_bounds__(256) void nn_search_kernel(IcpBatch b, SceneNNDev s
     for (int i = 0; i < 12; ++i) M[i] = xf ? pm.xform[i] : 0.0f;
     const float accept = scene.max_dist_diff * scene.max_dist_diff;
 
-    uint32_t chain = kNoPrev;                                    // winner of this lane's previous query of this pass
-    const uint32_t j0 = first + threadIdx.x * run;
+    // Two phases.  (1) Every lane takes one point per chunk (lane t of chunk k: point first + 256 k + t -- adjacent lanes hold
+    // adjacent points), applies the pending update and tries the cheap way: the bound from the previous pass' winner and, if that
+    // bound is a pixel or two wide, the exact window scan.  (2) What is left -- a few per cent of the points once aligned, most of
+    // them on the first passes -- is packed into dense lanes (in point order, so neighbours stay neighbours) and only then pays for
+    // the descent through the representative points and the tree search.  Without the packing four of five wavefronts ran a whole
+    // tree search for two or three of their lanes.
+    // the hypothesis' queue lives next to its winners (same indexing, so it can never overflow): (point, bound) per entry, filled
+    // through this pass' counter of the hypothesis (two counters alternate between passes; nn_tree_kernel re-arms the idle one)
+    uint2 *queue = b.nn_queue + pm.start;
+    uint32_t *q_count = b.nn_qcount + 2u * pose + (b.iter & 1u);
+    __shared__ uint32_t wg_count, wg_base;
+    __shared__ uint32_t wave_base[4];
+    if (threadIdx.x == 0) wg_count = 0u;
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t j0 = first + threadIdx.x;
     NNCount cnt;
-    uint32_t n_query = 0, n_window = 0, n_tree = 0, n_pyramid = 0, n_cells = 0;
+    uint32_t n_query = 0, n_window = 0, n_cells = 0, n_kept = 0;
+    float *slk = b.nn_slack + pm.start;
     for (uint32_t k = 0; k < run; ++k) {
-        const uint32_t j = j0 + k;
-        if (j >= n) break;
-        float x = cl[(size_t)j * 3], y = cl[(size_t)j * 3 + 1], z = cl[(size_t)j * 3 + 2];
-        float moved = FLT_MAX;                                   // squared step of this point since the pass its winner is from
-        if (xf) {                                                // icp.cu:142-153 transform_pcd_cuda
-            const float tx = M[0] * x + M[1] * y + M[2]  * z + M[3];
-            const float ty = M[4] * x + M[5] * y + M[6]  * z + M[7];
-            const float tz = M[8] * x + M[9] * y + M[10] * z + M[11];
-            moved = (tx - x) * (tx - x) + (ty - y) * (ty - y) + (tz - z) * (tz - z);
-            x = tx; y = ty; z = tz;
-            cl[(size_t)j * 3] = x; cl[(size_t)j * 3 + 1] = y; cl[(size_t)j * 3 + 2] = z;
-        }
+        const uint32_t j = j0 + k * kBlockThreads;
+        const bool live = j < n;
+        bool pending = false;
         float best = accept;
-        nn_seed_bound(scene, x, y, z, xf ? win[j] : kNoPrev, best);
-        nn_seed_bound(scene, x, y, z, chain, best);
+        if (live) {
+            pr_vec3 q = ld_off<pr_vec3>(cl, j * 12u);
+            float x = q.x, y = q.y, z = q.z;
+            bool still = false;                                  // has this point (nearly) kept the position its winner is from?
+            float step_sq = 0.0f;
+            if (xf) {                                            // icp.cu:142-153 transform_pcd_cuda
+                const float tx = M[0] * x + M[1] * y + M[2]  * z + M[3];
+                const float ty = M[4] * x + M[5] * y + M[6]  * z + M[7];
+                const float tz = M[8] * x + M[9] * y + M[10] * z + M[11];
+                step_sq = (tx - x) * (tx - x) + (ty - y) * (ty - y) + (tz - z) * (tz - z);
+                still = step_sq <= PR_NN_STILL;
+                x = tx; y = ty; z = tz;
+                st_off<pr_vec3>(cl, j * 12u, pr_vec3{ x, y, z });
+            }
+            ++n_query;
+            const uint32_t prev = xf ? win[j] : kNoPrev;
+            bool kept = false;
+            if (prev != kNoPrev) {
+                // KEEP THE WINNER WITHOUT SEARCHING.  `slack` is a lower bound on the distance from this point to every scene point
+                // other than its winner, already reduced by every step the point has taken since the bound was established (a step
+                // of length s changes any distance by at most s).  If the winner's distance -- computed here with the search's own
+                // expression -- is below that bound by more than the float error of a squared distance (3e-7 relative; 1e-5 is
+                // demanded), the winner is still the unique strict minimum, which is what the reference's search returns under any
+                // visiting order.
+                const pr_vec3 pw = ld_off<pr_vec3>(scene.pcd, prev * 12u);
+                const float d2 = (x - pw.x) * (x - pw.x) + (y - pw.y) * (y - pw.y) + (z - pw.z) * (z - pw.z);
+                const float slack = slk[j] - sqrtf(step_sq) * 1.000001f;
+                if (d2 < accept && sqrtf(d2) * 1.00001f < slack) { kept = true; slk[j] = slack; ++n_kept; }
+                else { const float bnd = d2 * 1.000001f + 1e-30f; if (bnd < best) best = bnd; }              // = nn_seed_bound
+            }
+            if (!kept) {
+                uint32_t w = kNoPrev;
+                float bsq = 0.0f, osq = 0.0f;
+                const bool settled = scene.grid && best < accept && grid_search(scene, x, y, z, best, w, &n_cells, &bsq, &osq);
+                if (settled) { ++n_window; win[j] = w; slk[j] = sqrtf(osq) * 0.99999f; }
+                else { pending = true; if (still) best = -best; }   // the sign carries "no descent needed" to nn_tree_kernel (best > 0 always)
+            }
+        }
+        // one slot range per workgroup and chunk: waves in order, lanes in order -- the queue keeps the points' order
+        const unsigned long long m = __ballot(pending);
+        if (lane == 0) wave_base[wave] = (uint32_t)__popcll(m);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t total = wave_base[0] + wave_base[1] + wave_base[2] + wave_base[3];
+            wg_base = total ? atomicAdd(q_count, total) : 0u;
+        }
+        __syncthreads();
+        if (pending) {
+            uint32_t slot = wg_base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            for (uint32_t w2 = 0; w2 < wave; ++w2) slot += wave_base[w2];
+            queue[slot] = make_uint2(j, __float_as_uint(best));
+        }
+        __syncthreads();
+    }
+    if (scene.counters) {                                        // instrumented runs only (option "nn_count")
+        const uint32_t v[8] = { n_query, n_window, 0u, 0u, 0u, 0u, 0u, n_cells };
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            uint32_t t = v[i];
+            for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
+            if ((threadIdx.x & 63u) == 0u && t) atomicAdd(&scene.counters[(size_t)b.iter * 8 + i], (unsigned long long)t);
+        }
+    }
+}
+
+// Second half of the search: the queued queries of every hypothesis in DENSE lanes (queue order = point order, so neighbouring lanes
+// still hold neighbouring points).  A fixed number of workgroups per hypothesis walks the queue in chunks of 256; per-lane stacks in
+// LDS as before.  Kept apart from the first half so that a handful of tree searches no longer pins a whole workgroup, its 32 KB of
+// stacks and its place on the CU for fifteen dependent round trips while the other 250 lanes have long finished.
+template <int kCode>
+__global__ __launch_bounds__(256) void nn_tree_kernel(IcpBatch b, SceneNNDev scene)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const uint32_t pose = blockIdx.y;
+    const PoseMeta &pm = b.meta[pose];
+    if (pm.state == kSkip) return;
+    uint32_t *counts = b.nn_qcount + 2u * pose;
+    const uint32_t queued = counts[b.iter & 1u];
+    if (blockIdx.x == 0 && threadIdx.x == 0) counts[(b.iter + 1u) & 1u] = 0u;         // re-arm the counter the NEXT pass will fill
+    if (blockIdx.x * kBlockThreads >= queued) return;
+    int *stk_node = reinterpret_cast<int *>(lds_raw) + threadIdx.x;
+    float *stk_lb = reinterpret_cast<float *>(lds_raw) + (size_t)(kCode & 0xff) * kBlockThreads + threadIdx.x;
+    const float *cl = reinterpret_cast<const float *>(b.cloud + pm.start);
+    uint32_t *win = b.nn_prev + pm.start;
+    float *slk = b.nn_slack + pm.start;
+    const uint2 *queue = b.nn_queue + pm.start;
+    const float accept = scene.max_dist_diff * scene.max_dist_diff;
+    NNCount cnt;
+    uint32_t n_window = 0, n_tree = 0, n_pyramid = 0, n_cells = 0;
+    for (uint32_t i = blockIdx.x * kBlockThreads + threadIdx.x; i < queued; i += gridDim.x * kBlockThreads) {
+        const uint2 e = queue[i];
+        const uint32_t j = e.x;
+        float best = __uint_as_float(e.y);
+        const bool still = best < 0.0f;
+        best = still ? -best : best;
+        const pr_vec3 q = ld_off<pr_vec3>(cl, j * 12u);          // as nn_search_kernel stored it
+        const float x = q.x, y = q.y, z = q.z;
         // A point that has hardly moved still has (nearly) its true neighbour as temporal seed: d_old - step <= d_new <= d_old + step.
         // Only queries without such a seed -- the first passes, while the updates are still millimetres -- pay for the descent
         // through the representative points.
-        { int wx, wy; if (scene.grid && moved > PR_NN_STILL && !grid_window(scene, x, y, z, best, wx, wy)) { grid_pyramid_bound(scene, x, y, z, best); ++n_pyramid; } }
         uint32_t w = kNoPrev;
-        bool settled = scene.grid && best < accept && grid_search(scene, x, y, z, best, w, &n_cells);
-        ++n_query;
+        bool settled = false;
+        float other = 0.0f;
+        if (scene.grid && !still) {
+            float bsq = 0.0f, osq = 0.0f;
+            grid_pyramid_bound(scene, x, y, z, best); ++n_pyramid;
+            settled = best < accept && grid_search(scene, x, y, z, best, w, &n_cells, &bsq, &osq);
+            if (settled) other = sqrtf(osq) * 0.99999f;
+        }
         if (settled) ++n_window;
         else {
             Corr c;
@@ -1895,10 +2038,10 @@ __global__ __launch_bounds__(256) void nn_search_kernel(IcpBatch b, SceneNNDev s
             if (!query_nn_stack_from<kCode, false>(scene, nullptr, stk_node, stk_lb, x, y, z, c, best, w, &cnt)) w = kNoPrev;
         }
         win[j] = w;
-        if (w != kNoPrev) chain = w;
+        slk[j] = other;                                           // a tree search does not report its runner-up: no shortcut next pass
     }
     if (scene.counters) {                                        // instrumented runs only (option "nn_count")
-        const uint32_t v[8] = { n_query, n_window, n_tree, n_pyramid, cnt.nodes, cnt.leaves, cnt.leaf_points, n_cells };
+        const uint32_t v[8] = { 0u, n_window, n_tree, n_pyramid, cnt.nodes, cnt.leaves, cnt.leaf_points, n_cells };
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             uint32_t t = v[i];
@@ -2795,16 +2938,19 @@ hipError_t launch_icp_pass_nn_winners(const IcpBatch &b, const SceneNNWinners &s
 hipError_t launch_nn_search(const IcpBatch &b, const SceneNNDev &sc, uint32_t n_poses, uint32_t max_points, uint32_t run, hipStream_t s)
 {
     if (n_poses == 0 || max_points == 0) return hipSuccess;
-    if (!sc.rec32 || (sc.stack_depth != 16 && sc.stack_depth != 24) || !b.nn_prev) return hipErrorInvalidValue;
+    if (!sc.rec32 || (sc.stack_depth != 16 && sc.stack_depth != 24) || !b.nn_prev || !b.nn_slack || !b.nn_queue || !b.nn_qcount) return hipErrorInvalidValue;
     if (run == 0) run = 1;
+    if (run > 8) run = 8;
     const uint32_t per_block = kBlockThreads * run;
     const uint32_t gx = (max_points + per_block - 1) / per_block;
+    const uint32_t tree_gx = gx < 8u ? gx : 8u;                      // workgroups per hypothesis walking its queue
     for (uint32_t p0 = 0; p0 < n_poses; p0 += 32768) {
         const uint32_t np = (n_poses - p0 < 32768) ? (n_poses - p0) : 32768;
         IcpBatch bb = b;
-        bb.meta += p0;
-        if (sc.stack_depth == 16) hipLaunchKernelGGL(HIP_KERNEL_NAME(nn_search_kernel<16 + 0x100>), dim3(gx, np), dim3(kBlockThreads), (size_t)16 * kBlockThreads * 8, s, bb, sc, run);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(nn_search_kernel<24 + 0x100>), dim3(gx, np), dim3(kBlockThreads), (size_t)24 * kBlockThreads * 8, s, bb, sc, run);
+        bb.meta += p0; bb.nn_qcount += 2u * p0;
+        hipLaunchKernelGGL(nn_search_kernel, dim3(gx, np), dim3(kBlockThreads), 0, s, bb, sc, run);
+        if (sc.stack_depth == 16) hipLaunchKernelGGL(HIP_KERNEL_NAME(nn_tree_kernel<16 + 0x100>), dim3(tree_gx, np), dim3(kBlockThreads), (size_t)16 * kBlockThreads * 8, s, bb, sc);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(nn_tree_kernel<24 + 0x100>), dim3(tree_gx, np), dim3(kBlockThreads), (size_t)24 * kBlockThreads * 8, s, bb, sc);
     }
     return hipGetLastError();
 }
