@@ -42,12 +42,12 @@ HBM_PEAK = 8.0e12                       # MI355X_MICROARCH.md: 8 TB/s spec
 BYTES_PER_POINT_PASS0, BYTES_PER_POINT_PASSK = 36.0, 48.0
 # HBM-side traffic of the correspondence kernel measured with rocprofv3 PMC passes (FETCH_SIZE x2 per the
 # gfx950 correction of MI355X_MICROARCH.md + WRITE_SIZE; both calibrated on max2zero_kernel, which moves a known
-# number of bytes): profiles/r02/README.md (projective 24.9 B/point, kd-tree 51.5 B/point over its two kernels).
+# number of bytes): profiles/r02/README.md (projective 24.8 B/point, kd-tree 67.9 B/point over its three kernels).
 # bench.py cannot collect PMCs itself (they need their own rocprofv3 passes): `traffic` is the committed per-point
 # measurement x the points of a launch, and `frac_hbm_counter` is that traffic over the launch time measured here.
-PMC_TRAFFIC_BYTES_PER_POINT = {"proj": 24.9, "nn": 51.5}
+PMC_TRAFFIC_BYTES_PER_POINT = {"proj": 24.8, "nn": 67.9}
 PMC_TRAFFIC_SOURCE = {"proj": "profiles/r02/pmc_proj_FETCH_SIZE.md + pmc_proj_WRITE_SIZE.md (icp_pass_kernel<SceneProjPacked>)",
-                      "nn": "profiles/r02/pmc_nn_FETCH_SIZE.md + pmc_nn_WRITE_SIZE.md (nn_search_kernel 33.9 + winners pass 17.6 B/point)"}
+                      "nn": "profiles/r02/pmc_nn_FETCH_SIZE.md + pmc_nn_WRITE_SIZE.md (nn_search_kernel 41.7 + nn_tree_kernel 8.5 + winners pass 17.7 B/point)"}
 
 
 def main():
@@ -232,6 +232,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "icp_pass_kernel (correspondence + 29-term reduce" + (" + finalize/solve tail)" if args.fused_solve and args.solve == "device" else ")"),
                          "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK,
+                         # (`frac` can exceed 1: SURVEY 8d's algorithmic bytes charge the reference's 24-byte scene gather and a cloud
+                         # that streams from HBM; the packed 16-byte scene record and the cache-resident clouds move fewer real bytes)
                          # two readings of the same launches: SURVEY 8d's ALGORITHMIC bytes (what `frac` is), and the HBM bytes the
                          # PMC counters saw for this kernel.  At <= 512 hypotheses per sub-batch the clouds are Infinity-Cache
                          # resident by design and the 16-byte scene records hit L2, so the counter figure is the lower one.

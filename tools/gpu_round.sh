@@ -28,11 +28,13 @@ for c in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"; do n=
   PR_RASTER_MODE=0 timeout 300 rocprofv3 --kernel-trace --pmc $c -d $OUT/pmc -o p_$n -- python tools/pmc_workload.py 256 > /dev/null 2>&1
   summ $OUT/pmc/p_${n}_results.db | sed -n '/PMC counters/,$p' | grep -E "counter|---|icp_pass|max2zero|fill_i32|raster_kernel" > $OUT/pmc_proj_$n.md
   PR_RASTER_MODE=0 timeout 300 rocprofv3 --kernel-trace --pmc $c -d $OUT/pmc -o n_$n -- python tools/pmc_workload.py 256 nn > /dev/null 2>&1
-  summ $OUT/pmc/n_${n}_results.db | sed -n '/PMC counters/,$p' | grep -E "counter|---|icp_pass|nn_search|max2zero|fill_i32" > $OUT/pmc_nn_$n.md
+  summ $OUT/pmc/n_${n}_results.db | sed -n '/PMC counters/,$p' | grep -E "counter|---|icp_pass|nn_search|nn_tree|max2zero|fill_i32" > $OUT/pmc_nn_$n.md
 done
 for c in "SQ_INSTS_VALU SQ_INSTS_VMEM SQ_INSTS_LDS" "SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TOTAL_ACCESSES_sum" "TA_BUSY_avr TA_TA_BUSY_sum GRBM_GUI_ACTIVE"; do n=$(echo $c | tr " " "_")
   PR_RASTER_MODE=0 timeout 300 rocprofv3 --kernel-trace --pmc $c -d $OUT/pmc -o s_$n -- python tools/pmc_workload.py 256 nn > /dev/null 2>&1
-  summ $OUT/pmc/s_${n}_results.db | sed -n '/PMC counters/,$p' | grep -E "counter|---|nn_search|icp_pass" > $OUT/sq_nn_$n.md
+  summ $OUT/pmc/s_${n}_results.db | sed -n '/PMC counters/,$p' | grep -E "counter|---|nn_search|nn_tree|icp_pass" > $OUT/sq_nn_$n.md
+  PR_RASTER_MODE=0 PR_OPTS="pose_groups=1" timeout 300 rocprofv3 --kernel-trace --pmc $c -d $OUT/pmc -o q_$n -- python tools/pmc_workload.py 256 > /dev/null 2>&1
+  summ $OUT/pmc/q_${n}_results.db | sed -n '/PMC counters/,$p' | grep -E "counter|---|icp_pass|raster_kernel" > $OUT/sq_proj_$n.md
 done
 python tools/nn_counters.py > $OUT/nn_work_counters.md 2>/dev/null
 bash tools/nn_passes.sh "nn_split=1" "nn_split=0" 2>/dev/null | grep -E "==|us:" > $OUT/nn_per_pass_us.txt
