@@ -162,3 +162,42 @@ def test_async_slots_random_job_stream(gpu):
         api.set_option("profile", 0)
         api.set_option("sub_batch", 512)
         api.set_option("solve", api.SOLVE_HOST)
+
+
+def test_arrival_protocol_stress_tiny_clouds(gpu):
+    """The fused finalize + solve tail hands a hypothesis' partial sums from the workgroups that produce them to the one that draws
+    the last ticket of the arrival counter (system-scope stores -> s_waitcnt -> agent-scope atomic -> system-scope loads).  That
+    rests on how the hardware orders those accesses, so it is hammered here where it is most exposed: hundreds of hypotheses whose
+    clouds have ONE (sometimes two or three) 2048-point blocks (a far-away object), i.e. almost every workgroup is a last arrival and hundreds of
+    tails run in the same few microseconds, over four pose groups on four streams and both asynchronous slots, 30 times.  Every
+    repetition must reproduce the synchronous, un-fused result bit for bit."""
+    import os
+    from pose_refine_amd import synth
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    model = api.Model(os.path.join(root, "tests", "golden", "obj_06.ply"))
+    K = synth.K_TEST; W, H = 640, 480
+    proj = api.compute_proj(K, W, H)
+    far = synth.scene_pose().copy(); far[2, 3] = 1400.0
+    sd = api.render_host(model, far[None], W, H, proj)[0]              # the scene: the object at 1.4 m (~1.1 k pixels)
+    scene = api.Scene_projective().init_Scene_projective_cuda(sd, K)
+    P = 768
+    poses = synth.hypotheses(P, seed=11)
+    poses.reshape(-1, 4, 4)[:, 2, 3] += 1080.0                         # hypotheses at ~1.4 m: clouds of one 2048-point block
+    poses.reshape(-1, 4, 4)[::7, 2, 3] -= 500.0                        # every seventh at ~0.9 m: two or three blocks
+    crit = api.ICPConvergenceCriteria(0.0, 0.0, 12)
+    api.set_option("solve", api.SOLVE_DEVICE)
+    try:
+        api.set_option("fused_solve", 0); api.set_option("pose_groups", 1); api.set_option("profile", 1)
+        ref, ref_sizes = api.refine_batch(model, poses, W, H, proj, K, scene, crit)
+        api.set_option("profile", 0); api.set_option("fused_solve", 1); api.set_option("pose_groups", 4)
+        assert 0 < ref_sizes.max() <= 3 * 2048 and (ref_sizes <= 2048).mean() > 0.5
+        for rep in range(15):
+            api.refine_submit(0, model, poses, W, H, proj, K, scene, crit)
+            api.refine_submit(1, model, poses[::-1].copy(), W, H, proj, K, scene, crit)
+            a, sa = api.refine_wait(0)
+            b, sb = api.refine_wait(1)
+            assert np.array_equal(sa, ref_sizes) and a.tobytes() == ref.tobytes(), rep
+            assert np.array_equal(sb, ref_sizes[::-1]) and b.tobytes() == ref[::-1].tobytes(), rep
+    finally:
+        api.set_option("profile", 0); api.set_option("fused_solve", 1); api.set_option("pose_groups", 2)
+        api.set_option("solve", api.SOLVE_HOST)
