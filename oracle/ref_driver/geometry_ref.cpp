@@ -6,7 +6,8 @@
 //
 // Emits one JSON object: for seeded float inputs, the bit patterns of
 //   mat4x4 * mat4x4      (geometry.h:292-298 -- what `result.transformation_ = extrinsic * result.transformation_` uses, icp.cu:212)
-//   mat4x4 * vec4, mat3x3 * vec3, vec * vec (dot), cross, transpose, identity, embed / proj, vec3i(vec3f) rounding
+//   mat4x4 * vec4, mat3x3 * vec3, vec * vec (dot), cross, transpose, identity, embed / proj, vec3i(vec3f) rounding,
+//   det / cofactor / get_minor / adjugate / invert_transpose / invert (geometry.h:164-179,222-262)
 // tests/golden/geometry_h.json is this output; tests compare the oracle, the C++ adapters and the solver's mat4_mul with it.
 #include <cstdint>
 #include <cstdio>
@@ -55,6 +56,10 @@ int main()
         dumpv("cross_pq", cross(P, Q));
         dumpv("p_plus_q", P + Q); dumpv("p_minus_q", P - Q); dumpv("p_times_s", P * v4[0]); dumpv("p_over_s", P / v4[1]);
         dumpv("embed4_p", embed<4>(P)); dumpv("proj3_v4", proj<3>(V4));
+        dump("K_adjugate", K.adjugate()); dump("K_invert_transpose", K.invert_transpose()); dump("K_invert", K.invert());
+        dump("A_adjugate", A.adjugate()); dump("A_invert", A.invert()); dump("A_minor_1_2", A.get_minor(1, 2));
+        dumpv("A_col2", A.col(2));
+        std::printf("\"det_K\": %u, \"det_A\": %u, \"cofactor_A_2_1\": %u, ", bits(K.det()), bits(A.det()), bits(A.cofactor(2, 1)));
         Vec3f scaled = P * 1000.0f;
         Vec3i rounded(scaled);                                        // vec<3,int>(vec<3,float>): int(v + .5f)
         std::printf("\"vec3i_of_1000p\": [%d, %d, %d], ", rounded.x, rounded.y, rounded.z);
