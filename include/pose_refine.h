@@ -223,7 +223,7 @@ int pr_refine_batch_roi(const pr_triangle *tris_dev, size_t n_tris, const pr_mat
  * fills results_host / cloud_sizes_host (results_dev is complete at that point as well).  Exactly one of results_host /
  * results_dev may be NULL.  poses_host is copied before the call returns; tris_dev, the scene arrays and every output
  * pointer must stay valid until the wait.  Two slots let a host enqueue batch k+1 while batch k runs.  Batches the
- * asynchronous path does not cover (host solve, kd-tree scenes, timed calls) run to completion inside pr_refine_submit. */
+ * asynchronous path does not cover (host solve, instrumented and timed calls) run to completion inside pr_refine_submit. */
 int pr_refine_submit(int slot, const pr_triangle *tris_dev, size_t n_tris, const pr_mat4 *poses_host, uint32_t n_poses,
                      uint32_t width, uint32_t height, const pr_mat4 *proj, const float K[9],
                      int scene_kind, const void *scene, pr_criteria crit,
