@@ -2,7 +2,9 @@
 """Where a pipelined step's time goes: from a rocprofv3 --kernel-trace database of `bench.py`, over the steady-state middle of
 the run: GPU busy fraction (union of kernel intervals), idle gaps, and per kernel the time it runs ALONE vs overlapped.
 
-    rocprofv3 --kernel-trace -d out -o b -- python bench.py --no-cpu-baseline --no-kdtree-extra ; python tools/step_timeline.py out/b_results.db
+    rocprofv3 --kernel-trace -d out -o b -- python bench.py --no-cpu-baseline --no-kdtree-extra ; python tools/step_timeline.py out/b_results.db [--dump]
+
+--dump also lists every launch of two consecutive steps from the middle of the run (start relative to the first, duration, queue).
 """
 import sqlite3
 import sys
@@ -34,3 +36,13 @@ print(f"steps {steps}, {span / steps / 1e3:.1f} us per step, GPU busy {100 * bus
 print("| kernel | running (us/step) | running alone (us/step) |\n|---|---:|---:|")
 for k in sorted(total, key=lambda k: -total[k]):
     print(f"| `{k[:60]}` | {total[k] / steps / 1e3:.1f} | {alone.get(k, 0) / steps / 1e3:.1f} |")
+
+if "--dump" in sys.argv:
+    cols = [r[1] for r in c.execute("pragma table_info(kernels)")]
+    qcol = "queue_id" if "queue_id" in cols else ("stream_id" if "stream_id" in cols else "0")
+    mid = len(ras) // 2
+    a, b = rows[ras[mid]][1], rows[ras[mid + 2]][1]
+    print("\n| start (us) | dur (us) | queue | grid | kernel |\n|---:|---:|---:|---|---|")
+    gcol = "grid_size_x || 'x' || grid_size_y" if "grid_size_x" in cols else "''"
+    for n, s_, e_, q, gsz in c.execute(f"select name, start, end, {qcol}, {gcol} from kernels where start >= {a} and start < {b} order by start"):
+        print(f"| {(s_ - a) / 1e3:.1f} | {(e_ - s_) / 1e3:.1f} | {q} | {gsz} | `{n.split('(')[0].replace('void ', '').replace('prk::', '')[:50]}` |")
