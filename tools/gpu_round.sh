@@ -19,6 +19,7 @@ $B --steps 20 --warmup 3 --scene nn 2>/dev/null | tail -1 > $OUT/bench_p256_nn.j
 # rocprofv3 kernel stats of the same commands
 rocprofv3 --kernel-trace --stats -d $OUT/stats -o bench -- python bench.py --no-cpu-baseline --no-kdtree-extra > $OUT/bench_under_rocprof.json 2>/dev/null
 summ $OUT/stats/bench_results.db > $OUT/kernel_stats_bench_p256.md
+python tools/step_timeline.py $OUT/stats/bench_results.db > $OUT/step_timeline.md
 rocprofv3 --kernel-trace --stats -d $OUT/stats1 -o bench -- python bench.py --sequential --no-cpu-baseline > $OUT/bench_under_rocprof_sequential.json 2>/dev/null
 summ $OUT/stats1/bench_results.db > $OUT/kernel_stats_bench_p256_sequential.md
 rocprofv3 --kernel-trace --stats -d $OUT/stats2 -o bench -- python bench.py --steps 20 --warmup 3 --scene nn --no-cpu-baseline > $OUT/bench_nn_under_rocprof.json 2>/dev/null
