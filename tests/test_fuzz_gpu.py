@@ -164,6 +164,54 @@ def test_async_slots_random_job_stream(gpu):
         api.set_option("solve", api.SOLVE_HOST)
 
 
+def test_async_slots_with_two_alternating_kdtree_scenes(gpu):
+    """Kd-tree batches on the two slots against TWO scenes: the traversal records and the pixel grid are shared by the slots and
+    hold one scene at a time, so a batch for the other scene rebuilds them while the previous batch may still be in flight
+    (the rebuild drains the slots first).  Mixed with projective batches; every result bit for bit equal to the synchronous path."""
+    import os
+    from pose_refine_amd import synth
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    model = api.Model(os.path.join(root, "tests", "golden", "obj_06.ply"))
+    K = synth.K_TEST; W, H = 640, 480
+    proj = api.compute_proj(K, W, H)
+    sd = api.render_host(model, synth.scene_pose()[None], W, H, proj)[0]
+    other = synth.scene_pose().copy()
+    other.reshape(4, 4)[0, 3] += 15.0; other.reshape(4, 4)[2, 3] += 25.0
+    sd2 = api.render_host(model, other[None], W, H, proj)[0]
+    scenes = [api.Scene_projective().init_Scene_projective_cuda(sd, K), api.Scene_nn().init_Scene_nn_cuda(sd, K),
+              api.Scene_nn().init_Scene_nn_cuda(sd2, K)]
+    rng = np.random.default_rng(11)
+    jobs = []
+    for i in range(18):
+        which = int(rng.integers(3))
+        P = int(rng.choice([1, 3, 31, 33, 64, 65])) if which else int(rng.choice([33, 200, 300]))
+        poses = synth.hypotheses(P, seed=300 + i)
+        if P > 2 and rng.random() < 0.3:
+            poses.reshape(-1, 4, 4)[1, 0, 3] += 1e6                # off-screen hypothesis -> empty cloud
+        jobs.append((poses, api.ICPConvergenceCriteria(0.0, 0.0, int(rng.choice([0, 3, 8]))), scenes[which]))
+    api.set_option("solve", api.SOLVE_DEVICE)
+    try:
+        api.set_option("profile", 1)                               # forces the synchronous path
+        refs = [api.refine_batch(model, p, W, H, proj, K, sc, c) for p, c, sc in jobs]
+        api.set_option("profile", 0)
+        got, inflight = [None] * len(jobs), [None, None]
+        for i, (p, c, sc) in enumerate(jobs):
+            b = i & 1
+            if inflight[b] is not None:
+                got[inflight[b]] = api.refine_wait(b)
+            api.refine_submit(b, model, p, W, H, proj, K, sc, c)
+            inflight[b] = i
+        for b in (0, 1):
+            if inflight[b] is not None:
+                got[inflight[b]] = api.refine_wait(b)
+        for i, (g, r) in enumerate(zip(got, refs)):
+            assert np.array_equal(g[1], r[1]), i
+            assert g[0].tobytes() == r[0].tobytes(), (i, len(jobs[i][0]))
+    finally:
+        api.set_option("profile", 0)
+        api.set_option("solve", api.SOLVE_HOST)
+
+
 def test_arrival_protocol_stress_tiny_clouds(gpu):
     """The fused finalize + solve tail hands a hypothesis' partial sums from the workgroups that produce them to the one that draws
     the last ticket of the arrival counter (system-scope stores -> s_waitcnt -> agent-scope atomic -> system-scope loads).  That
