@@ -140,6 +140,7 @@ struct Options {
                                      // 256 poses and 35 % slower at 1024), 0 = one launch per pass + per solve
     int use_graph = 1;               // PR_SOLVE_DEVICE, single pose group only (the runtime serialises the branches of a captured multi-stream
                                      // graph, which forfeits the overlap): capture the whole iteration loop in a hipGraph and replay it
+    int eager_streams = 1;           // asynchronous path: create the streams of both slots in one run (see slot_streams)
     int raster_mode = 0;             // fused path: 0 = global atomicMin inside the per-pose pixel box (reference scheme), 1 = LDS depth bands (int32),
                                      // 2 = one workgroup per hypothesis with its whole box in LDS as 16-bit depth offsets (global path for boxes that do not fit)
     int scene_cache = 1;             // keep the packed projective scene / kd traversal records of the latest scene between calls (pr_scene_invalidate)
@@ -895,15 +896,29 @@ int refine_impl(const pr_triangle *tris_dev, size_t n_tris, const pr_mat4 *poses
 // Here the host computes the per-pose pixel boxes itself (same arithmetic as pose_bbox_kernel, 8 corners per pose), which
 // bounds every cloud by its box area, the start state is written by a kernel from the device-side counts, and a batch is
 // only waited for when its results are wanted -- so the next batch can be enqueued while this one runs.
+// The streams of BOTH slots are created together, in one run: main and first side stream of slot 0, then of slot 1.  Which
+// hardware queue -- and with it which of the command processor's four pipes -- a stream lands on follows from the order in which
+// the process created its queues (queue k -> pipe k mod 4), and two of these four streams on one pipe cost up to half the
+// throughput (tools/queue_fairness.hip: two chains of dependent launches on one pipe take 2.1x a lone chain each, on two pipes
+// 1.25x; bench.py with PR_STREAM_PADS-style gaps: 250 k -> 118-213 k poses/s).  Created lazily, slot by slot, anything the host does
+// in between (its first synchronous copy creates the null stream's queue) shifts slot 1 onto slot 0's pipes; four queues
+// created back to back always sit on four different pipes.  Further side streams (3-4 pose groups) come lazily, ensure_stream.
 int slot_streams(Slot &sl)
 {
     if (sl.stream) return PR_OK;
-    HIP_TRY(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
-    HIP_TRY(hipEventCreateWithFlags(&sl.scene_ready, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&sl.fork, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&sl.progress, hipEventDisableTiming));
-    return PR_OK;                                                // side streams: ensure_stream, when a batch has pose groups
+    for (Slot &o : g->slots) {
+        if (o.stream || (!opt.eager_streams && &o != &sl)) continue;
+        HIP_TRY(hipStreamCreateWithFlags(&o.stream, hipStreamNonBlocking));
+        if (opt.eager_streams) PR_TRY(ensure_stream(o.side[0], &o.join[0]));
+    }
+    for (Slot &o : g->slots) {
+        if (o.done) continue;
+        HIP_TRY(hipEventCreateWithFlags(&o.scene_ready, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&o.fork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&o.done, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&o.progress, hipEventDisableTiming));
+    }
+    return PR_OK;
 }
 // wait for everything a slot has in flight (its stream and side streams)
 void slot_drain(Slot &sl)
@@ -1753,6 +1768,7 @@ int pr_set_option(const char *name, int value)
     else if (n == "sub_batch") opt.sub_batch = std::max(32, value);
     else if (n == "overlap_pass") opt.overlap_pass = std::max(-1, value);
     else if (n == "pose_groups") opt.pose_groups = std::min(4, std::max(1, value));
+    else if (n == "eager_streams") opt.eager_streams = value ? 1 : 0;
     else if (n == "raster_mode") { if (value < 0 || value > 2) { set_error("raster_mode must be 0, 1 or 2"); return PR_ERR_INVALID; } opt.raster_mode = value; }
     else { set_error("unknown option %s", name); return PR_ERR_INVALID; }
     return PR_OK;
@@ -1777,6 +1793,7 @@ int pr_get_option(const char *name, int *value)
     else if (n == "nn_grid") *value = opt.nn_grid;
     else if (n == "nn_count") *value = opt.nn_count;
     else if (n == "raster_mode") *value = opt.raster_mode;
+    else if (n == "eager_streams") *value = opt.eager_streams;
     else if (n == "graph") *value = opt.use_graph;
     else if (n == "icp_flow") *value = opt.icp_flow;
     else if (n == "fused_solve") *value = opt.fused_solve;
