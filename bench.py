@@ -178,18 +178,19 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    # profile 2: HIP events around every launch of one step in `period`.  A sampled step runs synchronously as one pose group with
-    # the other slot drained (so that the timed launches have the chip to themselves) and costs ~0.6 ms more than a pipelined
-    # one -- inside the timed region, where it counts against `value`.  Four sampled steps (84 launches) from 40 steps up, two
-    # (42 launches) below that: at the driver's --steps 20 four would cost 10 % of the reported throughput.
-    n_samples = 4 if args.steps >= 40 else 2
-    period = min(32, max(1, -(-args.steps // n_samples)))
-    api.set_option("sample_period", period)
-    api.set_option("profile", 1 if args.sequential else 2)
+    # Roofline samples: the LAST n_samples steps of the timed region run with profile 1 -- synchronously, as one pose group, with the
+    # other slot drained, HIP events around every correspondence launch -- so that the timed launches have the chip to themselves.
+    # A synchronous step costs ~0.45 ms more than a pipelined one and counts against `value`; at the end of the region the drain
+    # it needs is the drain the closing fence needs anyway (sampled in the middle, every sample also cost an empty pipeline
+    # afterwards: -3 % at 100 steps, -6 % at the driver's 20).  Four sampled steps (84 launches) from 40 steps up, two (42) below.
+    n_samples = min(args.steps, 4 if args.steps >= 40 else 2)
+    api.set_option("profile", 1 if args.sequential else 0)
     api.profile_reset()
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        if i == args.steps - n_samples and not args.sequential:
+            api.set_option("profile", 1)
         step()
     fence()
     elapsed = time.perf_counter() - t0
@@ -246,7 +247,7 @@ def main():
                          "avg_launch_us": avg_launch_s * 1e6, "launches": int(launches),
                          "algorithmic_bytes_per_launch": bytes_per_launch, "points_per_launch": pts_per_launch,
                          "timing": ("HIP events on the library stream around every launch (--sequential: synchronous single-group steps)" if args.sequential else
-                                    f"HIP events on the library stream around every launch of one step in {period}; "
+                                    f"HIP events on the library stream around every launch of the last {n_samples} steps of the timed region; "
                                     "a timed step runs synchronously as one pose group (other slot drained) so the launch has the chip to itself")},
             "gather": ("none (1 rank)" if world == 1 else ("pr_gather_results: grouped ncclSend/ncclRecv on the library stream (C ABI over RCCL)" if gather_mode == "cabi" else "torch.distributed.gather")),
             "phase_ms_per_timed_step": {"render": prof["render_ms"] / max(1, launches // (args.iters + 1)),
