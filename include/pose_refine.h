@@ -262,7 +262,7 @@ int pr_gather_results(const pr_result *send_dev, uint32_t n_local, uint32_t n_to
  *   "graph"            [1]     device solve, one pose group, synchronous path: replay the loop as a hipGraph
  *   "icp_flow"         [0]     device solve: one persistent dataflow launch for all iterations
  *   "sub_batch"        [512]   asynchronous path: hypotheses per sub-batch (cache residency of the clouds)
- *   "overlap_pass"     [-1]    asynchronous path: the other slot's render may start after this pass of a slot's loop (-1 = 70 %)
+ *   "overlap_pass"     [-1]    asynchronous path: the other slot's render may start after this pass of a slot's loop (-1 = chosen per batch)
  *   "raster_mode"      [0]     fused render: 0 = global atomicMin inside the pose's pixel box, 1 = LDS depth bands (synchronous path)
  *   "nn_stack"         [1]     kd-tree query: per-lane LDS stack (1) or the reference's stackless walk (0)
  *   "nn_compact"       [1]     stack query on 32-byte node records with 16-bit outward-rounded boxes (0: exact 64-byte records)

@@ -132,7 +132,7 @@ struct Options {
     int nn_run = 1;                  // 256-point chunks a workgroup of the search kernel takes (lane t of chunk k: point 256 k + t)
     int nn_grid = 1;                 // fused path: pixel grid of the scene points (seeds + window search); 0 = tree only
     int nn_count = 0;                // instrumented runs: the search kernel counts its work per pass (pr_nn_counters)
-    int overlap_pass = -1;           // asynchronous path: the other slot's render may start once this slot has issued this pass of its loop
+    int overlap_pass = -1;           // asynchronous path: the other slot's render may start once this slot has issued this pass of its loop (-1: chosen per batch, see refine_submit_async)
                                      // (-1: 70 % of the passes -- measured best of 6/10/14/17 at 256 and 512 poses per batch)
     int sub_batch = 512;             // asynchronous fused path: hypotheses per sub-batch (cache residency of the clouds)
     int fused_solve = 1;             // PR_SOLVE_DEVICE: the workgroup delivering a hypothesis' last partial sum also runs its finalize + solve (no second launch per iteration)
@@ -1193,6 +1193,18 @@ int refine_submit_async(Slot &sl, const pr_triangle *tris_dev, size_t n_tris, ui
             HIP_TRY(hipEventRecord(sl.fork, st));
             for (uint32_t k = 1; k < n_groups; ++k) HIP_TRY(hipStreamWaitEvent(sl.side[k - 1], sl.fork, 0));
         }
+        // When may the OTHER slot start rendering?  Measured optimum (256 x 21 passes of obj_06, overlap_pass swept per batch size):
+        // pass 4 or earlier at 128 hypotheses, 9-10 at 256, 17 at 384 and 512 -- i.e. when about 2500 hypothesis-passes of this loop
+        // are left, whatever the batch size: that much loop work is what a render hides behind without stretching the passes it
+        // runs beside.  The render's own weight scales that figure: triangles per hypothesis against cloud points per hypothesis
+        // (31 468 and ~22 000 there; cloud_hint = the largest cloud of the previous batch).
+        uint32_t auto_overlap = 0;
+        {
+            const double weight = ((double)std::max<size_t>(n_tris, 1) / 31468.0) * (22000.0 / (double)std::max(g->cloud_hint, 1000u));
+            const double left = 2500.0 * weight / (double)std::max(nq, 1u);           // passes of this sub-batch's loop still to run
+            const double passes = (double)crit.max_iteration + 1.0;
+            auto_overlap = left >= passes ? 0u : (uint32_t)(passes - left + 0.5);
+        }
         prk::IcpBatch b{};
         b.cloud = sl.cloud.as<pr_vec3>(); b.nblk = nblk; b.grid_x = grid_x; b.steps = steps;
         if (nn_prev) {
@@ -1212,7 +1224,7 @@ int refine_submit_async(Slot &sl, const pr_triangle *tris_dev, size_t n_tris, ui
                 HIP_TRY(launch_pass(bb, sc, np, gs));
                 if (!fused) HIP_TRY(prk::launch_icp_finalize_solve(bb.partial, meta + p0, nblk, steps, dstate + p0, crit, it, np, gs));
             }
-            if (q0 + sub >= P && it == std::min<uint32_t>((uint32_t)crit.max_iteration, opt.overlap_pass >= 0 ? (uint32_t)opt.overlap_pass : (uint32_t)((crit.max_iteration + 1) * 7 / 10))) {
+            if (q0 + sub >= P && it == std::min<uint32_t>((uint32_t)crit.max_iteration, opt.overlap_pass >= 0 ? (uint32_t)opt.overlap_pass : auto_overlap)) {
                 HIP_TRY(hipEventRecord(sl.progress, st));
                 sl.progress_valid = true;
             }
