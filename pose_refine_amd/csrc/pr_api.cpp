@@ -1193,15 +1193,15 @@ int refine_submit_async(Slot &sl, const pr_triangle *tris_dev, size_t n_tris, ui
             HIP_TRY(hipEventRecord(sl.fork, st));
             for (uint32_t k = 1; k < n_groups; ++k) HIP_TRY(hipStreamWaitEvent(sl.side[k - 1], sl.fork, 0));
         }
-        // When may the OTHER slot start rendering?  Measured optimum (256 x 21 passes of obj_06, overlap_pass swept per batch size):
-        // pass 4 or earlier at 128 hypotheses, 9-10 at 256, 17 at 384 and 512 -- i.e. when about 2500 hypothesis-passes of this loop
-        // are left, whatever the batch size: that much loop work is what a render hides behind without stretching the passes it
-        // runs beside.  The render's own weight scales that figure: triangles per hypothesis against cloud points per hypothesis
-        // (31 468 and ~22 000 there; cloud_hint = the largest cloud of the previous batch).
+        // When may the OTHER slot start rendering?  Measured optimum (21 passes of obj_06, overlap_pass swept per batch size):
+        // pass 4 or earlier at 128 hypotheses, 9-10 at 256, 14-16 at 384, 16 at 512 -- i.e. when about 2800 hypothesis-passes of
+        // this loop are left (never fewer than 5 passes): that much loop work is what a render hides behind without stretching the
+        // passes it runs beside.  The render's own weight scales that figure: triangles per hypothesis against cloud points per
+        // hypothesis (31 468 and 27 400 there; cloud_hint = the largest cloud of the previous batch).
         uint32_t auto_overlap = 0;
         {
-            const double weight = ((double)std::max<size_t>(n_tris, 1) / 31468.0) * (22000.0 / (double)std::max(g->cloud_hint, 1000u));
-            const double left = 2500.0 * weight / (double)std::max(nq, 1u);           // passes of this sub-batch's loop still to run
+            const double weight = ((double)std::max<size_t>(n_tris, 1) / 31468.0) * (27400.0 / (double)std::max(g->cloud_hint, 1000u));
+            const double left = std::max(5.0, 2800.0 * weight / (double)std::max(nq, 1u));   // passes of this sub-batch's loop still to run
             const double passes = (double)crit.max_iteration + 1.0;
             auto_overlap = left >= passes ? 0u : (uint32_t)(passes - left + 0.5);
         }
