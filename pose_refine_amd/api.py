@@ -17,6 +17,7 @@ computes on the CPU (model import, scene preparation).
 from __future__ import annotations
 
 import ctypes as C
+import threading
 from dataclasses import dataclass
 from typing import Optional, Sequence
 
@@ -42,6 +43,13 @@ def init(device: int = 0):
 def set_device(device: int):
     """Bind the calling thread to the shared context of ``device`` (one host thread per GPU)."""
     check(_lib.load().pr_set_device(device))
+
+
+def shutdown():
+    """``pr_shutdown``: release the calling thread's context (workspaces, streams, communicator).  Device buffers handed out by
+    this module (DeviceVector, Model, scenes) stay valid; the next call re-creates the context."""
+    _slots().clear()
+    check(_lib.load().pr_shutdown())
 
 
 def thread_context(enable: bool = True):
@@ -469,7 +477,16 @@ def refine_batch(tris, poses, width: int, height: int, proj, K, scene,
     return None, sizes
 
 
-_inflight = {}
+_tls = threading.local()
+
+
+def _slots() -> dict:
+    """Outputs (and input owners) of the batches in flight, per host thread: a thread with a private context
+    (``thread_context``) has slots of its own, and the arrays the library writes into at ``refine_wait`` must stay alive until then."""
+    d = getattr(_tls, "inflight", None)
+    if d is None:
+        d = _tls.inflight = {}
+    return d
 
 
 def refine_submit(slot: int, tris, poses, width: int, height: int, proj, K, scene,
@@ -486,13 +503,13 @@ def refine_submit(slot: int, tris, poses, width: int, height: int, proj, K, scen
     check(_lib.load().pr_refine_submit_roi(int(slot), td.data(), td.size() // 9, ptr(poses), len(poses), width, height, ptr(pj), ptr(k),
                                            scene.kind, C.addressof(d), criteria.c(), Roi(*roi), ptr(res) if res is not None else None,
                                            int(results_dev) if results_dev is not None else None, ptr(sizes)))
-    _inflight[int(slot)] = (res, sizes, td, scene)              # keep the output arrays (and the inputs' owners) alive
+    _slots()[int(slot)] = (res, sizes, td, scene)              # keep the output arrays (and the inputs' owners) alive
 
 
 def refine_wait(slot: int):
     """Block until the batch submitted on ``slot`` is finished; returns (records or None, cloud sizes)."""
     check(_lib.load().pr_refine_wait(int(slot)))
-    res, sizes, _, _ = _inflight.pop(int(slot))
+    res, sizes, _, _ = _slots().pop(int(slot))
     return res, sizes
 
 

@@ -268,6 +268,49 @@ def test_host_threads_with_private_contexts(gpu, scenario, gscenes):
         assert g.fitness_ == w.fitness_ and g.inlier_rmse_ == w.inlier_rmse_ and np.array_equal(g.transformation_, w.transformation_)
 
 
+def test_async_slots_in_private_contexts_and_across_shutdown(gpu, model, scenario, gscenes):
+    """Every host thread with a private context has two asynchronous slots of its own (and the Python mirror keeps each thread's
+    in-flight output arrays alive separately); pr_shutdown releases a context, the next call builds a new one."""
+    crit = api.ICPConvergenceCriteria(0.0, 0.0, 5)
+    poses = synth.hypotheses(70)
+    api.set_option("nn_count", 1)                                # instrumented kd-tree runs are synchronous
+    api.set_option("profile", 1)                                 # timed calls are synchronous
+    try:
+        want, want_sizes = api.refine_batch(model, poses, W, H, scenario["proj"], scenario["K"], gscenes["proj"], crit)
+        want_nn, _ = api.refine_batch(model, poses[:20], W, H, scenario["proj"], scenario["K"], gscenes["nn"], crit)
+    finally:
+        api.set_option("profile", 0)
+        api.set_option("nn_count", 0)
+
+    def both_slots(tag):
+        for _ in range(3):
+            api.refine_submit(0, model, poses, W, H, scenario["proj"], scenario["K"], gscenes["proj"], crit)
+            api.refine_submit(1, model, poses[:20], W, H, scenario["proj"], scenario["K"], gscenes["nn"], crit)
+            a, sa = api.refine_wait(0)
+            b, _ = api.refine_wait(1)
+            assert a.tobytes() == want.tobytes() and np.array_equal(sa, want_sizes), tag
+            assert b.tobytes() == want_nn.tobytes(), tag
+
+    both_slots("shared context")
+    api.shutdown()
+    both_slots("after pr_shutdown")
+    errs = []
+
+    def work(k):
+        try:
+            api.thread_context(True)
+            both_slots(f"private context of thread {k}")
+            api.thread_context(False)
+        except Exception as e:                                   # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
+    both_slots("shared context again")
+
+
 # ---- kd-tree scenes on the asynchronous two-slot path (VERDICT r01 missing #4) -------------------------------------------------
 def test_kdtree_batches_on_both_slots_equal_the_synchronous_path(gpu, model, scenario, gscenes):
     crit = api.ICPConvergenceCriteria(0.0, 0.0, 6)
