@@ -1,4 +1,6 @@
-"""BASELINE.json configs[3] and configs[4] at their per-GPU share (-m gpu).
+"""BASELINE.json configs[2], configs[3] and configs[4] at their full / per-GPU size (-m gpu).
+
+configs[2]: obj_06.ply, 256 hypotheses, kd-tree nearest-neighbour association.
 
 configs[3]: obj_06.ply, 4096 hypotheses over 8 GPUs -> 512 per GPU, projective association.
 configs[4]: 1M-triangle synthetic mesh (UV sphere 1000 x 500 quads, bumpy radius), 1280x720,
@@ -79,6 +81,52 @@ def config5(gpu):
     scene_depth = api.render_host(model, synth.scene_pose()[None], W, H, proj)[0]
     return dict(W=W, H=H, K=K, tris=tris, model=model, proj=proj, scene_depth=scene_depth,
                 scene=api.Scene_projective().init_Scene_projective_cuda(scene_depth, K, W, H))
+
+
+def test_config2_256_hypotheses_kdtree(gpu, scenario, golden_dir):
+    """configs[2] at full size.  The oracle's kd-tree ICP needs ~1.5 s per hypothesis on the CPU: three hypotheses go to it, the
+    rest is held by properties -- order and batch composition do not matter, the slots and the synchronous path agree."""
+    model = api.Model(os.path.join(golden_dir, "obj_06.ply"))
+    W, H, K = synth.WIDTH, synth.HEIGHT, scenario["K"]
+    scene = api.Scene_nn().init_Scene_nn_cuda(scenario["depth"][1], K)
+    P = 256
+    poses = synth.hypotheses(P)
+    crit = api.ICPConvergenceCriteria(0.0, 0.0, 20)
+    res, sizes = api.refine_batch(model, poses, W, H, scenario["proj"], K, scene, crit)
+    assert rigid(res["T"]) and np.all(res["fitness"] > 0.5)
+    perm = np.random.default_rng(5).permutation(P)
+    res_p, sizes_p = api.refine_batch(model, poses[perm], W, H, scenario["proj"], K, scene, crit)
+    assert np.array_equal(sizes[perm], sizes_p) and res[perm].tobytes() == res_p.tobytes()
+    for i in (0, 101, 255):
+        one, s1 = api.refine_batch(model, poses[i:i + 1], W, H, scenario["proj"], K, scene, crit)
+        assert s1[0] == sizes[i] and one.tobytes() == res[i:i + 1].tobytes()
+    api.set_option("nn_count", 1)                                # instrumented = synchronous path
+    try:
+        res_s, sizes_s = api.refine_batch(model, poses, W, H, scenario["proj"], K, scene, crit)
+    finally:
+        api.set_option("nn_count", 0)
+    assert np.array_equal(sizes, sizes_s) and res.tobytes() == res_s.tobytes()
+    pick = [0, 101, 255]
+    ores, osizes, _ = O.refine_batch(scenario["tris"], poses[pick], W, H, scenario["proj"], K, scenario["nn_scene"], (0.0, 0.0, 20),
+                                     O.SUM_CANONICAL, api.get_option("points_per_block"))
+    assert np.array_equal(sizes[pick], osizes) and np.array_equal(res["fitness"][pick], ores["fitness"])
+    assert np.allclose(res["T"][pick], ores["T"], rtol=0, atol=TOL_T)
+
+
+def test_render_is_the_pixelwise_minimum_over_any_split_of_the_mesh(gpu, scenario, golden_dir):
+    """Size-independent property of the raster (renderer.cu:124-149: atomicMin per pixel): rendering the whole mesh equals the
+    pixelwise minimum (over covered pixels) of rendering any two parts of it -- 64 hypotheses, full frame, three different splits."""
+    tris = scenario["tris"].reshape(-1, 9)
+    W, H = synth.WIDTH, synth.HEIGHT
+    poses = synth.hypotheses(64)
+    full = api.render_host(tris, poses, W, H, scenario["proj"])
+    big = np.iinfo(np.int32).max
+    for cut in (1, len(tris) // 3, len(tris) - 7):
+        a = api.render_host(tris[:cut], poses, W, H, scenario["proj"]).astype(np.int64)
+        b = api.render_host(tris[cut:], poses, W, H, scenario["proj"]).astype(np.int64)
+        a[a == 0] = big; b[b == 0] = big
+        m = np.minimum(a, b); m[m == big] = 0
+        assert np.array_equal(m.astype(np.int32), full)
 
 
 def test_config5_scene_render_bit_exact(config5):
