@@ -225,12 +225,14 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"obj_06.ply, {P}-pose batch per GPU, 640x480 synthetic depth, "
-                                   f"{'projective' if args.scene == 'proj' else 'kd-tree NN (near-first depth-first search, per-lane LDS stack on compact 32-byte node records)'} association, "
+                                   f"{'projective' if args.scene == 'proj' else 'kd-tree NN (exact search with the reference tie-breaks: keep-the-winner test and pixel-window scan where the bound allows, near-first depth-first tree walk with per-lane LDS stacks on compact 32-byte node records otherwise)'} association, "
                                    f"{args.iters} ICP iterations (21 passes), solve on {args.solve}"
                                    + (f", {args.pose_groups} pose groups" if args.solve == "device" else ""),
                        "poses_per_gpu": P, "global_batch": P * world, "points_per_pose_mean": float(np.mean(sizes)),
                        "parallelism": f"pose-shard x{world}, 1 RCCL gather"},
-            "roofline": {"bound": "hbm", "kernel": "icp_pass_kernel (correspondence + 29-term reduce" + (" + finalize/solve tail)" if args.fused_solve and args.solve == "device" else ")"),
+            "roofline": {"bound": "hbm", "kernel": ("icp_pass_kernel (correspondence + 29-term reduce" if args.scene == "proj" else
+                                                     "one correspondence pass = nn_search_kernel + nn_tree_kernel + icp_pass_kernel<SceneNNWinners> (search, tree walk of the queued queries, 29-term reduce over the winners")
+                                                    + (" + finalize/solve tail)" if args.fused_solve and args.solve == "device" else ")"),
                          "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK,
                          # (`frac` can exceed 1: SURVEY 8d's algorithmic bytes charge the reference's 24-byte scene gather and a cloud
