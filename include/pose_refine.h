@@ -266,6 +266,8 @@ int pr_gather_results(const pr_result *send_dev, uint32_t n_local, uint32_t n_to
  *   "raster_mode"      [0]     fused render: 0 = global atomicMin inside the pose's pixel box, 1 = LDS depth bands (synchronous path)
  *   "nn_stack"         [1]     kd-tree query: per-lane LDS stack (1) or the reference's stackless walk (0)
  *   "nn_compact"       [1]     stack query on 32-byte node records with 16-bit outward-rounded boxes (0: exact 64-byte records)
+ *   "nn_wide"          [1]     queued tree searches walk 128-byte lines (wide nodes of eight subtree boxes, one line per leaf) in nearest-first
+ *                              order; a query whose minimum is attained by more than one point is repeated by the ordered binary walk (0: binary walk only)
  *   "nn_seed"          [1]     compact records: start every search from the previous pass' / previous point's winner distance
  *   "nn_split"         [1]     compact records: the search runs in a kernel of its own (adjacent lanes = adjacent cloud points, a workgroup
  *                              takes "nn_run" [1] chunks of 256 points) and the pass gathers its winners in canonical order
@@ -288,6 +290,10 @@ int  pr_nn_counters(uint64_t *out, uint32_t passes);
 int  pr_profile_reset(void);
 int  pr_profile_read(double *kernel_ms, uint64_t *launches, uint64_t *points, uint64_t *algorithmic_bytes,
                      double *render_ms, double *cloud_ms);
+/* HIP-event time of the pr_gather_results exchanges issued while option "profile" was non-zero (events on the context's stream around
+ * the grouped send / receive; accumulated since pr_profile_reset).  Waits for the stream.  New in this library -- the reference has
+ * no multi-device code (test.cpp:14). */
+int  pr_gather_profile(double *gather_ms, uint64_t *gathers);
 
 #ifdef __cplusplus
 }

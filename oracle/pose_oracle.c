@@ -713,6 +713,19 @@ int po_icp(po_vec3 *cloud, size_t n, int kind, const void *scene, po_criteria cr
     return passes;
 }
 
+/* number of OpenMP threads the batch loop below uses (0: leave the runtime's choice); returns the setting in force.  bench.py sets
+ * it to what the host really grants the process -- min(affinity mask, cgroup cpu.max quota) -- because omp_get_max_threads() reports
+ * every online CPU of the box, and a cgroup with a 16-CPU quota runs 256 such threads on 16 CPUs' worth of time. */
+int po_set_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+    return omp_get_max_threads();
+#else
+    (void)n; return 1;
+#endif
+}
+
 /* whole path per hypothesis: render_cpu(1 pose) -> depth2cloud_cpu -> ICP_Point2Plane_cpu
  * (the per-pose loop of BASELINE.md section 3), OpenMP across hypotheses. */
 int po_refine_batch(const po_tri *tris, size_t n_tris, const float *poses16, size_t n_poses,
@@ -728,14 +741,20 @@ int po_refine_batch(const po_tri *tris, size_t n_tris, const float *poses16, siz
        extracted with tl = (roi.x, roi.y) (icp.h:57-60), which restores full-frame coordinates */
     const int has_roi = roi.width > 0 && roi.height > 0;
     const size_t rw = has_roi ? (size_t)roi.width : width, rh = has_roi ? (size_t)roi.height : height;
-#pragma omp parallel for schedule(dynamic, 1)
-    for (long ip = 0; ip < (long)n_poses; ip++) {
+    /* every thread keeps ONE depth image and ONE cloud for all its hypotheses (the reference's per-pose loop returns fresh
+       std::vectors, but 128 threads each mmap-ing and faulting 4.9 MB per hypothesis measure the kernel's page-fault path,
+       not the algorithm: a baseline should not be slowed by that) */
+#pragma omp parallel
+    {
         int32_t *depth = (int32_t *)malloc(width * height * sizeof(int32_t));
         po_vec3 *cloud = (po_vec3 *)malloc(width * height * sizeof(po_vec3));
-        po_render(tris, n_tris, poses16 + 16 * (size_t)ip, 1, width, height, proj, roi, depth);
-        size_t n = po_depth2cloud_i32(depth, (uint32_t)rw, (uint32_t)rh, K, 1, has_roi ? (uint32_t)roi.x : 0u, has_roi ? (uint32_t)roi.y : 0u, cloud);
-        po_icp(cloud, n, kind, scene, crit, sum_mode, ppb, &results[ip], NULL);
-        if (cloud_sizes) cloud_sizes[ip] = (uint32_t)n;
+#pragma omp for schedule(dynamic, 1)
+        for (long ip = 0; ip < (long)n_poses; ip++) {
+            po_render(tris, n_tris, poses16 + 16 * (size_t)ip, 1, width, height, proj, roi, depth);
+            size_t n = po_depth2cloud_i32(depth, (uint32_t)rw, (uint32_t)rh, K, 1, has_roi ? (uint32_t)roi.x : 0u, has_roi ? (uint32_t)roi.y : 0u, cloud);
+            po_icp(cloud, n, kind, scene, crit, sum_mode, ppb, &results[ip], NULL);
+            if (cloud_sizes) cloud_sizes[ip] = (uint32_t)n;
+        }
         free(cloud); free(depth);
     }
     return threads;

@@ -117,6 +117,7 @@ void po_sum29(const po_vec3 *cloud, size_t n, int scene_kind, const void *scene,
 
 /* whole path for a batch of hypotheses (render -> cloud -> ICP), OpenMP over poses; used for
  * known answers at small P and as bench.py's cpu_baseline.  Returns threads used. */
+int po_set_threads(int n);   /* OpenMP threads of po_refine_batch (0 = query only); returns the setting in force */
 int po_refine_batch(const po_tri *tris, size_t n_tris, const float *poses16, size_t n_poses,
                     size_t width, size_t height, const float proj[16], const float K[9],
                     int scene_kind, const void *scene, po_criteria crit,

@@ -114,6 +114,7 @@ SIGNATURES = {
     "pr_profile_reset": (_i32, []),
     "pr_profile_read": (_i32, [C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
                                 C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "pr_gather_profile": (_i32, [C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
 }
 
 _lib = None

@@ -125,6 +125,13 @@ def profile_read():
                 render_ms=rms.value, cloud_ms=cms.value)
 
 
+def gather_profile():
+    """HIP-event time of the gathers issued while option ``profile`` was on: (total ms, count).  Waits for the library stream."""
+    ms, n = C.c_double(), C.c_uint64()
+    check(_lib.load().pr_gather_profile(C.byref(ms), C.byref(n)))
+    return ms.value, n.value
+
+
 def nn_counters(passes: int = 21) -> np.ndarray:
     """Per-pass work counters of the kd-tree search kernel (option ``nn_count``): (passes, 8) uint64 --
     queries, settled by window, tree searches, pyramid descents, tree nodes, leaves, leaf points, window cells."""

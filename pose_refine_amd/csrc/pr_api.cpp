@@ -127,6 +127,7 @@ struct Options {
     int nn_lds_records = 0;          // stack traversal: leading 64-byte node records staged in LDS; measured 0/64/128/256/512 -> 42.2/41.6/45.2/45.4/58.2 ms per step (occupancy lost to the extra LDS outweighs the saved L1 lookups)
     int nn_seed = 1;                 // compact kd records: start every search from the previous pass' winner distance
     int nn_compact = 1;              // stack traversal: 32-byte node records with 16-bit outward-rounded child boxes (half the L1 traffic)
+    int nn_wide = 1;                 // queued tree searches: order-free walk over 128-byte lines (eight subtree boxes per wide node, one line per leaf); ties go to the binary walk
     int nn_stack = 1;                // kd-tree query: per-lane LDS stack (1) or the reference's stackless walk (0)
     int nn_split = 1;                // kd-tree scenes on compact records: search kernel (runs of consecutive points, grid window) + winners pass
     int nn_run = 1;                  // 256-point chunks a workgroup of the search kernel takes (lane t of chunk k: point 256 k + t)
@@ -210,11 +211,11 @@ struct Ctx {
     const void *mesh_key = nullptr; size_t mesh_n = 0;   // triangle buffer aabb_host belongs to
     uint32_t cloud_hint = 0;          // largest cloud of the latest finished asynchronous batch: sizes the next batch's grid
     // workspaces
-    DevBuf aabb, aabb_keys, bbox, poses, depth, row_count, row_off, counts, cloud, meta, partial, sums, topo, bmin, bmax, pts, nnrec, nnrec32, nndesc, nn_prev, nndepth, dstate, dresults, vbdesc, flowsync, arrive, conv16, conv8, kd_idx, kd_scratch, kd_child, kd_ctrl, kd_tmp, nn_full;
+    DevBuf aabb, aabb_keys, bbox, poses, depth, row_count, row_off, counts, cloud, meta, partial, sums, topo, bmin, bmax, pts, nnrec, nnrec32, nndesc, nnwide, nnwq, nn_prev, nndepth, dstate, dresults, vbdesc, flowsync, arrive, conv16, conv8, kd_idx, kd_scratch, kd_child, kd_ctrl, kd_tmp, nn_full;
     PinBuf h_sums, h_meta, h_counts, h_results, h_dstate, h_flow;
     PackedCache packed;              // synchronous paths (the asynchronous slots keep their own)
     struct { const void *pcd = nullptr, *normal = nullptr, *nodes = nullptr; uint32_t n_points = 0, n_nodes = 0; uint64_t gen = 0; bool valid = false;
-             uint32_t info[8] = { 0 };
+             uint32_t info[16] = { 0 };
              bool grid_valid = false, grid_usable = false; uint32_t gw = 0, gh = 0; float gk[4] = { 0, 0, 0, 0 }; } nn_cache;   // kd traversal records (topo ... nndesc) + pixel grid of the latest kd-tree scene
     DevBuf nn_cells, nn_grid, nn_counters, tile_info, overflow;
     // profiling
@@ -228,6 +229,8 @@ struct Ctx {
     // RCCL communicator this context is a rank of (pr_comm_init_rank / pr_comm_init_all), or null
     ncclComm_t comm = nullptr; int comm_rank = 0, comm_world = 1;
     DevBuf gather_tmp;
+    // HIP events around the gathers issued while option "profile" is on (pr_gather_profile)
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> gather_ev; size_t gather_ev_used = 0; double gather_ms = 0; uint64_t gather_n = 0;
 };
 
 // ---- context registry --------------------------------------------------------------------------------
@@ -408,12 +411,16 @@ int make_scene(int kind, const void *scene, bool want_packed, SceneSel &out, Pac
             PR_TRY(g->bmax.ensure((size_t)s->n_nodes * sizeof(float4)));
             PR_TRY(g->pts.ensure((size_t)s->n_points * sizeof(float4)));
             PR_TRY(g->nnrec.ensure((size_t)s->n_nodes * 4 * sizeof(float4)));
-            PR_TRY(g->nndepth.ensure(8 * sizeof(uint32_t)));
+            PR_TRY(g->nndepth.ensure(16 * sizeof(uint32_t)));
             PR_TRY(g->nnrec32.ensure((size_t)s->n_nodes * 2 * sizeof(uint4)));
             PR_TRY(g->nndesc.ensure((size_t)s->n_nodes * sizeof(uint2)));
+            // wide records: one 128-byte line per wide node
+            PR_TRY(g->nnwide.ensure(prk::nn_wide_capacity(s->n_nodes) * 128));
+            PR_TRY(g->nnwq.ensure(prk::nn_wide_capacity(s->n_nodes) * 2 * sizeof(uint32_t)));
             HIP_TRY(prk::launch_build_nn_accel(s->nodes, s->n_nodes, s->pcd, s->n_points, g->topo.as<int4>(), g->bmin.as<float4>(),
                                                g->bmax.as<float4>(), g->pts.as<float4>(), g->nnrec.as<float4>(), g->nnrec32.as<uint4>(),
-                                               g->nndesc.as<uint2>(), g->nndepth.as<uint32_t>(), g->stream));
+                                               g->nndesc.as<uint2>(), g->nndepth.as<uint32_t>(), g->stream,
+                                               g->nnwide.as<uint4>(), g->nnwq.as<uint32_t>()));
             HIP_TRY(hipMemcpyAsync(nc.info, g->nndepth.p, sizeof nc.info, hipMemcpyDeviceToHost, g->stream));
             HIP_TRY(hipStreamSynchronize(g->stream));
             nc.pcd = s->pcd; nc.normal = s->normal; nc.nodes = s->nodes; nc.n_points = s->n_points; nc.n_nodes = s->n_nodes; nc.gen = gen; nc.valid = true;
@@ -433,6 +440,7 @@ int make_scene(int kind, const void *scene, bool want_packed, SceneSel &out, Pac
         if (stack && opt.nn_compact && info[1] == 1u) {
             out.nn.rec32 = g->nnrec32.as<uint4>();
             for (int a = 0; a < 3; ++a) { std::memcpy(&out.nn.qmin[a], &info[2 + a], 4); std::memcpy(&out.nn.qscale[a], &info[5 + a], 4); }
+            if (opt.nn_wide && info[8] == 1u && info[9] > 0u) { out.nn.wide = g->nnwide.as<uint4>(); out.nn.n_wide = info[9]; }
         }
         // pixel grid of the scene points under the hypotheses' camera (fused paths only: a bare ICP call has no camera).  Usable
         // when every scene point owns a cell -- a Scene_nn made from a depth image with these intrinsics -- else the tree alone.
@@ -527,13 +535,14 @@ int icp_drive(pr_vec3 *cloud_base, const uint32_t *start_h, const uint32_t *coun
     if (sc.kind == PR_SCENE_NN && sc.nn.rec32 && (opt.nn_seed || sc.nn_split)) {     // winners, indexed like the cloud points
         size_t span = 1;
         for (uint32_t i = 0; i < P; ++i) span = std::max(span, (size_t)start_h[i] + count_h[i]);
-        // winners | slack of the keep-the-winner test | queue of unsettled queries (8 B each) | two queue counters per hypothesis
-        PR_TRY(g->nn_prev.ensure(sizeof(uint32_t) * (span * 4 + 2 * (size_t)P) + 64));
+        // winners | slack of the keep-the-winner test | queue 1 and queue 2 of unsettled queries (8 B per entry) | queue counters per hypothesis
+        PR_TRY(g->nn_prev.ensure(sizeof(uint32_t) * (span * prk::kNNWordsPerPoint + prk::kQCountStride * (size_t)P) + 64));
         b.nn_prev = g->nn_prev.as<uint32_t>();
         b.nn_slack = reinterpret_cast<float *>(b.nn_prev + span);
         b.nn_queue = reinterpret_cast<uint2 *>(b.nn_prev + 2 * span);
-        b.nn_qcount = b.nn_prev + 4 * span;
-        HIP_TRY(hipMemsetAsync(b.nn_qcount, 0, sizeof(uint32_t) * 2 * P, g->stream));
+        b.nn_queue2 = reinterpret_cast<uint2 *>(b.nn_prev + 4 * span);
+        b.nn_qcount = b.nn_prev + 6 * span;
+        HIP_TRY(hipMemsetAsync(b.nn_qcount, 0, sizeof(uint32_t) * prk::kQCountStride * P, g->stream));
     }
 
     prk::PoseMeta *h_meta = g->h_meta.as<prk::PoseMeta>();
@@ -632,7 +641,7 @@ int icp_drive(pr_vec3 *cloud_base, const uint32_t *start_h, const uint32_t *coun
                     const uint32_t p0 = group_begin(grp), np = group_begin(grp + 1) - p0;
                     hipStream_t st = grp ? g->side[grp - 1] : g->stream;
                     prk::IcpBatch bb = b;
-                    bb.meta += p0; bb.partial += (size_t)p0 * nblk * prk::kAccStride; if (bb.nn_qcount) bb.nn_qcount += 2 * (size_t)p0;
+                    bb.meta += p0; bb.partial += (size_t)p0 * nblk * prk::kAccStride; if (bb.nn_qcount) bb.nn_qcount += prk::kQCountStride * (size_t)p0;
                     bb.iter = it;
                     if (fused) { bb.fused = 1; bb.crit = crit; bb.st = g->dstate.as<prk::DevIcpState>() + p0; bb.arrive = g->arrive.as<uint32_t>() + p0; }
                     bb.score_only = (it == (uint32_t)crit.max_iteration) ? 1u : 0u;
@@ -667,6 +676,7 @@ int icp_drive(pr_vec3 *cloud_base, const uint32_t *start_h, const uint32_t *coun
             GraphKey key;
             key.add(P); key.add(nblk); key.add(steps); key.add(crit); key.add(sc); key.add(cloud_base); key.add(g->meta.p); key.add(g->partial.p);
             key.add(g->dstate.p); key.add(dres); key.add(results_host != nullptr); key.add(res); key.add(h_meta); key.add(init); key.add(opt.profile); key.add(opt.pose_groups); key.add(opt.fused_solve); key.add(g->arrive.p); key.add(b.nn_prev);
+            key.add(b.nn_slack); key.add(b.nn_queue); key.add(b.nn_queue2); key.add(b.nn_qcount);    // laid out behind nn_prev at multiples of `span` (max start+count): same P / max_n, other offsets => other addresses
             CachedGraph *hit = nullptr;
             for (auto &c : g->graphs) if (c.exec && c.key == key) { hit = &c; break; }
             if (!hit) {
@@ -1155,7 +1165,7 @@ int refine_submit_async(Slot &sl, const pr_triangle *tris_dev, size_t n_tris, ui
         sc.nn_split = (sc.nn.rec32 && opt.nn_split) ? 1u : 0u;
         sc.nn_max_points = (uint32_t)std::min<size_t>(max_area, 0xffffffffu);
         if (sc.nn.rec32 && (opt.nn_seed || sc.nn_split)) {
-            PR_TRY(sl.nn_prev.ensure(sizeof(uint32_t) * (nn_span * 4 + 2 * (size_t)sub) + 64));
+            PR_TRY(sl.nn_prev.ensure(sizeof(uint32_t) * (nn_span * prk::kNNWordsPerPoint + prk::kQCountStride * (size_t)sub) + 64));
             nn_prev = sl.nn_prev.as<uint32_t>();
         }
     }
@@ -1187,7 +1197,7 @@ int refine_submit_async(Slot &sl, const pr_triangle *tris_dev, size_t n_tris, ui
         // the iteration loop: (max_iteration+1) x [pass (+ fused finalize/solve)], pose groups on the slot's side streams
         const uint32_t n_groups = std::max(1u, std::min({ (uint32_t)std::max(1, opt.pose_groups), 4u, nq / 32u }));
         auto group_begin = [&](uint32_t grp) { return (uint32_t)(((uint64_t)nq * grp) / n_groups); };
-        if (nn_prev) HIP_TRY(hipMemsetAsync(nn_prev + 4 * nn_span, 0, sizeof(uint32_t) * 2 * nq, st));
+        if (nn_prev) HIP_TRY(hipMemsetAsync(nn_prev + 6 * nn_span, 0, sizeof(uint32_t) * prk::kQCountStride * nq, st));
         if (n_groups > 1) {
             for (uint32_t k = 1; k < n_groups; ++k) PR_TRY(ensure_stream(sl.side[k - 1], &sl.join[k - 1]));
             HIP_TRY(hipEventRecord(sl.fork, st));
@@ -1209,7 +1219,7 @@ int refine_submit_async(Slot &sl, const pr_triangle *tris_dev, size_t n_tris, ui
         b.cloud = sl.cloud.as<pr_vec3>(); b.nblk = nblk; b.grid_x = grid_x; b.steps = steps;
         if (nn_prev) {
             b.nn_prev = nn_prev; b.nn_slack = reinterpret_cast<float *>(nn_prev + nn_span);
-            b.nn_queue = reinterpret_cast<uint2 *>(nn_prev + 2 * nn_span); b.nn_qcount = nn_prev + 4 * nn_span;
+            b.nn_queue = reinterpret_cast<uint2 *>(nn_prev + 2 * nn_span); b.nn_queue2 = reinterpret_cast<uint2 *>(nn_prev + 4 * nn_span); b.nn_qcount = nn_prev + 6 * nn_span;
         }
         for (uint32_t it = 0; it <= (uint32_t)crit.max_iteration; ++it) {
             for (uint32_t grp = 0; grp < n_groups; ++grp) {
@@ -1217,7 +1227,7 @@ int refine_submit_async(Slot &sl, const pr_triangle *tris_dev, size_t n_tris, ui
                 hipStream_t gs = grp ? sl.side[grp - 1] : st;
                 prk::IcpBatch bb = b;
                 bb.meta = meta + p0; bb.partial = sl.partial.as<float>() + (size_t)p0 * nblk * prk::kAccStride;
-                if (bb.nn_qcount) bb.nn_qcount += 2 * (size_t)p0;
+                if (bb.nn_qcount) bb.nn_qcount += prk::kQCountStride * (size_t)p0;
                 bb.iter = it;
                 if (fused) { bb.fused = 1; bb.crit = crit; bb.st = dstate + p0; bb.arrive = arrive + p0; }
                 bb.score_only = (it == (uint32_t)crit.max_iteration) ? 1u : 0u;
@@ -1344,12 +1354,14 @@ void ctx_teardown(Ctx *c)        // c->mu held (or c unreachable); the calling t
     hipStreamSynchronize(c->stream);
     for (Slot &sl : c->slots) slot_release(sl);
     for (DevBuf *b : { &c->aabb, &c->aabb_keys, &c->bbox, &c->poses, &c->depth, &c->row_count, &c->row_off, &c->counts, &c->cloud, &c->meta, &c->partial,
-                       &c->sums, &c->packed.rec, &c->topo, &c->bmin, &c->bmax, &c->pts, &c->nnrec, &c->nnrec32, &c->nndesc, &c->nn_prev, &c->nndepth, &c->dstate, &c->dresults, &c->vbdesc, &c->flowsync, &c->arrive, &c->conv16, &c->conv8, &c->kd_idx, &c->kd_scratch, &c->kd_child, &c->kd_ctrl, &c->kd_tmp, &c->nn_full, &c->gather_tmp, &c->nn_cells, &c->nn_grid, &c->nn_counters, &c->tile_info, &c->overflow }) b->release();
+                       &c->sums, &c->packed.rec, &c->topo, &c->bmin, &c->bmax, &c->pts, &c->nnrec, &c->nnrec32, &c->nndesc, &c->nnwide, &c->nnwq, &c->nn_prev, &c->nndepth, &c->dstate, &c->dresults, &c->vbdesc, &c->flowsync, &c->arrive, &c->conv16, &c->conv8, &c->kd_idx, &c->kd_scratch, &c->kd_child, &c->kd_ctrl, &c->kd_tmp, &c->nn_full, &c->gather_tmp, &c->nn_cells, &c->nn_grid, &c->nn_counters, &c->tile_info, &c->overflow }) b->release();
     for (PinBuf *b : { &c->h_sums, &c->h_meta, &c->h_counts, &c->h_results, &c->h_dstate, &c->h_flow }) b->release();
     c->packed = PackedCache(); c->nn_cache.valid = false;
     for (auto &gr : c->graphs) destroy_graph(gr);
     c->graphs.clear();
     for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);
+    for (auto &e : c->gather_ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    c->gather_ev.clear(); c->gather_ev_used = 0;
     c->ev_pool.clear(); c->ev_used = 0; c->spans.clear();
     hipStreamDestroy(c->stream);
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
@@ -1741,6 +1753,12 @@ int pr_gather_results(const pr_result *send_dev, uint32_t n_local, uint32_t n_to
         if (n_local) g_writes.note(recv_dev, sizeof(pr_result) * n_local);
         return PR_OK;
     }
+    std::pair<hipEvent_t, hipEvent_t> *ev = nullptr;                // option "profile": the exchange's own time on the stream it runs on
+    if (opt.profile != 0) {
+        if (g->gather_ev_used == g->gather_ev.size()) { std::pair<hipEvent_t, hipEvent_t> e; HIP_TRY(hipEventCreate(&e.first)); HIP_TRY(hipEventCreate(&e.second)); g->gather_ev.push_back(e); }
+        ev = &g->gather_ev[g->gather_ev_used++];
+        HIP_TRY(hipEventRecord(ev->first, g->stream));
+    }
     NCCL_TRY(g_rccl.GroupStart());
     if (n_local) NCCL_TRY(g_rccl.Send(send_dev, (size_t)n_local * sizeof(pr_result), ncclChar, root, g->comm, g->stream));
     if (rank == root) {
@@ -1752,6 +1770,20 @@ int pr_gather_results(const pr_result *send_dev, uint32_t n_local, uint32_t n_to
         g_writes.note(recv_dev, sizeof(pr_result) * n_total);
     }
     NCCL_TRY(g_rccl.GroupEnd());
+    if (ev) HIP_TRY(hipEventRecord(ev->second, g->stream));
+    return PR_OK;
+}
+int pr_gather_profile(double *gather_ms, uint64_t *gathers)
+{
+    PR_ENTER();
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    for (size_t i = 0; i < g->gather_ev_used; ++i) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, g->gather_ev[i].first, g->gather_ev[i].second) == hipSuccess) { g->gather_ms += ms; g->gather_n++; }
+    }
+    g->gather_ev_used = 0;
+    if (gather_ms) *gather_ms = g->gather_ms;
+    if (gathers) *gathers = g->gather_n;
     return PR_OK;
 }
 
@@ -1768,6 +1800,7 @@ int pr_set_option(const char *name, int value)
     else if (n == "nn_lds_nodes") opt.nn_lds_nodes = std::max(0, value);
     else if (n == "nn_lds_records") opt.nn_lds_records = std::max(0, value);
     else if (n == "nn_compact") opt.nn_compact = value ? 1 : 0;
+    else if (n == "nn_wide") opt.nn_wide = value ? 1 : 0;
     else if (n == "nn_seed") opt.nn_seed = value ? 1 : 0;
     else if (n == "nn_stack") opt.nn_stack = value ? 1 : 0;
     else if (n == "nn_split") opt.nn_split = value ? 1 : 0;
@@ -1798,6 +1831,7 @@ int pr_get_option(const char *name, int *value)
     else if (n == "nn_lds_nodes") *value = opt.nn_lds_nodes;
     else if (n == "nn_lds_records") *value = opt.nn_lds_records;
     else if (n == "nn_compact") *value = opt.nn_compact;
+    else if (n == "nn_wide") *value = opt.nn_wide;
     else if (n == "nn_seed") *value = opt.nn_seed;
     else if (n == "nn_stack") *value = opt.nn_stack;
     else if (n == "nn_split") *value = opt.nn_split;
@@ -1835,6 +1869,7 @@ int pr_profile_reset(void)
     PR_TRY(bind_default());
     std::lock_guard<std::mutex> lk(g->mu);
     g->icp_ms = g->render_ms = g->cloud_ms = 0; g->icp_launches = g->icp_points = g->icp_bytes = 0; g->sample_clock = 0;
+    g->gather_ms = 0; g->gather_n = 0; g->gather_ev_used = 0;
     return PR_OK;
 }
 int pr_profile_read(double *kernel_ms, uint64_t *launches, uint64_t *points, uint64_t *algorithmic_bytes, double *render_ms, double *cloud_ms)

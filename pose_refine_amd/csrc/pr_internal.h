@@ -15,6 +15,8 @@ constexpr uint32_t kBlockThreads   = 256;                       // 4 wavefronts
 constexpr uint32_t kPointsPerLane  = 4;                         // consecutive points per lane per step
 constexpr uint32_t kPointsPerStep  = kBlockThreads * kPointsPerLane;   // 1024
 constexpr uint32_t kAccStride      = 32;                        // 29 sums padded to 32 floats
+constexpr uint32_t kQCountStride   = 4;                         // queue counters per hypothesis (IcpBatch::nn_qcount)
+constexpr uint32_t kNNWordsPerPoint = 6;                        // per cloud point: winner | slack | queue 1 (2 words) | queue 2 (2 words)
 
 // per-hypothesis run state consumed by the correspondence kernel
 enum : int32_t { kSkip = 0, kRun = 1, kRunWithTransform = 2 };
@@ -50,8 +52,10 @@ struct IcpBatch {
     float          *nn_slack;   // kd-tree scenes, search kernel: per cloud point, a lower bound on the distance of every scene point OTHER than the
                                 // winner, minus the distance the point has travelled since that bound was established (<= 0: none)
     uint2          *nn_queue;   // search kernel -> tree kernel: per hypothesis (same indexing as the cloud) the (point, bound) of every query the first
-                                // half could not settle;  nn_qcount: two counters per hypothesis (same pose indexing as `meta`), alternating per pass
+                                // half could not settle;  nn_qcount: kQCountStride counters per hypothesis (same pose indexing as `meta`): fill levels
+                                // of queue 1 and of queue 2, two each, alternating per pass
     uint32_t       *nn_qcount;
+    uint2          *nn_queue2;  // bound kernel -> task walk: what the pixel window could not settle either, (point, bound)
     uint32_t        pre_transformed;   // 1: the pending update has already been applied to the cloud (nn_search_kernel): the pass must not apply it again
     pr_criteria     crit;
 };
@@ -97,6 +101,10 @@ struct SceneNNDev {
     // three coarser levels of the same grid: one representative scene point per 4 x 4, 16 x 16 and 64 x 64 pixel block
     // (the occupied sub-block nearest the block's centre, recursively), same {x, y, z, index} cells
     const float4 *pyr4, *pyr16, *pyr64;
+    // wide records (nn_wide_build_kernel): one 128-byte line per wide node = eight slots {subtree box, reference}; null when the tree
+    // cannot be expressed that way (the binary walk of nn_tree_kernel is used)
+    const uint4 *wide;
+    uint32_t n_wide;
     // instrumented runs (option "nn_count"): per ICP pass (IcpBatch::iter) eight 64-bit counters -- queries, settled by the pixel
     // window, handed to the tree, pyramid descents, tree nodes visited, leaves scanned, leaf points tested, window cells read; else null
     unsigned long long *counters;
@@ -226,8 +234,12 @@ hipError_t launch_pack_proj_scene(const pr_vec3 *pcd, const pr_vec3 *normal, flo
                                   uint32_t width, uint32_t height, float fx, float fy, float cx, float cy, uint32_t tl_x, uint32_t tl_y,
                                   uint32_t *exact, hipStream_t s);
 // info[0] = tree depth, info[1] = 1 when the 32-byte records are valid, info[2..7] = qmin[3], qscale[3] (float bits)
+// info[8] = 1 when the wide records are valid, info[9] = number of wide nodes; wide: nn_wide_capacity(n_nodes) lines of 128 bytes,
+// wide_scratch: 2 * nn_wide_capacity(n_nodes) words (both may be null: no wide records are built)
+inline size_t nn_wide_capacity(uint32_t n_nodes) { return (size_t)n_nodes / 2 + 2; }
 hipError_t launch_build_nn_accel(const pr_kdnode *nodes, uint32_t n_nodes, const pr_vec3 *pcd, uint32_t n_points,
-                                 int4 *topo, float4 *bmin, float4 *bmax, float4 *pts, float4 *rec, uint4 *rec32, uint2 *desc, uint32_t *info, hipStream_t s);
+                                 int4 *topo, float4 *bmin, float4 *bmax, float4 *pts, float4 *rec, uint4 *rec32, uint2 *desc, uint32_t *info, hipStream_t s,
+                                 uint4 *wide = nullptr, uint32_t *wide_scratch = nullptr);
 
 }  // namespace prk
 

@@ -13,6 +13,8 @@
 #include <hip/hip_runtime.h>
 #include <limits.h>
 #include <float.h>
+#include <atomic>
+#include <stdlib.h>
 
 #include "pr_internal.h"
 
@@ -1128,6 +1130,68 @@ __device__ __forceinline__ bool query_nn_stack(const SceneNNDev &s, const float4
     return query_nn_stack_from<kCode>(s, lds_rec, stk_node, stk_lb, sx, sy, sz, c, best, winner);
 }
 
+// ---- wide records: eight subtree boxes per 128-byte line, searched as tasks of four lanes (nn_tree_wide_kernel) -----------------
+// A per-lane walk pays for every (lane, load instruction) pair: 44 records of 32 bytes per query while a hypothesis is still
+// centimetres off the surface, each lane on a line of its own.  (Measured first: the same wide nodes walked one query per lane --
+// 15 node visits instead of 44, but eight 16-byte loads per visit and lane: pass 0 went from 5.2 to 6.8 ms.)  The wide form is made
+// for cooperative access instead: a WIDE NODE is one 128-byte line of eight 16-byte slots {box as 6 x uint16 in the root-box
+// frame, rounded OUTWARDS and verified with nn_deq_fma | reference}, one slot per descendant of a binary node (the frontier the
+// builder reaches by repeatedly opening the largest box, about three binary levels).  A group of four adjacent lanes handles one
+// (query, node): lane c loads slots 2c and 2c+1 -- the group's loads are ONE coalesced line -- and tests those two boxes.  A leaf
+// reference carries (first point, count): the group reads the leaf's points from the padded point array, two 16-byte points per lane.
+//   reference: kWideLeaf | count << 27 | first point   (leaf, count 1..15)   |   index of a wide node   |   kWideEmpty
+// The search is ORDER-FREE: every admitted child becomes a task of its own.  That finds the minimum squared distance m and every
+// point attaining it, because a box is only skipped when its lower bound EXCEEDS the query's bound (>= m).  The reference's answer (pcd_scene.h:60-136) is the first point at distance m in ITS visiting order: if exactly one
+// point attains m, that is the answer under any order (the argument the pixel window already rests on); if several do, or a stack
+// overflows, the query is repeated by the ordered stackless walk (query_nn_bounded), started from m.  `second`, a lower bound on the
+// squared distance of every scene point other than the winner (skipped boxes count with their bound), lets the following passes
+// keep this winner without searching (nn_search_kernel) -- the ordered walks cannot report it.
+constexpr uint32_t kWideLeaf = 0x80000000u, kWideEmpty = 0xffffffffu;
+constexpr uint32_t kWideMaxLeafPoints = 15u, kWideFirstMask = 0x07ffffffu;
+__device__ __forceinline__ float nn_deq_fma(uint32_t q, float qmin, float qscale) { return __builtin_fmaf((float)q, qscale, qmin); }
+__device__ __forceinline__ float wide_box_lb(float sx, float sy, float sz, uint32_t u0, uint32_t u1, uint32_t u2, const SceneNNDev &s)
+{
+    const float lox = nn_deq_fma(u0 & 0xffffu, s.qmin[0], s.qscale[0]), loy = nn_deq_fma(u0 >> 16, s.qmin[1], s.qscale[1]);
+    const float loz = nn_deq_fma(u1 & 0xffffu, s.qmin[2], s.qscale[2]), hix = nn_deq_fma(u1 >> 16, s.qmin[0], s.qscale[0]);
+    const float hiy = nn_deq_fma(u2 & 0xffffu, s.qmin[1], s.qscale[1]), hiz = nn_deq_fma(u2 >> 16, s.qmin[2], s.qscale[2]);
+    // = box_dist_sq: per axis (lo - q)^2 below the box, (hi - q)^2 == (q - hi)^2 above it, 0 inside
+    const float dx = fmaxf(fmaxf(lox - sx, sx - hix), 0.0f), dy = fmaxf(fmaxf(loy - sy, sy - hiy), 0.0f), dz = fmaxf(fmaxf(loz - sz, sz - hiz), 0.0f);
+    return dx * dx + dy * dy + dz * dz;
+}
+// Scene_nn::query pcd_scene.h:60-136 as query_nn above, started from a bound (an existing point's distance, inflated: nn_seed_bound) and
+// reporting the winner's index: the ordered walk ties and overflows of the wide search fall back to.  No LDS.
+__device__ __forceinline__ uint32_t query_nn_bounded(const SceneNNDev &s, float sx, float sy, float sz, float best_init)
+{
+    int cur = 0, prev = -1, best_i = -1;
+    bool climbing = false;
+    float best = best_init;
+    while (cur >= 0) {
+        const int4 t = s.topo[cur];
+        const int parent = (t.w & 0x3fffffff) - 1;
+        if (!climbing && t.z < 0) {
+            for (int i = t.x; i < t.y; ++i) {
+                const float4 p = s.pts[i];
+                const float d2 = (sx - p.x) * (sx - p.x) + (sy - p.y) * (sy - p.y) + (sz - p.z) * (sz - p.z);
+                if (d2 < best) { best = d2; best_i = i; }
+            }
+            climbing = true; prev = cur; cur = parent;
+            continue;
+        }
+        const int dim = (int)((uint32_t)t.w >> 30);
+        const float q = (dim == 0) ? sx : ((dim == 1) ? sy : sz);
+        const float diff = q - __int_as_float(t.x);
+        const int near_c = (diff < 0) ? t.y : t.z;
+        const int far_c  = (diff < 0) ? t.z : t.y;
+        if (!climbing) { prev = cur; cur = near_c; continue; }
+        if (prev == near_c) {
+            const float lb = box_dist_sq(sx, sy, sz, s.bmin[far_c], s.bmax[far_c]);
+            if (lb <= best) { prev = cur; cur = far_c; climbing = false; continue; }
+        }
+        prev = cur; cur = parent;
+    }
+    return (best_i >= 0 && best < s.max_dist_diff * s.max_dist_diff) ? (uint32_t)best_i : kNoPrev;
+}
+
 // ---- pixel grid of a kd-tree scene ---------------------------------------------------------------------------------------
 // A Scene_nn is made from a depth image (pcd_scene.cpp:10-29), so its points are the pixels of that image: cell (px, py) of the
 // grid holds the point that projects into it.  With a valid upper bound B on the squared nearest-neighbour distance (from a
@@ -1907,7 +1971,7 @@ __global__ __launch_bounds__(256) void nn_search_kernel(IcpBatch b, SceneNNDev s
     // the hypothesis' queue lives next to its winners (same indexing, so it can never overflow): (point, bound) per entry, filled
     // through this pass' counter of the hypothesis (two counters alternate between passes; nn_tree_kernel re-arms the idle one)
     uint2 *queue = b.nn_queue + pm.start;
-    uint32_t *q_count = b.nn_qcount + 2u * pose + (b.iter & 1u);
+    uint32_t *q_count = b.nn_qcount + kQCountStride * pose + (b.iter & 1u);
     __shared__ uint32_t wg_count, wg_base;
     __shared__ uint32_t wave_base[4];
     if (threadIdx.x == 0) wg_count = 0u;
@@ -1998,7 +2062,7 @@ __global__ __launch_bounds__(256) void nn_tree_kernel(IcpBatch b, SceneNNDev sce
     const uint32_t pose = blockIdx.y;
     const PoseMeta &pm = b.meta[pose];
     if (pm.state == kSkip) return;
-    uint32_t *counts = b.nn_qcount + 2u * pose;
+    uint32_t *counts = b.nn_qcount + kQCountStride * pose;
     const uint32_t queued = counts[b.iter & 1u];
     if (blockIdx.x == 0 && threadIdx.x == 0) counts[(b.iter + 1u) & 1u] = 0u;         // re-arm the counter the NEXT pass will fill
     if (blockIdx.x * kBlockThreads >= queued) return;
@@ -2038,7 +2102,7 @@ __global__ __launch_bounds__(256) void nn_tree_kernel(IcpBatch b, SceneNNDev sce
             if (!query_nn_stack_from<kCode, false>(scene, nullptr, stk_node, stk_lb, x, y, z, c, best, w, &cnt)) w = kNoPrev;
         }
         win[j] = w;
-        slk[j] = other;                                           // a tree search does not report its runner-up: no shortcut next pass
+        slk[j] = other;                                           // the ordered binary walk does not report its runner-up: no shortcut next pass
     }
     if (scene.counters) {                                        // instrumented runs only (option "nn_count")
         const uint32_t v[8] = { 0u, n_window, n_tree, n_pyramid, cnt.nodes, cnt.leaves, cnt.leaf_points, n_cells };
@@ -2047,6 +2111,234 @@ __global__ __launch_bounds__(256) void nn_tree_kernel(IcpBatch b, SceneNNDev sce
             uint32_t t = v[i];
             for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
             if ((threadIdx.x & 63u) == 0u) atomicAdd(&scene.counters[(size_t)b.iter * 8 + i], (unsigned long long)t);
+        }
+    }
+}
+
+// The queued queries of every hypothesis, searched over the wide records as TASKS (see "wide records" above).  Two walks over the same
+// records came first and both lost to the binary per-lane walk's 5.1 ms in pass 0 (256 hypotheses, 5.4 M tree searches): one query per
+// lane (eight 16-byte loads per visit and lane: 6.8 ms, bound by the rate of divergent loads) and one query per group of eight / four
+// lanes with a stack per group (6.6 / 6.0 ms: every lane of a wavefront pays for the node branch AND the leaf branch of every iteration
+// and for the longest walk among its groups -- VALU-bound at a quarter of the lanes doing useful work).  So the walk is cut into
+// uniform pieces: a NODE TASK = (query, wide node): four lanes test the node's eight boxes, two each; a LEAF TASK = (query, leaf): four
+// lanes test its points, two each per round.  A wavefront owns 64 queries at a time and two LIFO task queues in LDS; a step pops sixteen
+// tasks of ONE kind (one per group of four lanes), so all lanes run the same code, and pushes what the boxes admit.  What a query has
+// found so far lives in LDS and is updated with LDS atomics: `bound` (float bits, atomicMin), `best` = (distance bits << 32 | point index)
+// (64-bit atomicMin: smallest distance, lowest index among equals), `tied` (smallest distance two different points were seen at),
+// `second` (smallest distance / box bound of everything that is not the best).  When both queues are empty all 64 queries are finished:
+// exactly one point at the minimum -> that is the reference's answer under any visiting order; a tie (tied == minimum) or a queue
+// overflow -> the ordered stackless walk repeats the query from the minimum, as the reference would resolve it.
+// The bound (descent through the representative points) and the exact pixel window run in a kernel of their own, nn_bound_kernel, which
+// hands what it cannot settle to nn_tree_wide_kernel through a second queue: the descent needs twice the registers of the task walk, and
+// in one kernel (as first built: 3.6 ms for pass 0) it held the walk to four wavefronts per SIMD and three workgroup barriers per chunk.
+#ifndef PR_WIDE_WAVES
+#define PR_WIDE_WAVES 6                                        // wavefronts per SIMD the task walk is compiled for
+#endif
+#ifndef PR_WIDE_QCAP
+#define PR_WIDE_QCAP 256
+#endif
+#ifndef PR_WIDE_LCAP
+#define PR_WIDE_LCAP 160
+#endif
+constexpr uint32_t kTaskQCap = PR_WIDE_QCAP, kTaskLCap = PR_WIDE_LCAP;   // entries of the node / leaf task queue of a wavefront (a leaf queue is drained from 16 entries on)
+constexpr uint32_t kNoIdx = 0xffffffffu;
+// minimum over the four lanes of a group (a quad), in every lane
+__device__ __forceinline__ float group4_min(float v)
+{
+    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true)));     // quad_perm [1,0,3,2]
+    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true)));     // quad_perm [2,3,0,1]
+    return v;
+}
+// Queue 1 (nn_search_kernel's leftovers) -> bound + pixel window, one query per lane -> winners, or queue 2 (point, bound).
+__global__ __launch_bounds__(256) void nn_bound_kernel(IcpBatch b, SceneNNDev scene)
+{
+    __shared__ uint32_t wave_n[4], wg_base;
+    const uint32_t pose = blockIdx.y;
+    const PoseMeta &pm = b.meta[pose];
+    if (pm.state == kSkip) return;
+    uint32_t *counts = b.nn_qcount + kQCountStride * pose;
+    const uint32_t queued = counts[b.iter & 1u];
+    if (blockIdx.x == 0 && threadIdx.x == 0) counts[(b.iter + 1u) & 1u] = 0u;         // re-arm the counter the NEXT pass' search kernel will fill
+    if (blockIdx.x * kBlockThreads >= queued) return;
+    const float *cl = reinterpret_cast<const float *>(b.cloud + pm.start);
+    uint32_t *win = b.nn_prev + pm.start;
+    float *slk = b.nn_slack + pm.start;
+    const uint2 *queue = b.nn_queue + pm.start;
+    uint2 *queue2 = b.nn_queue2 + pm.start;
+    uint32_t *q2_count = counts + 2u + (b.iter & 1u);
+    const float accept = scene.max_dist_diff * scene.max_dist_diff;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t n_window = 0, n_pyramid = 0, n_cells = 0;
+    for (uint32_t i0 = blockIdx.x * kBlockThreads; i0 < queued; i0 += gridDim.x * kBlockThreads) {
+        const uint32_t i = i0 + threadIdx.x;
+        bool pending = false;
+        uint32_t j = 0; float bst = 0.0f;
+        if (i < queued) {
+            const uint2 e = queue[i];
+            j = e.x;
+            bst = __uint_as_float(e.y);
+            const bool still = bst < 0.0f;                       // the sign carries "no descent needed" (nn_search_kernel)
+            bst = still ? -bst : bst;
+            pending = true;
+            if (scene.grid && !still) {
+                const pr_vec3 q = ld_off<pr_vec3>(cl, j * 12u);
+                uint32_t w = kNoPrev; float bsq = 0.0f, osq = 0.0f;
+                grid_pyramid_bound(scene, q.x, q.y, q.z, bst); ++n_pyramid;
+                if (bst < accept && grid_search(scene, q.x, q.y, q.z, bst, w, &n_cells, &bsq, &osq)) { pending = false; ++n_window; win[j] = w; slk[j] = sqrtf(osq) * 0.99999f; }
+            }
+        }
+        const unsigned long long m = __ballot(pending);
+        if (lane == 0) wave_n[wave] = (uint32_t)__popcll(m);
+        __syncthreads();
+        if (threadIdx.x == 0) { const uint32_t t = wave_n[0] + wave_n[1] + wave_n[2] + wave_n[3]; wg_base = t ? atomicAdd(q2_count, t) : 0u; }
+        __syncthreads();
+        if (pending) {
+            uint32_t slot = wg_base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            for (uint32_t w2 = 0; w2 < wave; ++w2) slot += wave_n[w2];
+            queue2[slot] = make_uint2(j, __float_as_uint(bst));
+        }
+        __syncthreads();
+    }
+    if (scene.counters) {                                        // instrumented runs only (option "nn_count")
+        const uint32_t v[8] = { 0u, n_window, 0u, n_pyramid, 0u, 0u, 0u, n_cells };
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            uint32_t t = v[i];
+            for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
+            if ((threadIdx.x & 63u) == 0u && t) atomicAdd(&scene.counters[(size_t)b.iter * 8 + i], (unsigned long long)t);
+        }
+    }
+}
+// Queue 2 -> the task walk.  Wavefronts are independent (no workgroup barrier): each takes 64 queries at a time.
+__global__ __launch_bounds__(256, PR_WIDE_WAVES) void nn_tree_wide_kernel(IcpBatch b, SceneNNDev scene)
+{
+    __shared__ uint2 s_nodeq[4][kTaskQCap], s_leafq[4][kTaskLCap];               // {reference, bound bits (low 6 bits cleared: rounded DOWN) | query slot}
+    __shared__ float s_qx[4][64], s_qy[4][64], s_qz[4][64];
+    __shared__ uint32_t s_bound[4][64], s_second[4][64], s_tied[4][64], s_ovf[4][64];
+    __shared__ unsigned long long s_best[4][64];
+    const uint32_t pose = blockIdx.y;
+    const PoseMeta &pm = b.meta[pose];
+    if (pm.state == kSkip) return;
+    uint32_t *counts = b.nn_qcount + kQCountStride * pose + 2u;
+    const uint32_t queued = counts[b.iter & 1u];
+    if (blockIdx.x == 0 && threadIdx.x == 0) counts[(b.iter + 1u) & 1u] = 0u;         // re-arm the counter the NEXT pass' bound kernel will fill
+    if (blockIdx.x * kBlockThreads >= queued) return;
+    const float *cl = reinterpret_cast<const float *>(b.cloud + pm.start);
+    uint32_t *win = b.nn_prev + pm.start;
+    float *slk = b.nn_slack + pm.start;
+    const uint2 *todo = b.nn_queue2 + pm.start;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, c = lane & 3u, grp = lane >> 2;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    uint2 *nodeq = s_nodeq[wave], *leafq = s_leafq[wave];
+    float *qx = s_qx[wave], *qy = s_qy[wave], *qz = s_qz[wave];
+    uint32_t *bound = s_bound[wave], *second = s_second[wave], *tied = s_tied[wave], *ovf = s_ovf[wave];
+    unsigned long long *best = s_best[wave];
+    uint32_t n_tree = 0, n_nodes = 0, n_leaves = 0, n_leaf_points = 0, n_redo_q = 0;
+    for (uint32_t base = (blockIdx.x * 4u + wave) * 64u; base < queued; base += gridDim.x * 256u) {
+        const bool have_q = base + lane < queued;
+        uint32_t nN = 0, nL = 0;                                    // fill levels of the two queues (wave-uniform)
+        const uint2 mine = have_q ? todo[base + lane] : make_uint2(0u, 0u);    // this lane's query: (point, bound bits)
+        {
+            const pr_vec3 q = have_q ? ld_off<pr_vec3>(cl, mine.x * 12u) : pr_vec3{ 0.0f, 0.0f, 0.0f };
+            qx[lane] = q.x; qy[lane] = q.y; qz[lane] = q.z;
+            bound[lane] = mine.y;
+            best[lane] = ((unsigned long long)mine.y << 32) | kNoIdx;
+            second[lane] = 0x7f7fffffu; tied[lane] = 0xffffffffu; ovf[lane] = 0u;
+            const unsigned long long m = __ballot(have_q);
+            if (have_q) { nodeq[__popcll(m & lt)] = make_uint2(0u, lane); ++n_tree; }      // root task: wide node 0, bound 0.0f
+            nN = (uint32_t)__builtin_amdgcn_readfirstlane((int)__popcll(m));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        while (nN | nL) {
+            const bool leaf_step = (nL >= 16u) || (nN == 0u);
+            const uint32_t avail = leaf_step ? nL : nN, k = avail < 16u ? avail : 16u;
+            const bool active = grp < k;
+            const uint2 e = active ? (leaf_step ? leafq : nodeq)[avail - 1u - grp] : make_uint2(0u, 0u);
+            if (leaf_step) nL -= k; else nN -= k;
+            const uint32_t q = e.y & 63u, ref = e.x;
+            const float lb_in = __uint_as_float(e.y & ~63u);
+            const float sx = qx[q], sy = qy[q], sz = qz[q];
+            const float bnd = __uint_as_float(bound[q]);
+            const bool alive = active && lb_in <= bnd;
+            float sec_l = (active && !alive) ? lb_in : FLT_MAX;      // what this lane rules out (lower bounds of other points' distances)
+            if (!leaf_step) {
+                // ---------------- sixteen node tasks: lane c of a group tests slots 2c and 2c+1
+                uint4 r0 = make_uint4(0u, 0u, 0u, kWideEmpty), r1 = r0;
+                if (alive) { const uint4 *rec = scene.wide + (size_t)ref * 8u + 2u * c; r0 = rec[0]; r1 = rec[1]; if (c == 0u) ++n_nodes; }
+                const bool v0 = r0.w != kWideEmpty, v1 = r1.w != kWideEmpty;
+                const float lb0 = wide_box_lb(sx, sy, sz, r0.x, r0.y, r0.z, scene), lb1 = wide_box_lb(sx, sy, sz, r1.x, r1.y, r1.z, scene);
+                const bool k0 = v0 && lb0 <= bnd, k1 = v1 && lb1 <= bnd;
+                if (v0 && !k0) sec_l = fminf(sec_l, lb0);
+                if (v1 && !k1) sec_l = fminf(sec_l, lb1);
+                const bool f0 = (r0.w & kWideLeaf) != 0u, f1 = (r1.w & kWideLeaf) != 0u;
+                const unsigned long long mI0 = __ballot(k0 && !f0), mI1 = __ballot(k1 && !f1), mL0 = __ballot(k0 && f0), mL1 = __ballot(k1 && f1);
+                const uint32_t pos0 = (f0 ? nL + (uint32_t)__popcll(mL0 & lt) : nN + (uint32_t)__popcll(mI0 & lt));
+                const uint32_t pos1 = (f1 ? nL + (uint32_t)__popcll(mL0) + (uint32_t)__popcll(mL1 & lt) : nN + (uint32_t)__popcll(mI0) + (uint32_t)__popcll(mI1 & lt));
+                if (k0) { if (pos0 < (f0 ? kTaskLCap : kTaskQCap)) (f0 ? leafq : nodeq)[pos0] = make_uint2(r0.w, (__float_as_uint(lb0) & ~63u) | q); else ovf[q] = 1u; }
+                if (k1) { if (pos1 < (f1 ? kTaskLCap : kTaskQCap)) (f1 ? leafq : nodeq)[pos1] = make_uint2(r1.w, (__float_as_uint(lb1) & ~63u) | q); else ovf[q] = 1u; }
+                nN += (uint32_t)__popcll(mI0) + (uint32_t)__popcll(mI1); if (nN > kTaskQCap) nN = kTaskQCap;
+                nL += (uint32_t)__popcll(mL0) + (uint32_t)__popcll(mL1); if (nL > kTaskLCap) nL = kTaskLCap;
+            } else {
+                // ---------------- sixteen leaf tasks: two points per lane and round, both loaded before either is looked at
+                const uint32_t first = ref & kWideFirstMask, cnt = alive ? ((ref >> 27) & 15u) : 0u;
+                if (alive && c == 0u) { ++n_leaves; n_leaf_points += cnt; }
+                for (uint32_t kb = 0; kb < cnt; kb += 8u) {
+                    const uint32_t ka = kb + 2u * c;
+                    const bool h0 = ka < cnt, h1 = ka + 1u < cnt;
+                    const float4 *pp = scene.pts + first + (h0 ? ka : 0u);
+                    const float4 pa = pp[0], pb = pp[h1 ? 1 : 0];
+                    float d2[2] = { (sx - pa.x) * (sx - pa.x) + (sy - pa.y) * (sy - pa.y) + (sz - pa.z) * (sz - pa.z),       // pcd_scene.h:88-91
+                                    (sx - pb.x) * (sx - pb.x) + (sy - pb.y) * (sy - pb.y) + (sz - pb.z) * (sz - pb.z) };
+                    const bool hh[2] = { h0, h1 };
+#pragma unroll
+                    for (uint32_t h = 0; h < 2u; ++h) {
+                        if (hh[h] && d2[h] <= bnd) {                   // rare: a point that may be the minimum
+                            const uint32_t idx = first + ka + h, db = __float_as_uint(d2[h]);
+                            const unsigned long long key = ((unsigned long long)db << 32) | idx;
+                            const unsigned long long old = atomicMin(&best[q], key);
+                            const uint32_t old_d = (uint32_t)(old >> 32), old_i = (uint32_t)old;
+                            if (old_d == db && old_i != idx && old_i != kNoIdx) atomicMin(&tied[q], db);
+                            if (key < old) { if (old_i != kNoIdx) sec_l = fminf(sec_l, __uint_as_float(old_d)); if (d2[h] < bnd) atomicMin(&bound[q], db); }
+                            else sec_l = fminf(sec_l, d2[h]);
+                        } else if (hh[h]) sec_l = fminf(sec_l, d2[h]);
+                    }
+                }
+            }
+            nN = (uint32_t)__builtin_amdgcn_readfirstlane((int)nN); nL = (uint32_t)__builtin_amdgcn_readfirstlane((int)nL);     // wave-uniform by construction
+            const float sec_g = group4_min(sec_l);
+            if (c == 0u && sec_g < FLT_MAX) atomicMin(&second[q], __float_as_uint(sec_g));
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        // all 64 queries of this wavefront are finished: one lane per query delivers
+        if (have_q) {
+            const unsigned long long key = best[lane];
+            const uint32_t m_bits = (uint32_t)(key >> 32), idx = (uint32_t)key, b0 = mine.y, j = mine.x;
+            const bool found = idx != kNoIdx && m_bits < b0;
+            if (ovf[lane] != 0u || (found && tied[lane] == m_bits)) {
+                // a tie or a dropped task: the ordered walk, from the minimum found (= nn_seed_bound: an existing point's distance)
+                ++n_redo_q;
+                const float bnd = found ? fminf(__uint_as_float(b0), __uint_as_float(m_bits) * 1.000001f + 1e-30f) : __uint_as_float(b0);
+                win[j] = query_nn_bounded(scene, qx[lane], qy[lane], qz[lane], bnd);
+                slk[j] = 0.0f;                                      // an ordered walk does not report its runner-up: no shortcut next pass
+            } else if (found) { win[j] = idx; slk[j] = sqrtf(__uint_as_float(second[lane])) * 0.99999f; }
+            else { win[j] = kNoPrev; slk[j] = 0.0f; }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (scene.counters) {                                        // instrumented runs only (option "nn_count")
+        uint32_t n_pyr = 0u;
+#ifdef PR_COUNT_REDO
+        n_pyr = n_redo_q;                                           // experiment builds: the 'pyramid' column also counts the queries handed to the ordered walk
+#endif
+        (void)n_redo_q;
+        const uint32_t v[8] = { 0u, 0u, n_tree, n_pyr, n_nodes, n_leaves, n_leaf_points, 0u };
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            uint32_t t = v[i];
+            for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
+            if ((threadIdx.x & 63u) == 0u && t) atomicAdd(&scene.counters[(size_t)b.iter * 8 + i], (unsigned long long)t);
         }
     }
 }
@@ -2740,10 +3032,135 @@ __global__ __launch_bounds__(256) void nn_records32_kernel(const int4 *__restric
     if (!ok) info[1] = 0u;                                       // any node that does not fit: the 64-byte records are used instead
 }
 
+// ---- wide records (query_nn_wide) ---------------------------------------------------------------------------------------------
+// Box of a binary node as 6 uint16 in the root-box frame, rounded outwards and checked with the dequantisation the query uses.
+__device__ __forceinline__ bool wide_quant_box(const float4 lo4, const float4 hi4, const uint32_t *__restrict__ info, uint32_t (&u)[3])
+{
+    const float lo[3] = { lo4.x, lo4.y, lo4.z }, hi[3] = { hi4.x, hi4.y, hi4.z };
+    uint32_t q[6];
+    bool ok = true;
+    for (int a = 0; a < 3; ++a) {
+        const float qmin = __uint_as_float(info[2 + a]), qs = __uint_as_float(info[5 + a]);
+        const float fl = floorf((lo[a] - qmin) / qs) - 1.0f;
+        uint32_t ql = fl > 0.0f ? (fl < 65535.0f ? (uint32_t)fl : 65535u) : 0u;
+        while (ql > 0 && !(nn_deq_fma(ql, qmin, qs) <= lo[a])) --ql;
+        if (!(nn_deq_fma(ql, qmin, qs) <= lo[a])) ok = false;
+        const float fh = ceilf((hi[a] - qmin) / qs) + 1.0f;
+        uint32_t qh = fh > 0.0f ? (fh < 65535.0f ? (uint32_t)fh : 65535u) : 0u;
+        while (qh < 65535u && !(nn_deq_fma(qh, qmin, qs) >= hi[a])) ++qh;
+        if (!(nn_deq_fma(qh, qmin, qs) >= hi[a])) ok = false;
+        q[a] = ql; q[3 + a] = qh;
+    }
+    u[0] = q[0] | (q[1] << 16); u[1] = q[2] | (q[3] << 16); u[2] = q[4] | (q[5] << 16);
+    return ok;
+}
+// One workgroup builds the wide nodes level by level (a scene is prepared once; 6 287 binary nodes give 5 levels).  Per level:
+// (A) every wide node opens its binary root into a frontier of up to eight descendants -- repeatedly the internal frontier node
+// with the longest box diagonal -- and counts the internal ones, (B) an exclusive scan of those counts numbers the next level's
+// wide nodes (deterministic: a wide node's index does not depend on timing), (C) the records are written.  `wq[k]` = binary root
+// of wide node k, `cnt[k]` = scan scratch.  A tree whose links are out of order (child index <= parent index) clears info[8].
+constexpr uint32_t kWideBuildThreads = 1024;
+__global__ __launch_bounds__(kWideBuildThreads) void nn_wide_build_kernel(const int4 *__restrict__ topo, const float4 *__restrict__ bmin,
+                                                                           const float4 *__restrict__ bmax, uint32_t n_nodes, uint4 *__restrict__ wide,
+                                                                           uint32_t cap_wide, uint32_t *__restrict__ wq, uint32_t *__restrict__ cnt,
+                                                                           uint32_t n_points, uint32_t *__restrict__ info)
+{
+    __shared__ uint32_t part[kWideBuildThreads];
+    __shared__ uint32_t s_bad;
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) { wq[0] = 0u; s_bad = (info[1] == 1u) ? 0u : 1u; }
+    __syncthreads();
+    uint32_t begin = 0, end = 1;
+    for (int level = 0; level < 64 && begin < end && !s_bad; ++level) {
+        // (A) frontiers; the words of the record hold binary node ids for now
+        for (uint32_t k = begin + tid; k < end; k += kWideBuildThreads) {
+            uint32_t fr[8]; float fsz[8]; int nf = 1;
+            fr[0] = wq[k];
+            auto size_of = [&](uint32_t n) -> float {              // -1 for a leaf (never opened)
+                if (topo[n].z < 0) return -1.0f;
+                const float4 a = bmin[n], b = bmax[n];
+                return (b.x - a.x) * (b.x - a.x) + (b.y - a.y) * (b.y - a.y) + (b.z - a.z) * (b.z - a.z);
+            };
+            fsz[0] = (topo[fr[0]].z < 0) ? -1.0f : FLT_MAX;        // the root of a wide node is always opened (unless the whole tree is one leaf)
+            while (nf < 8) {
+                int pick = -1;
+                for (int i = 0; i < nf; ++i) if (fsz[i] >= 0.0f && (pick < 0 || fsz[i] > fsz[pick])) pick = i;
+                if (pick < 0) break;
+                const uint32_t n = fr[pick];
+                const int4 t = topo[n];
+                if (!((uint32_t)t.y < n_nodes && (uint32_t)t.z < n_nodes && (uint32_t)t.y > n && (uint32_t)t.z > n)) { s_bad = 1u; fsz[pick] = -1.0f; continue; }
+                fr[pick] = (uint32_t)t.y; fsz[pick] = size_of((uint32_t)t.y);
+                fr[nf] = (uint32_t)t.z;   fsz[nf] = size_of((uint32_t)t.z);
+                ++nf;
+            }
+            uint32_t internal = 0;
+            for (int c = 0; c < 8; ++c) {                            // slot c = {box, reference}; internal children carry their BINARY id until (C)
+                uint32_t u[3] = { 0u, 0u, 0u }, ref = kWideEmpty;
+                if (c < nf) {
+                    const uint32_t n = fr[c];
+                    const int4 t = topo[n];
+                    if (!wide_quant_box(bmin[n], bmax[n], info, u)) s_bad = 1u;
+                    if (t.z < 0) {
+                        const int lo = t.x, hi = t.y;
+                        if (lo >= 0 && hi > lo && (uint32_t)(hi - lo) <= kWideMaxLeafPoints && (uint32_t)lo <= kWideFirstMask && (uint32_t)hi <= n_points)
+                            ref = kWideLeaf | ((uint32_t)(hi - lo) << 27) | (uint32_t)lo;
+                        else if (hi != lo) s_bad = 1u;               // (an empty leaf stays an empty slot)
+                    } else { ref = n; ++internal; if (n >= 0x7fffffffu) s_bad = 1u; }
+                }
+                wide[(size_t)k * 8 + c] = make_uint4(u[0], u[1], u[2], ref);
+            }
+            cnt[k] = internal;
+        }
+        __syncthreads();
+        // (B) exclusive scan of cnt[begin, end): contiguous chunk per thread, Hillis-Steele over the chunk sums
+        const uint32_t span = end - begin, chunk = (span + kWideBuildThreads - 1) / kWideBuildThreads;
+        const uint32_t c0 = begin + tid * chunk, c1 = (c0 + chunk < end) ? c0 + chunk : end;
+        uint32_t sum = 0;
+        for (uint32_t k = c0; k < c1 && k >= begin; ++k) sum += cnt[k];
+        part[tid] = sum;
+        __syncthreads();
+        for (uint32_t off = 1; off < kWideBuildThreads; off <<= 1) {
+            const uint32_t v = (tid >= off) ? part[tid - off] : 0u;
+            __syncthreads();
+            part[tid] += v;
+            __syncthreads();
+        }
+        const uint32_t total = part[kWideBuildThreads - 1];
+        uint32_t run = part[tid] - sum;                              // exclusive prefix of this thread's chunk
+        for (uint32_t k = c0; k < c1 && k >= begin; ++k) { const uint32_t v = cnt[k]; cnt[k] = run; run += v; }
+        if (tid == 0 && (size_t)end + total > (size_t)cap_wide) s_bad = 1u;
+        __syncthreads();
+        if (s_bad) break;
+        // (C) number the internal children: wide node k's go to end + cnt[k] ...
+        for (uint32_t k = begin + tid; k < end; k += kWideBuildThreads) {
+            uint32_t next = end + cnt[k];
+            for (int c = 0; c < 8; ++c) {
+                uint4 r = wide[(size_t)k * 8 + c];
+                if (r.w != kWideEmpty && !(r.w & kWideLeaf)) { wq[next] = r.w; r.w = next; ++next; wide[(size_t)k * 8 + c] = r; }
+            }
+        }
+        __syncthreads();
+        begin = end; end = end + total;
+    }
+    __syncthreads();
+    if (tid == 0) { info[8] = (s_bad || begin < end) ? 0u : 1u; info[9] = end; }
+}
 // ================================================================================================
 //  launchers
 // ================================================================================================
 uint32_t tile_cap_px() { return kTileCapPx; }
+// Dynamic LDS beyond 64 KiB is an opt-in PER DEVICE (hipFuncSetAttribute applies to the current device): one flag per kernel slot and
+// device, so that a process driving several GPUs (one host thread each) opts in on every one of them.
+static bool lds_opt_in(const void *fn, int slot, uint32_t bytes)
+{
+    static std::atomic<uint64_t> done[4];                         // bit = device ordinal (<= 64 devices), one word per kernel slot
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    if (done[slot].load(std::memory_order_acquire) & (1ull << dev)) return true;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return false;
+    done[slot].fetch_or(1ull << dev, std::memory_order_release);
+    return true;
+}
 static inline uint32_t cap_grid(size_t want) { return (uint32_t)(want < 1 ? 1 : (want > 8192 ? 8192 : want)); }
 
 hipError_t launch_fill_i32(int32_t *dst, size_t n, int32_t v, hipStream_t s)
@@ -2938,7 +3355,7 @@ hipError_t launch_icp_pass_nn_winners(const IcpBatch &b, const SceneNNWinners &s
 hipError_t launch_nn_search(const IcpBatch &b, const SceneNNDev &sc, uint32_t n_poses, uint32_t max_points, uint32_t run, hipStream_t s)
 {
     if (n_poses == 0 || max_points == 0) return hipSuccess;
-    if (!sc.rec32 || (sc.stack_depth != 16 && sc.stack_depth != 24) || !b.nn_prev || !b.nn_slack || !b.nn_queue || !b.nn_qcount) return hipErrorInvalidValue;
+    if (!sc.rec32 || (sc.stack_depth != 16 && sc.stack_depth != 24) || !b.nn_prev || !b.nn_slack || !b.nn_queue || !b.nn_queue2 || !b.nn_qcount) return hipErrorInvalidValue;
     if (run == 0) run = 1;
     if (run > 8) run = 8;
     const uint32_t per_block = kBlockThreads * run;
@@ -2947,9 +3364,13 @@ hipError_t launch_nn_search(const IcpBatch &b, const SceneNNDev &sc, uint32_t n_
     for (uint32_t p0 = 0; p0 < n_poses; p0 += 32768) {
         const uint32_t np = (n_poses - p0 < 32768) ? (n_poses - p0) : 32768;
         IcpBatch bb = b;
-        bb.meta += p0; bb.nn_qcount += 2u * p0;
+        bb.meta += p0; bb.nn_qcount += kQCountStride * p0;
         hipLaunchKernelGGL(nn_search_kernel, dim3(gx, np), dim3(kBlockThreads), 0, s, bb, sc, run);
-        if (sc.stack_depth == 16) hipLaunchKernelGGL(HIP_KERNEL_NAME(nn_tree_kernel<16 + 0x100>), dim3(tree_gx, np), dim3(kBlockThreads), (size_t)16 * kBlockThreads * 8, s, bb, sc);
+        if (sc.wide) {
+            hipLaunchKernelGGL(nn_bound_kernel, dim3(tree_gx, np), dim3(kBlockThreads), 0, s, bb, sc);
+            hipLaunchKernelGGL(nn_tree_wide_kernel, dim3(tree_gx, np), dim3(kBlockThreads), 0, s, bb, sc);
+        }
+        else if (sc.stack_depth == 16) hipLaunchKernelGGL(HIP_KERNEL_NAME(nn_tree_kernel<16 + 0x100>), dim3(tree_gx, np), dim3(kBlockThreads), (size_t)16 * kBlockThreads * 8, s, bb, sc);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(nn_tree_kernel<24 + 0x100>), dim3(tree_gx, np), dim3(kBlockThreads), (size_t)24 * kBlockThreads * 8, s, bb, sc);
     }
     return hipGetLastError();
@@ -3114,16 +3535,21 @@ hipError_t launch_pack_proj_scene(const pr_vec3 *pcd, const pr_vec3 *normal, flo
     return hipGetLastError();
 }
 hipError_t launch_build_nn_accel(const pr_kdnode *nodes, uint32_t n_nodes, const pr_vec3 *pcd, uint32_t n_points,
-                                 int4 *topo, float4 *bmin, float4 *bmax, float4 *pts, float4 *rec, uint4 *rec32, uint2 *desc, uint32_t *info, hipStream_t s)
+                                 int4 *topo, float4 *bmin, float4 *bmax, float4 *pts, float4 *rec, uint4 *rec32, uint2 *desc, uint32_t *info, hipStream_t s,
+                                 uint4 *wide, uint32_t *wide_scratch)
 {
     const uint32_t m = (n_nodes > n_points) ? n_nodes : n_points;
     if (m == 0) return hipSuccess;
     hipLaunchKernelGGL(nn_accel_kernel, dim3((m + 255) / 256), dim3(256), 0, s, nodes, n_nodes, pcd, n_points, topo, bmin, bmax, pts);
-    hipError_t e = hipMemsetAsync(info, 0, 8 * sizeof(uint32_t), s);
+    hipError_t e = hipMemsetAsync(info, 0, 16 * sizeof(uint32_t), s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(nn_records_kernel, dim3((n_nodes + 255) / 256), dim3(256), 0, s, topo, bmin, bmax, n_nodes, rec, info);
     hipLaunchKernelGGL(nn_frame_kernel, dim3(1), dim3(64), 0, s, bmin, bmax, info);
     hipLaunchKernelGGL(nn_records32_kernel, dim3((n_nodes + 255) / 256), dim3(256), 0, s, topo, bmin, bmax, n_nodes, rec32, desc, info);
+    if (wide && wide_scratch) {
+        const uint32_t cap = (uint32_t)nn_wide_capacity(n_nodes);
+        hipLaunchKernelGGL(nn_wide_build_kernel, dim3(1), dim3(kWideBuildThreads), 0, s, topo, bmin, bmax, n_nodes, wide, cap, wide_scratch, wide_scratch + cap, n_points, info);
+    }
     return hipGetLastError();
 }
 

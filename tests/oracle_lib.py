@@ -86,6 +86,8 @@ def lib():
         L.po_icp.restype = C.c_int
         L.po_icp.argtypes = [f32p, C.c_size_t, C.c_int, C.c_void_p, Criteria, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p]
         L.po_sum29.argtypes = [f32p, C.c_size_t, C.c_int, C.c_void_p, C.c_int, C.c_uint32, f32p]
+        L.po_set_threads.restype = C.c_int
+        L.po_set_threads.argtypes = [C.c_int]
         L.po_refine_batch.restype = C.c_int
         L.po_refine_batch.argtypes = [f32p, C.c_size_t, f32p, C.c_size_t, C.c_size_t, C.c_size_t, f32p, f32p,
                                       C.c_int, C.c_void_p, Criteria, C.c_int, C.c_uint32, Roi, C.c_void_p, u32p]
@@ -226,6 +228,11 @@ def solve666(A, b):
     T = np.zeros(16, np.float32)
     lib().po_solve666(_f32(A).reshape(-1), _f32(b).reshape(-1), T)
     return T.reshape(4, 4)
+
+
+def set_threads(n=0):
+    """OpenMP threads of refine_batch (0: query); returns the setting in force."""
+    return int(lib().po_set_threads(int(n)))
 
 
 def refine_batch(tris, poses, width, height, proj, K, scene, criteria=(0.0, 0.0, 20),

@@ -261,18 +261,21 @@ def test_fused_raster_modes_agree(gpu, model, scenario, gscenes):
 
 
 def test_nn_stack_and_stackless_traversals_agree(gpu, scenario, gscenes):
-    """The per-lane-stack kd query with compact 32-byte node records (default: child boxes quantised to 16 bits, rounded
-    outwards), the same with exact 64-byte records, and the reference-style stackless walk give bit-identical ICP results
+    """The order-free walk over 128-byte wide nodes / leaf lines (default), the per-lane-stack kd query with compact 32-byte node
+    records (child boxes quantised to 16 bits, rounded outwards), the same with exact 64-byte records, and the reference-style
+    stackless walk give bit-identical ICP results
     (same winners, same tie-breaks) -- 21 passes on the test.cpp cloud, whose first passes start centimetres off the surface."""
     out = []
-    for stack, compact in ((1, 1), (1, 0), (0, 0)):
+    for stack, compact, wide in ((1, 1, 1), (1, 1, 0), (1, 0, 0), (0, 0, 0)):      # (1, 1, 1) = default: order-free walk over 128-byte lines first
         api.set_option("nn_stack", stack)
         api.set_option("nn_compact", compact)
+        api.set_option("nn_wide", wide)
         dev = api.DeviceVector.from_host(scenario["cloud"].reshape(-1))
         r = api.ICP_Point2Plane(dev, gscenes["nn"], api.ICPConvergenceCriteria(0.0, 0.0, 20))
         out.append((r.transformation_.copy(), r.fitness_, r.inlier_rmse_, dev.to_host()))
     api.set_option("nn_stack", 1)
     api.set_option("nn_compact", 1)
+    api.set_option("nn_wide", 1)
     for o in out[1:]:
         assert np.array_equal(out[0][0], o[0]) and out[0][1] == o[1] and out[0][2] == o[2]
         assert np.array_equal(out[0][3], o[3])
@@ -427,7 +430,7 @@ def test_device_kdtree_build_random_points_with_ties(gpu, max_leaf, n):
     assert np.array_equal(dp.to_host(), hp.reshape(-1)) and np.array_equal(dn.to_host(), hn.reshape(-1))
 
 
-@pytest.mark.parametrize("seed,n,max_leaf", [(1, 4000, 10), (2, 900, 3), (3, 6000, 10)])
+@pytest.mark.parametrize("seed,n,max_leaf", [(1, 4000, 10), (2, 900, 3), (3, 6000, 10), (4, 3000, 24)])    # 24 > 10 points per leaf: no leaf lines, binary walk
 def test_nn_variants_agree_on_tie_heavy_clouds(gpu, seed, n, max_leaf):
     """Scene and model points on a coarse lattice with duplicates: many candidate neighbours are at EXACTLY the same distance,
     so the winner is decided by the traversal order alone.  The compact/seeded/near-test stack search, the exact 64-byte
@@ -454,8 +457,8 @@ def test_nn_variants_agree_on_tie_heavy_clouds(gpu, seed, n, max_leaf):
             api.set_option("solve", solve)
             for crit in ((0.0, 0.0, 12), (1e-5, 1e-5, 30)):
                 out = []
-                for stack, compact, seeded in ((1, 1, 1), (1, 1, 0), (1, 0, 0), (0, 0, 0)):
-                    api.set_option("nn_stack", stack); api.set_option("nn_compact", compact); api.set_option("nn_seed", seeded)
+                for stack, compact, seeded, wide in ((1, 1, 1, 1), (1, 1, 1, 0), (1, 1, 0, 1), (1, 1, 0, 0), (1, 0, 0, 0), (0, 0, 0, 0)):
+                    api.set_option("nn_stack", stack); api.set_option("nn_compact", compact); api.set_option("nn_seed", seeded); api.set_option("nn_wide", wide)
                     dev = api.DeviceVector.from_host(cloud.reshape(-1))
                     r = api.ICP_Point2Plane(dev, scene, api.ICPConvergenceCriteria(*crit))
                     out.append((r.transformation_.copy(), r.fitness_, r.inlier_rmse_, dev.to_host()))
@@ -464,5 +467,5 @@ def test_nn_variants_agree_on_tie_heavy_clouds(gpu, seed, n, max_leaf):
                     assert np.array_equal(out[-1][0], o[0]) and out[-1][1] == o[1] and out[-1][2] == o[2], (solve, crit)
                     assert np.array_equal(out[-1][3], o[3]), (solve, crit)
     finally:
-        api.set_option("nn_stack", 1); api.set_option("nn_compact", 1); api.set_option("nn_seed", 1)
+        api.set_option("nn_stack", 1); api.set_option("nn_compact", 1); api.set_option("nn_seed", 1); api.set_option("nn_wide", 1)
         api.set_option("solve", api.SOLVE_HOST)

@@ -7,7 +7,7 @@ sys.path.insert(0, ROOT)
 from pose_refine_amd import api, synth
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 scene_kind = sys.argv[2] if len(sys.argv) > 2 else "proj"
-api.init(0); api.set_option("solve", 1); api.set_option("raster_mode", int(os.environ.get("PR_RASTER_MODE", "1")))
+api.init(0); api.set_option("solve", 1); api.set_option("raster_mode", int(os.environ.get("PR_RASTER_MODE", "0")))
 for kv in filter(None, os.environ.get("PR_OPTS", "").split(",")):      # e.g. PR_OPTS=nn_run=8,nn_grid=0,pose_groups=1
     k, v = kv.split("="); api.set_option(k, int(v))
 model = api.Model(os.path.join(ROOT, "tests/golden/obj_06.ply"))
