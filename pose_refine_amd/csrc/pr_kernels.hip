@@ -960,6 +960,12 @@ constexpr uint32_t kNoPrev = 0xffffffffu;
 #ifndef PR_NN_COVER_PAD
 #define PR_NN_COVER_PAD 5.0e-4f                                 // metres a window search looks beyond its bound for the runner-up (about one pixel at 300 mm)
 #endif
+#ifndef PR_NN_NODESCENT
+#define PR_NN_NODESCENT 2.5e-7f                                // squared step up to which the previous winner's distance is bound enough (no descent through the representatives)
+#endif
+#ifndef PR_NN_SETTLE
+#define PR_NN_SETTLE 1                                           // grid_search: widest cover for points that have stopped moving
+#endif
 #ifndef PR_NN_STILL
 #define PR_NN_STILL 2.5e-7f                                     // (0.5 mm)^2: below this step a point's previous winner is taken as a tight seed
 #endif
@@ -1259,16 +1265,27 @@ __device__ __forceinline__ void grid_pyramid_bound(const SceneNNDev &s, float sx
     if (b < best) best = b;
 }
 __device__ __forceinline__ bool grid_search(const SceneNNDev &s, float sx, float sy, float sz, float bound, uint32_t &winner, uint32_t *cells = nullptr,
-                                            float *best_sq = nullptr, float *other_sq = nullptr)
+                                            float *best_sq = nullptr, float *other_sq = nullptr, bool settle = false)
 {
     int wx, wy;
     // The window has to hold every point closer than sqrt(bound) for the search to be exact.  When a slightly larger window still
     // fits it is taken instead: the extra ring costs a few cells and tells how far the RUNNER-UP is (other_sq), which is what lets
-    // the following passes keep this winner without searching (nn_search_kernel).
+    // the following passes keep this winner without searching (nn_search_kernel).  `settle`: the point has (nearly) stopped moving,
+    // so whatever margin is found will last for the rest of the loop -- the radius is then not sqrt(bound) + half a millimetre but the
+    // largest the 5 x 5 window covers (du(r) = fx (z + |x|) r / (z (z - r)) <= W  <=>  r <= W z^2 / (fx (z + |x|) + W z)): with the
+    // fixed pad a point whose neighbour is more than half a millimetre away (a quarter of them: the depth image is in whole
+    // millimetres) never got a margin at all and went through the window in every pass.
     float cover = bound;
     if (other_sq) {
-        const float rc = sqrtf(bound) + PR_NN_COVER_PAD;
-        if (grid_window(s, sx, sy, sz, rc * rc, wx, wy)) cover = rc * rc;
+        const float rb = sqrtf(bound);
+        float rc = rb + PR_NN_COVER_PAD;
+        if (settle) {
+            const float W = (float)kGridMaxW - 4e-3f;
+            const float rx = W * sz * sz / (s.gfx * (sz + fabsf(sx)) + W * sz), ry = W * sz * sz / (s.gfy * (sz + fabsf(sy)) + W * sz);
+            rc = fminf(rx, ry) * 0.999f;
+        }
+        if (rc > rb && grid_window(s, sx, sy, sz, rc * rc, wx, wy)) cover = rc * rc;
+        else if (settle) { rc = rb + PR_NN_COVER_PAD; if (grid_window(s, sx, sy, sz, rc * rc, wx, wy)) cover = rc * rc; }
     }
     if (cover == bound && !grid_window(s, sx, sy, sz, bound, wx, wy)) return false;
     float u, v;
@@ -2019,9 +2036,9 @@ __global__ __launch_bounds__(256) void nn_search_kernel(IcpBatch b, SceneNNDev s
             if (!kept) {
                 uint32_t w = kNoPrev;
                 float bsq = 0.0f, osq = 0.0f;
-                const bool settled = scene.grid && best < accept && grid_search(scene, x, y, z, best, w, &n_cells, &bsq, &osq);
+                const bool settled = scene.grid && best < accept && grid_search(scene, x, y, z, best, w, &n_cells, &bsq, &osq, still && PR_NN_SETTLE);
                 if (settled) { ++n_window; win[j] = w; slk[j] = sqrtf(osq) * 0.99999f; }
-                else { pending = true; if (still) best = -best; }   // the sign carries "no descent needed" to nn_tree_kernel (best > 0 always)
+                else { pending = true; if (prev != kNoPrev && step_sq <= PR_NN_NODESCENT) best = -best; }   // the sign carries "no descent needed" to the next kernel (best > 0 always)
             }
         }
         // one slot range per workgroup and chunk: waves in order, lanes in order -- the queue keeps the points' order
@@ -2132,23 +2149,19 @@ __global__ __launch_bounds__(256) void nn_tree_kernel(IcpBatch b, SceneNNDev sce
 // hands what it cannot settle to nn_tree_wide_kernel through a second queue: the descent needs twice the registers of the task walk, and
 // in one kernel (as first built: 3.6 ms for pass 0) it held the walk to four wavefronts per SIMD and three workgroup barriers per chunk.
 #ifndef PR_WIDE_WAVES
-#define PR_WIDE_WAVES 6                                        // wavefronts per SIMD the task walk is compiled for
+#define PR_WIDE_WAVES 5                                        // wavefronts per SIMD the task walk is compiled for
+#endif
+#ifndef PR_WIDE_LANES
+#define PR_WIDE_LANES 2                                        // lanes per task
 #endif
 #ifndef PR_WIDE_QCAP
-#define PR_WIDE_QCAP 256
+#define PR_WIDE_QCAP 384
 #endif
 #ifndef PR_WIDE_LCAP
-#define PR_WIDE_LCAP 160
+#define PR_WIDE_LCAP 288
 #endif
 constexpr uint32_t kTaskQCap = PR_WIDE_QCAP, kTaskLCap = PR_WIDE_LCAP;   // entries of the node / leaf task queue of a wavefront (a leaf queue is drained from 16 entries on)
 constexpr uint32_t kNoIdx = 0xffffffffu;
-// minimum over the four lanes of a group (a quad), in every lane
-__device__ __forceinline__ float group4_min(float v)
-{
-    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true)));     // quad_perm [1,0,3,2]
-    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true)));     // quad_perm [2,3,0,1]
-    return v;
-}
 // Queue 1 (nn_search_kernel's leftovers) -> bound + pixel window, one query per lane -> winners, or queue 2 (point, bound).
 __global__ __launch_bounds__(256) void nn_bound_kernel(IcpBatch b, SceneNNDev scene)
 {
@@ -2183,7 +2196,8 @@ __global__ __launch_bounds__(256) void nn_bound_kernel(IcpBatch b, SceneNNDev sc
             if (scene.grid && !still) {
                 const pr_vec3 q = ld_off<pr_vec3>(cl, j * 12u);
                 uint32_t w = kNoPrev; float bsq = 0.0f, osq = 0.0f;
-                grid_pyramid_bound(scene, q.x, q.y, q.z, bst); ++n_pyramid;
+                grid_pyramid_bound(scene, q.x, q.y, q.z, bst);
+                ++n_pyramid;
                 if (bst < accept && grid_search(scene, q.x, q.y, q.z, bst, w, &n_cells, &bsq, &osq)) { pending = false; ++n_window; win[j] = w; slk[j] = sqrtf(osq) * 0.99999f; }
             }
         }
@@ -2209,12 +2223,30 @@ __global__ __launch_bounds__(256) void nn_bound_kernel(IcpBatch b, SceneNNDev sc
         }
     }
 }
-// Queue 2 -> the task walk.  Wavefronts are independent (no workgroup barrier): each takes 64 queries at a time.
+// exclusive prefix sum over the 64 lanes of a wavefront (and the total): in-row Hillis-Steele with DPP row shifts, row totals by readlane
+__device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t &total)
+{
+    uint32_t x = v;
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true);      // row_shr:1 (lanes shifted in from outside the row read 0)
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true);      // row_shr:2
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true);      // row_shr:4
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true);      // row_shr:8
+    const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)x, 15), t1 = (uint32_t)__builtin_amdgcn_readlane((int)x, 31),
+                   t2 = (uint32_t)__builtin_amdgcn_readlane((int)x, 47), t3 = (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+    const uint32_t row = (threadIdx.x & 63u) >> 4;
+    x += (row > 0u ? t0 : 0u) + (row > 1u ? t1 : 0u) + (row > 2u ? t2 : 0u);
+    total = t0 + t1 + t2 + t3;
+    return x - v;
+}
+// Queue 2 -> the task walk.  Wavefronts are independent (no workgroup barrier): each takes 64 queries at a time.  kLanes lanes share a task:
+// 8 / kLanes boxes of a node, or 8 / kLanes points of a leaf per round, per lane; a step pops 64 / kLanes tasks of one kind.
+template <int kLanes>
 __global__ __launch_bounds__(256, PR_WIDE_WAVES) void nn_tree_wide_kernel(IcpBatch b, SceneNNDev scene)
 {
+    constexpr uint32_t kPer = 8u / kLanes, kTasks = 64u / kLanes;
     __shared__ uint2 s_nodeq[4][kTaskQCap], s_leafq[4][kTaskLCap];               // {reference, bound bits (low 6 bits cleared: rounded DOWN) | query slot}
-    __shared__ float s_qx[4][64], s_qy[4][64], s_qz[4][64];
-    __shared__ uint32_t s_bound[4][64], s_second[4][64], s_tied[4][64], s_ovf[4][64];
+    __shared__ float4 s_q[4][64];                                                // query point | bound (float bits, lowered with atomicMin)
+    __shared__ uint32_t s_second[4][64], s_tied[4][64], s_ovf[4][64], s_root[4][64];
     __shared__ unsigned long long s_best[4][64];
     const uint32_t pose = blockIdx.y;
     const PoseMeta &pm = b.meta[pose];
@@ -2227,100 +2259,151 @@ __global__ __launch_bounds__(256, PR_WIDE_WAVES) void nn_tree_wide_kernel(IcpBat
     uint32_t *win = b.nn_prev + pm.start;
     float *slk = b.nn_slack + pm.start;
     const uint2 *todo = b.nn_queue2 + pm.start;
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, c = lane & 3u, grp = lane >> 2;
-    const unsigned long long lt = (1ull << lane) - 1ull;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, c = lane % kLanes, grp = lane / kLanes;
     uint2 *nodeq = s_nodeq[wave], *leafq = s_leafq[wave];
-    float *qx = s_qx[wave], *qy = s_qy[wave], *qz = s_qz[wave];
-    uint32_t *bound = s_bound[wave], *second = s_second[wave], *tied = s_tied[wave], *ovf = s_ovf[wave];
+    float4 *qs = s_q[wave];
+    uint32_t *second = s_second[wave], *tied = s_tied[wave], *ovf = s_ovf[wave], *root = s_root[wave];
     unsigned long long *best = s_best[wave];
     uint32_t n_tree = 0, n_nodes = 0, n_leaves = 0, n_leaf_points = 0, n_redo_q = 0;
     for (uint32_t base = (blockIdx.x * 4u + wave) * 64u; base < queued; base += gridDim.x * 256u) {
         const bool have_q = base + lane < queued;
         uint32_t nN = 0, nL = 0;                                    // fill levels of the two queues (wave-uniform)
         const uint2 mine = have_q ? todo[base + lane] : make_uint2(0u, 0u);    // this lane's query: (point, bound bits)
+        uint32_t bound_now = mine.y;                                // the bound this lane's query was (last) started from
         {
             const pr_vec3 q = have_q ? ld_off<pr_vec3>(cl, mine.x * 12u) : pr_vec3{ 0.0f, 0.0f, 0.0f };
-            qx[lane] = q.x; qy[lane] = q.y; qz[lane] = q.z;
-            bound[lane] = mine.y;
+            qs[lane] = make_float4(q.x, q.y, q.z, __uint_as_float(mine.y));
             best[lane] = ((unsigned long long)mine.y << 32) | kNoIdx;
-            second[lane] = 0x7f7fffffu; tied[lane] = 0xffffffffu; ovf[lane] = 0u;
-            const unsigned long long m = __ballot(have_q);
-            if (have_q) { nodeq[__popcll(m & lt)] = make_uint2(0u, lane); ++n_tree; }      // root task: wide node 0, bound 0.0f
-            nN = (uint32_t)__builtin_amdgcn_readfirstlane((int)__popcll(m));
+            second[lane] = 0x7f7fffffu; tied[lane] = 0xffffffffu; ovf[lane] = 0u; root[lane] = lane;
+            if (have_q) ++n_tree;
         }
+        // The walks of the 64 queries are started kTasks at a time, whenever the node queue runs low: all 64 root tasks at once would
+        // spread three levels of every walk over the queues before the first leaf is reached (depth-first order keeps them short).
+        // A query that lost a task to a full queue is walked again in a second round, alone with the other such queries and from the
+        // minimum it did find (a handful of queries cannot fill the queues); only if that fails too does it go to the ordered walk.
+        uint32_t n_q = (queued - base < 64u) ? (queued - base) : 64u;
+        for (int round = 0; round < 2 && n_q; ++round) {
+        uint32_t started = 0;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        while (nN | nL) {
-            const bool leaf_step = (nL >= 16u) || (nN == 0u);
-            const uint32_t avail = leaf_step ? nL : nN, k = avail < 16u ? avail : 16u;
+        while (nN | nL | (n_q - started)) {
+            if (nN < kTasks && started < n_q) {                     // root tasks: wide node 0, bound 0.0f
+                const uint32_t add = (n_q - started < kTasks) ? (n_q - started) : kTasks;
+                if (lane < add) nodeq[nN + lane] = make_uint2(0u, root[started + lane]);
+                nN += add; started += add;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+            const bool leaf_step = (nL >= kTasks) || (nN == 0u);
+            const uint32_t avail = leaf_step ? nL : nN, k = avail < kTasks ? avail : kTasks;
             const bool active = grp < k;
             const uint2 e = active ? (leaf_step ? leafq : nodeq)[avail - 1u - grp] : make_uint2(0u, 0u);
             if (leaf_step) nL -= k; else nN -= k;
             const uint32_t q = e.y & 63u, ref = e.x;
             const float lb_in = __uint_as_float(e.y & ~63u);
-            const float sx = qx[q], sy = qy[q], sz = qz[q];
-            const float bnd = __uint_as_float(bound[q]);
+            const float4 qp = qs[q];
+            const float sx = qp.x, sy = qp.y, sz = qp.z, bnd = qp.w;
+            uint32_t *bound_q = reinterpret_cast<uint32_t *>(&qs[q]) + 3;
             const bool alive = active && lb_in <= bnd;
             float sec_l = (active && !alive) ? lb_in : FLT_MAX;      // what this lane rules out (lower bounds of other points' distances)
             if (!leaf_step) {
-                // ---------------- sixteen node tasks: lane c of a group tests slots 2c and 2c+1
-                uint4 r0 = make_uint4(0u, 0u, 0u, kWideEmpty), r1 = r0;
-                if (alive) { const uint4 *rec = scene.wide + (size_t)ref * 8u + 2u * c; r0 = rec[0]; r1 = rec[1]; if (c == 0u) ++n_nodes; }
-                const bool v0 = r0.w != kWideEmpty, v1 = r1.w != kWideEmpty;
-                const float lb0 = wide_box_lb(sx, sy, sz, r0.x, r0.y, r0.z, scene), lb1 = wide_box_lb(sx, sy, sz, r1.x, r1.y, r1.z, scene);
-                const bool k0 = v0 && lb0 <= bnd, k1 = v1 && lb1 <= bnd;
-                if (v0 && !k0) sec_l = fminf(sec_l, lb0);
-                if (v1 && !k1) sec_l = fminf(sec_l, lb1);
-                const bool f0 = (r0.w & kWideLeaf) != 0u, f1 = (r1.w & kWideLeaf) != 0u;
-                const unsigned long long mI0 = __ballot(k0 && !f0), mI1 = __ballot(k1 && !f1), mL0 = __ballot(k0 && f0), mL1 = __ballot(k1 && f1);
-                const uint32_t pos0 = (f0 ? nL + (uint32_t)__popcll(mL0 & lt) : nN + (uint32_t)__popcll(mI0 & lt));
-                const uint32_t pos1 = (f1 ? nL + (uint32_t)__popcll(mL0) + (uint32_t)__popcll(mL1 & lt) : nN + (uint32_t)__popcll(mI0) + (uint32_t)__popcll(mI1 & lt));
-                if (k0) { if (pos0 < (f0 ? kTaskLCap : kTaskQCap)) (f0 ? leafq : nodeq)[pos0] = make_uint2(r0.w, (__float_as_uint(lb0) & ~63u) | q); else ovf[q] = 1u; }
-                if (k1) { if (pos1 < (f1 ? kTaskLCap : kTaskQCap)) (f1 ? leafq : nodeq)[pos1] = make_uint2(r1.w, (__float_as_uint(lb1) & ~63u) | q); else ovf[q] = 1u; }
-                nN += (uint32_t)__popcll(mI0) + (uint32_t)__popcll(mI1); if (nN > kTaskQCap) nN = kTaskQCap;
-                nL += (uint32_t)__popcll(mL0) + (uint32_t)__popcll(mL1); if (nL > kTaskLCap) nL = kTaskLCap;
+                // ---------------- node tasks: lane c of a group tests slots kPer*c .. kPer*c + kPer-1
+                uint4 r[kPer];
+#pragma unroll
+                for (uint32_t i = 0; i < kPer; ++i) r[i] = make_uint4(0u, 0u, 0u, kWideEmpty);
+                if (alive) {
+                    const uint4 *rec = scene.wide + (size_t)ref * 8u + kPer * c;
+#pragma unroll
+                    for (uint32_t i = 0; i < kPer; ++i) r[i] = rec[i];
+                    if (c == 0u) ++n_nodes;
+                }
+                uint32_t cntI = 0, cntL = 0;
+                float lb[kPer]; bool keep[kPer], leaf[kPer];
+#pragma unroll
+                for (uint32_t i = 0; i < kPer; ++i) {
+                    const bool v = r[i].w != kWideEmpty;
+                    lb[i] = wide_box_lb(sx, sy, sz, r[i].x, r[i].y, r[i].z, scene);
+                    keep[i] = v && lb[i] <= bnd;
+                    leaf[i] = (r[i].w & kWideLeaf) != 0u;
+                    if (v && !keep[i]) sec_l = fminf(sec_l, lb[i]);
+                    cntI += (keep[i] && !leaf[i]) ? 1u : 0u; cntL += (keep[i] && leaf[i]) ? 1u : 0u;
+                }
+                uint32_t tot = 0;
+                const uint32_t ex = wave_excl_scan(cntI | (cntL << 16), tot);
+                uint32_t pI = nN + (ex & 0xffffu), pL = nL + (ex >> 16);
+#pragma unroll
+                for (uint32_t i = 0; i < kPer; ++i) {
+                    if (!keep[i]) continue;
+                    const uint2 ent = make_uint2(r[i].w, (__float_as_uint(lb[i]) & ~63u) | q);
+                    if (leaf[i]) { if (pL < kTaskLCap) leafq[pL] = ent; else ovf[q] = 1u; ++pL; }
+                    else { if (pI < kTaskQCap) nodeq[pI] = ent; else ovf[q] = 1u; ++pI; }
+                }
+                nN += tot & 0xffffu; if (nN > kTaskQCap) nN = kTaskQCap;
+                nL += tot >> 16; if (nL > kTaskLCap) nL = kTaskLCap;
             } else {
-                // ---------------- sixteen leaf tasks: two points per lane and round, both loaded before either is looked at
+                // ---------------- leaf tasks: kPer points per lane and round, all loaded before any is looked at
                 const uint32_t first = ref & kWideFirstMask, cnt = alive ? ((ref >> 27) & 15u) : 0u;
                 if (alive && c == 0u) { ++n_leaves; n_leaf_points += cnt; }
                 for (uint32_t kb = 0; kb < cnt; kb += 8u) {
-                    const uint32_t ka = kb + 2u * c;
-                    const bool h0 = ka < cnt, h1 = ka + 1u < cnt;
-                    const float4 *pp = scene.pts + first + (h0 ? ka : 0u);
-                    const float4 pa = pp[0], pb = pp[h1 ? 1 : 0];
-                    float d2[2] = { (sx - pa.x) * (sx - pa.x) + (sy - pa.y) * (sy - pa.y) + (sz - pa.z) * (sz - pa.z),       // pcd_scene.h:88-91
-                                    (sx - pb.x) * (sx - pb.x) + (sy - pb.y) * (sy - pb.y) + (sz - pb.z) * (sz - pb.z) };
-                    const bool hh[2] = { h0, h1 };
+                    const uint32_t ka = kb + kPer * c;
+                    float4 pt[kPer];
 #pragma unroll
-                    for (uint32_t h = 0; h < 2u; ++h) {
-                        if (hh[h] && d2[h] <= bnd) {                   // rare: a point that may be the minimum
-                            const uint32_t idx = first + ka + h, db = __float_as_uint(d2[h]);
+                    for (uint32_t h = 0; h < kPer; ++h) pt[h] = scene.pts[first + (ka + h < cnt ? ka + h : 0u)];
+#pragma unroll
+                    for (uint32_t h = 0; h < kPer; ++h) {
+                        if (ka + h >= cnt) continue;
+                        const float d2 = (sx - pt[h].x) * (sx - pt[h].x) + (sy - pt[h].y) * (sy - pt[h].y) + (sz - pt[h].z) * (sz - pt[h].z);   // pcd_scene.h:88-91
+                        if (d2 <= bnd) {                               // rare: a point that may be the minimum
+                            const uint32_t idx = first + ka + h, db = __float_as_uint(d2);
                             const unsigned long long key = ((unsigned long long)db << 32) | idx;
                             const unsigned long long old = atomicMin(&best[q], key);
                             const uint32_t old_d = (uint32_t)(old >> 32), old_i = (uint32_t)old;
                             if (old_d == db && old_i != idx && old_i != kNoIdx) atomicMin(&tied[q], db);
-                            if (key < old) { if (old_i != kNoIdx) sec_l = fminf(sec_l, __uint_as_float(old_d)); if (d2[h] < bnd) atomicMin(&bound[q], db); }
-                            else sec_l = fminf(sec_l, d2[h]);
-                        } else if (hh[h]) sec_l = fminf(sec_l, d2[h]);
+                            if (key < old) { if (old_i != kNoIdx) sec_l = fminf(sec_l, __uint_as_float(old_d)); if (d2 < bnd) atomicMin(bound_q, db); }
+                            else sec_l = fminf(sec_l, d2);
+                        } else sec_l = fminf(sec_l, d2);
                     }
                 }
             }
             nN = (uint32_t)__builtin_amdgcn_readfirstlane((int)nN); nL = (uint32_t)__builtin_amdgcn_readfirstlane((int)nL);     // wave-uniform by construction
-            const float sec_g = group4_min(sec_l);
+            float sec_g = sec_l;
+            if (kLanes >= 2) sec_g = fminf(sec_l, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sec_l), 0xB1, 0xf, 0xf, true)));          // quad_perm [1,0,3,2]
+            if (kLanes == 4) sec_g = fminf(sec_g, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sec_g), 0x4E, 0xf, 0xf, true)));   // quad_perm [2,3,0,1]
             if (c == 0u && sec_g < FLT_MAX) atomicMin(&second[q], __float_as_uint(sec_g));
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
+            n_q = 0u;
+            if (round == 0) {                                       // queries that lost a task: reset, tighten, list for the second round
+                const bool lost = have_q && ovf[lane] != 0u;
+                const unsigned long long ml = __ballot(lost);
+                if (ml) {
+                    if (lost) {
+                        const unsigned long long key = best[lane];
+                        const uint32_t m_bits = (uint32_t)(key >> 32), idx = (uint32_t)key;
+                        uint32_t bb = mine.y;                         // (positive float bits order like the floats)
+                        if (idx != kNoIdx && m_bits < bb) { const uint32_t t = __float_as_uint(__uint_as_float(m_bits) * 1.000001f + 1e-30f); if (t < bb) bb = t; }   // = nn_seed_bound
+                        reinterpret_cast<uint32_t *>(&qs[lane])[3] = bb;
+                        best[lane] = ((unsigned long long)bb << 32) | kNoIdx;
+                        second[lane] = 0x7f7fffffu; tied[lane] = 0xffffffffu; ovf[lane] = 0u;
+                        root[__popcll(ml & ((1ull << lane) - 1ull))] = lane;
+                        bound_now = bb;
+                    }
+                    n_q = (uint32_t)__builtin_amdgcn_readfirstlane((int)__popcll(ml));
+                }
+            }
+        }
         // all 64 queries of this wavefront are finished: one lane per query delivers
         if (have_q) {
             const unsigned long long key = best[lane];
-            const uint32_t m_bits = (uint32_t)(key >> 32), idx = (uint32_t)key, b0 = mine.y, j = mine.x;
+            const uint32_t m_bits = (uint32_t)(key >> 32), idx = (uint32_t)key, b0 = bound_now, j = mine.x;
             const bool found = idx != kNoIdx && m_bits < b0;
             if (ovf[lane] != 0u || (found && tied[lane] == m_bits)) {
                 // a tie or a dropped task: the ordered walk, from the minimum found (= nn_seed_bound: an existing point's distance)
                 ++n_redo_q;
                 const float bnd = found ? fminf(__uint_as_float(b0), __uint_as_float(m_bits) * 1.000001f + 1e-30f) : __uint_as_float(b0);
-                win[j] = query_nn_bounded(scene, qx[lane], qy[lane], qz[lane], bnd);
+                const float4 qp = qs[lane];
+                win[j] = query_nn_bounded(scene, qp.x, qp.y, qp.z, bnd);
                 slk[j] = 0.0f;                                      // an ordered walk does not report its runner-up: no shortcut next pass
             } else if (found) { win[j] = idx; slk[j] = sqrtf(__uint_as_float(second[lane])) * 0.99999f; }
             else { win[j] = kNoPrev; slk[j] = 0.0f; }
@@ -3368,7 +3451,7 @@ hipError_t launch_nn_search(const IcpBatch &b, const SceneNNDev &sc, uint32_t n_
         hipLaunchKernelGGL(nn_search_kernel, dim3(gx, np), dim3(kBlockThreads), 0, s, bb, sc, run);
         if (sc.wide) {
             hipLaunchKernelGGL(nn_bound_kernel, dim3(tree_gx, np), dim3(kBlockThreads), 0, s, bb, sc);
-            hipLaunchKernelGGL(nn_tree_wide_kernel, dim3(tree_gx, np), dim3(kBlockThreads), 0, s, bb, sc);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(nn_tree_wide_kernel<PR_WIDE_LANES>), dim3(tree_gx, np), dim3(kBlockThreads), 0, s, bb, sc);
         }
         else if (sc.stack_depth == 16) hipLaunchKernelGGL(HIP_KERNEL_NAME(nn_tree_kernel<16 + 0x100>), dim3(tree_gx, np), dim3(kBlockThreads), (size_t)16 * kBlockThreads * 8, s, bb, sc);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(nn_tree_kernel<24 + 0x100>), dim3(tree_gx, np), dim3(kBlockThreads), (size_t)24 * kBlockThreads * 8, s, bb, sc);
