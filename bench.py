@@ -11,11 +11,15 @@ ICPConvergenceCriteria(0,0,20) => exactly 21 correspondence passes / 20 solves p
 timed region includes the pose upload (64 B/pose), every kernel, the per-iteration host solve
 round trips (PR_SOLVE_HOST) or the device solve, and the result gather.
 
-Multi-GPU (weak scaling): rank r refines hypotheses [r*P, (r+1)*P) of the seeded stream -- no
-data-path collective -- then ONE RCCL gather of the P x 72-byte RegistrationResult records to
-rank 0 over xGMI: pr_gather_results of the C ABI (grouped ncclSend/ncclRecv on the library's
-stream; the communicator's 128-byte id travels over torch.distributed, which also provides the
-barrier and the max-over-ranks clock).  PR_BENCH_GATHER=torch uses torch.distributed.gather instead.
+Multi-GPU: the global batch is cut into contiguous shards (pr_shard_range), rank r refines its shard of
+the seeded stream -- no data-path collective -- then ONE RCCL gather of the 72-byte RegistrationResult
+records to rank 0 over xGMI: pr_gather_results of the C ABI (grouped ncclSend/ncclRecv on the library's
+stream; the communicator's 128-byte id travels over torch.distributed, which also provides the barrier
+and the max-over-ranks clock).  PR_BENCH_GATHER=torch uses torch.distributed.gather instead.
+  --scaling weak   (default) per-GPU batch fixed: --poses 256 per GPU, or --global-poses G / N
+  --scaling strong the global batch is fixed (--global-poses, default 4096 = BASELINE configs[3]) and split over the N ranks
+      python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29500 \
+             bench.py --gpus 8 --global-poses 4096          # configs[3]: 512 hypotheses per GPU
 
 Prints ONE JSON line on rank 0 (contract in the task statement) including `roofline` for the
 dominant kernel (the correspondence kernel, HIP-event timed on the library's own stream) and
@@ -36,18 +40,52 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12                       # MI355X_MICROARCH.md: 8 TB/s spec
+VALU_PEAK = 256 * 4 * 2.4e9 / 4         # wave-instructions/s: 256 CUs x 4 SIMDs, one VALU instruction per 4 cycles at 2.4 GHz = 6.1e11
 # SURVEY.md 8d algorithmic bytes of the correspondence kernel: per pass 12 B source read + 24 B
 # destination/normal gather, + 12 B write-back on every pass after the first:
 # N*(21*36 + 20*12) = 996 N bytes per pose over 21 launches.
 BYTES_PER_POINT_PASS0, BYTES_PER_POINT_PASSK = 36.0, 48.0
-# HBM-side traffic of the correspondence kernel measured with rocprofv3 PMC passes (FETCH_SIZE x2 per the
-# gfx950 correction of MI355X_MICROARCH.md + WRITE_SIZE; both calibrated on max2zero_kernel, which moves a known
-# number of bytes): profiles/r02/README.md (projective 24.8 B/point, kd-tree 67.9 B/point over its three kernels).
-# bench.py cannot collect PMCs itself (they need their own rocprofv3 passes): `traffic` is the committed per-point
-# measurement x the points of a launch, and `frac_hbm_counter` is that traffic over the launch time measured here.
+# Committed rocprofv3 PMC measurements of the correspondence kernel (bench.py cannot collect counters itself -- they need rocprofv3 passes
+# of their own): fabric-side bytes per point (FETCH_SIZE x2 per the gfx950 correction of MI355X_MICROARCH.md + WRITE_SIZE, both calibrated on
+# max2zero_kernel, which moves a known number of bytes) and VALU wave-instructions per point (SQ_INSTS_VALU).  FETCH_SIZE counts what the
+# L2s fetch from the fabric, Infinity-Cache hits included (guide, HBM section): the counter figure is FABRIC traffic, an upper bound of DRAM
+# traffic -- with <= 512 hypotheses per sub-batch the clouds are Infinity-Cache resident by design.
 PMC_TRAFFIC_BYTES_PER_POINT = {"proj": 24.8, "nn": 67.9}
-PMC_TRAFFIC_SOURCE = {"proj": "profiles/r02/pmc_proj_FETCH_SIZE.md + pmc_proj_WRITE_SIZE.md (icp_pass_kernel<SceneProjPacked>)",
-                      "nn": "profiles/r02/pmc_nn_FETCH_SIZE.md + pmc_nn_WRITE_SIZE.md (nn_search_kernel 41.7 + nn_tree_kernel 8.5 + winners pass 17.7 B/point)"}
+PMC_VALU_WAVE_INSTR_PER_POINT = {"proj": 2.296, "nn": None}
+PMC_TRAFFIC_SOURCE = {"proj": "profiles/r03/pmc_proj_FETCH_SIZE.md + pmc_proj_WRITE_SIZE.md + sq_proj_SQ_INSTS_VALU*.md (icp_pass_kernel<SceneProjPacked>)",
+                      "nn": "profiles/r03/pmc_nn_FETCH_SIZE.md + pmc_nn_WRITE_SIZE.md (search + bound + task walk + winners pass)"}
+
+
+def effective_cpus():
+    """CPUs this process may really use: the affinity mask, capped by the cgroup CPU quota (cpu.max: a box with 256 online CPUs and a
+    quota of 16 runs 256 OpenMP threads on 16 CPUs' worth of time).  Returns (usable, facts)."""
+    facts = {"online": os.cpu_count(), "affinity": len(os.sched_getaffinity(0))}
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        facts["cgroup_cpu_max"] = f"{q} {per}"
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            facts["cgroup_cfs"] = f"{q} {per}"
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    usable = facts["affinity"]
+    if quota is not None:
+        usable = max(1, min(usable, int(quota + 0.5)))
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                facts["model"] = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return usable, facts
 
 
 def main():
@@ -55,7 +93,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--poses", type=int, default=256, help="hypotheses per GPU per step")
+    ap.add_argument("--poses", type=int, default=256, help="hypotheses per GPU per step (weak scaling)")
+    ap.add_argument("--global-poses", type=int, default=0, help="hypotheses per step over ALL GPUs (0: --poses x GPUs); BASELINE configs[3] = 4096 on 8 GPUs")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: per-GPU batch fixed (--poses, or --global-poses / N); strong: the global batch is fixed (--global-poses, default 4096) and split over the ranks")
     ap.add_argument("--scene", choices=["proj", "nn"], default="proj")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--solve", choices=["host", "device"], default=os.environ.get("PR_BENCH_SOLVE", "device"))
@@ -99,18 +140,21 @@ def main():
     api.init(local_rank)
     # the gather of the solved transforms: C ABI (RCCL directly) unless told otherwise or the communicator cannot be formed
     gather_mode = "torch" if (share_device or os.environ.get("PR_BENCH_GATHER", "cabi") == "torch") else "cabi"
+    gather_note = None
     if world > 1 and gather_mode == "cabi":
         try:
             ident = [api.comm_id() if rank == 0 else None]
             dist.broadcast_object_list(ident, src=0)               # 128 bytes, once
             api.comm_init_rank(ident[0], rank, world)
         except Exception as e:                                     # noqa: BLE001 -- a failed bootstrap must not cost the measurement
-            print(f"[bench] rank {rank}: C-ABI communicator unavailable ({e}); falling back to torch.distributed.gather", file=sys.stderr)
+            print(f"[bench] rank {rank}: C-ABI communicator unavailable ({e}); falling back to torch.distributed.gather", file=sys.stderr, flush=True)
             gather_mode = "torch"
-        flags = [gather_mode == "cabi"] * world
-        dist.all_gather_object(flags, gather_mode == "cabi")
-        if not all(flags):
+            gather_note = f"C-ABI bootstrap failed on rank {rank}: {e}"
+        notes = [None] * world
+        dist.all_gather_object(notes, gather_note)
+        if any(notes):                                             # one rank without a communicator: every rank uses torch's gather, and the line says why
             gather_mode = "torch"
+            gather_note = "; ".join(n for n in notes if n)
     api.set_option("solve", api.SOLVE_DEVICE if args.solve == "device" else api.SOLVE_HOST)
     api.set_option("pose_groups", args.pose_groups)
     api.set_option("fused_solve", args.fused_solve)
@@ -121,20 +165,28 @@ def main():
         api.set_option(name, int(value))
 
     W, H, K = synth.WIDTH, synth.HEIGHT, synth.K_TEST
-    P = args.poses
+    # this rank's shard: contiguous hypotheses [first, first + P) of the seeded stream (prd.shard_bounds == pr_shard_range of the C ABI)
+    if args.scaling == "strong":
+        global_poses = args.global_poses or 4096
+    else:
+        global_poses = args.global_poses or args.poses * world
+    first, P = prd.shard_bounds(global_poses, rank, world)
+    P_max = prd.shard_bounds(global_poses, 0, world)[1]
+    if P == 0:
+        raise SystemExit(f"rank {rank}: empty shard ({global_poses} hypotheses over {world} ranks)")
     model = api.Model(os.path.join(ROOT, "tests", "golden", "obj_06.ply"))
     proj = api.compute_proj(K, W, H)
     scene_depth = api.render_host(model, synth.scene_pose()[None], W, H, proj)[0]
     scene = (api.Scene_projective().init_Scene_projective_cuda(scene_depth, K) if args.scene == "proj"
              else api.Scene_nn().init_Scene_nn_cuda(scene_depth, K))
-    poses = synth.hypotheses(P, seed=6, first=rank * P)          # this rank's shard of the global batch
+    poses = synth.hypotheses(P, seed=6, first=first)             # this rank's shard of the global batch
     crit = api.ICPConvergenceCriteria(0.0, 0.0, args.iters)
 
     # P x RegistrationResult (72 B) on the device, double-buffered.  Step k is SUBMITTED on slot k&1 (everything enqueued, no
     # host round trip) and only then is step k-1 waited for and its results handed to the gather -- the GPU always has the
     # next batch queued, and the gather of step k-1 (RCCL's stream) overlaps step k.
     results = [torch.zeros(P * 18, dtype=torch.float32, device="cuda") for _ in range(2)]
-    gathered = [torch.zeros(P * world * 18, dtype=torch.float32, device="cuda") for _ in range(2)] if (world > 1 and rank == 0 and gather_mode == "cabi") else [None, None]
+    gathered = [torch.zeros(global_poses * 18, dtype=torch.float32, device="cuda") for _ in range(2)] if (world > 1 and rank == 0 and gather_mode == "cabi") else [None, None]
     pending = [None, None]                                       # gather handle per buffer
     inflight = [False, False]                                    # submitted, not yet waited for
     step_no = [0]
@@ -147,10 +199,10 @@ def main():
         inflight[b] = False
         last_sizes[0] = sizes
         if world > 1 and gather_mode == "cabi":                 # the single RCCL exchange of the job: P x 72 B per rank to rank 0,
-            api.gather_results(results[b].data_ptr(), P, P * world, 0,      # enqueued on the library's stream behind this batch
+            api.gather_results(results[b].data_ptr(), P, global_poses, 0,   # enqueued on the library's stream behind this batch
                                gathered[b].data_ptr() if rank == 0 else None)
         elif world > 1:
-            pending[b] = prd.gather_results(results[b].cpu() if share_device else results[b], world, rank, dst=0, max_count=P, async_op=True)
+            pending[b] = prd.gather_results(results[b].cpu() if share_device else results[b], world, rank, dst=0, max_count=P_max, async_op=True)
 
     def step():
         b = step_no[0] & 1
@@ -198,13 +250,18 @@ def main():
     api.set_option("profile", 0)
     prof = api.profile_read()
 
+    gather_ms, gather_n = (api.gather_profile() if (world > 1 and gather_mode == "cabi") else (0.0, 0))
+    per_rank_ms = [1e3 * elapsed / args.steps]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share_device else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        mine = 1e3 * elapsed / args.steps
+        per_rank_ms = [None] * world
+        dist.all_gather_object(per_rank_ms, mine)
         elapsed = float(t.item())
 
     if rank == 0:
-        total_poses = P * world * args.steps
+        total_poses = global_poses * args.steps
         launches = max(1, prof["icp_launches"])
         pts_per_launch = prof["icp_points"] / launches
         bytes_per_launch = prof["icp_bytes"] / launches          # 36 B/point on pass 0, 48 B/point afterwards
@@ -220,18 +277,26 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"obj_06.ply, {P}-pose batch per GPU, 640x480 synthetic depth, "
-                                   f"{'projective' if args.scene == 'proj' else 'kd-tree NN (exact search with the reference tie-breaks: keep-the-winner test and pixel-window scan where the bound allows, near-first depth-first tree walk with per-lane LDS stacks on compact 32-byte node records otherwise)'} association, "
+            "config": {"workload": f"obj_06.ply, {P_max}-pose batch per GPU, 640x480 synthetic depth, "
+                                   f"{'projective' if args.scene == 'proj' else 'kd-tree NN (exact search with the reference tie-breaks: keep-the-winner test and pixel-window scan where the bound allows, order-free task walk over 128-byte wide nodes otherwise, ties repeated by the ordered walk)'} association, "
                                    f"{args.iters} ICP iterations (21 passes), solve on {args.solve}"
                                    + (f", {args.pose_groups} pose groups" if args.solve == "device" else ""),
-                       "poses_per_gpu": P, "global_batch": P * world, "points_per_pose_mean": float(np.mean(sizes)),
-                       "parallelism": f"pose-shard x{world}, 1 RCCL gather"},
-            "roofline": {"bound": "hbm", "kernel": ("icp_pass_kernel (correspondence + 29-term reduce" if args.scene == "proj" else
-                                                     "one correspondence pass = nn_search_kernel + nn_tree_kernel + icp_pass_kernel<SceneNNWinners> (search, tree walk of the queued queries, 29-term reduce over the winners")
+                       "poses_per_gpu": P_max, "global_batch": global_poses, "points_per_pose_mean": float(np.mean(sizes)),
+                       "parallelism": (f"pose-shard x{world}, no data-path collective, "
+                                       + ("no gather (1 rank)" if world == 1 else
+                                          ("1 RCCL gather per step (pr_gather_results)" if gather_mode == "cabi" else
+                                           ("1 gloo gather per step on host copies (ranks share one device: test mode)" if share_device else "1 torch.distributed gather per step (RCCL backend)"))))},
+            # `bound`: what the counters say limits this kernel.  `frac` is the contract's figure -- SURVEY 8d's ALGORITHMIC bytes over the launch
+            # time, against the HBM peak; it exceeds what HBM really carries (the packed 16-byte scene record, Infinity-Cache-resident clouds), so
+            # it is a throughput score, not a statement that the kernel sits on the HBM roof: the projective pass is VALU-bound (`valu_frac`).
+            "roofline": {"bound": ("valu" if args.scene == "proj" else "l1/lds + valu (cache-resident search: HBM carries only clouds and winners)"),
+                         "bound_contract_enum": "hbm",
+                         "kernel": ("icp_pass_kernel (correspondence + 29-term reduce" if args.scene == "proj" else
+                                                     "one correspondence pass = nn_search_kernel + nn_bound_kernel + nn_tree_wide_kernel + icp_pass_kernel<SceneNNWinners> (search, bound + window, task walk of the queued queries, 29-term reduce over the winners")
                                                     + (" + finalize/solve tail)" if args.fused_solve and args.solve == "device" else ")"),
                          "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK,
@@ -241,7 +306,12 @@ def main():
                          # PMC counters saw for this kernel.  At <= 512 hypotheses per sub-batch the clouds are Infinity-Cache
                          # resident by design and the 16-byte scene records hit L2, so the counter figure is the lower one.
                          "frac_algorithmic": achieved / HBM_PEAK,
-                         "frac_hbm_counter": (traffic / avg_launch_s / HBM_PEAK) if (traffic and avg_launch_s > 0) else None,
+                         # committed counter figures x this run's points and launch time: fabric bytes (FETCH_SIZE counts Infinity-Cache hits
+                         # too, so this is an UPPER bound of DRAM traffic) and VALU issue slots (SQ_INSTS_VALU wave-instructions / 6.1e11 per s)
+                         "frac_fabric_counter": (traffic / avg_launch_s / HBM_PEAK) if (traffic and avg_launch_s > 0) else None,
+                         "valu_frac": (PMC_VALU_WAVE_INSTR_PER_POINT[args.scene] * pts_per_launch / avg_launch_s / VALU_PEAK)
+                                      if (PMC_VALU_WAVE_INSTR_PER_POINT[args.scene] and avg_launch_s > 0) else None,
+                         "valu_peak_wave_instr_per_s": VALU_PEAK,
                          "traffic": traffic,
                          "traffic_source": ("committed rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE passes, "
                                             + PMC_TRAFFIC_SOURCE[args.scene] + f": {PMC_TRAFFIC_BYTES_PER_POINT[args.scene]} B/point x points of a launch"),
@@ -251,14 +321,23 @@ def main():
                          "timing": ("HIP events on the library stream around every launch (--sequential: synchronous single-group steps)" if args.sequential else
                                     f"HIP events on the library stream around every launch of the last {n_samples} steps of the timed region; "
                                     "a timed step runs synchronously as one pose group (other slot drained) so the launch has the chip to itself")},
-            "gather": ("none (1 rank)" if world == 1 else ("pr_gather_results: grouped ncclSend/ncclRecv on the library stream (C ABI over RCCL)" if gather_mode == "cabi" else "torch.distributed.gather")),
+            "gather": ("none (1 rank)" if world == 1 else ("pr_gather_results: grouped ncclSend/ncclRecv on the library stream (C ABI over RCCL)" if gather_mode == "cabi" else
+                                                            ("torch.distributed.gather (gloo, host copies: ranks share one device)" if share_device else "torch.distributed.gather (RCCL)"))),
+            "gather_note": gather_note,
+            "gather_event_us": (1e3 * gather_ms / gather_n) if gather_n else None,      # HIP events around the exchange on the library stream, sampled steps (rank 0)
+            "gather_events": int(gather_n),
+            "per_rank_ms_per_step": per_rank_ms,
             "phase_ms_per_timed_step": {"render": prof["render_ms"] / max(1, launches // (args.iters + 1)),
                                         "cloud": prof["cloud_ms"] / max(1, launches // (args.iters + 1))},
         }
+        if world == 1 and args.scene == "proj" and args.solve == "device" and not args.sequential and not args.no_kdtree_extra:
+            out["solve_on_host"] = host_solve_extra(args, api, model, poses, W, H, proj, K, scene)
         if world == 1 and args.scene == "proj" and not args.no_kdtree_extra and not args.sequential:
             out["config2_kdtree"] = kdtree_extra(args, api, model, poses, scene_depth, W, H, proj, K)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, model.tris, poses, scene_depth, K, W, H)
+            out["cpu_baseline"] = cpu_baseline(args, args.scene, model.tris, scene_depth, K, W, H)
+            if "config2_kdtree" in out:
+                out["config2_kdtree"]["cpu_baseline"] = cpu_baseline(args, "nn", model.tris, scene_depth, K, W, H)
         print(json.dumps(out), flush=True)
 
     if world > 1:
@@ -269,7 +348,7 @@ def main():
 def kdtree_extra(args, api, model, poses, scene_depth, W, H, proj, K, steps=8):
     """BASELINE.json configs[2] next to the headline: the same 256-hypothesis batch against the kd-tree scene (Scene_nn), a
     few steps through the two asynchronous slots, plus one instrumented (synchronous) batch whose work counters give the LOGICAL bytes of the
-    search (nodes x 32 B + leaf points x 12 B + window cells x 16 B + 28 B per query for cloud and winner)."""
+    search (wide nodes x 128 B + leaf points x 16 B + window cells x 16 B + 28 B per query for cloud and winner)."""
     import numpy as np
     crit = api.ICPConvergenceCriteria(0.0, 0.0, args.iters)
     scene = api.Scene_nn().init_Scene_nn_cuda(scene_depth, K)
@@ -288,11 +367,12 @@ def kdtree_extra(args, api, model, poses, scene_depth, W, H, proj, K, steps=8):
     c = api.nn_counters(args.iters + 1).astype(np.float64)
     api.set_option("nn_count", 0)
     tot = c.sum(0)
-    logical = tot[4] * 32 + tot[6] * 12 + tot[7] * 16 + tot[0] * 28
+    logical = tot[4] * 128 + tot[6] * 16 + tot[7] * 16 + tot[0] * 28          # wide nodes are 128-byte lines, leaf points 16-byte records
     hbm = PMC_TRAFFIC_BYTES_PER_POINT["nn"] * tot[0] if PMC_TRAFFIC_BYTES_PER_POINT["nn"] else None
     return {"workload": f"obj_06.ply, {len(poses)}-pose batch, 640x480, kd-tree nearest-neighbour association (Scene_nn: exact search, "
-                        "reference tie-breaks; search kernel = pixel-window scan where the bound allows it, near-first tree search "
-                        f"on compact 32-byte node records otherwise), {args.iters} ICP iterations, two asynchronous slots",
+                        "reference tie-breaks; search kernel = keep-the-winner test and pixel-window scan where the bound allows it, bound kernel = "
+                        "descent through the representative points + window, task walk over 128-byte wide nodes for the rest, ties repeated by the ordered walk), "
+                        f"{args.iters} ICP iterations, two asynchronous slots",
             "value": len(poses) / dt, "unit": "poses/s", "ms_per_step": dt * 1e3, "steps": steps,
             "queries_per_step": tot[0], "settled_by_pixel_window_frac": tot[1] / max(tot[0], 1.0), "tree_searches_frac": tot[2] / max(tot[0], 1.0),
             "tree_nodes_per_tree_search": tot[4] / max(tot[2], 1.0), "leaf_points_per_tree_search": tot[6] / max(tot[2], 1.0),
@@ -303,27 +383,59 @@ def kdtree_extra(args, api, model, poses, scene_depth, W, H, proj, K, steps=8):
                     "lives in L2, so HBM carries only the clouds and winners; `logical` counts every byte the search asks the caches for"}
 
 
-def cpu_baseline(args, tris, poses, scene_depth, K, W, H):
-    """The CPU oracle (a port of the reference CPU path, oracle/pose_oracle.c) on a bounded sample of
-    the same workload: per-pose render_cpu -> depth2cloud_cpu -> ICP_Point2Plane_cpu with the same
-    fixed 20 iterations, OpenMP across hypotheses on all host cores."""
+def host_solve_extra(args, api, model, poses, W, H, proj, K, scene, steps=12):
+    """The same batch with the 6x6 solve ON THE HOST, as `north_star` words it ("SVD solve on host"): one launch + one 128-byte-per-pose
+    read-back + host solve + one 64-byte-per-pose upload per iteration (PR_SOLVE_HOST).  The headline keeps the iterations on the device."""
+    crit = api.ICPConvergenceCriteria(0.0, 0.0, args.iters)
+    api.set_option("solve", api.SOLVE_HOST)
+    try:
+        for _ in range(2):
+            api.refine_batch(model, poses, W, H, proj, K, scene, crit)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            api.refine_batch(model, poses, W, H, proj, K, scene, crit)
+        dt = (time.perf_counter() - t0) / steps
+    finally:
+        api.set_option("solve", api.SOLVE_DEVICE)
+    return {"value": len(poses) / dt, "unit": "poses/s", "ms_per_step": dt * 1e3, "steps": steps,
+            "note": "PR_SOLVE_HOST: 21 launches, each followed by a read-back of the 29 sums, the host solve (pivoted LDLT in double, as Eigen) and an upload of the update"}
+
+
+def cpu_baseline(args, scene_kind, tris, scene_depth, K, W, H):
+    """The CPU oracle (a port of the reference CPU path, oracle/pose_oracle.c at the reference's flags) on a bounded sample of the same
+    workload: per-pose render_cpu -> depth2cloud_cpu -> ICP_Point2Plane_cpu with the same fixed 20 iterations, OpenMP across hypotheses
+    on the CPUs this process really has (affinity mask capped by the cgroup quota), plus the single-thread rate."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["PR_ORACLE_BUILD"] = "o3"                          # the restatement with the reference's flags (-O3 -fopenmp)
     import oracle_lib as O
-    cores = os.cpu_count() or 1
-    per_pose_s = 0.06 if args.scene == "proj" else 1.5             # single-thread estimates (BASELINE.md section 2)
-    n = args.cpu_poses or int(max(cores, min(20000, round(12.0 * cores / per_pose_s))))
     from pose_refine_amd import synth
-    poses = synth.hypotheses(n)                                     # same seeded stream, longer prefix
-    oscene = O.ProjScene(scene_depth, K) if args.scene == "proj" else O.NNScene(scene_depth, K)
+    usable, facts = effective_cpus()
+    threads = int(os.environ.get("PR_BENCH_CPU_THREADS", usable))
+    per_pose_s = 0.012 if scene_kind == "proj" else 0.42           # single-thread seconds per hypothesis on the GPU box's host (profiles/r03/cpu_sweep_*.md)
+    budget_s = 10.0 if scene_kind == "proj" else 8.0
+    n = args.cpu_poses or int(max(2 * threads, min(20000, round(budget_s * threads / per_pose_s))))
+    n1 = max(2, int(round((1.5 if scene_kind == "proj" else 1.3) / per_pose_s)))
+    oscene = O.ProjScene(scene_depth, K) if scene_kind == "proj" else O.NNScene(scene_depth, K)
     proj = O.compute_proj(K, W, H)
+    crit = (0.0, 0.0, args.iters)
+    O.set_threads(1)
     t0 = time.perf_counter()
-    _, _, threads = O.refine_batch(tris, poses[:n], W, H, proj, K, oscene, (0.0, 0.0, args.iters), O.SUM_SEQUENTIAL)
+    O.refine_batch(tris, synth.hypotheses(n1), W, H, proj, K, oscene, crit, O.SUM_SEQUENTIAL)
+    dt1 = time.perf_counter() - t0
+    O.set_threads(threads)
+    poses = synth.hypotheses(n)                                     # same seeded stream, longer prefix
+    t0 = time.perf_counter()
+    _, _, used = O.refine_batch(tris, poses, W, H, proj, K, oscene, crit, O.SUM_SEQUENTIAL)
     dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "poses/s", "cores": int(threads), "kind": "port",
-            "sample": f"first {n} hypotheses of the same seeded stream, {dt:.1f} s wall, OpenMP over poses",
-            "build": "oracle/pose_oracle.c at the reference's flags (-O3 -fopenmp); per-row check against the verbatim "
-                     "reference timings: profiles/r02/cpu_fairness.md"}
+    ms_thread, ms_thread1 = 1e3 * dt * used / n, 1e3 * dt1 / n1
+    return {"value": n / dt, "unit": "poses/s", "cores": int(used), "kind": "port",
+            "sample": f"first {n} hypotheses of the same seeded stream, {dt:.1f} s wall, OpenMP over hypotheses on {used} threads",
+            "single_thread": {"value": n1 / dt1, "unit": "poses/s", "sample": f"{n1} hypotheses, {dt1:.1f} s"},
+            "ms_per_pose_per_thread": ms_thread, "ms_per_pose_single_thread": ms_thread1, "thread_efficiency": ms_thread1 / ms_thread if ms_thread > 0 else None,
+            "host": facts, "threads_rule": "min(affinity mask, cgroup cpu.max quota); PR_BENCH_CPU_THREADS overrides; sweep: profiles/r03/cpu_sweep_*.md",
+            "association": "projective" if scene_kind == "proj" else "kd-tree (Scene_nn)",
+            "build": "oracle/pose_oracle.c at the reference's flags (-O3 -fopenmp), every thread reusing one depth image and one cloud; per-row check "
+                     "against the verbatim reference timings: profiles/r02/cpu_fairness.md"}
 
 
 if __name__ == "__main__":

@@ -963,6 +963,9 @@ constexpr uint32_t kNoPrev = 0xffffffffu;
 #ifndef PR_NN_NODESCENT
 #define PR_NN_NODESCENT 2.5e-7f                                // squared step up to which the previous winner's distance is bound enough (no descent through the representatives)
 #endif
+#ifndef PR_RING_ROWS
+#define PR_RING_ROWS 2
+#endif
 #ifndef PR_NN_SETTLE
 #define PR_NN_SETTLE 1                                           // grid_search: widest cover for points that have stopped moving
 #endif
@@ -1234,16 +1237,24 @@ __device__ __forceinline__ void grid_ring_min(const float4 *__restrict__ level, 
                                               float &dmin, int &bx, int &by)
 {
     dmin = FLT_MAX; bx = min(max(x0, 0), lw - 1); by = min(max(y0, 0), lh - 1);
-    for (int dy = 0; dy < nb; ++dy) {
-        const int y = min(max(y0 + dy, 0), lh - 1);
-        float4 c[6];
+    // kRingRows rows (6 cells each) are in flight at a time: the descent is a chain of dependent round trips, three levels of them
+    constexpr int kRingRows = PR_RING_ROWS;
+    for (int dy0 = 0; dy0 < nb; dy0 += kRingRows) {
+        float4 c[kRingRows][6];
+        int yy[kRingRows];
 #pragma unroll
-        for (int dx = 0; dx < 6; ++dx) c[dx] = level[(size_t)y * lw + min(max(x0 + dx, 0), lw - 1)];
+        for (int r = 0; r < kRingRows; ++r) {
+            yy[r] = min(max(y0 + min(dy0 + r, nb - 1), 0), lh - 1);
 #pragma unroll
-        for (int dx = 0; dx < 6; ++dx) {
-            const float d2 = (sx - c[dx].x) * (sx - c[dx].x) + (sy - c[dx].y) * (sy - c[dx].y) + (sz - c[dx].z) * (sz - c[dx].z);
-            if (d2 < dmin) { dmin = d2; bx = min(max(x0 + dx, 0), lw - 1); by = y; }
+            for (int dx = 0; dx < 6; ++dx) c[r][dx] = level[(size_t)yy[r] * lw + min(max(x0 + dx, 0), lw - 1)];
         }
+#pragma unroll
+        for (int r = 0; r < kRingRows; ++r)
+#pragma unroll
+            for (int dx = 0; dx < 6; ++dx) {
+                const float d2 = (sx - c[r][dx].x) * (sx - c[r][dx].x) + (sy - c[r][dx].y) * (sy - c[r][dx].y) + (sz - c[r][dx].z) * (sz - c[r][dx].z);
+                if (d2 < dmin) { dmin = d2; bx = min(max(x0 + dx, 0), lw - 1); by = yy[r]; }
+            }
     }
 }
 __device__ __forceinline__ void grid_pyramid_bound(const SceneNNDev &s, float sx, float sy, float sz, float &best)
