@@ -110,7 +110,7 @@ int pr_sync(void);                               /* wait for the context's strea
 
 /* device_vector_holder<T> storage: common.cu:3-40, renderer.cu:15-50 */
 int pr_malloc(void **dev_ptr, size_t bytes);
-int pr_free(void *dev_ptr);
+int pr_free(void *dev_ptr);                     /* waits for everything the DEVICE is running (any context's batches included) before the memory goes */
 int pr_memcpy_h2d(void *dev_dst, const void *host_src, size_t bytes);
 int pr_memcpy_d2h(void *host_dst, const void *dev_src, size_t bytes);
 int pr_memcpy_d2d(void *dev_dst, const void *dev_src, size_t bytes);
@@ -199,7 +199,8 @@ int pr_icp_batch(pr_vec3 *clouds_dev, const uint32_t *offsets_host, uint32_t n_c
 
 /* ---- fused hypothesis refinement: render -> cloud -> ICP for n_poses hypotheses --------------- */
 /* test.cpp:143-172 for a whole batch, everything resident on the device; results on the host.
- * cloud_sizes_host (optional) receives the model-cloud size of every hypothesis. */
+ * cloud_sizes_host (optional) receives the model-cloud size of every hypothesis.  The synchronous calls (pr_refine_batch, _dev, _roi) run on
+ * whichever asynchronous slot of the context holds no unfinished batch; with both slots pending they return PR_ERR_INVALID. */
 int pr_refine_batch(const pr_triangle *tris_dev, size_t n_tris, const pr_mat4 *poses_host, uint32_t n_poses,
                     uint32_t width, uint32_t height, const pr_mat4 *proj, const float K[9],
                     int scene_kind, const void *scene, pr_criteria crit,

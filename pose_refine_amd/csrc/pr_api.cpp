@@ -163,7 +163,7 @@ struct Resubmit {
     pr_result *results_dev = nullptr;
 };
 struct Slot {
-    DevBuf poses_bbox, depth, row_count, row_off, counts, cloud, meta, partial, dstate, dresults, arrive, aabb_keys, overflow, nn_prev;
+    DevBuf poses_bbox, depth, row_count, row_off, counts, cloud, meta, partial, dstate, dresults, arrive, aabb_keys, nn_prev;
     PackedCache packed;
     PinBuf h_in, h_out;
     Resubmit again;
@@ -217,7 +217,7 @@ struct Ctx {
     struct { const void *pcd = nullptr, *normal = nullptr, *nodes = nullptr; uint32_t n_points = 0, n_nodes = 0; uint64_t gen = 0; bool valid = false;
              uint32_t info[16] = { 0 };
              bool grid_valid = false, grid_usable = false; uint32_t gw = 0, gh = 0; float gk[4] = { 0, 0, 0, 0 }; } nn_cache;   // kd traversal records (topo ... nndesc) + pixel grid of the latest kd-tree scene
-    DevBuf nn_cells, nn_grid, nn_counters, tile_info, overflow;
+    DevBuf nn_cells, nn_grid, nn_counters;
     // profiling
     std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
     struct Span { size_t e0, e1; int kind; };
@@ -846,7 +846,6 @@ int refine_impl(const pr_triangle *tris_dev, size_t n_tris, const pr_mat4 *poses
     PR_TRY(g->aabb.ensure(6 * sizeof(float)));
     PR_TRY(g->aabb_keys.ensure(6 * sizeof(uint32_t)));
     HIP_TRY(prk::launch_model_aabb(tris_dev, (uint32_t)n_tris, g->aabb_keys.as<uint32_t>(), g->aabb.as<float>(), nullptr, nullptr, g->stream));
-    bool tile_off = false;
     for (uint32_t p0 = 0; p0 < P; p0 += chunk) {
         const uint32_t np = std::min(chunk, P - p0);
         PR_TRY(g->depth.ensure(sizeof(int32_t) * img * np));
@@ -865,24 +864,13 @@ int refine_impl(const pr_triangle *tris_dev, size_t n_tris, const pr_mat4 *poses
                 HIP_TRY(prk::launch_render_bands(tris_dev, (uint32_t)n_tris, g->poses.as<pr_mat4>(), np, g->aabb.as<float>(), g->bbox.as<int4>(),
                                                  g->depth.as<int32_t>(), g->row_count.as<uint32_t>(), g->row_off.as<uint32_t>(),
                                                  g->counts.as<uint32_t>(), W, H, *proj, roi, (uint32_t)g->n_cus, g->stream));
-            else if (opt.raster_mode == 2 && !tile_off) {
-                PR_TRY(g->tile_info.ensure(sizeof(int2) * np));
-                PR_TRY(g->overflow.ensure(sizeof(uint32_t)));
-                HIP_TRY(hipMemsetAsync(g->overflow.p, 0, sizeof(uint32_t), g->stream));
-                HIP_TRY(prk::launch_render_boxes(tris_dev, (uint32_t)n_tris, g->poses.as<pr_mat4>(), np, g->aabb.as<float>(), g->bbox.as<int4>(),
-                                                 g->depth.as<int32_t>(), g->row_count.as<uint32_t>(), g->row_off.as<uint32_t>(),
-                                                 g->counts.as<uint32_t>(), W, H, *proj, roi, g->stream, true, nullptr, nullptr, nullptr, 0,
-                                                 g->tile_info.as<int2>(), g->overflow.as<uint32_t>(), false));
-            } else
+            else
                 HIP_TRY(prk::launch_render_boxes(tris_dev, (uint32_t)n_tris, g->poses.as<pr_mat4>(), np, g->aabb.as<float>(), g->bbox.as<int4>(),
                                                  g->depth.as<int32_t>(), g->row_count.as<uint32_t>(), g->row_off.as<uint32_t>(),
                                                  g->counts.as<uint32_t>(), W, H, *proj, roi, g->stream));
         }
         HIP_TRY(hipMemcpyAsync(h_counts, g->counts.p, sizeof(uint32_t) * np, hipMemcpyDeviceToHost, g->stream));
-        uint32_t overflowed = 0;
-        if (opt.raster_mode == 2 && !tile_off) HIP_TRY(hipMemcpyAsync(&overflowed, g->overflow.p, sizeof overflowed, hipMemcpyDeviceToHost, g->stream));
         HIP_TRY(hipStreamSynchronize(g->stream));
-        if (overflowed) { tile_off = true; p0 -= chunk; continue; }    // a fragment left the 16-bit range (tile_record's bound failed): draw this chunk again through the global path
         uint32_t max_n = 0;
         for (uint32_t i = 0; i < np; ++i) max_n = std::max(max_n, h_counts[i]);
         const size_t cstride = ((size_t)max_n + 3) & ~(size_t)3;           // keeps every cloud 16-byte aligned
@@ -944,7 +932,7 @@ void slot_release(Slot &sl)
 {
     slot_drain(sl);
     for (DevBuf *b : { &sl.poses_bbox, &sl.depth, &sl.row_count, &sl.row_off, &sl.counts, &sl.cloud, &sl.meta, &sl.partial, &sl.dstate,
-                       &sl.dresults, &sl.arrive, &sl.aabb_keys, &sl.overflow, &sl.nn_prev, &sl.packed.rec }) b->release();
+                       &sl.dresults, &sl.arrive, &sl.aabb_keys, &sl.nn_prev, &sl.packed.rec }) b->release();
     sl.packed = PackedCache();
     sl.h_in.release(); sl.h_out.release();
     for (int i = 0; i < 3; ++i) {
@@ -1012,14 +1000,22 @@ void pose_bbox_host(const float *aabb, const pr_mat4 &pose, const pr_mat4 &proj,
     out[0] = x0; out[1] = y0; out[2] = x1; out[3] = y1;
 }
 
+// the synchronous entry points run on whichever slot holds no unfinished batch of the caller's (-1: none)
+int free_slot() { for (int i = 0; i < kSlots; ++i) if (!g->slots[i].pending) return i; return -1; }
+
 int refine_wait(int slot)
 {
     if (slot < 0 || slot >= kSlots) { set_error("slot must be 0..%d", kSlots - 1); return PR_ERR_INVALID; }
     Slot &sl = g->slots[slot];
     if (!sl.pending) { set_error("pr_refine_wait: nothing was submitted on slot %d", slot); return PR_ERR_INVALID; }
+    if (sl.delivered) { sl.pending = false; return PR_OK; }
+    {
+        // the slot stays occupied until its batch has really finished: if the wait itself fails, everything the slot has in flight is
+        // drained before the error goes back (a later submit must never reuse the slot's buffers under a running batch)
+        const hipError_t we = hipEventSynchronize(sl.done);
+        if (we != hipSuccess) { slot_drain(sl); sl.pending = false; set_error("pr_refine_wait: hipEventSynchronize failed: %s", hipGetErrorString(we)); return PR_ERR_HIP; }
+    }
     sl.pending = false;
-    if (sl.delivered) return PR_OK;
-    HIP_TRY(hipEventSynchronize(sl.done));
     const unsigned char *h_out = sl.h_out.as<unsigned char>();
     if (*reinterpret_cast<const volatile uint32_t *>(h_out + sl.flag_off) != 0u) {
         // the triangle buffer no longer has the box this batch was sized with: forget the host copy and run the batch again,
@@ -1354,7 +1350,7 @@ void ctx_teardown(Ctx *c)        // c->mu held (or c unreachable); the calling t
     hipStreamSynchronize(c->stream);
     for (Slot &sl : c->slots) slot_release(sl);
     for (DevBuf *b : { &c->aabb, &c->aabb_keys, &c->bbox, &c->poses, &c->depth, &c->row_count, &c->row_off, &c->counts, &c->cloud, &c->meta, &c->partial,
-                       &c->sums, &c->packed.rec, &c->topo, &c->bmin, &c->bmax, &c->pts, &c->nnrec, &c->nnrec32, &c->nndesc, &c->nnwide, &c->nnwq, &c->nn_prev, &c->nndepth, &c->dstate, &c->dresults, &c->vbdesc, &c->flowsync, &c->arrive, &c->conv16, &c->conv8, &c->kd_idx, &c->kd_scratch, &c->kd_child, &c->kd_ctrl, &c->kd_tmp, &c->nn_full, &c->gather_tmp, &c->nn_cells, &c->nn_grid, &c->nn_counters, &c->tile_info, &c->overflow }) b->release();
+                       &c->sums, &c->packed.rec, &c->topo, &c->bmin, &c->bmax, &c->pts, &c->nnrec, &c->nnrec32, &c->nndesc, &c->nnwide, &c->nnwq, &c->nn_prev, &c->nndepth, &c->dstate, &c->dresults, &c->vbdesc, &c->flowsync, &c->arrive, &c->conv16, &c->conv8, &c->kd_idx, &c->kd_scratch, &c->kd_child, &c->kd_ctrl, &c->kd_tmp, &c->nn_full, &c->gather_tmp, &c->nn_cells, &c->nn_grid, &c->nn_counters }) b->release();
     for (PinBuf *b : { &c->h_sums, &c->h_meta, &c->h_counts, &c->h_results, &c->h_dstate, &c->h_flow }) b->release();
     c->packed = PackedCache(); c->nn_cache.valid = false;
     for (auto &gr : c->graphs) destroy_graph(gr);
@@ -1470,9 +1466,11 @@ int pr_free(void *dev_ptr)
 {
     if (!dev_ptr) return PR_OK;
     PR_ENTER();
-    // nothing this context still has in flight may outlive the buffer: the library stream and every slot with an unfinished batch
+    // nothing may outlive the buffer: this context's stream and slots, and -- a private-context thread or another host thread's shared
+    // context can have a batch in flight on the same buffer -- everything else the device is running
     HIP_TRY(hipStreamSynchronize(g->stream));
     for (Slot &sl : g->slots) if (sl.pending && !sl.delivered) slot_drain(sl);
+    HIP_TRY(hipDeviceSynchronize());
     g_writes.note(dev_ptr, 0);                                     // the address may come back with other content
     if (dev_ptr == g->mesh_key) { g->mesh_key = nullptr; g->aabb_host_valid = false; }
     HIP_TRY(hipFree(dev_ptr));
@@ -1624,8 +1622,10 @@ int pr_refine_batch_roi(const pr_triangle *tris_dev, size_t n_tris, const pr_mat
     PR_ENTER();
     if (!results_host) { set_error("pr_refine_batch: results_host is null"); return PR_ERR_INVALID; }
     if (n_poses == 0) return PR_OK;
-    PR_TRY(refine_submit(0, tris_dev, n_tris, poses_host, n_poses, width, height, proj, K, scene_kind, scene, crit, roi, results_host, nullptr, cloud_sizes_host));
-    return refine_wait(0);
+    const int slot = free_slot();
+    if (slot < 0) { set_error("pr_refine_batch: both asynchronous slots hold unfinished batches (pr_refine_wait one of them first)"); return PR_ERR_INVALID; }
+    PR_TRY(refine_submit(slot, tris_dev, n_tris, poses_host, n_poses, width, height, proj, K, scene_kind, scene, crit, roi, results_host, nullptr, cloud_sizes_host));
+    return refine_wait(slot);
 }
 int pr_refine_batch(const pr_triangle *tris_dev, size_t n_tris, const pr_mat4 *poses_host, uint32_t n_poses, uint32_t width, uint32_t height,
                     const pr_mat4 *proj, const float K[9], int scene_kind, const void *scene, pr_criteria crit,
@@ -1640,8 +1640,10 @@ int pr_refine_batch_dev(const pr_triangle *tris_dev, size_t n_tris, const pr_mat
     PR_ENTER();
     if (!results_dev) { set_error("pr_refine_batch_dev: results_dev is null"); return PR_ERR_INVALID; }
     if (n_poses == 0) return PR_OK;
-    PR_TRY(refine_submit(0, tris_dev, n_tris, poses_host, n_poses, width, height, proj, K, scene_kind, scene, crit, pr_roi{ 0, 0, 0, 0 }, nullptr, results_dev, cloud_sizes_host));
-    return refine_wait(0);
+    const int slot = free_slot();
+    if (slot < 0) { set_error("pr_refine_batch_dev: both asynchronous slots hold unfinished batches (pr_refine_wait one of them first)"); return PR_ERR_INVALID; }
+    PR_TRY(refine_submit(slot, tris_dev, n_tris, poses_host, n_poses, width, height, proj, K, scene_kind, scene, crit, pr_roi{ 0, 0, 0, 0 }, nullptr, results_dev, cloud_sizes_host));
+    return refine_wait(slot);
 }
 int pr_refine_submit_roi(int slot, const pr_triangle *tris_dev, size_t n_tris, const pr_mat4 *poses_host, uint32_t n_poses, uint32_t width, uint32_t height,
                          const pr_mat4 *proj, const float K[9], int scene_kind, const void *scene, pr_criteria crit, pr_roi roi,
@@ -1814,7 +1816,7 @@ int pr_set_option(const char *name, int value)
     else if (n == "overlap_pass") opt.overlap_pass = std::max(-1, value);
     else if (n == "pose_groups") opt.pose_groups = std::min(4, std::max(1, value));
     else if (n == "eager_streams") opt.eager_streams = value ? 1 : 0;
-    else if (n == "raster_mode") { if (value < 0 || value > 2) { set_error("raster_mode must be 0, 1 or 2"); return PR_ERR_INVALID; } opt.raster_mode = value; }
+    else if (n == "raster_mode") { if (value < 0 || value > 1) { set_error("raster_mode must be 0 or 1"); return PR_ERR_INVALID; } opt.raster_mode = value; }
     else { set_error("unknown option %s", name); return PR_ERR_INVALID; }
     return PR_OK;
 }

@@ -162,35 +162,7 @@ hipError_t launch_render_bands(const pr_triangle *tris, uint32_t n_tris, const p
 hipError_t launch_render_boxes(const pr_triangle *tris, uint32_t n_tris, const pr_mat4 *poses_dev, uint32_t n_poses, const float *aabb,
                                int4 *bbox, int32_t *depth, uint32_t *row_count, uint32_t *row_off, uint32_t *counts,
                                uint32_t width, uint32_t height, const pr_mat4 &proj, pr_roi roi, hipStream_t s, bool compute_boxes = true,
-                               PoseMeta *meta = nullptr, DevIcpState *st = nullptr, uint32_t *arrive = nullptr, uint32_t cloud_stride = 0,
-                               int2 *tile_info = nullptr, uint32_t *overflow = nullptr, bool all_tiled = false);
-// tile raster (option raster_mode 2): tile_info[pose] = {depth base, eligible}; written by pose_bbox_kernel (compute_boxes) or by the
-// host (tile_record, same rule); `overflow` is set if a fragment of an eligible hypothesis ever leaves the 16-bit range; all_tiled:
-// the host knows every hypothesis is eligible, so the global-path kernels are not even launched
-uint32_t tile_cap_px();
-#if defined(__HIP__)
-#define PR_HOST_DEVICE __host__ __device__
-#else
-#define PR_HOST_DEVICE
-#endif
-// Tile record of a hypothesis: {depth base, eligible}.  raster_tile_kernel keeps the whole pixel box of an eligible hypothesis in
-// LDS as 16-bit depth offsets from `base`: that needs the box to fit (tile_cap_px pixels) and every fragment depth to lie in
-// [base, base + 65534].  A fragment's depth is a convex combination (in 1/z) of its triangle's vertex depths, every vertex lies in
-// the model box, and z is linear in the vertex, so the depths of the 8 transformed box corners bound all of them; two millimetres
-// of margin on each side cover the rounding of the transform and of int(frag + 0.5f).
-PR_HOST_DEVICE inline int2 tile_record(bool front_and_finite, float mnz, float mxz, int x0, int y0, int x1, int y1, uint32_t tile_cap_px)
-{
-    int2 r; r.x = 0; r.y = 0;
-    if (!front_and_finite || !(mnz > 1e-3f) || !(mxz < 1.0e9f)) return r;
-    if (x1 < x0 || y1 < y0) { r.y = 1; return r; }               // empty box: nothing to draw, trivially handled
-    const long long area = (long long)(x1 - x0 + 1) * (long long)(y1 - y0 + 1);
-    if (area > (long long)tile_cap_px) return r;
-    const float lo = floorf(mnz) - 2.0f, hi = ceilf(mxz) + 2.0f;
-    if (!(hi - lo < 65000.0f)) return r;
-    r.x = (int)lo; r.y = 1;
-    return r;
-}
-
+                               PoseMeta *meta = nullptr, DevIcpState *st = nullptr, uint32_t *arrive = nullptr, uint32_t cloud_stride = 0);
 hipError_t launch_pack_export(const DevIcpState *st, pr_result *out, const uint32_t *counts, uint32_t *host_counts, pr_result *host_results,
                               uint32_t n, hipStream_t s);
 hipError_t launch_stage_words(const void *src_host_mapped, void *dst, size_t bytes, hipStream_t s);

@@ -213,15 +213,15 @@ __device__ __forceinline__ void wave_raster(const TriSetup &t, int n, float (*w)
 __global__ __launch_bounds__(256) void raster_kernel(const pr_triangle *__restrict__ tris, uint32_t n_tris,
                                                      const pr_mat4 *__restrict__ poses, int32_t *__restrict__ depth,
                                                      uint32_t width, uint32_t height, pr_mat4 proj, pr_roi roi,
-                                                     uint32_t rw, uint32_t rh, const int4 *__restrict__ boxes, const int2 *__restrict__ tile_info)
+                                                     uint32_t rw, uint32_t rh, const int4 *__restrict__ boxes)
 {
     __shared__ float sh[4][kSetupWords][64];
     __shared__ uint32_t shq[4][128];
-    if (tile_info && tile_info[blockIdx.y].y) return;            // drawn by raster_tile_kernel
+    const uint32_t bx = blockIdx.x, by = blockIdx.y;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t ti = blockIdx.x * 256 + threadIdx.x;
-    const float *M = poses[blockIdx.y].m;                        // wave-uniform -> scalar loads
-    int32_t *img = depth + (size_t)blockIdx.y * rw * rh;
+    const uint32_t ti = bx * 256 + threadIdx.x;
+    const float *M = poses[by].m;                                // wave-uniform -> scalar loads
+    int32_t *img = depth + (size_t)by * rw * rh;
 
     float cmin0 = 0.0f, cmin1 = 0.0f, cmax0 = (float)(width - 1), cmax1 = (float)(height - 1);
     if (roi.width > 0 && roi.height > 0) {                       // renderer.cu:106-113 (image is flipped in y)
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void raster_kernel(const pr_triangle *__restri
         cmax1 = (float)((unsigned long long)(height - 1) - (unsigned long long)(long long)roi.y);
     }
     if (boxes) {                                                 // fused path: the hypothesis' pixel box (already intersected with the caller's ROI,
-        const int4 bb = boxes[blockIdx.y];                       // if any); a conservative box clips nothing, an ROI clips like renderer.cu:106-113
+        const int4 bb = boxes[by];                               // if any); a conservative box clips nothing, an ROI clips like renderer.cu:106-113
         cmin0 = (float)bb.x; cmin1 = (float)bb.y; cmax0 = (float)bb.z; cmax1 = (float)bb.w;
     }
 
@@ -305,13 +305,12 @@ __global__ void model_aabb_finish_kernel(const uint32_t *__restrict__ keys, floa
 // as long as all of them are in front of the camera, and 2 pixels of padding cover float rounding.
 // Any corner at or behind the camera plane -> the whole frame.
 __global__ __launch_bounds__(256) void pose_bbox_kernel(const float *__restrict__ aabb, const pr_mat4 *__restrict__ poses, uint32_t n_poses,
-                                                        pr_mat4 proj, uint32_t width, uint32_t height, pr_roi roi, int4 *__restrict__ bbox,
-                                                        int2 *__restrict__ tile_info, uint32_t tile_cap_px)
+                                                        pr_mat4 proj, uint32_t width, uint32_t height, pr_roi roi, int4 *__restrict__ bbox)
 {
     const uint32_t p = blockIdx.x * 256 + threadIdx.x;
     if (p >= n_poses) return;
     const float *M = poses[p].m;
-    float mnx = FLT_MAX, mny = FLT_MAX, mxx = -FLT_MAX, mxy = -FLT_MAX, mnz = FLT_MAX, mxz = -FLT_MAX;
+    float mnx = FLT_MAX, mny = FLT_MAX, mxx = -FLT_MAX, mxy = -FLT_MAX;
     bool all_front = true;
     for (int c = 0; c < 8; ++c) {
         const float x = aabb[(c & 1) ? 3 : 0], y = aabb[(c & 2) ? 4 : 1], z = aabb[(c & 4) ? 5 : 2];
@@ -324,7 +323,6 @@ __global__ __launch_bounds__(256) void pose_bbox_kernel(const float *__restrict_
         const float sx = cxp / lz * (float)width / 2.0f + (float)width / 2.0f;
         const float sy = cyp / lz * (float)height / 2.0f + (float)height / 2.0f;
         mnx = fminf(mnx, sx); mxx = fmaxf(mxx, sx); mny = fminf(mny, sy); mxy = fmaxf(mxy, sy);
-        mnz = fminf(mnz, lz); mxz = fmaxf(mxz, lz);
     }
     int x0 = 0, y0 = 0, x1 = (int)width - 1, y1 = (int)height - 1;
     const bool finite = (mnx > -1e8f) && (mxx < 1e8f) && (mny > -1e8f) && (mxy < 1e8f);
@@ -337,17 +335,14 @@ __global__ __launch_bounds__(256) void pose_bbox_kernel(const float *__restrict_
         y0 = max(y0, (int)height - 1 - (roi.y + roi.height - 1));  y1 = min(y1, (int)height - 1 - roi.y);
     }
     bbox[p] = make_int4(x0, y0, x1, y1);
-    if (tile_info) tile_info[p] = tile_record(all_front && finite, mnz, mxz, x0, y0, x1, y1, tile_cap_px);
 }
 
 // INT_MAX-fill and per-row valid counts restricted to each hypothesis' pixel box (image rows are
 // the flipped raster rows).  One wavefront per image row; rows outside the box only write count 0.
 constexpr uint32_t kBoxRowsPerBlock = 16;                        // 4 wavefronts x 4 rows: few, fatter workgroups (dispatch-bound otherwise)
-__global__ __launch_bounds__(256) void fill_box_kernel(int32_t *__restrict__ depth, const int4 *__restrict__ bbox, uint32_t width, uint32_t height,
-                                                       const int2 *__restrict__ tile_info)
+__global__ __launch_bounds__(256) void fill_box_kernel(int32_t *__restrict__ depth, const int4 *__restrict__ bbox, uint32_t width, uint32_t height)
 {
     const uint32_t lane = threadIdx.x & 63;
-    if (tile_info && tile_info[blockIdx.y].y) return;            // drawn by raster_tile_kernel
     const int4 bb = bbox[blockIdx.y];
     for (uint32_t r = 0; r < 4; ++r) {
         const uint32_t row = blockIdx.x * kBoxRowsPerBlock + (threadIdx.x >> 6) * 4 + r;
@@ -359,11 +354,10 @@ __global__ __launch_bounds__(256) void fill_box_kernel(int32_t *__restrict__ dep
     }
 }
 __global__ __launch_bounds__(256) void count_box_kernel(const int32_t *__restrict__ depth, const int4 *__restrict__ bbox, uint32_t width,
-                                                        uint32_t height, uint32_t *__restrict__ row_count, const int2 *__restrict__ tile_info)
+                                                        uint32_t height, uint32_t *__restrict__ row_count)
 {
     // latency-bound, not bandwidth-bound: every lane keeps 4 rows x 4 column chunks = 16 loads in flight before the first ballot
     const uint32_t lane = threadIdx.x & 63;
-    if (tile_info && tile_info[blockIdx.y].y) return;            // counted by raster_tile_kernel
     const int4 bb = bbox[blockIdx.y];
     const uint32_t row0 = blockIdx.x * kBoxRowsPerBlock + (threadIdx.x >> 6) * 4;
     uint32_t cnt[4] = { 0, 0, 0, 0 };
@@ -472,97 +466,6 @@ __global__ __launch_bounds__(1024) void raster_band_kernel(const pr_triangle *__
             if (lane == 0) row_count[(size_t)pose * height + yw] = cnt;
         }
         __syncthreads();
-    }
-}
-
-// ================================================================================================
-//  Tile raster: ONE workgroup per hypothesis keeps the hypothesis' whole pixel box in LDS as 16-bit depth offsets (an object
-//  at the usual distance covers ~220 x 224 px: 98 KB as uint16, twice that as int32 -- which is what made the int32 band variant
-//  rasterise every triangle twice).  Triangles are walked wave-cooperatively exactly like raster_kernel (same wave_raster, same
-//  per-candidate arithmetic); only the depth test differs: a compare-and-swap on the 32-bit LDS word that holds the pixel's 16
-//  bits instead of a returnless global atomicMin (170 of the global variant's ~400 us per 256 hypotheses are that atomic backing
-//  up the memory pipeline).  The box is then written out once -- INT_MAX where nothing was drawn, like the cleared frame -- with
-//  its per-row valid counts, so these hypotheses need neither the box clear nor the row-count pass.
-//  Hypotheses whose box does not fit, or whose depth range is not safely 16 bits wide (tile_record), are left to the global path.
-// ================================================================================================
-constexpr uint32_t kTileThreads = 512;                           // 8 wavefronts: their raster scratch (35 KB) + the tile must fit 160 KB
-constexpr uint32_t kTileCapPx = 61440;                           // 120 KB of uint16
-__global__ __launch_bounds__(kTileThreads) void raster_tile_kernel(const pr_triangle *__restrict__ tris, uint32_t n_tris,
-                                                                   const pr_mat4 *__restrict__ poses, const int4 *__restrict__ bbox,
-                                                                   const int2 *__restrict__ tile_info, int32_t *__restrict__ depth,
-                                                                   uint32_t *__restrict__ row_count, uint32_t width, uint32_t height,
-                                                                   pr_mat4 proj, uint32_t *__restrict__ overflow)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char tile_raw[];
-    const uint32_t pose = blockIdx.x;
-    const int2 ti = tile_info[pose];
-    if (!ti.y) return;
-    const int4 bb = bbox[pose];
-    const int bw = bb.z - bb.x + 1, bh = bb.w - bb.y + 1;
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t *rc = row_count + (size_t)pose * height;
-    if (bw <= 0 || bh <= 0) {                                    // nothing can be drawn: all rows empty
-        for (uint32_t r = threadIdx.x; r < height; r += kTileThreads) rc[r] = 0u;
-        return;
-    }
-    const uint32_t n_px = (uint32_t)bw * (uint32_t)bh;
-    uint32_t *tile32 = reinterpret_cast<uint32_t *>(tile_raw);
-    const uint32_t tile_words = (n_px + 1u) / 2u;
-    float (*scratch)[64] = reinterpret_cast<float (*)[64]>(tile_raw + (size_t)((tile_words * 4u + 15u) & ~15u)) + (size_t)wave * (kSetupWords + 2);
-    uint32_t *queue = reinterpret_cast<uint32_t *>(scratch + kSetupWords);                  // 128 words
-    for (uint32_t i = threadIdx.x; i < tile_words; i += kTileThreads) tile32[i] = 0xffffffffu;
-    __syncthreads();
-
-    const float *M = poses[pose].m;
-    const float cmin0 = (float)bb.x, cmin1 = (float)bb.y, cmax0 = (float)bb.z, cmax1 = (float)bb.w;
-    const int dbase = ti.x;
-    bool bad = false;
-    for (uint32_t base = wave * 64u; base < n_tris; base += (kTileThreads / 64u) * 64u) {
-        const uint32_t t_i = base + lane;
-        TriSetup t;
-        int n = 0;
-        if (t_i < n_tris) {
-            tri_setup(reinterpret_cast<const float *>(tris + t_i), M, proj, width, height, cmin0, cmin1, cmax0, cmax1, t);
-            n = t.nx * t.ny;
-        } else { t.nx = t.ny = 0; t.x0 = t.y0 = 0; t.base_inv = 0; for (int k = 0; k < 3; ++k) t.px[k] = t.py[k] = t.w3[k] = 0; }
-        wave_raster(t, n, scratch, queue, [&](int x, int y, int d) {
-            const uint32_t off = (uint32_t)(y - bb.y) * (uint32_t)bw + (uint32_t)(x - bb.x);
-            const long long rel = (long long)d - (long long)dbase;
-            if (rel < 0 || rel > 65534) { bad = true; return; }   // cannot happen for an eligible hypothesis (tile_record); reported, never hidden
-            const uint32_t v = (uint32_t)rel, shift = (off & 1u) * 16u;
-            uint32_t *word = tile32 + (off >> 1);
-            uint32_t seen = *word;
-            for (;;) {
-                if (v >= ((seen >> shift) & 0xffffu)) break;
-                const uint32_t want = (seen & ~(0xffffu << shift)) | (v << shift);
-                const uint32_t prev = atomicCAS(word, seen, want);
-                if (prev == seen) break;
-                seen = prev;
-            }
-        });
-    }
-    if (__ballot(bad) != 0ull && lane == 0) atomicOr(overflow, 1u);
-    __syncthreads();
-
-    // write the box out (raster row y lands on image row height-1-y, renderer.cu:142) with its per-row counts; rows outside: count 0
-    int32_t *img = depth + (size_t)pose * width * height;
-    const uint16_t *tile16 = reinterpret_cast<const uint16_t *>(tile_raw);
-    for (uint32_t row = wave; row < height; row += kTileThreads / 64u) {
-        const int ry = (int)height - 1 - (int)row;
-        if (ry < bb.y || ry > bb.w) { if (lane == 0) rc[row] = 0u; continue; }
-        const uint32_t r = (uint32_t)(ry - bb.y);
-        uint32_t cnt = 0;
-        for (int c0 = 0; c0 < bw; c0 += 64) {
-            const int c = c0 + (int)lane;
-            int32_t dv = INT_MAX;
-            if (c < bw) {
-                const uint32_t v = tile16[r * (uint32_t)bw + (uint32_t)c];
-                dv = (v == 0xffffu) ? INT_MAX : dbase + (int32_t)v;
-                img[(size_t)row * width + (uint32_t)(bb.x + c)] = dv;
-            }
-            cnt += (uint32_t)__popcll(__ballot(c < bw && dv > 0 && dv != INT_MAX));
-        }
-        if (lane == 0) rc[row] = cnt;
     }
 }
 
@@ -962,6 +865,9 @@ constexpr uint32_t kNoPrev = 0xffffffffu;
 #endif
 #ifndef PR_NN_NODESCENT
 #define PR_NN_NODESCENT 2.5e-7f                                // squared step up to which the previous winner's distance is bound enough (no descent through the representatives)
+#endif
+#ifndef PR_ARRIVE_ACQ_REL
+#define PR_ARRIVE_ACQ_REL 0
 #endif
 #ifndef PR_RING_ROWS
 #define PR_RING_ROWS 2
@@ -1934,7 +1840,14 @@ __global__ __launch_bounds__(256, PR_PASS_WAVES) void icp_pass_kernel(IcpBatch b
         if (threadIdx.x < 29) st_sys_f32(slot + threadIdx.x, t);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         uint32_t ticket = 0;
+#if PR_ARRIVE_ACQ_REL
+        // the memory-model form: release / acquire on the arrival counter itself (buffer_wbl2 sc1 + buffer_inv sc1 around the atomic).
+        // Measured against the default below: the default is the guide's "sc1 payload -> vmcnt(0) -> flag, sc1
+        // loads on the consumer" hand-off, which needs neither cache operation because the payload never rests in L1 / L2.
+        if (threadIdx.x == 0) ticket = __hip_atomic_fetch_add(&b.arrive[pose], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+#else
         if (threadIdx.x == 0) ticket = atomicAdd(&b.arrive[pose], 1u);
+#endif
         ticket = __builtin_amdgcn_readfirstlane(ticket);
         if (ticket + 1u != used) continue;
         if (threadIdx.x == 0) st_sys_u32(&b.arrive[pose], 0u);
@@ -3242,7 +3155,6 @@ __global__ __launch_bounds__(kWideBuildThreads) void nn_wide_build_kernel(const 
 // ================================================================================================
 //  launchers
 // ================================================================================================
-uint32_t tile_cap_px() { return kTileCapPx; }
 // Dynamic LDS beyond 64 KiB is an opt-in PER DEVICE (hipFuncSetAttribute applies to the current device): one flag per kernel slot and
 // device, so that a process driving several GPUs (one host thread each) opts in on every one of them.
 static bool lds_opt_in(const void *fn, int slot, uint32_t bytes)
@@ -3280,7 +3192,7 @@ hipError_t launch_raster(const pr_triangle *tris, uint32_t n_tris, const pr_mat4
     for (uint32_t p0 = 0; p0 < n_poses; p0 += 32768) {
         const uint32_t np = (n_poses - p0 < 32768) ? (n_poses - p0) : 32768;
         hipLaunchKernelGGL(raster_kernel, dim3((n_tris + 255) / 256, np), dim3(256), 0, s, tris, n_tris, poses_dev + p0,
-                           depth + (size_t)p0 * rw * rh, width, height, proj, roi, rw, rh, (const int4 *)nullptr, (const int2 *)nullptr);
+                           depth + (size_t)p0 * rw * rh, width, height, proj, roi, rw, rh, (const int4 *)nullptr);
     }
     return hipGetLastError();
 }
@@ -3315,7 +3227,7 @@ hipError_t launch_render_bands(const pr_triangle *tris, uint32_t n_tris, const p
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(pose_bbox_kernel, dim3((n_poses + 255) / 256), dim3(256), 0, s, aabb, poses_dev, n_poses, proj, width, height, roi, bbox, (int2 *)nullptr, 0u);
+    hipLaunchKernelGGL(pose_bbox_kernel, dim3((n_poses + 255) / 256), dim3(256), 0, s, aabb, poses_dev, n_poses, proj, width, height, roi, bbox);
     hipError_t e = hipMemsetAsync(row_count, 0, sizeof(uint32_t) * (size_t)n_poses * height, s);
     if (e != hipSuccess) return e;
     const uint32_t rows_min = cap_px / width > 0 ? cap_px / width : 1;
@@ -3332,38 +3244,21 @@ hipError_t launch_render_bands(const pr_triangle *tris, uint32_t n_tris, const p
 hipError_t launch_render_boxes(const pr_triangle *tris, uint32_t n_tris, const pr_mat4 *poses_dev, uint32_t n_poses, const float *aabb,
                                int4 *bbox, int32_t *depth, uint32_t *row_count, uint32_t *row_off, uint32_t *counts,
                                uint32_t width, uint32_t height, const pr_mat4 &proj, pr_roi roi, hipStream_t s, bool compute_boxes,
-                               PoseMeta *meta, DevIcpState *st, uint32_t *arrive, uint32_t cloud_stride,
-                               int2 *tile_info, uint32_t *overflow, bool all_tiled)
+                               PoseMeta *meta, DevIcpState *st, uint32_t *arrive, uint32_t cloud_stride)
 {
     if (n_poses == 0) return hipSuccess;
     if (compute_boxes)
-        hipLaunchKernelGGL(pose_bbox_kernel, dim3((n_poses + 255) / 256), dim3(256), 0, s, aabb, poses_dev, n_poses, proj, width, height, roi, bbox,
-                           tile_info, kTileCapPx);
+        hipLaunchKernelGGL(pose_bbox_kernel, dim3((n_poses + 255) / 256), dim3(256), 0, s, aabb, poses_dev, n_poses, proj, width, height, roi, bbox);
     const pr_roi none{ 0, 0, 0, 0 };
-    if (tile_info && n_tris > 0) {                               // hypotheses whose pixel box fits the LDS tile (see raster_tile_kernel)
-        static bool attr_set = false;
-        const size_t lds = (size_t)kTileCapPx * 2 + 16 + (size_t)(kTileThreads / 64) * (kSetupWords + 2) * 64 * sizeof(float);
-        if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(raster_tile_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-            attr_set = true;
-        }
-        for (uint32_t p0 = 0; p0 < n_poses; p0 += 32768) {
-            const uint32_t np = (n_poses - p0 < 32768) ? (n_poses - p0) : 32768;
-            hipLaunchKernelGGL(raster_tile_kernel, dim3(np), dim3(kTileThreads), lds, s, tris, n_tris, poses_dev + p0, bbox + p0, tile_info + p0,
-                               depth + (size_t)p0 * width * height, row_count + (size_t)p0 * height, width, height, proj, overflow);
-        }
-    }
-    const int2 *skip = (tile_info && n_tris > 0) ? tile_info : nullptr;
-    for (uint32_t p0 = 0; p0 < n_poses && !(skip && all_tiled); p0 += 32768) {
+    for (uint32_t p0 = 0; p0 < n_poses; p0 += 32768) {
         const uint32_t np = (n_poses - p0 < 32768) ? (n_poses - p0) : 32768;
         const size_t off = (size_t)p0 * width * height;
-        hipLaunchKernelGGL(fill_box_kernel, dim3((height + kBoxRowsPerBlock - 1) / kBoxRowsPerBlock, np), dim3(256), 0, s, depth + off, bbox + p0, width, height, skip ? skip + p0 : nullptr);
+        hipLaunchKernelGGL(fill_box_kernel, dim3((height + kBoxRowsPerBlock - 1) / kBoxRowsPerBlock, np), dim3(256), 0, s, depth + off, bbox + p0, width, height);
         if (n_tris > 0)                                          // an empty mesh renders nothing: every cloud is empty
         hipLaunchKernelGGL(raster_kernel, dim3((n_tris + 255) / 256, np), dim3(256), 0, s, tris, n_tris, poses_dev + p0, depth + off,
-                           width, height, proj, none, width, height, (const int4 *)(bbox + p0), skip ? skip + p0 : nullptr);
+                           width, height, proj, none, width, height, (const int4 *)(bbox + p0));
         hipLaunchKernelGGL(count_box_kernel, dim3((height + kBoxRowsPerBlock - 1) / kBoxRowsPerBlock, np), dim3(256), 0, s, depth + off, bbox + p0, width, height,
-                           row_count + (size_t)p0 * height, skip ? skip + p0 : nullptr);
+                           row_count + (size_t)p0 * height);
     }
     if (meta) hipLaunchKernelGGL(d2c_scan_init_kernel, dim3(n_poses), dim3(256), 0, s, row_count, height, row_off, counts, meta, st, arrive, cloud_stride);
     else hipLaunchKernelGGL(d2c_scan_kernel, dim3(n_poses), dim3(256), 0, s, row_count, height, row_off, counts);

@@ -266,16 +266,20 @@ def test_nn_stack_and_stackless_traversals_agree(gpu, scenario, gscenes):
     stackless walk give bit-identical ICP results
     (same winners, same tie-breaks) -- 21 passes on the test.cpp cloud, whose first passes start centimetres off the surface."""
     out = []
-    for stack, compact, wide in ((1, 1, 1), (1, 1, 0), (1, 0, 0), (0, 0, 0)):      # (1, 1, 1) = default: order-free walk over 128-byte lines first
+    # (1, 1, 1, 1) = default: search kernel + bound kernel + task walk over 128-byte wide nodes; wide 0: binary per-lane walk of the queue;
+    # split 0: the search fused into the correspondence pass (what trees without compact records run)
+    for stack, compact, wide, split in ((1, 1, 1, 1), (1, 1, 0, 1), (1, 1, 0, 0), (1, 0, 0, 1), (0, 0, 0, 1)):
         api.set_option("nn_stack", stack)
         api.set_option("nn_compact", compact)
         api.set_option("nn_wide", wide)
+        api.set_option("nn_split", split)
         dev = api.DeviceVector.from_host(scenario["cloud"].reshape(-1))
         r = api.ICP_Point2Plane(dev, gscenes["nn"], api.ICPConvergenceCriteria(0.0, 0.0, 20))
         out.append((r.transformation_.copy(), r.fitness_, r.inlier_rmse_, dev.to_host()))
     api.set_option("nn_stack", 1)
     api.set_option("nn_compact", 1)
     api.set_option("nn_wide", 1)
+    api.set_option("nn_split", 1)
     for o in out[1:]:
         assert np.array_equal(out[0][0], o[0]) and out[0][1] == o[1] and out[0][2] == o[2]
         assert np.array_equal(out[0][3], o[3])
@@ -457,8 +461,9 @@ def test_nn_variants_agree_on_tie_heavy_clouds(gpu, seed, n, max_leaf):
             api.set_option("solve", solve)
             for crit in ((0.0, 0.0, 12), (1e-5, 1e-5, 30)):
                 out = []
-                for stack, compact, seeded, wide in ((1, 1, 1, 1), (1, 1, 1, 0), (1, 1, 0, 1), (1, 1, 0, 0), (1, 0, 0, 0), (0, 0, 0, 0)):
+                for stack, compact, seeded, wide, split in ((1, 1, 1, 1, 1), (1, 1, 1, 0, 1), (1, 1, 1, 0, 0), (1, 1, 0, 1, 1), (1, 1, 0, 0, 1), (1, 0, 0, 0, 1), (0, 0, 0, 0, 1)):
                     api.set_option("nn_stack", stack); api.set_option("nn_compact", compact); api.set_option("nn_seed", seeded); api.set_option("nn_wide", wide)
+                    api.set_option("nn_split", split)
                     dev = api.DeviceVector.from_host(cloud.reshape(-1))
                     r = api.ICP_Point2Plane(dev, scene, api.ICPConvergenceCriteria(*crit))
                     out.append((r.transformation_.copy(), r.fitness_, r.inlier_rmse_, dev.to_host()))
@@ -467,5 +472,5 @@ def test_nn_variants_agree_on_tie_heavy_clouds(gpu, seed, n, max_leaf):
                     assert np.array_equal(out[-1][0], o[0]) and out[-1][1] == o[1] and out[-1][2] == o[2], (solve, crit)
                     assert np.array_equal(out[-1][3], o[3]), (solve, crit)
     finally:
-        api.set_option("nn_stack", 1); api.set_option("nn_compact", 1); api.set_option("nn_seed", 1); api.set_option("nn_wide", 1)
+        api.set_option("nn_stack", 1); api.set_option("nn_compact", 1); api.set_option("nn_seed", 1); api.set_option("nn_wide", 1); api.set_option("nn_split", 1)
         api.set_option("solve", api.SOLVE_HOST)

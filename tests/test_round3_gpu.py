@@ -1,0 +1,147 @@
+"""GPU tests (-m gpu) of round 3: the task walk over wide kd-tree records (pcd_scene.h:60-136 semantics kept through ties), the graph
+cache key of kd-tree batches, synchronous calls next to a pending slot, pr_free with work in flight."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from pose_refine_amd import _lib, api, synth
+
+pytestmark = pytest.mark.gpu
+
+W, H = synth.WIDTH, synth.HEIGHT
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    api.init(0)
+    api.set_option("solve", api.SOLVE_DEVICE)
+    yield True
+    api.set_option("solve", api.SOLVE_HOST)
+
+
+@pytest.fixture(scope="module")
+def model(gpu, golden_dir):
+    return api.Model(os.path.join(golden_dir, "obj_06.ply"))
+
+
+@pytest.fixture(scope="module")
+def gscenes(gpu, scenario):
+    d = scenario["depth"][1]
+    return dict(proj=api.Scene_projective().init_Scene_projective_cuda(d, scenario["K"]),
+                nn=api.Scene_nn().init_Scene_nn_cuda(d, scenario["K"]))
+
+
+def make_scene(pts, nrm, max_leaf, max_dist=0.1):
+    nodes = np.zeros(2 * len(pts) + 1, _lib.KDNODE); cnt = C.c_uint32()
+    _lib.check(_lib.load().pr_kdtree_build(pts.ctypes.data, nrm.ctypes.data, len(pts), max_leaf, nodes.ctypes.data, len(nodes), C.byref(cnt)))
+    scene = api.Scene_nn()
+    scene.max_dist_diff = max_dist
+    scene.pcd_host, scene.normal_host, scene.nodes_host = pts, nrm, np.ascontiguousarray(nodes[:cnt.value])
+    scene.pcd_buffer = api.DeviceVector.from_host(pts.reshape(-1))
+    scene.normal_buffer = api.DeviceVector.from_host(nrm.reshape(-1))
+    scene.nodes = api.DeviceVector.from_host(scene.nodes_host)
+    return scene
+
+
+def brute_force_first_minimum(cloud, pts, max_dist):
+    """Lowest distance per query in the reference's float arithmetic (pcd_scene.h:88-91) and whether it is attained once."""
+    d = cloud[:, None, :].astype(np.float32) - pts[None, :, :].astype(np.float32)
+    d2 = (d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]
+    m = d2.min(1)
+    return m, (d2 == m[:, None]).sum(1), d2.argmin(1)
+
+
+@pytest.mark.parametrize("n,max_leaf,seed", [(20000, 10, 1), (60000, 10, 2), (3000, 15, 3), (2500, 16, 4), (9, 10, 5), (1, 10, 6)])
+def test_task_walk_on_random_scenes_equals_ordered_walks(gpu, n, max_leaf, seed):
+    """Random (tie-free) point sets of several sizes -- up to six levels of wide nodes, leaves of up to 15 points (the most a leaf
+    reference holds) and of 16 (no wide records: the binary walk runs), a scene that is one leaf, a scene of one point: the task walk,
+    the binary per-lane walk and the reference-style stackless walk return bit-identical ICP results, and the first pass' inlier count
+    equals a brute-force count in the reference's arithmetic."""
+    rng = np.random.default_rng(seed)
+    pts = rng.uniform(-0.15, 0.15, size=(n, 3)).astype(np.float32)
+    nrm = rng.normal(size=(n, 3)).astype(np.float32)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    scene = make_scene(pts, nrm, max_leaf, max_dist=0.02)
+    cloud = rng.uniform(-0.16, 0.16, size=(4000, 3)).astype(np.float32)
+    m, _, _ = brute_force_first_minimum(cloud[:500], pts, 0.02)
+    out = []
+    try:
+        for stack, wide in ((1, 1), (1, 0), (0, 0)):
+            api.set_option("nn_stack", stack); api.set_option("nn_wide", wide)
+            dev = api.DeviceVector.from_host(cloud.reshape(-1))
+            r = api.ICP_Point2Plane(dev, scene, api.ICPConvergenceCriteria(0.0, 0.0, 4))
+            r0 = api.ICP_Point2Plane(api.DeviceVector.from_host(cloud[:500].reshape(-1)), scene, api.ICPConvergenceCriteria(0.0, 0.0, 0))
+            out.append((r.transformation_.copy(), r.fitness_, r.inlier_rmse_, dev.to_host(), r0.fitness_))
+    finally:
+        api.set_option("nn_stack", 1); api.set_option("nn_wide", 1)
+    for o in out[1:]:
+        assert np.array_equal(out[0][0], o[0]) and out[0][1] == o[1] and out[0][2] == o[2] and np.array_equal(out[0][3], o[3])
+    assert round(out[0][4] * 500) == int((m < np.float32(0.02) * np.float32(0.02)).sum())
+
+
+def test_graph_cache_keeps_kdtree_batches_of_equal_shape_apart(gpu, scenario, gscenes):
+    """two kd-tree batches with the same number of clouds and the same largest cloud but a different LAST cloud lay
+    their winner / slack / queue arrays out at different offsets; a captured graph of the first must not be replayed for the second."""
+    base = scenario["cloud"]
+    crit = api.ICPConvergenceCriteria(0.0, 0.0, 4)                # even max_iteration: the case the advisor describes
+    api.set_option("pose_groups", 1)
+    try:
+        got = {}
+        for graph in (1, 0):
+            api.set_option("graph", graph)
+            res = []
+            for last in (2000, 2600, 2000):                       # same P, same max_n (3000), other span
+                counts = [1000, 3000, last]
+                offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint32)
+                cl = np.concatenate([base[:c] for c in counts]).astype(np.float32)
+                buf = np.zeros((7000, 3), np.float32); buf[: len(cl)] = cl
+                dev = api.DeviceVector.from_host(buf.reshape(-1))
+                res.append(api.ICP_Point2Plane_batch(dev, offs, gscenes["nn"], crit).tobytes())
+            got[graph] = res
+        assert got[1] == got[0]
+    finally:
+        api.set_option("graph", 1); api.set_option("pose_groups", 2)
+
+
+def test_synchronous_call_while_slot_0_is_pending(gpu, model, scenario, gscenes):
+    """pr_refine_batch used to be submit(0) + wait(0) and failed with a batch pending on slot 0; it now takes the free slot,
+    and reports PR_ERR_INVALID only when both slots are taken."""
+    crit = api.ICPConvergenceCriteria(0.0, 0.0, 5)
+    a, b = synth.hypotheses(40, first=0), synth.hypotheses(24, first=40)
+    want_a = api.refine_batch(model, a, W, H, scenario["proj"], scenario["K"], gscenes["proj"], crit)
+    want_b = api.refine_batch(model, b, W, H, scenario["proj"], scenario["K"], gscenes["proj"], crit)
+    api.refine_submit(0, model, a, W, H, scenario["proj"], scenario["K"], gscenes["proj"], crit)
+    got_b = api.refine_batch(model, b, W, H, scenario["proj"], scenario["K"], gscenes["proj"], crit)       # runs on slot 1
+    api.refine_submit(1, model, b, W, H, scenario["proj"], scenario["K"], gscenes["proj"], crit)
+    with pytest.raises(api.PoseRefineError):
+        api.refine_batch(model, b, W, H, scenario["proj"], scenario["K"], gscenes["proj"], crit)
+    got_a = api.refine_wait(0)
+    got_b2 = api.refine_wait(1)
+    assert got_a[0].tobytes() == want_a[0].tobytes() and got_b[0].tobytes() == want_b[0].tobytes() and got_b2[0].tobytes() == want_b[0].tobytes()
+
+
+def test_free_with_a_batch_in_flight(gpu, model, scenario, gscenes):
+    """pr_free waits for everything the device is running: freeing the device-side results buffer of a batch that was only just
+    submitted returns after that batch has finished (the wait that follows finds it done), and the library stays usable."""
+    crit = api.ICPConvergenceCriteria(0.0, 0.0, 20)
+    poses = synth.hypotheses(64)
+    want = api.refine_batch(model, poses, W, H, scenario["proj"], scenario["K"], gscenes["proj"], crit)
+    dev = api.DeviceVector(64 * 18, np.float32)
+    api.refine_submit(0, model, poses, W, H, scenario["proj"], scenario["K"], gscenes["proj"], crit, results_dev=dev.data())
+    del dev                                                       # pr_free: drains the device first
+    api.refine_wait(0)
+    again = api.refine_batch(model, poses, W, H, scenario["proj"], scenario["K"], gscenes["proj"], crit)
+    assert again[0].tobytes() == want[0].tobytes()
+
+
+def test_raster_repeated_64_hypotheses_is_deterministic(gpu, model, scenario):
+    """The depth resolve is an integer atomicMin: twenty renders of the same 64 hypotheses give the same bits (and the oracle's)."""
+    poses = synth.hypotheses(64)
+    ref = O.render(scenario["tris"], poses[:3], W, H, scenario["proj"])
+    imgs = [np.asarray(api.render_host(model, poses, W, H, scenario["proj"])) for _ in range(20)]
+    for im in imgs[1:]:
+        assert np.array_equal(im, imgs[0])
+    assert np.array_equal(imgs[0][:3].reshape(3, -1), ref.reshape(3, -1))
