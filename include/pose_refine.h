@@ -110,7 +110,7 @@ int pr_sync(void);                               /* wait for the context's strea
 
 /* device_vector_holder<T> storage: common.cu:3-40, renderer.cu:15-50 */
 int pr_malloc(void **dev_ptr, size_t bytes);
-int pr_free(void *dev_ptr);                     /* waits for everything the DEVICE is running (any context's batches included) before the memory goes */
+int pr_free(void *dev_ptr);                     /* waits for what every context of the device has in flight (the caller's and, one at a time, the others') before the memory goes */
 int pr_memcpy_h2d(void *dev_dst, const void *host_src, size_t bytes);
 int pr_memcpy_d2h(void *host_dst, const void *dev_src, size_t bytes);
 int pr_memcpy_d2d(void *dev_dst, const void *dev_src, size_t bytes);
@@ -257,7 +257,7 @@ int pr_gather_results(const pr_result *send_dev, uint32_t n_local, uint32_t n_to
 /* pr_set_option names (all int; defaults in brackets).  None of them changes a result bit, except "points_per_block", which
  * selects the reduction tree and therefore the last bits of the sums (DESIGN.md "canonical tree").
  *   "solve"            [PR_SOLVE_HOST] PR_SOLVE_HOST = reference-style host solve per iteration, PR_SOLVE_DEVICE = loop on the device
- *   "points_per_block" [2048]  points per workgroup of the correspondence pass (multiple of 1024)
+ *   "points_per_block" [3072]  points per workgroup of the correspondence pass (multiple of 1024)
  *   "fused_solve"      [1]     device solve: finalize + 6x6 solve in the tail of the pass kernel instead of a second launch
  *   "pose_groups"      [2]     device solve: streams the batch is split over (1..4)
  *   "graph"            [1]     device solve, one pose group, synchronous path: replay the loop as a hipGraph

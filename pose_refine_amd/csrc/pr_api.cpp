@@ -120,7 +120,7 @@ struct Options {
     int pose_groups = 2;             // PR_SOLVE_DEVICE: split the batch over this many streams (1..4); 2 measured best (1.31 vs 1.45 ms/step at
                                      // 256 poses); launches of different groups overlap, so timed calls fall back to one group
     int solve_mode = PR_SOLVE_HOST;
-    int steps = 2;                   // 1024-point steps per workgroup -> 2048 points per workgroup
+    int steps = 3;                   // 1024-point steps per workgroup -> 3072 points per workgroup (9 workgroups per 26 k-point cloud: measured 3-5 % faster than 2048 / 4096)
     int profile = 0;
     int sample_period = 32;          // profile 2: one timed (synchronous, single-group) call in this many
     int nn_lds_nodes = 1024;
@@ -243,6 +243,12 @@ int g_default_device = -1;
 thread_local Ctx *g = nullptr;
 struct PrivateCtx { Ctx *c = nullptr; ~PrivateCtx(); };   // destructor below, once the teardown helpers exist
 thread_local PrivateCtx tl_private;
+// every private context alive, so that pr_free can drain the device's contexts one by one (lock order: g_private_mu, then a context's mu;
+// nothing takes them the other way round: contexts register before and unregister after they are used)
+std::mutex g_private_mu;
+std::vector<Ctx *> g_private;
+void private_register(Ctx *c) { std::lock_guard<std::mutex> lk(g_private_mu); g_private.push_back(c); }
+void private_unregister(Ctx *c) { std::lock_guard<std::mutex> lk(g_private_mu); for (size_t i = 0; i < g_private.size(); ++i) if (g_private[i] == c) { g_private.erase(g_private.begin() + (long)i); break; } }
 
 void drop_graphs() { for (auto &c : g->graphs) destroy_graph(c); g->graphs.clear(); }
 void comm_teardown(Ctx *c);
@@ -1373,6 +1379,7 @@ void ctx_teardown(Ctx *c)        // c->mu held (or c unreachable); the calling t
 PrivateCtx::~PrivateCtx()               // a thread that ends with a private context releases it
 {
     if (!c) return;
+    private_unregister(c);
     { std::lock_guard<std::mutex> lk(c->mu); comm_teardown(c); ctx_teardown(c); }
     delete c; c = nullptr;
 }
@@ -1431,12 +1438,14 @@ int pr_thread_context(int enable)
         if (tl_private.c) return PR_OK;
         Ctx *c = new Ctx();
         c->device = g->device; c->is_private = true;
+        private_register(c);
         tl_private.c = c; g = c;
         std::lock_guard<std::mutex> lk(g->mu);
         return require_ctx();
     }
     if (!tl_private.c) return PR_OK;
     const int dev = tl_private.c->device;
+    private_unregister(tl_private.c);
     { std::lock_guard<std::mutex> lk(tl_private.c->mu); comm_teardown(tl_private.c); ctx_teardown(tl_private.c); }
     delete tl_private.c; tl_private.c = nullptr; g = nullptr;
     return bind_shared(dev);
@@ -1465,14 +1474,33 @@ int pr_invalidate(const void *dev_ptr, size_t bytes)
 int pr_free(void *dev_ptr)
 {
     if (!dev_ptr) return PR_OK;
-    PR_ENTER();
-    // nothing may outlive the buffer: this context's stream and slots, and -- a private-context thread or another host thread's shared
-    // context can have a batch in flight on the same buffer -- everything else the device is running
-    HIP_TRY(hipStreamSynchronize(g->stream));
-    for (Slot &sl : g->slots) if (sl.pending && !sl.delivered) slot_drain(sl);
-    HIP_TRY(hipDeviceSynchronize());
-    g_writes.note(dev_ptr, 0);                                     // the address may come back with other content
-    if (dev_ptr == g->mesh_key) { g->mesh_key = nullptr; g->aabb_host_valid = false; }
+    Ctx *self = nullptr;
+    {
+        PR_ENTER();
+        self = g;
+        // nothing this context still has in flight may outlive the buffer: the library stream and every slot with an unfinished batch
+        HIP_TRY(hipStreamSynchronize(g->stream));
+        for (Slot &sl : g->slots) if (sl.pending && !sl.delivered) slot_drain(sl);
+        g_writes.note(dev_ptr, 0);                                     // the address may come back with other content
+        if (dev_ptr == g->mesh_key) { g->mesh_key = nullptr; g->aabb_host_valid = false; }
+    }
+    // ... nor anything another context of this device has in flight (a private-context thread, or another thread on the shared context,
+    // may have a batch running on the buffer): every other context is locked -- i.e. between two of its calls, never inside a stream
+    // capture -- and its streams are waited for, one context at a time.  (hipDeviceSynchronize would do it in one call, but it breaks
+    // a graph capture another thread has open.)
+    {
+        std::vector<Ctx *> others;
+        { std::lock_guard<std::mutex> lk(g_reg_mu); for (Ctx *c : g_shared) if (c && c != self && c->device == self->device) others.push_back(c); }
+        std::lock_guard<std::mutex> plk(g_private_mu);
+        for (Ctx *c : g_private) if (c != self && c->device == self->device) others.push_back(c);
+        for (Ctx *c : others) {
+            std::lock_guard<std::mutex> lk(c->mu);
+            if (!c->ready) continue;
+            if (c->stream) (void)hipStreamSynchronize(c->stream);
+            for (hipStream_t sd : c->side) if (sd) (void)hipStreamSynchronize(sd);
+            for (Slot &sl : c->slots) slot_drain(sl);
+        }
+    }
     HIP_TRY(hipFree(dev_ptr));
     return PR_OK;
 }

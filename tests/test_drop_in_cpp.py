@@ -38,8 +38,10 @@ def test_drop_in_driver_matches_oracle(scenario):
     assert got["depth_sum"] == [int(scenario["depth"][0].sum()), int(scenario["depth"][1].sum())]
     assert got["pose_renderer"]["depth_sum"] == got["depth_sum"]                 # PoseRenderer + raw2depth_mask
     assert got["pose_renderer"]["mask_px"] == [int((scenario["depth"][i] > 0).sum()) for i in range(2)]
+    from pose_refine_amd import api
+    ppb = api.get_option("points_per_block")                      # the C++ driver runs with the library's defaults: the oracle sums in the same tree
     for key, sk, crit in [("proj_default", "proj_scene", (1e-5, 1e-5, 30)), ("nn_fixed20", "nn_scene", (0.0, 0.0, 20))]:
-        ref, _, _, _ = O.icp(scenario["cloud"], scenario[sk], crit, O.SUM_CANONICAL, 2048)
+        ref, _, _, _ = O.icp(scenario["cloud"], scenario[sk], crit, O.SUM_CANONICAL, ppb)
         assert np.float32(got[key]["fitness"]) == ref["fitness"]
         assert np.allclose(np.array(got[key]["T"], np.float32), ref["T"], rtol=0, atol=1e-4)
         assert got[key]["rmse"] == pytest.approx(float(ref["inlier_rmse"]), rel=1e-6)

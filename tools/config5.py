@@ -31,7 +31,7 @@ if check:
     osd = O.render(tris, synth.scene_pose()[None], W, H, oproj)[0]
     assert np.array_equal(osd, sd), "scene render differs from oracle"
     oscene = O.ProjScene(sd, K)
-    ores, osizes, _ = O.refine_batch(tris, poses[:2], W, H, oproj, K, oscene, (0.0, 0.0, 20), O.SUM_CANONICAL, 2048)
+    ores, osizes, _ = O.refine_batch(tris, poses[:2], W, H, oproj, K, oscene, (0.0, 0.0, 20), O.SUM_CANONICAL, api.get_option("points_per_block"))
     assert np.array_equal(osizes, sizes[:2]), (osizes, sizes[:2])
     assert np.array_equal(ores["fitness"], res["fitness"][:2]), (ores["fitness"], res["fitness"][:2])
     assert np.allclose(ores["T"], res["T"][:2], atol=1e-4)
