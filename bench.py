@@ -234,8 +234,9 @@ def main():
     # other slot drained, HIP events around every correspondence launch -- so that the timed launches have the chip to themselves.
     # A synchronous step costs ~0.45 ms more than a pipelined one and counts against `value`; at the end of the region the drain
     # it needs is the drain the closing fence needs anyway (sampled in the middle, every sample also cost an empty pipeline
-    # afterwards: -3 % at 100 steps, -6 % at the driver's 20).  Four sampled steps (84 launches) from 40 steps up, two (42) below.
-    n_samples = min(args.steps, 4 if args.steps >= 40 else 2)
+    # afterwards: -3 % at 100 steps, -6 % at the driver's 20).  Four sampled steps (84 launches) from 40 steps up, one (21 launches: the
+    # very last step, whose tail has nothing left to overlap with anyway) below.
+    n_samples = min(args.steps, 4 if args.steps >= 40 else 1)
     api.set_option("profile", 1 if args.sequential else 0)
     api.profile_reset()
     fence()

@@ -869,6 +869,9 @@ constexpr uint32_t kNoPrev = 0xffffffffu;
 #ifndef PR_ARRIVE_ACQ_REL
 #define PR_ARRIVE_ACQ_REL 0
 #endif
+#ifndef PR_PYR_LOCAL64
+#define PR_PYR_LOCAL64 1
+#endif
 #ifndef PR_RING_ROWS
 #define PR_RING_ROWS 2
 #endif
@@ -1168,6 +1171,24 @@ __device__ __forceinline__ void grid_pyramid_bound(const SceneNNDev &s, float sx
     const int w4 = ((int)s.gw + 3) / 4, h4 = ((int)s.gh + 3) / 4, w16 = (w4 + 3) / 4, h16 = (h4 + 3) / 4, w64 = (w16 + 3) / 4, h64 = (h16 + 3) / 4;
     float dmin = FLT_MAX, dall;
     int bx = 0, by = 0;
+#if PR_PYR_LOCAL64
+    {   // the 3 x 3 blocks of 64 x 64 pixels around the query's own projection first: a hypothesis within a few centimetres / degrees of the
+        // scene pose has its neighbour there; only a query that finds nothing there looks at all blocks
+        float u, v;
+        grid_project(s, sx, sy, sz, u, v);
+        if (u > -1e6f && u < 1e6f && v > -1e6f && v < 1e6f) {
+            const int cx = min(max((int)floorf(u) >> 6, 0), w64 - 1), cy = min(max((int)floorf(v) >> 6, 0), h64 - 1);
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const int x = min(max(cx + k % 3 - 1, 0), w64 - 1), y = min(max(cy + k / 3 - 1, 0), h64 - 1);
+                const float4 c = s.pyr64[y * w64 + x];
+                const float d2 = (sx - c.x) * (sx - c.x) + (sy - c.y) * (sy - c.y) + (sz - c.z) * (sz - c.z);
+                if (d2 < dmin) { dmin = d2; bx = x; by = y; }
+            }
+        }
+    }
+    if (!(dmin < 1.0e20f))
+#endif
     for (int i = 0; i < w64 * h64; ++i) {                          // wave-uniform addresses: every lane reads the same few cache lines
         const float4 c = s.pyr64[i];
         const float d2 = (sx - c.x) * (sx - c.x) + (sy - c.y) * (sy - c.y) + (sz - c.z) * (sz - c.z);
