@@ -29,16 +29,23 @@ for c in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"; do n=
   PR_RASTER_MODE=0 timeout 300 rocprofv3 --kernel-trace --pmc $c -d $OUT/pmc -o p_$n -- python tools/pmc_workload.py 256 > /dev/null 2>&1
   summ $OUT/pmc/p_${n}_results.db | sed -n '/PMC counters/,$p' | grep -E "counter|---|icp_pass|max2zero|fill_i32|raster_kernel" > $OUT/pmc_proj_$n.md
   PR_RASTER_MODE=0 timeout 300 rocprofv3 --kernel-trace --pmc $c -d $OUT/pmc -o n_$n -- python tools/pmc_workload.py 256 nn > /dev/null 2>&1
-  summ $OUT/pmc/n_${n}_results.db | sed -n '/PMC counters/,$p' | grep -E "counter|---|icp_pass|nn_search|nn_tree|max2zero|fill_i32" > $OUT/pmc_nn_$n.md
+  summ $OUT/pmc/n_${n}_results.db | sed -n '/PMC counters/,$p' | grep -E "counter|---|icp_pass|nn_search|nn_bound|nn_tree|max2zero|fill_i32" > $OUT/pmc_nn_$n.md
 done
 for c in "SQ_INSTS_VALU SQ_INSTS_VMEM SQ_INSTS_LDS" "SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TOTAL_ACCESSES_sum" "TA_BUSY_avr TA_TA_BUSY_sum GRBM_GUI_ACTIVE"; do n=$(echo $c | tr " " "_")
   PR_RASTER_MODE=0 timeout 300 rocprofv3 --kernel-trace --pmc $c -d $OUT/pmc -o s_$n -- python tools/pmc_workload.py 256 nn > /dev/null 2>&1
-  summ $OUT/pmc/s_${n}_results.db | sed -n '/PMC counters/,$p' | grep -E "counter|---|nn_search|nn_tree|icp_pass" > $OUT/sq_nn_$n.md
+  summ $OUT/pmc/s_${n}_results.db | sed -n '/PMC counters/,$p' | grep -E "counter|---|nn_search|nn_bound|nn_tree|icp_pass" > $OUT/sq_nn_$n.md
   PR_RASTER_MODE=0 PR_OPTS="pose_groups=1" timeout 300 rocprofv3 --kernel-trace --pmc $c -d $OUT/pmc -o q_$n -- python tools/pmc_workload.py 256 > /dev/null 2>&1
   summ $OUT/pmc/q_${n}_results.db | sed -n '/PMC counters/,$p' | grep -E "counter|---|icp_pass|raster_kernel" > $OUT/sq_proj_$n.md
 done
+for c in "FETCH_SIZE" "WRITE_SIZE"; do
+  PR_OPTS="sub_batch=1024,pose_groups=1" timeout 300 rocprofv3 --kernel-trace --pmc $c -d $OUT/pmc -o big_$c -- python tools/pmc_workload.py 1024 > /dev/null 2>&1
+  summ $OUT/pmc/big_${c}_results.db | sed -n '/PMC counters/,$p' | grep -E "counter|---|icp_pass|max2zero|fill_i32|raster_kernel" > $OUT/pmc_proj_p1024_onebatch_$c.md
+done
+PR_OPTS="sub_batch=1024,pose_groups=1" rocprofv3 --kernel-trace --stats -d $OUT/stats4 -o big -- python tools/pmc_workload.py 1024 > /dev/null 2>&1
+summ $OUT/stats4/big_results.db > $OUT/kernel_stats_p1024_onebatch.md
 python tools/nn_counters.py > $OUT/nn_work_counters.md 2>/dev/null
-bash tools/nn_passes.sh "nn_split=1" "nn_split=0" 2>/dev/null | grep -E "==|us:" > $OUT/nn_per_pass_us.txt
+bash tools/nn_passes_env.sh "PR_OPTS_EXTRA=default" 2>/dev/null | grep -E "==|us:" > $OUT/nn_per_pass_us.txt
+bash tools/nn_passes.sh "nn_wide=0" 2>/dev/null | grep -E "==|us:" >> $OUT/nn_per_pass_us.txt
 # BASELINE configs[4]: 1M triangles, 1280x720, 128 hypotheses (the per-GPU share of 1024 over 8)
 timeout 600 python tools/config5.py 128 --check > $OUT/config5.txt 2>&1; tail -4 $OUT/config5.txt
 rocprofv3 --kernel-trace --stats -d $OUT/stats3 -o c5 -- python tools/config5.py 128 > /dev/null 2>&1
@@ -47,8 +54,9 @@ summ $OUT/stats3/c5_results.db > $OUT/kernel_stats_config5.md
 PR_BENCH_SHARE_DEVICE=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 40 --warmup 5 2>/dev/null | tail -1 > $OUT/bench_2ranks_share_device.json
 # C++ host: shard driver
 g++ -std=c++14 -O2 -pthread -Iinclude tests/cpp/shard_test.cpp -o tests/cpp/shard_test -Lpose_refine_amd/lib -lpose_refine_hip -Wl,-rpath,$PWD/pose_refine_amd/lib && ./tests/cpp/shard_test tests/golden/ 4096 2>&1 | tail -1 > $OUT/shard_test_4096.json; cat $OUT/shard_test_4096.json
-rm -rf $OUT/stats $OUT/stats1 $OUT/stats2 $OUT/stats3 $OUT/pmc
-lscpu | grep -E 'Model name|^CPU\(s\)|Socket|Core' > $OUT/host_cpu.txt
+python -c "from pose_refine_amd import api; print('visible devices:', api.device_count())" >> $OUT/shard_test_4096.json 2>/dev/null
+rm -rf $OUT/stats $OUT/stats1 $OUT/stats2 $OUT/stats3 $OUT/stats4 $OUT/pmc
+lscpu | grep -E 'Model name|^CPU\(s\)|Socket|Core' > $OUT/host_cpu.txt; cat /sys/fs/cgroup/cpu.max >> $OUT/host_cpu.txt 2>/dev/null
 for f in $OUT/bench_*.json; do echo "== $f"; python -c "
 import json
 d=json.loads(open('$f').read().strip().splitlines()[-1])
