@@ -88,6 +88,16 @@ def effective_cpus():
     return usable, facts
 
 
+def flush_c_stdio():
+    """RCCL prints its version banner through C stdio when NCCL_DEBUG=VERSION (set in this image); with stdout redirected that text sits in a
+    C buffer until the process exits -- i.e. it would land AFTER the JSON line.  Flushing it when it is written keeps the JSON line last."""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:                                              # noqa: BLE001
+        pass
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -113,6 +123,9 @@ def main():
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # PR_BENCH_FORCE_COMM=1 (test mode for one-GPU boxes): run the whole N > 1 machinery -- process group on the RCCL backend, C-ABI communicator,
+    # pr_gather_results per step -- with a world of ONE rank, so that torch's RCCL and the library's use of it meet in one process
+    multi = world > 1 or os.environ.get("PR_BENCH_FORCE_COMM", "0") == "1"
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
 
@@ -131,7 +144,7 @@ def main():
     if share_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if share_device:
             dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -141,7 +154,7 @@ def main():
     # the gather of the solved transforms: C ABI (RCCL directly) unless told otherwise or the communicator cannot be formed
     gather_mode = "torch" if (share_device or os.environ.get("PR_BENCH_GATHER", "cabi") == "torch") else "cabi"
     gather_note = None
-    if world > 1 and gather_mode == "cabi":
+    if multi and gather_mode == "cabi":
         try:
             ident = [api.comm_id() if rank == 0 else None]
             dist.broadcast_object_list(ident, src=0)               # 128 bytes, once
@@ -155,6 +168,9 @@ def main():
         if any(notes):                                             # one rank without a communicator: every rank uses torch's gather, and the line says why
             gather_mode = "torch"
             gather_note = "; ".join(n for n in notes if n)
+    if multi:
+        dist.barrier()                                              # every rank's communicators exist (and have printed what they print)
+    flush_c_stdio()
     api.set_option("solve", api.SOLVE_DEVICE if args.solve == "device" else api.SOLVE_HOST)
     api.set_option("pose_groups", args.pose_groups)
     api.set_option("fused_solve", args.fused_solve)
@@ -186,7 +202,7 @@ def main():
     # host round trip) and only then is step k-1 waited for and its results handed to the gather -- the GPU always has the
     # next batch queued, and the gather of step k-1 (RCCL's stream) overlaps step k.
     results = [torch.zeros(P * 18, dtype=torch.float32, device="cuda") for _ in range(2)]
-    gathered = [torch.zeros(global_poses * 18, dtype=torch.float32, device="cuda") for _ in range(2)] if (world > 1 and rank == 0 and gather_mode == "cabi") else [None, None]
+    gathered = [torch.zeros(global_poses * 18, dtype=torch.float32, device="cuda") for _ in range(2)] if (multi and rank == 0 and gather_mode == "cabi") else [None, None]
     pending = [None, None]                                       # gather handle per buffer
     inflight = [False, False]                                    # submitted, not yet waited for
     step_no = [0]
@@ -198,10 +214,10 @@ def main():
         _, sizes = api.refine_wait(b)
         inflight[b] = False
         last_sizes[0] = sizes
-        if world > 1 and gather_mode == "cabi":                 # the single RCCL exchange of the job: P x 72 B per rank to rank 0,
+        if multi and gather_mode == "cabi":                 # the single RCCL exchange of the job: P x 72 B per rank to rank 0,
             api.gather_results(results[b].data_ptr(), P, global_poses, 0,   # enqueued on the library's stream behind this batch
                                gathered[b].data_ptr() if rank == 0 else None)
-        elif world > 1:
+        elif multi:
             pending[b] = prd.gather_results(results[b].cpu() if share_device else results[b], world, rank, dst=0, max_count=P_max, async_op=True)
 
     def step():
@@ -222,9 +238,9 @@ def main():
             if pending[b] is not None:
                 pending[b].wait()
                 pending[b] = None
-        if world > 1 and gather_mode == "cabi":
+        if multi and gather_mode == "cabi":
             api.sync()                                           # the library stream carries the gathers
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -251,9 +267,9 @@ def main():
     api.set_option("profile", 0)
     prof = api.profile_read()
 
-    gather_ms, gather_n = (api.gather_profile() if (world > 1 and gather_mode == "cabi") else (0.0, 0))
+    gather_ms, gather_n = (api.gather_profile() if (multi and gather_mode == "cabi") else (0.0, 0))
     per_rank_ms = [1e3 * elapsed / args.steps]
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share_device else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         mine = 1e3 * elapsed / args.steps
@@ -261,6 +277,9 @@ def main():
         dist.all_gather_object(per_rank_ms, mine)
         elapsed = float(t.item())
 
+    flush_c_stdio()
+    if multi:
+        dist.barrier()                                              # nothing of any rank is left to be written before rank 0's line
     if rank == 0:
         total_poses = global_poses * args.steps
         launches = max(1, prof["icp_launches"])
@@ -288,7 +307,7 @@ def main():
                                    + (f", {args.pose_groups} pose groups" if args.solve == "device" else ""),
                        "poses_per_gpu": P_max, "global_batch": global_poses, "points_per_pose_mean": float(np.mean(sizes)),
                        "parallelism": (f"pose-shard x{world}, no data-path collective, "
-                                       + ("no gather (1 rank)" if world == 1 else
+                                       + ("no gather (1 rank)" if not multi else
                                           ("1 RCCL gather per step (pr_gather_results)" if gather_mode == "cabi" else
                                            ("1 gloo gather per step on host copies (ranks share one device: test mode)" if share_device else "1 torch.distributed gather per step (RCCL backend)"))))},
             # `bound`: what the counters say limits this kernel.  `frac` is the contract's figure -- SURVEY 8d's ALGORITHMIC bytes over the launch
@@ -322,7 +341,7 @@ def main():
                          "timing": ("HIP events on the library stream around every launch (--sequential: synchronous single-group steps)" if args.sequential else
                                     f"HIP events on the library stream around every launch of the last {n_samples} steps of the timed region; "
                                     "a timed step runs synchronously as one pose group (other slot drained) so the launch has the chip to itself")},
-            "gather": ("none (1 rank)" if world == 1 else ("pr_gather_results: grouped ncclSend/ncclRecv on the library stream (C ABI over RCCL)" if gather_mode == "cabi" else
+            "gather": ("none (1 rank)" if not multi else ("pr_gather_results: grouped ncclSend/ncclRecv on the library stream (C ABI over RCCL)" if gather_mode == "cabi" else
                                                             ("torch.distributed.gather (gloo, host copies: ranks share one device)" if share_device else "torch.distributed.gather (RCCL)"))),
             "gather_note": gather_note,
             "gather_event_us": (1e3 * gather_ms / gather_n) if gather_n else None,      # HIP events around the exchange on the library stream, sampled steps (rank 0)
@@ -339,9 +358,10 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args, args.scene, model.tris, scene_depth, K, W, H)
             if "config2_kdtree" in out:
                 out["config2_kdtree"]["cpu_baseline"] = cpu_baseline(args, "nn", model.tris, scene_depth, K, W, H)
+        flush_c_stdio()
         print(json.dumps(out), flush=True)
 
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 
