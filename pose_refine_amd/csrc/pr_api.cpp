@@ -150,7 +150,7 @@ Options opt;
 
 // packed projective scene (one 16-byte record per pixel + the two back-projection tables) of the latest scene it was built for
 struct PackedCache {
-    DevBuf rec;                      // [n] float4, colf[w], rowf[h], exact flag (uint32)
+    DevBuf rec;                      // [n] float4, colf[w], rowf[h], exact flag (uint32), sampled fingerprint of the source arrays (uint32)
     const void *pcd = nullptr, *normal = nullptr;
     uint64_t w = 0, h = 0; float k[4] = { 0, 0, 0, 0 }; uint32_t tl[2] = { 0, 0 };
     uint64_t gen = 0;
@@ -364,6 +364,7 @@ int ensure_packed(PackedCache &pc, const pr_scene_proj &s, uint32_t tl_x, uint32
     uint32_t *exact_dev = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(colf) + tables);
     HIP_TRY(prk::launch_pack_proj_scene(s.pcd, s.normal, pc.rec.as<float4>(), n, colf, rowf, (uint32_t)s.width, (uint32_t)s.height,
                                         k[0], k[1], k[2], k[3], tl_x, tl_y, exact_dev, st));
+    HIP_TRY(prk::launch_scene_fingerprint(s.pcd, n * sizeof(pr_vec3), s.normal, n * sizeof(pr_vec3), nullptr, 0, exact_dev + 1, nullptr, false, st));
     uint32_t exact = 0;
     HIP_TRY(hipMemcpyAsync(&exact, exact_dev, sizeof exact, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -427,6 +428,8 @@ int make_scene(int kind, const void *scene, bool want_packed, SceneSel &out, Pac
                                                g->bmax.as<float4>(), g->pts.as<float4>(), g->nnrec.as<float4>(), g->nnrec32.as<uint4>(),
                                                g->nndesc.as<uint2>(), g->nndepth.as<uint32_t>(), g->stream,
                                                g->nnwide.as<uint4>(), g->nnwq.as<uint32_t>()));
+            HIP_TRY(prk::launch_scene_fingerprint(s->pcd, (size_t)s->n_points * sizeof(pr_vec3), s->nodes, (size_t)s->n_nodes * sizeof(pr_kdnode), s->normal,
+                                                  (size_t)s->n_points * sizeof(pr_vec3), g->nndepth.as<uint32_t>() + 12, nullptr, false, g->stream));
             HIP_TRY(hipMemcpyAsync(nc.info, g->nndepth.p, sizeof nc.info, hipMemcpyDeviceToHost, g->stream));
             HIP_TRY(hipStreamSynchronize(g->stream));
             nc.pcd = s->pcd; nc.normal = s->normal; nc.nodes = s->nodes; nc.n_points = s->n_points; nc.n_nodes = s->n_nodes; nc.gen = gen; nc.valid = true;
@@ -1027,6 +1030,10 @@ int refine_wait(int slot)
         // the triangle buffer no longer has the box this batch was sized with: forget the host copy and run the batch again,
         // synchronously (that path derives every box on the device); outputs are overwritten in full
         g->aabb_host_valid = false; g->mesh_key = nullptr;
+        // (or a scene array no longer has the content its cached form was derived from: same cure)
+        drain_all_slots();
+        for (Slot &o : g->slots) o.packed.valid = false;
+        g->packed.valid = false; g->nn_cache.valid = false; g->nn_cache.grid_valid = false;
         const Resubmit &r = sl.again;
         const void *scene = (r.scene_kind == PR_SCENE_NN) ? static_cast<const void *>(&r.sn) : static_cast<const void *>(&r.sp);
         return refine_impl(r.tris, r.n_tris, sl.h_in.as<pr_mat4>(), sl.P, r.W, r.H, &r.proj, r.K, r.scene_kind, scene, r.crit, r.roi,
@@ -1120,6 +1127,22 @@ int refine_submit_async(Slot &sl, const pr_triangle *tris_dev, size_t n_tris, ui
     *reinterpret_cast<volatile uint32_t *>(sl.h_out.as<unsigned char>() + sl.flag_off) = 0u;
     HIP_TRY(prk::launch_model_aabb(tris_dev, (uint32_t)n_tris, sl.aabb_keys.as<uint32_t>(), nullptr, g->aabb_host,
                                    reinterpret_cast<uint32_t *>(static_cast<unsigned char *>(h_out_dev) + sl.flag_off), scene_stream));
+    if (opt.scene_cache) {
+        // ... and so are the scene caches: a sampled fingerprint of the caller's arrays against the one taken when the cache was built
+        // (after the box check on the same stream: that one writes the flag either way, this one only ever raises it)
+        uint32_t *flag = reinterpret_cast<uint32_t *>(static_cast<unsigned char *>(h_out_dev) + sl.flag_off);
+        if (scene_kind == PR_SCENE_NN) {
+            const pr_scene_nn *sn = static_cast<const pr_scene_nn *>(scene);
+            HIP_TRY(prk::launch_scene_fingerprint(sn->pcd, (size_t)sn->n_points * sizeof(pr_vec3), sn->nodes, (size_t)sn->n_nodes * sizeof(pr_kdnode), sn->normal,
+                                                  (size_t)sn->n_points * sizeof(pr_vec3), g->nndepth.as<uint32_t>() + 12, flag, true, scene_stream));
+        } else if (sl.packed.valid) {
+            const pr_scene_proj *sp = static_cast<const pr_scene_proj *>(scene);
+            const size_t n = (size_t)sp->width * sp->height;
+            const size_t tables = ((sp->width + sp->height) * sizeof(float) + 15) & ~(size_t)15;
+            uint32_t *exact_dev = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(sl.packed.rec.as<float4>() + n) + tables);
+            HIP_TRY(prk::launch_scene_fingerprint(sp->pcd, n * sizeof(pr_vec3), sp->normal, n * sizeof(pr_vec3), nullptr, 0, exact_dev + 1, flag, true, scene_stream));
+        }
+    }
     HIP_TRY(hipEventRecord(sl.scene_ready, scene_stream));
 
     // staging: [poses][boxes]; the cloud stride and the grid come from the largest box

@@ -3173,6 +3173,48 @@ __global__ __launch_bounds__(kWideBuildThreads) void nn_wide_build_kernel(const 
     __syncthreads();
     if (tid == 0) { info[8] = (s_bad || begin < end) ? 0u : 1u; info[9] = end; }
 }
+// ---- sampled fingerprint of caller-owned scene arrays -------------------------------------------------------------------------
+// The packed projective scene and the kd-tree search records are cached by the ADDRESS of the arrays they were derived from.  Writes that
+// go through this library drop them; a write the library cannot see (a caller's kernel, a raw hipMemcpy, an allocator handing the address
+// out again) would leave a stale cache behind.  Every asynchronous batch therefore re-reads 4096 words of each source array, spread over
+// the whole array, and compares their hash with the one taken when the cache was built: a frame that changed as a whole cannot pass, and
+// the batch is then repeated with fresh caches (refine_wait, like a stale model box).  A sampled check is not a proof -- an edit confined
+// to words it does not look at still needs pr_invalidate, as pose_refine.h says.
+__global__ __launch_bounds__(256) void scene_fingerprint_kernel(const uint32_t *__restrict__ a, unsigned long long na, const uint32_t *__restrict__ b,
+                                                                unsigned long long nb, const uint32_t *__restrict__ c, unsigned long long nc,
+                                                                uint32_t *__restrict__ expected, uint32_t *__restrict__ flag, int check)
+{
+    __shared__ uint32_t part[4];
+    uint32_t h = 0;
+    const uint32_t *arr[3] = { a, b, c };
+    const unsigned long long len[3] = { na, nb, nc };
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (!arr[k] || len[k] == 0) continue;
+        for (uint32_t i = 0; i < 16u; ++i) {
+            const unsigned long long s = (unsigned long long)(threadIdx.x * 16u + i);
+            const unsigned long long pos = (len[k] <= 4096ull) ? (s % len[k]) : (s * (len[k] / 4096ull) + (s * 2654435761ull) % (len[k] / 4096ull));
+            h += (arr[k][pos] ^ (uint32_t)pos) * 2654435761u + (uint32_t)k;      // a sum: the order of the lanes does not matter
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) h += __shfl_xor(h, off);
+    if ((threadIdx.x & 63u) == 0u) part[threadIdx.x >> 6] = h;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t v = part[0] + part[1] + part[2] + part[3];
+        if (check) { if (*expected != v) *flag = 1u; }
+        else *expected = v;
+    }
+}
+hipError_t launch_scene_fingerprint(const void *a, size_t a_bytes, const void *b, size_t b_bytes, const void *c, size_t c_bytes,
+                                    uint32_t *expected, uint32_t *flag, bool check, hipStream_t s)
+{
+    hipLaunchKernelGGL(scene_fingerprint_kernel, dim3(1), dim3(256), 0, s, static_cast<const uint32_t *>(a), (unsigned long long)(a_bytes / 4),
+                       static_cast<const uint32_t *>(b), (unsigned long long)(b_bytes / 4), static_cast<const uint32_t *>(c), (unsigned long long)(c_bytes / 4),
+                       expected, flag, check ? 1 : 0);
+    return hipGetLastError();
+}
+
 // ================================================================================================
 //  launchers
 // ================================================================================================

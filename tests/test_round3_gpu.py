@@ -145,3 +145,30 @@ def test_raster_repeated_64_hypotheses_is_deterministic(gpu, model, scenario):
     for im in imgs[1:]:
         assert np.array_equal(im, imgs[0])
     assert np.array_equal(imgs[0][:3].reshape(3, -1), ref.reshape(3, -1))
+
+
+def raw_d2d(dst_dev: int, src_dev: int, nbytes: int):
+    """A write the library cannot see: the HIP runtime called directly."""
+    hip = C.CDLL("libamdhip64.so.7")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    assert hip.hipMemcpy(dst_dev, src_dev, nbytes, 3) == 0
+    assert hip.hipDeviceSynchronize() == 0
+
+
+def test_scene_rewritten_behind_the_librarys_back_is_noticed(gpu, model, scenario):
+    """the packed projective scene (like the kd-tree search records) is cached by the address of the caller's arrays.  A frame
+    that is replaced as a whole through a raw hipMemcpy (no pr_invalidate) changes the sampled fingerprint every asynchronous batch takes
+    of those arrays: the batch is repeated with fresh caches and returns what a new scene object returns.  (A kd-tree scene of another
+    frame has other point and node counts, which are part of its cache key.)"""
+    crit = api.ICPConvergenceCriteria(0.0, 0.0, 6)
+    poses = synth.hypotheses(48)
+    K = scenario["K"]
+    a = api.Scene_projective().init_Scene_projective_cuda(scenario["depth"][1], K)
+    b = api.Scene_projective().init_Scene_projective_cuda(scenario["depth"][0], K)       # another frame of the same size
+    want_b = api.refine_batch(model, poses, W, H, scenario["proj"], K, b, crit)
+    first = api.refine_batch(model, poses, W, H, scenario["proj"], K, a, crit)      # the caches of `a` are built here
+    assert first[0].tobytes() != want_b[0].tobytes()
+    raw_d2d(a.normal_buffer.data(), b.normal_buffer.data(), a.normal_buffer.size() * 4)
+    raw_d2d(a.pcd_buffer.data(), b.pcd_buffer.data(), a.pcd_buffer.size() * 4)
+    got = api.refine_batch(model, poses, W, H, scenario["proj"], K, a, crit)
+    assert got[0].tobytes() == want_b[0].tobytes() and np.array_equal(got[1], want_b[1])
