@@ -3,7 +3,7 @@
 # stats, PMC passes, BASELINE configs[4], the 2-rank share-device run, the C++ shard driver.  Output: gpurun_out/round/
 set -u
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-OUT=gpurun_out/round; mkdir -p $OUT
+OUT=gpurun_out/round; rm -rf $OUT; mkdir -p $OUT                 # (gpurun merges into gpurun_out: start from an empty directory, nothing stale gets copied to profiles/)
 B="timeout 600 python bench.py"
 summ() { python tools/rocpd_summary.py "$1"; }
 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" | tail -3 > $OUT/pytest_gpu.txt; cat $OUT/pytest_gpu.txt
