@@ -2168,6 +2168,8 @@ __global__ __launch_bounds__(256) void nn_bound_kernel(IcpBatch b, SceneNNDev sc
         }
     }
 }
+// minimum of two floats that are known not to be NaN: one v_min_f32 (fminf's IEEE minNum semantics cost a canonicalising v_max per operand)
+__device__ __forceinline__ float min_f32(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 // exclusive prefix sum over the 64 lanes of a wavefront (and the total): in-row Hillis-Steele with DPP row shifts, row totals by readlane
 __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t &total)
 {
@@ -2209,7 +2211,7 @@ __global__ __launch_bounds__(256, PR_WIDE_WAVES) void nn_tree_wide_kernel(IcpBat
     float4 *qs = s_q[wave];
     uint32_t *second = s_second[wave], *tied = s_tied[wave], *ovf = s_ovf[wave], *root = s_root[wave];
     unsigned long long *best = s_best[wave];
-    uint32_t n_tree = 0, n_nodes = 0, n_leaves = 0, n_leaf_points = 0, n_redo_q = 0;
+    uint32_t n_tree = 0, n_nodes = 0, n_leaves = 0, n_leaf_points = 0, n_redo_q = 0, n_steps = 0;
     for (uint32_t base = (blockIdx.x * 4u + wave) * 64u; base < queued; base += gridDim.x * 256u) {
         const bool have_q = base + lane < queued;
         uint32_t nN = 0, nL = 0;                                    // fill levels of the two queues (wave-uniform)
@@ -2240,6 +2242,7 @@ __global__ __launch_bounds__(256, PR_WIDE_WAVES) void nn_tree_wide_kernel(IcpBat
                 __builtin_amdgcn_wave_barrier();
             }
             const bool leaf_step = (nL >= kTasks) || (nN == 0u);
+            if (lane == 0u) ++n_steps;
             const uint32_t avail = leaf_step ? nL : nN, k = avail < kTasks ? avail : kTasks;
             const bool active = grp < k;
             const uint2 e = active ? (leaf_step ? leafq : nodeq)[avail - 1u - grp] : make_uint2(0u, 0u);
@@ -2270,18 +2273,20 @@ __global__ __launch_bounds__(256, PR_WIDE_WAVES) void nn_tree_wide_kernel(IcpBat
                     lb[i] = wide_box_lb(sx, sy, sz, r[i].x, r[i].y, r[i].z, scene);
                     keep[i] = v && lb[i] <= bnd;
                     leaf[i] = (r[i].w & kWideLeaf) != 0u;
-                    if (v && !keep[i]) sec_l = fminf(sec_l, lb[i]);
+                    if (v && !keep[i]) sec_l = min_f32(sec_l, lb[i]);
                     cntI += (keep[i] && !leaf[i]) ? 1u : 0u; cntL += (keep[i] && leaf[i]) ? 1u : 0u;
                 }
                 uint32_t tot = 0;
                 const uint32_t ex = wave_excl_scan(cntI | (cntL << 16), tot);
                 uint32_t pI = nN + (ex & 0xffffu), pL = nL + (ex >> 16);
 #pragma unroll
-                for (uint32_t i = 0; i < kPer; ++i) {
-                    if (!keep[i]) continue;
-                    const uint2 ent = make_uint2(r[i].w, (__float_as_uint(lb[i]) & ~63u) | q);
-                    if (leaf[i]) { if (pL < kTaskLCap) leafq[pL] = ent; else ovf[q] = 1u; ++pL; }
-                    else { if (pI < kTaskQCap) nodeq[pI] = ent; else ovf[q] = 1u; ++pI; }
+                for (uint32_t i = 0; i < kPer; ++i) {                  // straight-line: destination by selects, one predicated store per slot
+                    const uint32_t pos = leaf[i] ? pL : pI, cap = leaf[i] ? kTaskLCap : kTaskQCap;
+                    uint2 *dst = (leaf[i] ? leafq : nodeq) + pos;
+                    const bool fits = pos < cap;
+                    if (keep[i] && fits) *dst = make_uint2(r[i].w, (__float_as_uint(lb[i]) & ~63u) | q);
+                    if (keep[i] && !fits) ovf[q] = 1u;
+                    pL += (keep[i] && leaf[i]) ? 1u : 0u; pI += (keep[i] && !leaf[i]) ? 1u : 0u;
                 }
                 nN += tot & 0xffffu; if (nN > kTaskQCap) nN = kTaskQCap;
                 nL += tot >> 16; if (nL > kTaskLCap) nL = kTaskLCap;
@@ -2304,16 +2309,16 @@ __global__ __launch_bounds__(256, PR_WIDE_WAVES) void nn_tree_wide_kernel(IcpBat
                             const unsigned long long old = atomicMin(&best[q], key);
                             const uint32_t old_d = (uint32_t)(old >> 32), old_i = (uint32_t)old;
                             if (old_d == db && old_i != idx && old_i != kNoIdx) atomicMin(&tied[q], db);
-                            if (key < old) { if (old_i != kNoIdx) sec_l = fminf(sec_l, __uint_as_float(old_d)); if (d2 < bnd) atomicMin(bound_q, db); }
-                            else sec_l = fminf(sec_l, d2);
-                        } else sec_l = fminf(sec_l, d2);
+                            if (key < old) { if (old_i != kNoIdx) sec_l = min_f32(sec_l, __uint_as_float(old_d)); if (d2 < bnd) atomicMin(bound_q, db); }
+                            else sec_l = min_f32(sec_l, d2);
+                        } else sec_l = min_f32(sec_l, d2);
                     }
                 }
             }
             nN = (uint32_t)__builtin_amdgcn_readfirstlane((int)nN); nL = (uint32_t)__builtin_amdgcn_readfirstlane((int)nL);     // wave-uniform by construction
             float sec_g = sec_l;
-            if (kLanes >= 2) sec_g = fminf(sec_l, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sec_l), 0xB1, 0xf, 0xf, true)));          // quad_perm [1,0,3,2]
-            if (kLanes == 4) sec_g = fminf(sec_g, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sec_g), 0x4E, 0xf, 0xf, true)));   // quad_perm [2,3,0,1]
+            if (kLanes >= 2) sec_g = min_f32(sec_l, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sec_l), 0xB1, 0xf, 0xf, true)));          // quad_perm [1,0,3,2]
+            if (kLanes == 4) sec_g = min_f32(sec_g, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sec_g), 0x4E, 0xf, 0xf, true)));   // quad_perm [2,3,0,1]
             if (c == 0u && sec_g < FLT_MAX) atomicMin(&second[q], __float_as_uint(sec_g));
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -2357,10 +2362,13 @@ __global__ __launch_bounds__(256, PR_WIDE_WAVES) void nn_tree_wide_kernel(IcpBat
     }
     if (scene.counters) {                                        // instrumented runs only (option "nn_count")
         uint32_t n_pyr = 0u;
+#ifdef PR_COUNT_STEPS
+        n_pyr = n_steps;                                            // experiment builds: the 'pyramid' column counts the steps of the task walk
+#endif
 #ifdef PR_COUNT_REDO
         n_pyr = n_redo_q;                                           // experiment builds: the 'pyramid' column also counts the queries handed to the ordered walk
 #endif
-        (void)n_redo_q;
+        (void)n_redo_q; (void)n_steps;
         const uint32_t v[8] = { 0u, 0u, n_tree, n_pyr, n_nodes, n_leaves, n_leaf_points, 0u };
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -3282,14 +3290,8 @@ hipError_t launch_render_bands(const pr_triangle *tris, uint32_t n_tris, const p
                                uint32_t width, uint32_t height, const pr_mat4 &proj, pr_roi roi, uint32_t n_cus, hipStream_t s)
 {
     if (n_poses == 0) return hipSuccess;
-    static bool attr_set = false;
     const uint32_t cap_px = 36864;                                  // 144 KiB of the 160 KiB LDS
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(raster_band_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)(cap_px * sizeof(int32_t)));
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    if (!lds_opt_in(reinterpret_cast<const void *>(raster_band_kernel), 0, (uint32_t)(cap_px * sizeof(int32_t)))) return hipErrorInvalidValue;   // per device
     hipLaunchKernelGGL(pose_bbox_kernel, dim3((n_poses + 255) / 256), dim3(256), 0, s, aabb, poses_dev, n_poses, proj, width, height, roi, bbox);
     hipError_t e = hipMemsetAsync(row_count, 0, sizeof(uint32_t) * (size_t)n_poses * height, s);
     if (e != hipSuccess) return e;
