@@ -117,6 +117,7 @@ def main():
                     help="every step through the synchronous single-group path with HIP events around EVERY correspondence launch "
                          "(profile 1): the mode in which rocprofv3's per-launch average and the event average measure the same thing")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="library option (pr_set_option), repeatable -- tuning runs")
+    ap.add_argument("--blocking-wait", type=int, default=-1, help="1: pr_refine_wait sleeps instead of spinning (default: 1 when more than one rank shares the host, else 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kdtree-extra", action="store_true", help="skip the short configs[2] (kd-tree association) measurement appended to the line")
     ap.add_argument("--cpu-poses", type=int, default=0, help="CPU baseline sample size (0 = auto)")
@@ -171,6 +172,7 @@ def main():
     if multi:
         dist.barrier()                                              # every rank's communicators exist (and have printed what they print)
     flush_c_stdio()
+    api.set_option("blocking_wait", (1 if world > 1 else 0) if args.blocking_wait < 0 else args.blocking_wait)
     api.set_option("solve", api.SOLVE_DEVICE if args.solve == "device" else api.SOLVE_HOST)
     api.set_option("pose_groups", args.pose_groups)
     api.set_option("fused_solve", args.fused_solve)
@@ -246,6 +248,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    cpu0 = time.process_time()
     # Roofline samples: the LAST n_samples steps of the timed region run with profile 1 -- synchronously, as one pose group, with the
     # other slot drained, HIP events around every correspondence launch -- so that the timed launches have the chip to themselves.
     # A synchronous step costs ~0.45 ms more than a pipelined one and counts against `value`; at the end of the region the drain
@@ -263,6 +266,7 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
+    host_cpu_s = time.process_time() - cpu0                          # CPU time of ALL threads of this process (timed region + the fence before it)
     sizes = last_sizes[0]
     api.set_option("profile", 0)
     prof = api.profile_read()
@@ -347,6 +351,8 @@ def main():
             "gather_event_us": (1e3 * gather_ms / gather_n) if gather_n else None,      # HIP events around the exchange on the library stream, sampled steps (rank 0)
             "gather_events": int(gather_n),
             "per_rank_ms_per_step": per_rank_ms,
+            "host_cpu_per_wall": host_cpu_s / elapsed if elapsed > 0 else None,   # rank 0: CPUs kept busy by this process during the timed region (spinning waits count)
+            "blocking_wait": bool(api.get_option("blocking_wait")),
             "phase_ms_per_timed_step": {"render": prof["render_ms"] / max(1, launches // (args.iters + 1)),
                                         "cloud": prof["cloud_ms"] / max(1, launches // (args.iters + 1))},
         }

@@ -127,6 +127,7 @@ struct Options {
     int nn_lds_records = 0;          // stack traversal: leading 64-byte node records staged in LDS; measured 0/64/128/256/512 -> 42.2/41.6/45.2/45.4/58.2 ms per step (occupancy lost to the extra LDS outweighs the saved L1 lookups)
     int nn_seed = 1;                 // compact kd records: start every search from the previous pass' winner distance
     int nn_compact = 1;              // stack traversal: 32-byte node records with 16-bit outward-rounded child boxes (half the L1 traffic)
+    int blocking_wait = 0;           // pr_refine_wait sleeps on the slot's event instead of spinning (set before the first asynchronous batch)
     int nn_wide = 1;                 // queued tree searches: order-free walk over 128-byte lines (eight subtree boxes per wide node, one line per leaf); ties go to the binary walk
     int nn_stack = 1;                // kd-tree query: per-lane LDS stack (1) or the reference's stackless walk (0)
     int nn_split = 1;                // kd-tree scenes on compact records: search kernel (runs of consecutive points, grid window) + winners pass
@@ -922,7 +923,9 @@ int slot_streams(Slot &sl)
         if (o.done) continue;
         HIP_TRY(hipEventCreateWithFlags(&o.scene_ready, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&o.fork, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&o.done, hipEventDisableTiming));
+        // `done` is the one event a host thread waits on (pr_refine_wait): option "blocking_wait" makes that wait sleep instead of spin --
+        // eight ranks spinning on a node whose cgroup grants sixteen CPUs leave nothing for RCCL's proxy threads
+        HIP_TRY(hipEventCreateWithFlags(&o.done, hipEventDisableTiming | (opt.blocking_wait ? hipEventBlockingSync : 0u)));
         HIP_TRY(hipEventCreateWithFlags(&o.progress, hipEventDisableTiming));
     }
     return PR_OK;
@@ -1854,6 +1857,7 @@ int pr_set_option(const char *name, int value)
     else if (n == "nn_lds_records") opt.nn_lds_records = std::max(0, value);
     else if (n == "nn_compact") opt.nn_compact = value ? 1 : 0;
     else if (n == "nn_wide") opt.nn_wide = value ? 1 : 0;
+    else if (n == "blocking_wait") opt.blocking_wait = value ? 1 : 0;
     else if (n == "nn_seed") opt.nn_seed = value ? 1 : 0;
     else if (n == "nn_stack") opt.nn_stack = value ? 1 : 0;
     else if (n == "nn_split") opt.nn_split = value ? 1 : 0;
@@ -1885,6 +1889,7 @@ int pr_get_option(const char *name, int *value)
     else if (n == "nn_lds_records") *value = opt.nn_lds_records;
     else if (n == "nn_compact") *value = opt.nn_compact;
     else if (n == "nn_wide") *value = opt.nn_wide;
+    else if (n == "blocking_wait") *value = opt.blocking_wait;
     else if (n == "nn_seed") *value = opt.nn_seed;
     else if (n == "nn_stack") *value = opt.nn_stack;
     else if (n == "nn_split") *value = opt.nn_split;
