@@ -209,44 +209,57 @@ __device__ __forceinline__ void wave_raster(const TriSetup &t, int n, float (*w)
     __builtin_amdgcn_wave_barrier();                             // the scratch may be refilled by the caller's next chunk
 }
 
-// one lane = one (triangle, hypothesis); depth resolved with int32 atomicMin in global memory (the reference scheme)
+// one lane = one (triangle, hypothesis); depth resolved with int32 atomicMin in global memory (the reference scheme).
+// A workgroup keeps its 256 triangles in registers and walks `pose_run` consecutive hypotheses with them: a mesh that does not fit
+// the L2 (the 1 M-triangle mesh of BASELINE configs[4]: 36 MB) is then streamed from the Infinity Cache / HBM once per pose_run
+// hypotheses instead of once per hypothesis -- at 128 hypotheses that stream (4.6 GB, 3.2 TB/s) was what bounded the kernel.
 __global__ __launch_bounds__(256) void raster_kernel(const pr_triangle *__restrict__ tris, uint32_t n_tris,
                                                      const pr_mat4 *__restrict__ poses, int32_t *__restrict__ depth,
                                                      uint32_t width, uint32_t height, pr_mat4 proj, pr_roi roi,
-                                                     uint32_t rw, uint32_t rh, const int4 *__restrict__ boxes)
+                                                     uint32_t rw, uint32_t rh, const int4 *__restrict__ boxes, uint32_t n_poses, uint32_t pose_run)
 {
     __shared__ float sh[4][kSetupWords][64];
     __shared__ uint32_t shq[4][128];
-    const uint32_t bx = blockIdx.x, by = blockIdx.y;
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t ti = bx * 256 + threadIdx.x;
-    const float *M = poses[by].m;                                // wave-uniform -> scalar loads
-    int32_t *img = depth + (size_t)by * rw * rh;
-
-    float cmin0 = 0.0f, cmin1 = 0.0f, cmax0 = (float)(width - 1), cmax1 = (float)(height - 1);
-    if (roi.width > 0 && roi.height > 0) {                       // renderer.cu:106-113 (image is flipped in y)
-        cmin0 = (float)roi.x;
-        cmin1 = (float)((unsigned long long)(height - 1) - (unsigned long long)(long long)(roi.y + roi.height - 1));
-        cmax0 = (float)((roi.x + roi.width) - 1);
-        cmax1 = (float)((unsigned long long)(height - 1) - (unsigned long long)(long long)roi.y);
-    }
-    if (boxes) {                                                 // fused path: the hypothesis' pixel box (already intersected with the caller's ROI,
-        const int4 bb = boxes[by];                               // if any); a conservative box clips nothing, an ROI clips like renderer.cu:106-113
-        cmin0 = (float)bb.x; cmin1 = (float)bb.y; cmax0 = (float)bb.z; cmax1 = (float)bb.w;
-    }
-
-    TriSetup t;
-    int n = 0;
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t ti = blockIdx.x * 256 + threadIdx.x;
+    float tv[9];
     if (ti < n_tris) {
-        tri_setup(reinterpret_cast<const float *>(tris + ti), M, proj, width, height, cmin0, cmin1, cmax0, cmax1, t);
-        n = t.nx * t.ny;
-    } else { t.nx = t.ny = 0; t.x0 = t.y0 = 0; t.base_inv = 0; for (int k = 0; k < 3; ++k) t.px[k] = t.py[k] = t.w3[k] = 0; }
-
-    wave_raster(t, n, sh[wave], shq[wave], [&](int x, int y, int d) {
-        const uint32_t xw = (uint32_t)(x - roi.x);
-        const uint32_t yw = (uint32_t)((int)height - 1 - y - roi.y);
-        atomicMin(&img[xw + (size_t)yw * rw], d);
-    });
+        const float *src = reinterpret_cast<const float *>(tris + ti);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) tv[k] = src[k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) tv[k] = 0.0f;
+    }
+    float rmin0 = 0.0f, rmin1 = 0.0f, rmax0 = (float)(width - 1), rmax1 = (float)(height - 1);
+    if (roi.width > 0 && roi.height > 0) {                       // renderer.cu:106-113 (image is flipped in y)
+        rmin0 = (float)roi.x;
+        rmin1 = (float)((unsigned long long)(height - 1) - (unsigned long long)(long long)(roi.y + roi.height - 1));
+        rmax0 = (float)((roi.x + roi.width) - 1);
+        rmax1 = (float)((unsigned long long)(height - 1) - (unsigned long long)(long long)roi.y);
+    }
+    for (uint32_t k = 0; k < pose_run; ++k) {
+        const uint32_t by = blockIdx.y * pose_run + k;
+        if (by >= n_poses) break;
+        const float *M = poses[by].m;                            // wave-uniform -> scalar loads
+        int32_t *img = depth + (size_t)by * rw * rh;
+        float cmin0 = rmin0, cmin1 = rmin1, cmax0 = rmax0, cmax1 = rmax1;
+        if (boxes) {                                             // fused path: the hypothesis' pixel box (already intersected with the caller's ROI,
+            const int4 bb = boxes[by];                           // if any); a conservative box clips nothing, an ROI clips like renderer.cu:106-113
+            cmin0 = (float)bb.x; cmin1 = (float)bb.y; cmax0 = (float)bb.z; cmax1 = (float)bb.w;
+        }
+        TriSetup t;
+        int n = 0;
+        if (ti < n_tris) {
+            tri_setup(tv, M, proj, width, height, cmin0, cmin1, cmax0, cmax1, t);
+            n = t.nx * t.ny;
+        } else { t.nx = t.ny = 0; t.x0 = t.y0 = 0; t.base_inv = 0; for (int j = 0; j < 3; ++j) t.px[j] = t.py[j] = t.w3[j] = 0; }
+        wave_raster(t, n, sh[wave], shq[wave], [&](int x, int y, int d) {
+            const uint32_t xw = (uint32_t)(x - roi.x);
+            const uint32_t yw = (uint32_t)((int)height - 1 - y - roi.y);
+            atomicMin(&img[xw + (size_t)yw * rw], d);
+        });
+    }
 }
 
 // ================================================================================================
@@ -3254,6 +3267,17 @@ hipError_t launch_max2zero(int32_t *depth, size_t n, hipStream_t s)
     return hipGetLastError();
 }
 
+// hypotheses a raster workgroup walks with its 256 triangles: 1 while the mesh is L2-resident and the grid is what fills the chip, more once
+// the mesh has to be streamed (PR_RASTER_RUN overrides: experiments)
+static uint32_t raster_pose_run(uint32_t n_tris, uint32_t n_poses)
+{
+    static const int env_run = getenv("PR_RASTER_RUN") ? atoi(getenv("PR_RASTER_RUN")) : 0;
+    uint32_t run = 1;
+    if (env_run > 0) run = (uint32_t)env_run;
+    else if ((size_t)n_tris * sizeof(pr_triangle) > ((size_t)3 << 20)) run = 8;      // beyond what one XCD's 4 MiB L2 keeps next to the depth images
+    if (run > n_poses) run = n_poses ? n_poses : 1u;
+    return run;
+}
 hipError_t launch_raster(const pr_triangle *tris, uint32_t n_tris, const pr_mat4 *poses_dev, uint32_t n_poses,
                          int32_t *depth, uint32_t width, uint32_t height, const pr_mat4 &proj, pr_roi roi,
                          uint32_t rw, uint32_t rh, hipStream_t s)
@@ -3262,8 +3286,9 @@ hipError_t launch_raster(const pr_triangle *tris, uint32_t n_tris, const pr_mat4
     // grid.y is limited to 65535: split very large batches
     for (uint32_t p0 = 0; p0 < n_poses; p0 += 32768) {
         const uint32_t np = (n_poses - p0 < 32768) ? (n_poses - p0) : 32768;
-        hipLaunchKernelGGL(raster_kernel, dim3((n_tris + 255) / 256, np), dim3(256), 0, s, tris, n_tris, poses_dev + p0,
-                           depth + (size_t)p0 * rw * rh, width, height, proj, roi, rw, rh, (const int4 *)nullptr);
+        const uint32_t run = raster_pose_run(n_tris, np);
+        hipLaunchKernelGGL(raster_kernel, dim3((n_tris + 255) / 256, (np + run - 1) / run), dim3(256), 0, s, tris, n_tris, poses_dev + p0,
+                           depth + (size_t)p0 * rw * rh, width, height, proj, roi, rw, rh, (const int4 *)nullptr, np, run);
     }
     return hipGetLastError();
 }
@@ -3320,8 +3345,9 @@ hipError_t launch_render_boxes(const pr_triangle *tris, uint32_t n_tris, const p
         const size_t off = (size_t)p0 * width * height;
         hipLaunchKernelGGL(fill_box_kernel, dim3((height + kBoxRowsPerBlock - 1) / kBoxRowsPerBlock, np), dim3(256), 0, s, depth + off, bbox + p0, width, height);
         if (n_tris > 0)                                          // an empty mesh renders nothing: every cloud is empty
-        hipLaunchKernelGGL(raster_kernel, dim3((n_tris + 255) / 256, np), dim3(256), 0, s, tris, n_tris, poses_dev + p0, depth + off,
-                           width, height, proj, none, width, height, (const int4 *)(bbox + p0));
+        { const uint32_t run = raster_pose_run(n_tris, np);
+        hipLaunchKernelGGL(raster_kernel, dim3((n_tris + 255) / 256, (np + run - 1) / run), dim3(256), 0, s, tris, n_tris, poses_dev + p0, depth + off,
+                           width, height, proj, none, width, height, (const int4 *)(bbox + p0), np, run); }
         hipLaunchKernelGGL(count_box_kernel, dim3((height + kBoxRowsPerBlock - 1) / kBoxRowsPerBlock, np), dim3(256), 0, s, depth + off, bbox + p0, width, height,
                            row_count + (size_t)p0 * height);
     }

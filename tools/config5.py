@@ -9,6 +9,8 @@ from pose_refine_amd import api, synth
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 check = "--check" in sys.argv
 api.init(0); api.set_option("solve", 1)
+for kv in filter(None, os.environ.get("PR_OPTS", "").split(",")):      # e.g. PR_OPTS=raster_groups=0
+    k, v = kv.split("="); api.set_option(k, int(v))
 W, H = 1280, 720
 K = synth.intrinsics_720p()
 tris = synth.uv_sphere_mesh()
