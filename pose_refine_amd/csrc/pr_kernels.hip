@@ -3212,11 +3212,18 @@ __global__ __launch_bounds__(256) void scene_fingerprint_kernel(const uint32_t *
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         if (!arr[k] || len[k] == 0) continue;
+        // sample s of 4096 sits in stripe s of the array, at a hashed offset inside it (32-bit arithmetic: __umulhi maps a hash onto a range)
+        const uint32_t n = len[k] > 0xffffffffull ? 0xffffffffu : (uint32_t)len[k];
+        const uint32_t stripe = n / 4096u;                            // 0 for short arrays: every word is visited, wrapping around
+        uint32_t w[16];
+#pragma unroll
         for (uint32_t i = 0; i < 16u; ++i) {
-            const unsigned long long s = (unsigned long long)(threadIdx.x * 16u + i);
-            const unsigned long long pos = (len[k] <= 4096ull) ? (s % len[k]) : (s * (len[k] / 4096ull) + (s * 2654435761ull) % (len[k] / 4096ull));
-            h += (arr[k][pos] ^ (uint32_t)pos) * 2654435761u + (uint32_t)k;      // a sum: the order of the lanes does not matter
+            const uint32_t s = threadIdx.x * 16u + i;
+            const uint32_t pos = stripe ? s * stripe + __umulhi(s * 2654435761u + 0x9e3779b9u, stripe) : (n >= 4096u ? s : s % n);
+            w[i] = arr[k][pos] ^ pos;
         }
+#pragma unroll
+        for (uint32_t i = 0; i < 16u; ++i) h += w[i] * 2654435761u + (uint32_t)k;      // a sum: the order of the lanes does not matter
     }
     for (int off = 32; off > 0; off >>= 1) h += __shfl_xor(h, off);
     if ((threadIdx.x & 63u) == 0u) part[threadIdx.x >> 6] = h;
@@ -3440,7 +3447,10 @@ hipError_t launch_nn_search(const IcpBatch &b, const SceneNNDev &sc, uint32_t n_
     if (run > 8) run = 8;
     const uint32_t per_block = kBlockThreads * run;
     const uint32_t gx = (max_points + per_block - 1) / per_block;
-    const uint32_t tree_gx = gx < 8u ? gx : 8u;                      // workgroups per hypothesis walking its queue
+#ifndef PR_TREE_GX
+#define PR_TREE_GX 8
+#endif
+    const uint32_t tree_gx = gx < (uint32_t)PR_TREE_GX ? gx : (uint32_t)PR_TREE_GX;      // workgroups per hypothesis walking its queue
     for (uint32_t p0 = 0; p0 < n_poses; p0 += 32768) {
         const uint32_t np = (n_poses - p0 < 32768) ? (n_poses - p0) : 32768;
         IcpBatch bb = b;
