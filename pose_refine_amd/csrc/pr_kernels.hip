@@ -2151,6 +2151,32 @@ __global__ __launch_bounds__(256) void nn_bound_kernel(IcpBatch b, SceneNNDev sc
             const bool still = bst < 0.0f;                       // the sign carries "no descent needed" (nn_search_kernel)
             bst = still ? -bst : bst;
             pending = true;
+            if (!scene.grid && !(bst < accept)) {
+                // No pixel grid (a bare ICP call has no camera) and nothing known about this query yet (the first pass): the task walk
+                // is order-free, so with the acceptance radius as its only bound it would open half the tree before a leaf near the
+                // query tightens it.  The classic descent does that first: follow the split planes to the query's own leaf (8 bytes
+                // per level) and take the nearest of its points as the seed -- an existing point's distance, inflated (nn_seed_bound).
+                const pr_vec3 q = ld_off<pr_vec3>(cl, j * 12u);
+                uint32_t cur = 0u;
+                for (int guard = 0; guard < 64; ++guard) {
+                    const uint2 d = scene.desc[cur];
+                    const uint32_t tag = d.y >> 30;
+                    if (tag == 3u) {
+                        float dmin = FLT_MAX;
+                        for (uint32_t i = d.x; i < (d.y & 0x3fffffffu); ++i) {
+                            const float4 p = scene.pts[i];
+                            const float d2 = (q.x - p.x) * (q.x - p.x) + (q.y - p.y) * (q.y - p.y) + (q.z - p.z) * (q.z - p.z);
+                            dmin = d2 < dmin ? d2 : dmin;
+                        }
+                        const float bb = dmin * 1.000001f + 1e-30f;
+                        if (bb < bst) bst = bb;
+                        break;
+                    }
+                    const float c = (tag == 0u) ? q.x : ((tag == 1u) ? q.y : q.z);
+                    const uint32_t c1 = d.y & 0x3fffffffu;
+                    cur = (c - __uint_as_float(d.x) < 0.0f) ? c1 : c1 + 1u;
+                }
+            }
             if (scene.grid && !still) {
                 const pr_vec3 q = ld_off<pr_vec3>(cl, j * 12u);
                 uint32_t w = kNoPrev; float bsq = 0.0f, osq = 0.0f;
@@ -2201,7 +2227,7 @@ __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t &total)
 // Queue 2 -> the task walk.  Wavefronts are independent (no workgroup barrier): each takes 64 queries at a time.  kLanes lanes share a task:
 // 8 / kLanes boxes of a node, or 8 / kLanes points of a leaf per round, per lane; a step pops 64 / kLanes tasks of one kind.
 template <int kLanes>
-__global__ __launch_bounds__(256, PR_WIDE_WAVES) void nn_tree_wide_kernel(IcpBatch b, SceneNNDev scene)
+__global__ __launch_bounds__(256, PR_WIDE_WAVES) void nn_tree_wide_kernel(IcpBatch b, SceneNNDev scene, uint32_t qbatch)
 {
     constexpr uint32_t kPer = 8u / kLanes, kTasks = 64u / kLanes;
     __shared__ uint2 s_nodeq[4][kTaskQCap], s_leafq[4][kTaskLCap];               // {reference, bound bits (low 6 bits cleared: rounded DOWN) | query slot}
@@ -2214,7 +2240,7 @@ __global__ __launch_bounds__(256, PR_WIDE_WAVES) void nn_tree_wide_kernel(IcpBat
     uint32_t *counts = b.nn_qcount + kQCountStride * pose + 2u;
     const uint32_t queued = counts[b.iter & 1u];
     if (blockIdx.x == 0 && threadIdx.x == 0) counts[(b.iter + 1u) & 1u] = 0u;         // re-arm the counter the NEXT pass' bound kernel will fill
-    if (blockIdx.x * kBlockThreads >= queued) return;
+    if (blockIdx.x * 4u * qbatch >= queued) return;               // qbatch = queries a wavefront takes at a time (64, or 16 when the whole launch has few)
     const float *cl = reinterpret_cast<const float *>(b.cloud + pm.start);
     uint32_t *win = b.nn_prev + pm.start;
     float *slk = b.nn_slack + pm.start;
@@ -2225,8 +2251,8 @@ __global__ __launch_bounds__(256, PR_WIDE_WAVES) void nn_tree_wide_kernel(IcpBat
     uint32_t *second = s_second[wave], *tied = s_tied[wave], *ovf = s_ovf[wave], *root = s_root[wave];
     unsigned long long *best = s_best[wave];
     uint32_t n_tree = 0, n_nodes = 0, n_leaves = 0, n_leaf_points = 0, n_redo_q = 0, n_steps = 0;
-    for (uint32_t base = (blockIdx.x * 4u + wave) * 64u; base < queued; base += gridDim.x * 256u) {
-        const bool have_q = base + lane < queued;
+    for (uint32_t base = (blockIdx.x * 4u + wave) * qbatch; base < queued; base += gridDim.x * 4u * qbatch) {
+        const bool have_q = lane < qbatch && base + lane < queued;
         uint32_t nN = 0, nL = 0;                                    // fill levels of the two queues (wave-uniform)
         const uint2 mine = have_q ? todo[base + lane] : make_uint2(0u, 0u);    // this lane's query: (point, bound bits)
         uint32_t bound_now = mine.y;                                // the bound this lane's query was (last) started from
@@ -2241,7 +2267,7 @@ __global__ __launch_bounds__(256, PR_WIDE_WAVES) void nn_tree_wide_kernel(IcpBat
         // spread three levels of every walk over the queues before the first leaf is reached (depth-first order keeps them short).
         // A query that lost a task to a full queue is walked again in a second round, alone with the other such queries and from the
         // minimum it did find (a handful of queries cannot fill the queues); only if that fails too does it go to the ordered walk.
-        uint32_t n_q = (queued - base < 64u) ? (queued - base) : 64u;
+        uint32_t n_q = (queued - base < qbatch) ? (queued - base) : qbatch;
         for (int round = 0; round < 2 && n_q; ++round) {
         uint32_t started = 0;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -3450,7 +3476,11 @@ hipError_t launch_nn_search(const IcpBatch &b, const SceneNNDev &sc, uint32_t n_
 #ifndef PR_TREE_GX
 #define PR_TREE_GX 8
 #endif
-    const uint32_t tree_gx = gx < (uint32_t)PR_TREE_GX ? gx : (uint32_t)PR_TREE_GX;      // workgroups per hypothesis walking its queue
+    // workgroups per hypothesis walking its queue: 8 when there are hundreds of hypotheses, more for a handful (a single cloud -- the
+    // reference's own ICP() call -- would otherwise run its tree searches on 8 CUs of 256)
+    uint32_t want = (uint32_t)PR_TREE_GX;
+    if (n_poses * want < 1024u) want = (1024u + n_poses - 1u) / n_poses;
+    const uint32_t tree_gx = gx < want ? gx : want;
     for (uint32_t p0 = 0; p0 < n_poses; p0 += 32768) {
         const uint32_t np = (n_poses - p0 < 32768) ? (n_poses - p0) : 32768;
         IcpBatch bb = b;
@@ -3458,7 +3488,11 @@ hipError_t launch_nn_search(const IcpBatch &b, const SceneNNDev &sc, uint32_t n_
         hipLaunchKernelGGL(nn_search_kernel, dim3(gx, np), dim3(kBlockThreads), 0, s, bb, sc, run);
         if (sc.wide) {
             hipLaunchKernelGGL(nn_bound_kernel, dim3(tree_gx, np), dim3(kBlockThreads), 0, s, bb, sc);
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(nn_tree_wide_kernel<PR_WIDE_LANES>), dim3(tree_gx, np), dim3(kBlockThreads), 0, s, bb, sc);
+            // a wavefront of the task walk takes 64 queries at a time -- unless the whole launch has too few to fill the chip that way (a single
+            // cloud: 26 k queries = 103 workgroups of 4 x 64): then 16 at a time in four times as many workgroups
+            uint32_t qbatch = 64u, walk_gx = tree_gx;
+            if ((size_t)np * max_points < (size_t)64 * 4 * 1024) { qbatch = 16u; walk_gx = (max_points + 4u * qbatch - 1u) / (4u * qbatch); if (walk_gx * np > 4096u) walk_gx = (4096u + np - 1u) / np; if (walk_gx < tree_gx) walk_gx = tree_gx; }
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(nn_tree_wide_kernel<PR_WIDE_LANES>), dim3(walk_gx, np), dim3(kBlockThreads), 0, s, bb, sc, qbatch);
         }
         else if (sc.stack_depth == 16) hipLaunchKernelGGL(HIP_KERNEL_NAME(nn_tree_kernel<16 + 0x100>), dim3(tree_gx, np), dim3(kBlockThreads), (size_t)16 * kBlockThreads * 8, s, bb, sc);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(nn_tree_kernel<24 + 0x100>), dim3(tree_gx, np), dim3(kBlockThreads), (size_t)24 * kBlockThreads * 8, s, bb, sc);
