@@ -2151,10 +2151,10 @@ __global__ __launch_bounds__(256) void nn_bound_kernel(IcpBatch b, SceneNNDev sc
             const bool still = bst < 0.0f;                       // the sign carries "no descent needed" (nn_search_kernel)
             bst = still ? -bst : bst;
             pending = true;
-            if (!scene.grid && !(bst < accept)) {
-                // No pixel grid (a bare ICP call has no camera) and nothing known about this query yet (the first pass): the task walk
-                // is order-free, so with the acceptance radius as its only bound it would open half the tree before a leaf near the
-                // query tightens it.  The classic descent does that first: follow the split planes to the query's own leaf (8 bytes
+            if (!scene.grid && !still) {
+                // No pixel grid (a bare ICP call has no camera) and the query is new or has moved (its previous winner, centimetres away
+                // now, is a loose bound): the task walk is order-free, so with a loose bound it would open a good part of the tree before
+                // a leaf near the query tightens it.  The classic descent does that first: follow the split planes to the query's own leaf (8 bytes
                 // per level) and take the nearest of its points as the seed -- an existing point's distance, inflated (nn_seed_bound).
                 const pr_vec3 q = ld_off<pr_vec3>(cl, j * 12u);
                 uint32_t cur = 0u;
