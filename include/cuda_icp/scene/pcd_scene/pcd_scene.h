@@ -38,6 +38,8 @@ class Scene_nn {
     Vec3f *pcd_ptr = nullptr, *normal_ptr = nullptr;
     Node_kdtree *node_ptr = nullptr;
     uint32_t n_points = 0, n_nodes = 0;      // added: the C ABI wants explicit sizes
+    float cam_[4] = { 0, 0, 0, 0 }; uint32_t cam_w_ = 0, cam_h_ = 0;   // added: the camera init_Scene_nn_* was given (the reference drops it): lets a bare ICP() index the scene by pixel
+    void remember_camera(Mat3x3f &K, int w, int h) { const float *k = K.data(); cam_[0] = k[0]; cam_[1] = k[4]; cam_[2] = k[2]; cam_[3] = k[5]; cam_w_ = (uint32_t)w; cam_h_ = (uint32_t)h; }
 public:
     void init_Scene_nn_cpu(cv::Mat &scene_depth, Mat3x3f &scene_K, KDTree_cpu &kdtree)      // pcd_scene.cpp:4-37
     {
@@ -48,6 +50,7 @@ public:
                                                      reinterpret_cast<pr_vec3 *>(kdtree.pcd_buffer.data()), reinterpret_cast<pr_vec3 *>(kdtree.normal_buffer.data()),
                                                      reinterpret_cast<pr_kdnode *>(kdtree.nodes.data()), kdtree.nodes.size(), &n_points, &n_nodes), "pr_scene_nn_prepare");
         kdtree.pcd_buffer.resize(n_points); kdtree.normal_buffer.resize(n_points); kdtree.nodes.resize(n_nodes);
+        remember_camera(scene_K, scene_depth.cols, scene_depth.rows);
         pcd_ptr = kdtree.pcd_buffer.data(); normal_ptr = kdtree.normal_buffer.data(); node_ptr = kdtree.nodes.data();
     }
     void init_Scene_nn_cuda(cv::Mat &scene_depth, Mat3x3f &scene_K, KDTree_cuda &kdtree)   // pcd_scene.cu:3-20
@@ -66,6 +69,7 @@ public:
         pose_refine_detail::must(pr_scene_nn_prepare_dev(scene_depth_dev, sizeof(T) == 4, scene_K.data(), width, height, max_leaf,
                                                          reinterpret_cast<pr_vec3 *>(kdtree.pcd_buffer.data()), reinterpret_cast<pr_vec3 *>(kdtree.normal_buffer.data()),
                                                          reinterpret_cast<pr_kdnode *>(kdtree.nodes.data()), 2 * px + 1, &n_points, &n_nodes), "pr_scene_nn_prepare_dev");
+        remember_camera(scene_K, width, height);
         pcd_ptr = kdtree.pcd_buffer.data(); normal_ptr = kdtree.normal_buffer.data(); node_ptr = kdtree.nodes.data();
     }
     // pcd_scene.h:60-136, host evaluation over host pointers
@@ -98,5 +102,6 @@ public:
         if (valid) { dst = pcd_ptr[best_i]; nrm = normal_ptr[best_i]; }
     }
     pr_scene_nn c_view() const { pr_scene_nn s; s.max_dist_diff = max_dist_diff; s.pcd = reinterpret_cast<const pr_vec3 *>(pcd_ptr); s.normal = reinterpret_cast<const pr_vec3 *>(normal_ptr);
-        s.nodes = reinterpret_cast<const pr_kdnode *>(node_ptr); s.n_points = n_points; s.n_nodes = n_nodes; return s; }
+        s.nodes = reinterpret_cast<const pr_kdnode *>(node_ptr); s.n_points = n_points; s.n_nodes = n_nodes;
+        s.cam_fx = cam_[0]; s.cam_fy = cam_[1]; s.cam_cx = cam_[2]; s.cam_cy = cam_[3]; s.cam_w = cam_w_; s.cam_h = cam_h_; return s; }
 };

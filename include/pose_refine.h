@@ -83,6 +83,11 @@ typedef struct {
     const pr_vec3 *normal;     /* dev, n_points */
     const pr_kdnode *nodes;    /* dev, n_nodes, level order, nodes[0] = root */
     uint32_t n_points, n_nodes;
+    /* Optional (not in the reference's struct, which drops K after init_Scene_nn_*): the camera of the depth image the scene was made
+     * from -- cam_w = 0: unknown.  With it a bare ICP call (no render, hence no camera of its own) can index the scene points by pixel as
+     * the fused path does; it is a HINT: the pixel grid is only used if every scene point really projects into a cell of its own. */
+    float cam_fx, cam_fy, cam_cx, cam_cy;
+    uint32_t cam_w, cam_h;
 } pr_scene_nn;
 
 /* A Scene_projective whose arrays cover only a window of the frame: pcd2dep(src, K, tl_x, tl_y) / dep2pcd(x, y, d, K, tl_x, tl_y)

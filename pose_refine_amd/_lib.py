@@ -51,7 +51,8 @@ class SceneProjCropDesc(C.Structure):
 
 class SceneNNDesc(C.Structure):
     _fields_ = [("max_dist_diff", C.c_float), ("pcd", C.c_void_p), ("normal", C.c_void_p), ("nodes", C.c_void_p),
-                ("n_points", C.c_uint32), ("n_nodes", C.c_uint32)]
+                ("n_points", C.c_uint32), ("n_nodes", C.c_uint32),
+                ("cam_fx", C.c_float), ("cam_fy", C.c_float), ("cam_cx", C.c_float), ("cam_cy", C.c_float), ("cam_w", C.c_uint32), ("cam_h", C.c_uint32)]
 
 
 # name -> (restype, argtypes); this table is also what tests/test_cabi_symbols.py checks against the header

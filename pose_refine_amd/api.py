@@ -389,6 +389,7 @@ class Scene_nn:
         self.max_dist_diff = 0.1
         self.pcd_buffer = self.normal_buffer = self.nodes = None
         self.pcd_host = self.normal_host = self.nodes_host = None
+        self.camera = None                                          # (fx, fy, cx, cy, w, h) of the depth image the scene was made from, if known
 
     def init_Scene_nn_cuda(self, scene_depth: np.ndarray, scene_K, max_leaf: int = 10, max_dist_diff: float = 0.1):
         if scene_depth.dtype not in (np.uint16, np.int32):          # pcd_scene.cpp:6-7 assert
@@ -403,6 +404,7 @@ class Scene_nn:
         check(_lib.load().pr_scene_nn_prepare(ptr(d), int(d.dtype == np.int32), ptr(k), w, h, max_leaf, ptr(pcd), ptr(nrm),
                                               ptr(nodes), len(nodes), C.byref(npts), C.byref(nnodes)))
         self.max_dist_diff = max_dist_diff
+        self.camera = (float(k[0]), float(k[4]), float(k[2]), float(k[5]), int(w), int(h))
         self.pcd_host = np.ascontiguousarray(pcd[:npts.value])
         self.normal_host = np.ascontiguousarray(nrm[:npts.value])
         self.nodes_host = np.ascontiguousarray(nodes[:nnodes.value])
@@ -424,6 +426,7 @@ class Scene_nn:
                                                   self.pcd_buffer.data(), self.normal_buffer.data(), self.nodes.data(), 2 * px + 1,
                                                   C.byref(npts), C.byref(nnodes)))
         self.max_dist_diff = max_dist_diff
+        self.camera = (float(k[0]), float(k[4]), float(k[2]), float(k[5]), int(width), int(height))
         self._n_points, self._n_nodes = npts.value, nnodes.value
         self.pcd_host = self.normal_host = self.nodes_host = None
         return self
@@ -431,7 +434,8 @@ class Scene_nn:
     def desc(self) -> SceneNNDesc:
         n_pts = len(self.pcd_host) if self.pcd_host is not None else self._n_points
         n_nodes = len(self.nodes_host) if self.nodes_host is not None else self._n_nodes
-        return SceneNNDesc(self.max_dist_diff, self.pcd_buffer.data(), self.normal_buffer.data(), self.nodes.data(), n_pts, n_nodes)
+        cam = self.camera if getattr(self, "camera", None) else (0.0, 0.0, 0.0, 0.0, 0, 0)
+        return SceneNNDesc(self.max_dist_diff, self.pcd_buffer.data(), self.normal_buffer.data(), self.nodes.data(), n_pts, n_nodes, *cam)
 
 
 def ICP_Point2Plane(model_pcd: DeviceVector, scene, criteria: ICPConvergenceCriteria = ICPConvergenceCriteria()) -> RegistrationResult:

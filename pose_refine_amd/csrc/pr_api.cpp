@@ -452,7 +452,10 @@ int make_scene(int kind, const void *scene, bool want_packed, SceneSel &out, Pac
             for (int a = 0; a < 3; ++a) { std::memcpy(&out.nn.qmin[a], &info[2 + a], 4); std::memcpy(&out.nn.qscale[a], &info[5 + a], 4); }
             if (opt.nn_wide && info[8] == 1u && info[9] > 0u) { out.nn.wide = g->nnwide.as<uint4>(); out.nn.n_wide = info[9]; }
         }
-        // pixel grid of the scene points under the hypotheses' camera (fused paths only: a bare ICP call has no camera).  Usable
+        // a bare ICP call has no camera of its own: the scene's hint, if it carries one (pose_refine.h)
+        Camera hinted;
+        if (!cam && s->cam_w && s->cam_h && s->cam_fx > 0.0f && s->cam_fy > 0.0f) { hinted = Camera{ s->cam_w, s->cam_h, s->cam_fx, s->cam_fy, s->cam_cx, s->cam_cy }; cam = &hinted; }
+        // pixel grid of the scene points under the hypotheses' camera (fused paths), or under the camera the scene says it was made with.  Usable
         // when every scene point owns a cell -- a Scene_nn made from a depth image with these intrinsics -- else the tree alone.
         if (cam && opt.nn_grid && out.nn.rec32 && (size_t)cam->w * cam->h <= ((size_t)1 << 24)) {
             const float gk[4] = { cam->fx, cam->fy, cam->cx, cam->cy };
