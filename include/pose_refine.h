@@ -30,9 +30,10 @@
  * pr_fill_i32, pr_free, pr_render, the *_prepare_dev / *_build_dev / *_crop_dev functions); a caller that rewrites a scene
  * array by other means (its own kernels, raw hipMemcpy) MUST announce it with pr_invalidate(ptr, bytes) before the next ICP /
  * refine call, or switch the caches off with pr_set_option("scene_cache", 0).
- * As a safety net every asynchronous batch (pr_refine_submit / pr_refine_batch) also compares a sampled fingerprint of the scene arrays (4096
- * words of each, spread over the array) with the one taken when the cache was built and repeats itself with fresh caches if they differ: a
- * frame replaced as a whole is noticed even without pr_invalidate, an edit confined to words the sample does not look at is not.
+ * As a safety net every call that finds a cached form also compares a sampled fingerprint of the scene arrays (4096 words of each, spread over
+ * the array) with the one taken when the cache was built -- asynchronous batches on an idle stream (a mismatch repeats the batch with fresh
+ * caches), synchronous calls on the spot (~15 us) -- so a frame replaced as a whole is noticed even without pr_invalidate; an edit confined to
+ * words the sample does not look at is not.
  */
 #ifndef POSE_REFINE_H
 #define POSE_REFINE_H

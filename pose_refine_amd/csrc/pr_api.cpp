@@ -345,7 +345,19 @@ struct Camera { uint32_t w = 0, h = 0; float fx = 0, fy = 0, cx = 0, cy = 0; };
 // Packed copy of a projective scene in `pc`: reused while the caller's arrays are unchanged as far as the library can tell
 // (option scene_cache, WriteLog above), rebuilt otherwise.  A rebuild also learns (one 4-byte read-back) whether the pcd array
 // is exactly what dep2pcd produces -- only then may the packed form stand in for it.
-int ensure_packed(PackedCache &pc, const pr_scene_proj &s, uint32_t tl_x, uint32_t tl_y, hipStream_t st)
+// Synchronous callers (pr_icp_*, the synchronous fused path) check a cache hit on the spot: the sampled fingerprint of the source arrays
+// against the one stored with the cache (`slot[0]`), `slot[1]` receives the verdict.  ~15 us; the asynchronous path checks on its idle stream.
+int fingerprint_differs(const void *a, size_t ab, const void *b, size_t bb, const void *c, size_t cb, uint32_t *slot, hipStream_t st, bool &differs)
+{
+    HIP_TRY(hipMemsetAsync(slot + 1, 0, sizeof(uint32_t), st));
+    HIP_TRY(prk::launch_scene_fingerprint(a, ab, b, bb, c, cb, slot, slot + 1, true, st));
+    uint32_t flag = 0;
+    HIP_TRY(hipMemcpyAsync(&flag, slot + 1, sizeof flag, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    differs = flag != 0u;
+    return PR_OK;
+}
+int ensure_packed(PackedCache &pc, const pr_scene_proj &s, uint32_t tl_x, uint32_t tl_y, hipStream_t st, bool verify_now = false)
 {
     const size_t n = (size_t)s.width * s.height;
     const float k[4] = { s.K[0], s.K[4], s.K[2], s.K[5] };
@@ -353,8 +365,13 @@ int ensure_packed(PackedCache &pc, const pr_scene_proj &s, uint32_t tl_x, uint32
                       std::memcmp(pc.k, k, sizeof k) == 0 && pc.tl[0] == tl_x && pc.tl[1] == tl_y;
     if (same && opt.scene_cache && !g_writes.written_since(pc.gen, s.pcd, n * sizeof(pr_vec3)) &&
         !g_writes.written_since(pc.gen, s.normal, n * sizeof(pr_vec3))) {
-        pc.gen = g_writes.now();
-        return PR_OK;
+        bool stale = false;
+        if (verify_now) {
+            const size_t tb = ((s.width + s.height) * sizeof(float) + 15) & ~(size_t)15;
+            uint32_t *ex = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(pc.rec.as<float4>() + n) + tb);
+            PR_TRY(fingerprint_differs(s.pcd, n * sizeof(pr_vec3), s.normal, n * sizeof(pr_vec3), nullptr, 0, ex + 1, st, stale));
+        }
+        if (!stale) { pc.gen = g_writes.now(); return PR_OK; }
     }
     pc.valid = false;
     const uint64_t gen = g_writes.now();
@@ -375,7 +392,8 @@ int ensure_packed(PackedCache &pc, const pr_scene_proj &s, uint32_t tl_x, uint32
 }
 
 void drain_all_slots();
-int make_scene(int kind, const void *scene, bool want_packed, SceneSel &out, PackedCache *pc_in = nullptr, hipStream_t st = nullptr, const Camera *cam = nullptr)
+int make_scene(int kind, const void *scene, bool want_packed, SceneSel &out, PackedCache *pc_in = nullptr, hipStream_t st = nullptr, const Camera *cam = nullptr,
+               bool verify_now = true)
 {
     PackedCache &pc = pc_in ? *pc_in : g->packed;
     if (!st) st = g->stream;
@@ -391,7 +409,7 @@ int make_scene(int kind, const void *scene, bool want_packed, SceneSel &out, Pac
                                      (float)tl_x, (float)tl_y, s->pcd, s->normal };
         out.packed = false;
         if (want_packed) {
-            PR_TRY(ensure_packed(pc, *s, tl_x, tl_y, st));
+            PR_TRY(ensure_packed(pc, *s, tl_x, tl_y, st, verify_now));
             if (pc.exact) {                                         // else: the caller's pcd is not dep2pcd's -- use the arrays as they are
                 const size_t n = (size_t)s->width * s->height;
                 float *colf = reinterpret_cast<float *>(pc.rec.as<float4>() + n);
@@ -407,8 +425,15 @@ int make_scene(int kind, const void *scene, bool want_packed, SceneSel &out, Pac
         if (!s || !s->pcd || !s->normal || !s->nodes || s->n_nodes == 0 || s->n_points == 0) { set_error("invalid pr_scene_nn"); return PR_ERR_INVALID; }
         auto &nc = g->nn_cache;
         const bool same = nc.valid && nc.pcd == s->pcd && nc.normal == s->normal && nc.nodes == s->nodes && nc.n_points == s->n_points && nc.n_nodes == s->n_nodes;
-        if (same && opt.scene_cache && !g_writes.written_since(nc.gen, s->pcd, (size_t)s->n_points * sizeof(pr_vec3)) &&
-            !g_writes.written_since(nc.gen, s->nodes, (size_t)s->n_nodes * sizeof(pr_kdnode))) {
+        bool hit = same && opt.scene_cache && !g_writes.written_since(nc.gen, s->pcd, (size_t)s->n_points * sizeof(pr_vec3)) &&
+                   !g_writes.written_since(nc.gen, s->nodes, (size_t)s->n_nodes * sizeof(pr_kdnode));
+        if (hit && verify_now) {
+            bool stale = false;
+            PR_TRY(fingerprint_differs(s->pcd, (size_t)s->n_points * sizeof(pr_vec3), s->nodes, (size_t)s->n_nodes * sizeof(pr_kdnode), s->normal,
+                                       (size_t)s->n_points * sizeof(pr_vec3), g->nndepth.as<uint32_t>() + 12, g->stream, stale));
+            hit = !stale;
+        }
+        if (hit) {
             nc.gen = g_writes.now();                                // (the normals are read through the caller's pointer, never copied)
         } else {
             drain_all_slots();                                      // the records below are shared by both slots' batches
@@ -1119,7 +1144,7 @@ int refine_submit_async(Slot &sl, const pr_triangle *tris_dev, size_t n_tris, ui
     for (uint32_t k = 1; k < groups_hint; ++k) PR_TRY(ensure_stream(sl.side[k - 1], &sl.join[k - 1]));
     hipStream_t scene_stream = groups_hint > 1 ? sl.side[0] : sl.stream;
     const Camera cam{ W, H, K[0], K[4], K[2], K[5] };            // kd-tree scenes: the pixel grid of the scene points under this camera
-    PR_TRY(make_scene(scene_kind, scene, /*want_packed=*/true, sc, &sl.packed, scene_stream, scene_kind == PR_SCENE_NN ? &cam : nullptr));
+    PR_TRY(make_scene(scene_kind, scene, /*want_packed=*/true, sc, &sl.packed, scene_stream, scene_kind == PR_SCENE_NN ? &cam : nullptr, /*verify_now=*/false));
 
     PR_TRY(ensure_model_box(tris_dev, n_tris));                 // once per triangle buffer ...
     const size_t res_off = ((size_t)P * 4 + 63) & ~(size_t)63;

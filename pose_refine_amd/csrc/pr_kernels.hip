@@ -1137,7 +1137,10 @@ __device__ __forceinline__ void grid_project(const SceneNNDev &s, float x, float
     u = x / z * s.gfx + s.gcx + 0.5f;
     v = y / z * s.gfy + s.gcy + 0.5f;
 }
-constexpr int kGridMaxW = 2;                                     // windows up to 5 x 5 cells; larger ones go to the tree
+#ifndef PR_GRID_MAXW
+#define PR_GRID_MAXW 2
+#endif
+constexpr int kGridMaxW = PR_GRID_MAXW;                                     // windows up to 5 x 5 cells; larger ones go to the tree
 // half-widths of the pixel window that holds every scene point closer than sqrt(bound); false when it exceeds kGridMaxW
 __device__ __forceinline__ bool grid_window(const SceneNNDev &s, float sx, float sy, float sz, float bound, int &wx, int &wy)
 {

@@ -172,3 +172,26 @@ def test_scene_rewritten_behind_the_librarys_back_is_noticed(gpu, model, scenari
     raw_d2d(a.pcd_buffer.data(), b.pcd_buffer.data(), a.pcd_buffer.size() * 4)
     got = api.refine_batch(model, poses, W, H, scenario["proj"], K, a, crit)
     assert got[0].tobytes() == want_b[0].tobytes() and np.array_equal(got[1], want_b[1])
+
+
+def test_kdtree_scene_rewritten_behind_the_librarys_back_is_noticed_by_a_bare_icp_call(gpu, scenario):
+    """The same for the kd-tree search records and a synchronous call (pr_icp_nn checks a cache hit on the spot): points and nodes of a
+    scene are replaced by those of a shifted copy with the same counts, through raw copies."""
+    rng = np.random.default_rng(11)
+    pts = rng.uniform(-0.1, 0.1, size=(5000, 3)).astype(np.float32)
+    nrm = rng.normal(size=(5000, 3)).astype(np.float32)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    a = make_scene(pts.copy(), nrm.copy(), 10)
+    b = make_scene((pts + np.float32(0.003)).astype(np.float32), nrm.copy(), 10)
+    if len(a.nodes_host) != len(b.nodes_host):
+        pytest.skip("the shifted copy built a tree of another size")
+    cloud = rng.uniform(-0.1, 0.1, size=(3000, 3)).astype(np.float32)
+    crit = api.ICPConvergenceCriteria(0.0, 0.0, 5)
+    run = lambda sc: api.ICP_Point2Plane(api.DeviceVector.from_host(cloud.reshape(-1)), sc, crit)
+    want_b, first = run(b), run(a)                                # the search records of `b`, then of `a`, are built here
+    assert not np.array_equal(first.transformation_, want_b.transformation_)
+    for dst, src in ((a.pcd_buffer, b.pcd_buffer), (a.normal_buffer, b.normal_buffer)):
+        raw_d2d(dst.data(), src.data(), dst.size() * 4)
+    raw_d2d(a.nodes.data(), b.nodes.data(), len(a.nodes_host) * 52)
+    got = run(a)
+    assert np.array_equal(got.transformation_, want_b.transformation_) and got.fitness_ == want_b.fitness_
