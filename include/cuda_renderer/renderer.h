@@ -1,6 +1,6 @@
 // renderer.h -- cuda_renderer:: API of cuda_renderer/renderer.h:25-248 over the C ABI.
 // Model keeps the public members the path uses (tris, vertices, faces, nested PODs); the assimp
-// scene graph members are gone (own ASCII-PLY reader behind pr_ply_load).
+// scene graph members are gone (own PLY / OBJ / glTF readers behind pr_mesh_load; the node walk of recursive_render happens there).
 #pragma once
 #include <cassert>
 #include <cstring>
@@ -32,7 +32,7 @@ public:
     Model() {}
     ~Model() {}
     explicit Model(const std::string &fileName) { LoadModel(fileName); }
-    void LoadModel(const std::string &fileName)              // renderer.cpp:16-58 (PLY / OBJ through pr_mesh_load instead of assimp)
+    void LoadModel(const std::string &fileName)              // renderer.cpp:16-58 (PLY / OBJ / glTF through pr_mesh_load instead of assimp)
     {
         size_t nt = 0, nv = 0;
         if (pr_mesh_count(fileName.c_str(), &nt, &nv) != PR_OK) { std::cerr << pr_last_error() << std::endl; std::exit(1); }

@@ -129,8 +129,11 @@ int pr_invalidate(const void *dev_ptr, size_t bytes);
 
 /* ---- host-side model / scene preparation (CPU in the reference too) --------------------------- */
 /* Model::Model(fileName) / LoadModel renderer.cpp:11-104 + get_bounding_box :106-150.  The reference imports through assimp; here:
- * PLY (ASCII, binary little / big endian, typed properties) and Wavefront OBJ, single mesh, identity node transform.
- * Faces with < 3 indices are dropped (renderer.cpp:78), polygons are fanned into triangles (assimp's aiProcess_Triangulate).
+ * PLY (ASCII, binary little / big endian, typed properties) and Wavefront OBJ (single mesh, identity node transform), and glTF 2.0
+ * (.gltf with external or base64 buffers, .glb) with its node hierarchy walked like recursive_render (renderer.cpp:69-104): node
+ * transforms multiplied down the tree, one mesh per primitive, triangles transformed, vertices_out untransformed and faces_out
+ * per-mesh indices exactly as the reference keeps them, the box over the TRANSFORMED vertices (get_bounding_box_for_node).
+ * Faces with < 3 indices are dropped (renderer.cpp:78), polygons / strips / fans become triangles (assimp's aiProcess_Triangulate).
  * Any output pointer may be NULL; faces_out receives 3 vertex indices per triangle (Model::faces), vertices_out the file's vertex
  * list (Model::vertices), bbox_min / bbox_max the component-wise extremes of the vertices (Model::bbox_min / bbox_max). */
 int pr_mesh_count(const char *path, size_t *n_triangles, size_t *n_vertices);

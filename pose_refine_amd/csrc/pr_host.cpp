@@ -35,8 +35,11 @@ namespace {
 //   vertices  the file's vertex list, faces the index triples (renderer.cpp:87-100)
 //   bbox      component-wise min / max over the vertices (get_bounding_box, renderer.cpp:106-150)
 struct Mesh {
-    std::vector<pr_vec3> vertices;
-    std::vector<int32_t> faces;          // 3 per triangle
+    std::vector<pr_vec3> vertices;       // as in the file, untransformed (renderer.cpp:93-99)
+    std::vector<int32_t> faces;          // 3 per triangle: indices into the vertex list of the MESH the face belongs to (renderer.cpp:87-91)
+    std::vector<pr_triangle> tris;       // hierarchical formats: triangles with the node transforms multiplied in (recursive_render);
+                                         // empty for the flat formats, whose triangles are vertices[faces]
+    bool has_box = false; float lo[3] = { 0, 0, 0 }, hi[3] = { 0, 0, 0 };   // hierarchical formats: box of the TRANSFORMED vertices (get_bounding_box_for_node)
     std::string error;
 };
 
@@ -160,6 +163,265 @@ bool load_obj(const char *path, Mesh &m)
     return true;
 }
 
+
+// ---- glTF 2.0 (.gltf + external / embedded buffers, .glb): the hierarchical format of this importer -------------------------------
+// What the reference gets from assimp for such a file and does with it (renderer.cpp:69-104 recursive_render): every node's matrix
+// is multiplied onto its parent's (m = m * node), every mesh of the node contributes its triangles with m applied to the three
+// vertices (mat_mul_vec: a1*x + a2*y + a3*z + a4 per row, in float), the vertex list stays untransformed, faces keep their per-mesh
+// indices, and the bounding box is taken over the transformed vertices (get_bounding_box_for_node).  A glTF primitive is an assimp
+// mesh; triangle lists, strips and fans are read (assimp triangulates the latter two), points and lines are skipped like the
+// reference skips faces with fewer than three indices.  assimp itself is absent from the reference tree (parity unpinned): node
+// matrices given as translation / rotation / scale are composed as T * R * S with the usual quaternion-to-matrix formula.
+struct Json {
+    enum Kind { kNull, kBool, kNum, kStr, kArr, kObj } kind = kNull;
+    double num = 0; bool b = false; std::string str;
+    std::vector<Json> arr; std::vector<std::pair<std::string, Json>> obj;
+    const Json *get(const char *key) const { for (const auto &kv : obj) if (kv.first == key) return &kv.second; return nullptr; }
+    double number(const char *key, double dflt) const { const Json *j = get(key); return (j && j->kind == kNum) ? j->num : dflt; }
+};
+struct JsonParser {
+    const char *p, *end; std::string err;
+    void ws() { while (p < end && (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r')) ++p; }
+    bool fail(const char *m) { if (err.empty()) err = m; return false; }
+    bool value(Json &out, int depth = 0)
+    {
+        if (depth > 64) return fail("JSON nested too deeply");
+        ws();
+        if (p >= end) return fail("unexpected end of JSON");
+        if (*p == '{') {
+            ++p; out.kind = Json::kObj; ws();
+            if (p < end && *p == '}') { ++p; return true; }
+            for (;;) {
+                Json k; ws();
+                if (p >= end || *p != '"' || !string(k.str)) return fail("JSON object key expected");
+                ws(); if (p >= end || *p != ':') return fail("':' expected"); ++p;
+                Json v; if (!value(v, depth + 1)) return false;
+                out.obj.emplace_back(std::move(k.str), std::move(v));
+                ws(); if (p < end && *p == ',') { ++p; continue; }
+                if (p < end && *p == '}') { ++p; return true; }
+                return fail("',' or '}' expected");
+            }
+        }
+        if (*p == '[') {
+            ++p; out.kind = Json::kArr; ws();
+            if (p < end && *p == ']') { ++p; return true; }
+            for (;;) {
+                Json v; if (!value(v, depth + 1)) return false;
+                out.arr.push_back(std::move(v));
+                ws(); if (p < end && *p == ',') { ++p; continue; }
+                if (p < end && *p == ']') { ++p; return true; }
+                return fail("',' or ']' expected");
+            }
+        }
+        if (*p == '"') { out.kind = Json::kStr; return string(out.str); }
+        if (end - p >= 4 && !strncmp(p, "true", 4)) { p += 4; out.kind = Json::kBool; out.b = true; return true; }
+        if (end - p >= 5 && !strncmp(p, "false", 5)) { p += 5; out.kind = Json::kBool; out.b = false; return true; }
+        if (end - p >= 4 && !strncmp(p, "null", 4)) { p += 4; out.kind = Json::kNull; return true; }
+        char *q = nullptr;
+        const std::string tmp(p, (size_t)std::min<ptrdiff_t>(end - p, 64));
+        out.num = strtod(tmp.c_str(), &q);
+        if (q == tmp.c_str()) return fail("JSON value expected");
+        p += q - tmp.c_str(); out.kind = Json::kNum; return true;
+    }
+    bool string(std::string &out)
+    {
+        ++p;                                                      // opening quote
+        while (p < end && *p != '"') {
+            if (*p == '\\' && p + 1 < end) {
+                ++p;
+                switch (*p) { case 'n': out += '\n'; break; case 't': out += '\t'; break; case 'r': out += '\r'; break; case 'b': out += '\b'; break; case 'f': out += '\f'; break;
+                              case 'u': { if (end - p < 5) return fail("bad \\u escape"); const unsigned c = (unsigned)strtoul(std::string(p + 1, 4).c_str(), nullptr, 16); out += (c < 128) ? (char)c : '?'; p += 4; break; }
+                              default: out += *p; }
+                ++p;
+            } else out += *p++;
+        }
+        if (p >= end) return fail("unterminated JSON string");
+        ++p; return true;
+    }
+};
+bool base64_decode(const std::string &in, size_t from, std::vector<unsigned char> &out)
+{
+    auto val = [](char c) -> int { if (c >= 'A' && c <= 'Z') return c - 'A'; if (c >= 'a' && c <= 'z') return c - 'a' + 26; if (c >= '0' && c <= '9') return c - '0' + 52; if (c == '+') return 62; if (c == '/') return 63; return -1; };
+    unsigned acc = 0; int bits = 0;
+    for (size_t i = from; i < in.size(); ++i) {
+        if (in[i] == '=') break;
+        const int v = val(in[i]);
+        if (v < 0) continue;
+        acc = (acc << 6) | (unsigned)v; bits += 6;
+        if (bits >= 8) { bits -= 8; out.push_back((unsigned char)((acc >> bits) & 0xffu)); }
+    }
+    return true;
+}
+struct Mat4 { float m[16]; };                                      // row-major a1..d4 like aiMatrix4x4
+Mat4 mat4_identity() { Mat4 r; for (int i = 0; i < 16; ++i) r.m[i] = (i % 5 == 0) ? 1.0f : 0.0f; return r; }
+Mat4 mat4_mul(const Mat4 &a, const Mat4 &t)                        // aiMultiplyMatrix4(&a, &t): a = a * t, sums in index order
+{
+    Mat4 r;
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j)
+        r.m[4 * i + j] = a.m[4 * i] * t.m[j] + a.m[4 * i + 1] * t.m[4 + j] + a.m[4 * i + 2] * t.m[8 + j] + a.m[4 * i + 3] * t.m[12 + j];
+    return r;
+}
+pr_vec3 mat4_apply(const Mat4 &m, const pr_vec3 &v)               // renderer.cpp:60-67 mat_mul_vec
+{
+    return pr_vec3{ m.m[0] * v.x + m.m[1] * v.y + m.m[2] * v.z + m.m[3], m.m[4] * v.x + m.m[5] * v.y + m.m[6] * v.z + m.m[7],
+                    m.m[8] * v.x + m.m[9] * v.y + m.m[10] * v.z + m.m[11] };
+}
+struct Gltf {
+    Json root; std::vector<std::vector<unsigned char>> buffers; std::string dir; Mesh *out = nullptr;
+    bool fail(const std::string &e) { if (out->error.empty()) out->error = e; return false; }
+    const Json *item(const char *array, long i) const { const Json *a = root.get(array); return (a && a->kind == Json::kArr && i >= 0 && (size_t)i < a->arr.size()) ? &a->arr[(size_t)i] : nullptr; }
+    // accessor -> doubles (count x components)
+    bool accessor(long index, int want_comps, std::vector<double> &vals)
+    {
+        const Json *acc = item("accessors", index);
+        if (!acc) return fail("glTF: accessor out of range");
+        const long count = (long)acc->number("count", 0), ctype = (long)acc->number("componentType", 0), view_i = (long)acc->number("bufferView", -1);
+        const Json *ty = acc->get("type");
+        const int comps = (ty && ty->str == "VEC3") ? 3 : ((ty && ty->str == "SCALAR") ? 1 : 0);
+        if (comps != want_comps) return fail("glTF: accessor of an unexpected type");
+        if (acc->get("sparse")) return fail("glTF: sparse accessors are not read");
+        const Json *view = item("bufferViews", view_i);
+        if (!view) return fail("glTF: accessor without a buffer view");
+        const long buf_i = (long)view->number("buffer", -1);
+        if (buf_i < 0 || (size_t)buf_i >= buffers.size()) return fail("glTF: buffer out of range");
+        const std::vector<unsigned char> &buf = buffers[(size_t)buf_i];
+        size_t csize = 0;
+        switch (ctype) { case 5120: case 5121: csize = 1; break; case 5122: case 5123: csize = 2; break; case 5125: case 5126: csize = 4; break; default: return fail("glTF: unknown component type"); }
+        const size_t off = (size_t)view->number("byteOffset", 0) + (size_t)acc->number("byteOffset", 0);
+        size_t stride = (size_t)view->number("byteStride", 0);
+        if (stride == 0) stride = csize * (size_t)comps;
+        if (count < 0 || (count > 0 && off + (size_t)(count - 1) * stride + csize * (size_t)comps > buf.size())) return fail("glTF: accessor reaches beyond its buffer");
+        vals.resize((size_t)count * (size_t)comps);
+        for (long i = 0; i < count; ++i) for (int c = 0; c < comps; ++c) {
+            const unsigned char *src = buf.data() + off + (size_t)i * stride + (size_t)c * csize;
+            double v = 0;
+            switch (ctype) { case 5120: v = *reinterpret_cast<const int8_t *>(src); break; case 5121: v = *src; break;
+                             case 5122: { int16_t t; std::memcpy(&t, src, 2); v = t; break; } case 5123: { uint16_t t; std::memcpy(&t, src, 2); v = t; break; }
+                             case 5125: { uint32_t t; std::memcpy(&t, src, 4); v = t; break; } case 5126: { float t; std::memcpy(&t, src, 4); v = t; break; } }
+            vals[(size_t)i * (size_t)comps + (size_t)c] = v;
+        }
+        return true;
+    }
+    Mat4 local(const Json &node) const
+    {
+        const Json *mj = node.get("matrix");
+        Mat4 r = mat4_identity();
+        if (mj && mj->kind == Json::kArr && mj->arr.size() == 16) { for (int c = 0; c < 4; ++c) for (int rr = 0; rr < 4; ++rr) r.m[4 * rr + c] = (float)mj->arr[(size_t)(4 * c + rr)].num; return r; }   // column-major in the file
+        float t[3] = { 0, 0, 0 }, q[4] = { 0, 0, 0, 1 }, sc[3] = { 1, 1, 1 };
+        auto read = [&](const char *k, float *dst, size_t n) { const Json *a = node.get(k); if (a && a->kind == Json::kArr && a->arr.size() == n) for (size_t i = 0; i < n; ++i) dst[i] = (float)a->arr[i].num; };
+        read("translation", t, 3); read("rotation", q, 4); read("scale", sc, 3);
+        const float x = q[0], y = q[1], z = q[2], w = q[3];
+        const float R[9] = { 1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
+                             2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+                             2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y) };
+        for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) r.m[4 * i + j] = R[3 * i + j] * sc[j]; r.m[4 * i + 3] = t[i]; }
+        return r;
+    }
+    bool node(long index, Mat4 m, int depth)
+    {
+        if (depth > 256) return fail("glTF: node hierarchy too deep (a cycle?)");
+        const Json *nd = item("nodes", index);
+        if (!nd) return fail("glTF: node out of range");
+        m = mat4_mul(m, local(*nd));                                // renderer.cpp:71
+        const Json *mesh_ref = nd->get("mesh");
+        if (mesh_ref && mesh_ref->kind == Json::kNum) {
+            const Json *mesh = item("meshes", (long)mesh_ref->num);
+            const Json *prims = mesh ? mesh->get("primitives") : nullptr;
+            if (!prims || prims->kind != Json::kArr) return fail("glTF: mesh without primitives");
+            for (const Json &pr : prims->arr) {                     // one assimp mesh per primitive
+                const long mode = (long)pr.number("mode", 4);
+                const Json *attrs = pr.get("attributes");
+                const Json *pos = attrs ? attrs->get("POSITION") : nullptr;
+                if (!pos || pos->kind != Json::kNum) continue;
+                std::vector<double> pv, iv;
+                if (!accessor((long)pos->num, 3, pv)) return false;
+                const size_t nv = pv.size() / 3;
+                const Json *ind = pr.get("indices");
+                if (ind && ind->kind == Json::kNum) { if (!accessor((long)ind->num, 1, iv)) return false; }
+                else { iv.resize(nv); for (size_t i = 0; i < nv; ++i) iv[i] = (double)i; }
+                std::vector<pr_vec3> verts(nv);
+                for (size_t i = 0; i < nv; ++i) verts[i] = pr_vec3{ (float)pv[3 * i], (float)pv[3 * i + 1], (float)pv[3 * i + 2] };
+                auto tri = [&](size_t a, size_t b, size_t c) -> bool {
+                    if (a >= nv || b >= nv || c >= nv) return fail("glTF: index refers to a vertex that does not exist");
+                    out->tris.push_back(pr_triangle{ mat4_apply(m, verts[a]), mat4_apply(m, verts[b]), mat4_apply(m, verts[c]) });
+                    out->faces.push_back((int32_t)a); out->faces.push_back((int32_t)b); out->faces.push_back((int32_t)c);
+                    return true;
+                };
+                if (mode == 4) { for (size_t k = 0; k + 2 < iv.size(); k += 3) if (!tri((size_t)iv[k], (size_t)iv[k + 1], (size_t)iv[k + 2])) return false; }
+                else if (mode == 5) { for (size_t k = 0; k + 2 < iv.size(); ++k) if (!((k & 1) ? tri((size_t)iv[k + 1], (size_t)iv[k], (size_t)iv[k + 2]) : tri((size_t)iv[k], (size_t)iv[k + 1], (size_t)iv[k + 2]))) return false; }
+                else if (mode == 6) { for (size_t k = 1; k + 1 < iv.size(); ++k) if (!tri((size_t)iv[0], (size_t)iv[k], (size_t)iv[k + 1])) return false; }
+                else continue;                                      // points, lines: faces with fewer than three indices (renderer.cpp:78)
+                for (const pr_vec3 &v : verts) {                    // renderer.cpp:93-99, and get_bounding_box_for_node on the transformed copy
+                    out->vertices.push_back(v);
+                    const pr_vec3 tv = mat4_apply(m, v);
+                    const float c3[3] = { tv.x, tv.y, tv.z };
+                    for (int a = 0; a < 3; ++a) { out->lo[a] = std::min(out->lo[a], c3[a]); out->hi[a] = std::max(out->hi[a], c3[a]); }
+                }
+            }
+        }
+        const Json *kids = nd->get("children");
+        if (kids && kids->kind == Json::kArr) for (const Json &k : kids->arr) if (!node((long)k.num, m, depth + 1)) return false;
+        return true;
+    }
+};
+bool read_file(const std::string &path, std::vector<unsigned char> &out)
+{
+    std::ifstream in(path, std::ios::binary);
+    if (!in) return false;
+    out.assign(std::istreambuf_iterator<char>(in), std::istreambuf_iterator<char>());
+    return true;
+}
+bool load_gltf(const char *path, Mesh &m, bool binary)
+{
+    std::vector<unsigned char> file;
+    if (!read_file(path, file)) { m.error = std::string("cannot open ") + path; return false; }
+    Gltf g; g.out = &m;
+    const std::string sp(path);
+    const size_t slash = sp.find_last_of("/\\");
+    g.dir = slash == std::string::npos ? "" : sp.substr(0, slash + 1);
+    std::string json;
+    std::vector<unsigned char> glb_bin; bool have_glb_bin = false;
+    if (binary) {
+        if (file.size() < 20 || std::memcmp(file.data(), "glTF", 4) != 0) { m.error = "not a GLB file"; return false; }
+        size_t off = 12;
+        while (off + 8 <= file.size()) {
+            uint32_t len, type; std::memcpy(&len, file.data() + off, 4); std::memcpy(&type, file.data() + off + 4, 4);
+            if (off + 8 + len > file.size()) { m.error = "GLB chunk reaches beyond the file"; return false; }
+            if (type == 0x4E4F534Au) json.assign(reinterpret_cast<const char *>(file.data() + off + 8), len);
+            else if (type == 0x004E4942u && !have_glb_bin) { glb_bin.assign(file.begin() + (long)(off + 8), file.begin() + (long)(off + 8 + len)); have_glb_bin = true; }
+            off += 8 + ((len + 3u) & ~3u);
+        }
+    } else json.assign(file.begin(), file.end());
+    JsonParser jp{ json.data(), json.data() + json.size(), std::string() };
+    if (!jp.value(g.root) || g.root.kind != Json::kObj) { m.error = "glTF: " + (jp.err.empty() ? std::string("not a JSON object") : jp.err); return false; }
+    const Json *bufs = g.root.get("buffers");
+    if (bufs && bufs->kind == Json::kArr) for (size_t i = 0; i < bufs->arr.size(); ++i) {
+        std::vector<unsigned char> data;
+        const Json *uri = bufs->arr[i].get("uri");
+        if (!uri || uri->kind != Json::kStr) { if (i == 0 && have_glb_bin) data = glb_bin; else { m.error = "glTF: buffer without a uri"; return false; } }
+        else if (uri->str.compare(0, 5, "data:") == 0) { const size_t comma = uri->str.find(','); if (comma == std::string::npos) { m.error = "glTF: malformed data uri"; return false; } base64_decode(uri->str, comma + 1, data); }
+        else if (!read_file(g.dir + uri->str, data)) { m.error = "glTF: cannot open buffer " + g.dir + uri->str; return false; }
+        g.buffers.push_back(std::move(data));
+    }
+    m.has_box = true;
+    for (int a = 0; a < 3; ++a) { m.lo[a] = 1e10f; m.hi[a] = -1e10f; }     // renderer.cpp:147-148
+    const Json *scenes = g.root.get("scenes");
+    const long scene_i = (long)g.root.number("scene", 0);
+    const Json *scene = g.item("scenes", scene_i);
+    if (scenes && scene) {
+        const Json *roots = scene->get("nodes");
+        if (roots && roots->kind == Json::kArr) for (const Json &r : roots->arr) if (!g.node((long)r.num, mat4_identity(), 0)) return false;
+    } else {                                                      // no scene: every node that is nobody's child is a root
+        const Json *nodes = g.root.get("nodes");
+        if (nodes && nodes->kind == Json::kArr) {
+            std::vector<char> is_child(nodes->arr.size(), 0);
+            for (const Json &n : nodes->arr) { const Json *k = n.get("children"); if (k && k->kind == Json::kArr) for (const Json &c : k->arr) if (c.num >= 0 && (size_t)c.num < is_child.size()) is_child[(size_t)c.num] = 1; }
+            for (size_t i = 0; i < nodes->arr.size(); ++i) if (!is_child[i] && !g.node((long)i, mat4_identity(), 0)) return false;
+        }
+    }
+    return m.error.empty();
+}
+
 bool load_mesh(const char *path, Mesh &m)
 {
     if (!path) { m.error = "null path"; return false; }
@@ -168,6 +430,8 @@ bool load_mesh(const char *path, Mesh &m)
     std::string ext = dot == std::string::npos ? "" : s.substr(dot + 1);
     for (char &c : ext) c = (char)tolower((unsigned char)c);
     if (ext == "obj") return load_obj(path, m);
+    if (ext == "gltf") return load_gltf(path, m, false);
+    if (ext == "glb") return load_gltf(path, m, true);
     return load_ply(path, m);                                     // .ply and anything that starts with the PLY magic
 }
 
@@ -203,7 +467,7 @@ int pr_mesh_load(const char *path, pr_triangle *tris_out, size_t cap_triangles, 
     const size_t nt = m.faces.size() / 3;
     for (size_t t = 0; t < nt && t < cap_triangles; ++t) {
         const int32_t *f = &m.faces[3 * t];
-        if (tris_out) tris_out[t] = pr_triangle{ m.vertices[(size_t)f[0]], m.vertices[(size_t)f[1]], m.vertices[(size_t)f[2]] };
+        if (tris_out) tris_out[t] = m.tris.empty() ? pr_triangle{ m.vertices[(size_t)f[0]], m.vertices[(size_t)f[1]], m.vertices[(size_t)f[2]] } : m.tris[t];
         if (faces_out) { faces_out[3 * t] = f[0]; faces_out[3 * t + 1] = f[1]; faces_out[3 * t + 2] = f[2]; }
     }
     if (vertices_out) for (size_t v = 0; v < m.vertices.size() && v < cap_vertices; ++v) vertices_out[v] = m.vertices[v];
@@ -215,6 +479,7 @@ int pr_mesh_load(const char *path, pr_triangle *tris_out, size_t cap_triangles, 
         lo[0] = std::min(lo[0], v.x); lo[1] = std::min(lo[1], v.y); lo[2] = std::min(lo[2], v.z);
         hi[0] = std::max(hi[0], v.x); hi[1] = std::max(hi[1], v.y); hi[2] = std::max(hi[2], v.z);
     }
+    if (m.has_box) for (int a = 0; a < 3; ++a) { lo[a] = m.lo[a]; hi[a] = m.hi[a]; }      // a hierarchical file: the box of the transformed vertices
     if (bbox_min) for (int a = 0; a < 3; ++a) bbox_min[a] = lo[a];
     if (bbox_max) for (int a = 0; a < 3; ++a) bbox_max[a] = hi[a];
     return PR_OK;
