@@ -6,7 +6,9 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/round; rm -rf $OUT; mkdir -p $OUT                 # (gpurun merges into gpurun_out: start from an empty directory, nothing stale gets copied to profiles/)
 B="timeout 600 python bench.py"
 summ() { python tools/rocpd_summary.py "$1"; }
-python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" | tail -3 > $OUT/pytest_gpu.txt; cat $OUT/pytest_gpu.txt
+# the GPU tests under a kernel trace: test summary + which kernel instantiations of the library they dispatched
+rocprofv3 --kernel-trace --stats -d $OUT/cov -o t -- python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" | tail -3 > $OUT/pytest_gpu.txt; cat $OUT/pytest_gpu.txt
+python tools/kernel_coverage.py $OUT/cov > $OUT/kernel_coverage.md; tail -1 $OUT/kernel_coverage.md; rm -rf $OUT/cov
 python __graft_entry__.py --smoke 2>&1 | tail -2 > $OUT/smoke.txt; cat $OUT/smoke.txt
 $B 2>/dev/null | tail -1 > $OUT/bench_p256_proj.json
 $B --steps 20 --warmup 5 2>/dev/null | tail -1 > $OUT/bench_p256_proj_steps20.json
