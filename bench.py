@@ -411,8 +411,9 @@ def kdtree_extra(args, api, model, poses, scene_depth, W, H, proj, K, steps=8):
 
 
 def host_solve_extra(args, api, model, poses, W, H, proj, K, scene, steps=12):
-    """The same batch with the 6x6 solve ON THE HOST, as `north_star` words it ("SVD solve on host"): one launch + one 128-byte-per-pose
-    read-back + host solve + one 64-byte-per-pose upload per iteration (PR_SOLVE_HOST).  The headline keeps the iterations on the device."""
+    """The same batch with the 6x6 solve ON THE HOST, as `north_star` words it ("SVD solve on host"): per iteration and pose group one launch
+    whose last workgroup per hypothesis leaves the 29 sums in pinned host memory, the host solve, and the update read back from pinned
+    memory by the next launch (PR_SOLVE_HOST).  The headline keeps the iterations on the device."""
     crit = api.ICPConvergenceCriteria(0.0, 0.0, args.iters)
     api.set_option("solve", api.SOLVE_HOST)
     try:
@@ -425,7 +426,7 @@ def host_solve_extra(args, api, model, poses, W, H, proj, K, scene, steps=12):
     finally:
         api.set_option("solve", api.SOLVE_DEVICE)
     return {"value": len(poses) / dt, "unit": "poses/s", "ms_per_step": dt * 1e3, "steps": steps,
-            "note": "PR_SOLVE_HOST: 21 launches, each followed by a read-back of the 29 sums, the host solve (pivoted LDLT in double, as Eigen) and an upload of the update"}
+            "note": "PR_SOLVE_HOST, one synchronous call per step: 21 launches per pose group (two groups on two streams, software-pipelined: the host solves one group while the other group's pass runs); the workgroup that delivers a hypothesis' last partial sum stores its 29 totals straight into pinned host memory, the host solves (pivoted LDLT in double, as Eigen) and the next pass reads the update from the pinned array"}
 
 
 def cpu_baseline(args, scene_kind, tris, scene_depth, K, W, H):

@@ -749,23 +749,60 @@ int icp_drive(pr_vec3 *cloud_base, const uint32_t *start_h, const uint32_t *coun
         return PR_OK;
     }
 
-    // PR_SOLVE_HOST: one launch + one small D2H per iteration, the per-pose logic of icp.cu:178-212 on the host
+    // PR_SOLVE_HOST: per iteration one launch + one small D2H, then the per-pose logic of icp.cu:178-212 on the host.  The batch runs
+    // as up to four pose groups, each on a stream of its own, software-pipelined: while the host waits for, solves and re-arms one
+    // group, the correspondence pass of the next group is on the chip -- the host's share of an iteration (copy latency, wake-up,
+    // 160 ns per 6x6 solve) is as long as the pass itself, and a single group leaves the GPU idle for all of it.  Results per
+    // hypothesis do not depend on the grouping (sums, solve and state are per hypothesis).  A timed call (profile 1) is one group.
     const uint32_t host_sample_it = (uint32_t)((g->sample_clock++ * 5 + 1) % (uint64_t)(crit.max_iteration + 1));
-    uint32_t active = 0;
-    for (uint32_t i = 0; i < P; ++i) active += (h_meta[i].state != prk::kSkip);
-    for (uint32_t it = 0; it <= (uint32_t)crit.max_iteration && active > 0; ++it) {
-        HIP_TRY(hipMemcpyAsync(g->meta.p, h_meta, sizeof(prk::PoseMeta) * P, hipMemcpyHostToDevice, g->stream));
-        b.iter = it;
-        if (opt.profile == 1 || (opt.profile == 2 && it == host_sample_it)) {
-            SpanGuard sp(kSpanIcp); HIP_TRY(launch_pass(b, sc, P));
-            for (uint32_t i = 0; i < P; ++i) if (h_meta[i].state != prk::kSkip) { g->icp_points += count_h[i]; g->icp_bytes += (uint64_t)count_h[i] * (it == 0 ? 36u : 48u); }
-        } else HIP_TRY(launch_pass(b, sc, P));
-        HIP_TRY(prk::launch_icp_finalize(g->partial.as<float>(), g->meta.as<prk::PoseMeta>(), nblk, steps,
-                                         g->sums.as<float>(), P, g->stream));
-        HIP_TRY(hipMemcpyAsync(h_sums, g->sums.p, sizeof(float) * prk::kAccStride * P, hipMemcpyDeviceToHost, g->stream));
-        HIP_TRY(hipStreamSynchronize(g->stream));
-        active = 0;
-        for (uint32_t i = 0; i < P; ++i) {
+    const uint32_t n_groups = (opt.profile == 1) ? 1u : std::max(1u, std::min({ (uint32_t)std::max(1, opt.pose_groups), 4u, P / 32u }));
+    auto group_begin = [&](uint32_t grp) { return (uint32_t)(((uint64_t)P * grp) / n_groups); };
+    if (opt.fused_solve) { PR_TRY(g->arrive.ensure(sizeof(uint32_t) * P)); HIP_TRY(hipMemsetAsync(g->arrive.p, 0, sizeof(uint32_t) * P, g->stream)); }
+    if (n_groups > 1) {
+        for (uint32_t k = 1; k < n_groups; ++k) PR_TRY(ensure_stream(g->side[k - 1], &g->ev_join[k - 1]));
+        HIP_TRY(hipEventRecord(g->ev_fork, g->stream));               // the groups start behind the render / cloud work of this call
+        for (uint32_t k = 1; k < n_groups; ++k) HIP_TRY(hipStreamWaitEvent(g->side[k - 1], g->ev_fork, 0));
+    }
+    auto group_stream = [&](uint32_t grp) { return grp ? g->side[grp - 1] : g->stream; };
+    // With option fused_solve the pass also adds up the workgroup sums of a hypothesis (the workgroup that arrives last does, as in the
+    // device-solve loop) and stores the 29 totals straight into the pinned host array: no finalize launch, no copy command -- two
+    // API calls and one copy-engine round trip less per group and iteration on a path that is bound by exactly those.
+    const bool host_fused = opt.fused_solve != 0;
+    float *sums_dev = nullptr;
+    if (host_fused) {
+        PR_TRY(g->arrive.ensure(sizeof(uint32_t) * P));
+        HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&sums_dev), h_sums, 0));
+    }
+    // Projective scenes also read the per-hypothesis state (64 bytes: cloud span, pending update) from the pinned host array instead
+    // of receiving it through a copy command: one uniform load per workgroup over the host link, 1.62 -> 1.54 ms per 256-hypothesis
+    // batch.  The four kernels of a kd-tree pass have ten times the workgroups; there the copy is cheaper (8.3 against 8.8 ms).
+    const prk::PoseMeta *meta_dev = nullptr;
+    if (host_fused && sc.kind != PR_SCENE_NN) HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(const_cast<prk::PoseMeta **>(&meta_dev)), h_meta, 0));
+    // one iteration of one group goes onto its stream: state upload, pass, block sums -> pose sums, download
+    auto enqueue_group = [&](uint32_t grp, uint32_t it) -> int {
+        const uint32_t p0 = group_begin(grp), np = group_begin(grp + 1) - p0;
+        hipStream_t st = group_stream(grp);
+        prk::IcpBatch bb = b;
+        if (meta_dev) bb.meta = meta_dev;                            // the pass reads the 64-byte state of its hypothesis from the pinned host array
+        else HIP_TRY(hipMemcpyAsync(g->meta.as<prk::PoseMeta>() + p0, h_meta + p0, sizeof(prk::PoseMeta) * np, hipMemcpyHostToDevice, st));
+        bb.meta += p0; bb.partial += (size_t)p0 * nblk * prk::kAccStride; if (bb.nn_qcount) bb.nn_qcount += prk::kQCountStride * (size_t)p0;
+        bb.iter = it;
+        if (host_fused) { bb.fused = 2; bb.arrive = g->arrive.as<uint32_t>() + p0; bb.sums_out = sums_dev + (size_t)p0 * prk::kAccStride; }
+        if (opt.profile == 1 || (opt.profile == 2 && it == host_sample_it && grp == 0 && n_groups == 1)) {
+            SpanGuard sp(kSpanIcp); HIP_TRY(launch_pass(bb, sc, np, st));
+            for (uint32_t i = p0; i < p0 + np; ++i) if (h_meta[i].state != prk::kSkip) { g->icp_points += count_h[i]; g->icp_bytes += (uint64_t)count_h[i] * (it == 0 ? 36u : 48u); }
+        } else HIP_TRY(launch_pass(bb, sc, np, st));
+        if (!host_fused) {
+            HIP_TRY(prk::launch_icp_finalize(bb.partial, g->meta.as<prk::PoseMeta>() + p0, nblk, steps, g->sums.as<float>() + (size_t)p0 * prk::kAccStride, np, st));
+            HIP_TRY(hipMemcpyAsync(h_sums + (size_t)p0 * prk::kAccStride, g->sums.as<float>() + (size_t)p0 * prk::kAccStride, sizeof(float) * prk::kAccStride * np,
+                                   hipMemcpyDeviceToHost, st));
+        }
+        return PR_OK;
+    };
+    // the host's part of an iteration for one group (its download has completed); returns how many of its hypotheses go on
+    auto solve_group = [&](uint32_t grp, uint32_t it) -> uint32_t {
+        uint32_t active = 0;
+        for (uint32_t i = group_begin(grp); i < group_begin(grp + 1); ++i) {
             if (h_meta[i].state == prk::kSkip) continue;
             const float *Ab = h_sums + (size_t)i * prk::kAccStride;
             pr_result &r = res[i];
@@ -787,7 +824,24 @@ int icp_drive(pr_vec3 *cloud_base, const uint32_t *start_h, const uint32_t *coun
             h_meta[i].state = prk::kRunWithTransform;
             ++active;
         }
+        return active;
+    };
+    bool live[4] = { false, false, false, false };
+    int rc_loop = PR_OK;
+    for (uint32_t grp = 0; grp < n_groups && rc_loop == PR_OK; ++grp) {
+        for (uint32_t i = group_begin(grp); i < group_begin(grp + 1); ++i) live[grp] |= (h_meta[i].state != prk::kSkip);
+        if (live[grp]) rc_loop = enqueue_group(grp, 0);
     }
+    for (uint32_t it = 0; it <= (uint32_t)crit.max_iteration && rc_loop == PR_OK && (live[0] || live[1] || live[2] || live[3]); ++it) {
+        for (uint32_t grp = 0; grp < n_groups && rc_loop == PR_OK; ++grp) {
+            if (!live[grp]) continue;
+            if (hipError_t e = hipStreamSynchronize(group_stream(grp)); e != hipSuccess) { set_error("HIP error: %s", hipGetErrorString(e)); rc_loop = PR_ERR_HIP; break; }
+            live[grp] = solve_group(grp, it) > 0;
+            if (live[grp]) rc_loop = enqueue_group(grp, it + 1);                          // it + 1 <= max_iteration: the last iteration leaves nobody active
+        }
+    }
+    for (uint32_t k = 1; k < n_groups; ++k) (void)hipStreamSynchronize(g->side[k - 1]);  // nothing of this call is left on a side stream, error or not
+    if (rc_loop != PR_OK) { (void)hipStreamSynchronize(g->stream); drain_spans(); return rc_loop; }
     if (results_host) std::memcpy(results_host, res, sizeof(pr_result) * P);
     if (results_dev) {
         HIP_TRY(hipMemcpyAsync(results_dev, res, sizeof(pr_result) * P, hipMemcpyHostToDevice, g->stream));

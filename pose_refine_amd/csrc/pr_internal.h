@@ -44,7 +44,9 @@ struct IcpBatch {
     // PR_SOLVE_DEVICE with the solve fused into the pass (option "fused_solve"): the workgroup that delivers the last
     // partial sum of a hypothesis also adds the partials up and runs that hypothesis' iteration logic
     uint32_t        score_only; // 1 on the pass of iteration == max_iteration (PR_SOLVE_DEVICE): only sums 27 (error) and 28 (count) are formed
-    uint32_t        fused;      // 0 = separate icp_finalize_solve launch
+    uint32_t        fused;      // 0 = separate icp_finalize[_solve] launch; 1 = finalize + solve in the pass; 2 = finalize in the pass, the 29 sums of a
+                                // hypothesis go to sums_out (PR_SOLVE_HOST: pinned host memory, read by the host after the stream has drained)
+    float          *sums_out;   // fused == 2: [P][kAccStride], same pose indexing as `meta`
     uint32_t        iter;       // iteration index of this pass (icp.cu:178 loop variable)
     DevIcpState    *st;         // [P]
     uint32_t       *arrive;     // [P] zero before the first pass; the solving workgroup re-zeroes its entry

@@ -1888,6 +1888,10 @@ __global__ __launch_bounds__(256, PR_PASS_WAVES) void icp_pass_kernel(IcpBatch b
         ticket = __builtin_amdgcn_readfirstlane(ticket);
         if (ticket + 1u != used) continue;
         if (threadIdx.x == 0) st_sys_u32(&b.arrive[pose], 0u);
+        if (b.fused == 2u) {                                     // solve on the host: the sums of the hypothesis, straight into host memory
+            if (threadIdx.x < 29) st_sys_f32(b.sums_out + (size_t)pose * kAccStride + threadIdx.x, sum_partials_sys(b.partial, pose, b.nblk, used, threadIdx.x));
+            return;
+        }
         DevIcpState s = b.st[pose];                              // uniform; in flight together with the partial sums
         float total = 0.0f;
         if (threadIdx.x < 29) total = sum_partials_sys(b.partial, pose, b.nblk, used, threadIdx.x);
