@@ -178,7 +178,20 @@ struct Json {
     std::vector<Json> arr; std::vector<std::pair<std::string, Json>> obj;
     const Json *get(const char *key) const { for (const auto &kv : obj) if (kv.first == key) return &kv.second; return nullptr; }
     double number(const char *key, double dflt) const { const Json *j = get(key); return (j && j->kind == kNum) ? j->num : dflt; }
+    // a field that must be a non-negative integer (an index, a count, a byte offset); false if it is present and is not one
+    bool index(const char *key, size_t dflt, size_t &out) const
+    {
+        const Json *j = get(key);
+        if (!j) { out = dflt; return true; }
+        if (j->kind != kNum || !(j->num >= 0.0) || !(j->num <= 4503599627370496.0) || j->num != std::floor(j->num)) return false;
+        out = (size_t)j->num; return true;
+    }
 };
+bool json_index(const Json &j, size_t &out)
+{
+    if (j.kind != Json::kNum || !(j.num >= 0.0) || !(j.num <= 4503599627370496.0) || j.num != std::floor(j.num)) return false;
+    out = (size_t)j.num; return true;
+}
 struct JsonParser {
     const char *p, *end; std::string err;
     void ws() { while (p < end && (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r')) ++p; }
@@ -267,38 +280,42 @@ pr_vec3 mat4_apply(const Mat4 &m, const pr_vec3 &v)               // renderer.cp
                     m.m[8] * v.x + m.m[9] * v.y + m.m[10] * v.z + m.m[11] };
 }
 struct Gltf {
-    Json root; std::vector<std::vector<unsigned char>> buffers; std::string dir; Mesh *out = nullptr;
+    Json root; std::vector<std::vector<unsigned char>> buffers; std::string dir; Mesh *out = nullptr; size_t visits = 0;
     bool fail(const std::string &e) { if (out->error.empty()) out->error = e; return false; }
-    const Json *item(const char *array, long i) const { const Json *a = root.get(array); return (a && a->kind == Json::kArr && i >= 0 && (size_t)i < a->arr.size()) ? &a->arr[(size_t)i] : nullptr; }
+    const Json *item(const char *array, size_t i) const { const Json *a = root.get(array); return (a && a->kind == Json::kArr && i < a->arr.size()) ? &a->arr[i] : nullptr; }
     // accessor -> doubles (count x components)
-    bool accessor(long index, int want_comps, std::vector<double> &vals)
+    bool accessor(size_t index, int want_comps, std::vector<double> &vals)
     {
         const Json *acc = item("accessors", index);
         if (!acc) return fail("glTF: accessor out of range");
-        const long count = (long)acc->number("count", 0), ctype = (long)acc->number("componentType", 0), view_i = (long)acc->number("bufferView", -1);
+        size_t count = 0, ctype = 0, view_i = 0, acc_off = 0, view_off = 0, stride = 0, buf_i = 0;
+        if (!acc->index("count", 0, count) || !acc->index("componentType", 0, ctype) || !acc->index("bufferView", (size_t)-1, view_i) || !acc->index("byteOffset", 0, acc_off))
+            return fail("glTF: accessor field is not a non-negative integer");
         const Json *ty = acc->get("type");
         const int comps = (ty && ty->str == "VEC3") ? 3 : ((ty && ty->str == "SCALAR") ? 1 : 0);
         if (comps != want_comps) return fail("glTF: accessor of an unexpected type");
         if (acc->get("sparse")) return fail("glTF: sparse accessors are not read");
         const Json *view = item("bufferViews", view_i);
         if (!view) return fail("glTF: accessor without a buffer view");
-        const long buf_i = (long)view->number("buffer", -1);
-        if (buf_i < 0 || (size_t)buf_i >= buffers.size()) return fail("glTF: buffer out of range");
-        const std::vector<unsigned char> &buf = buffers[(size_t)buf_i];
+        if (!view->index("buffer", (size_t)-1, buf_i) || !view->index("byteOffset", 0, view_off) || !view->index("byteStride", 0, stride))
+            return fail("glTF: buffer view field is not a non-negative integer");
+        if (buf_i >= buffers.size()) return fail("glTF: buffer out of range");
+        const std::vector<unsigned char> &buf = buffers[buf_i];
         size_t csize = 0;
         switch (ctype) { case 5120: case 5121: csize = 1; break; case 5122: case 5123: csize = 2; break; case 5125: case 5126: csize = 4; break; default: return fail("glTF: unknown component type"); }
-        const size_t off = (size_t)view->number("byteOffset", 0) + (size_t)acc->number("byteOffset", 0);
-        size_t stride = (size_t)view->number("byteStride", 0);
-        if (stride == 0) stride = csize * (size_t)comps;
-        if (count < 0 || (count > 0 && off + (size_t)(count - 1) * stride + csize * (size_t)comps > buf.size())) return fail("glTF: accessor reaches beyond its buffer");
-        vals.resize((size_t)count * (size_t)comps);
-        for (long i = 0; i < count; ++i) for (int c = 0; c < comps; ++c) {
-            const unsigned char *src = buf.data() + off + (size_t)i * stride + (size_t)c * csize;
+        // positions are floats, indices unsigned integers (glTF 2.0 3.6.2, 3.7.2.1; quantised positions are an extension that is not read)
+        if (want_comps == 3 ? ctype != 5126 : (ctype != 5121 && ctype != 5123 && ctype != 5125)) return fail("glTF: accessor of an unexpected component type");
+        const size_t off = view_off + acc_off, elem = csize * (size_t)comps;
+        if (stride == 0) stride = elem;
+        if (stride > 65536 || off > buf.size() || elem > buf.size() - off || (count > 0 && (count - 1) > (buf.size() - off - elem) / stride)) return fail("glTF: accessor reaches beyond its buffer");
+        vals.resize(count * (size_t)comps);
+        for (size_t i = 0; i < count; ++i) for (int c = 0; c < comps; ++c) {
+            const unsigned char *src = buf.data() + off + i * stride + (size_t)c * csize;
             double v = 0;
             switch (ctype) { case 5120: v = *reinterpret_cast<const int8_t *>(src); break; case 5121: v = *src; break;
                              case 5122: { int16_t t; std::memcpy(&t, src, 2); v = t; break; } case 5123: { uint16_t t; std::memcpy(&t, src, 2); v = t; break; }
                              case 5125: { uint32_t t; std::memcpy(&t, src, 4); v = t; break; } case 5126: { float t; std::memcpy(&t, src, 4); v = t; break; } }
-            vals[(size_t)i * (size_t)comps + (size_t)c] = v;
+            vals[i * (size_t)comps + (size_t)c] = v;
         }
         return true;
     }
@@ -317,27 +334,32 @@ struct Gltf {
         for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) r.m[4 * i + j] = R[3 * i + j] * sc[j]; r.m[4 * i + 3] = t[i]; }
         return r;
     }
-    bool node(long index, Mat4 m, int depth)
+    bool node(size_t index, Mat4 m, int depth)
     {
         if (depth > 256) return fail("glTF: node hierarchy too deep (a cycle?)");
+        if (++visits > (1u << 20)) return fail("glTF: more than 2^20 node visits (nodes shared between parents?)");
         const Json *nd = item("nodes", index);
         if (!nd) return fail("glTF: node out of range");
         m = mat4_mul(m, local(*nd));                                // renderer.cpp:71
         const Json *mesh_ref = nd->get("mesh");
-        if (mesh_ref && mesh_ref->kind == Json::kNum) {
-            const Json *mesh = item("meshes", (long)mesh_ref->num);
+        if (mesh_ref) {
+            size_t mesh_i = 0;
+            if (!json_index(*mesh_ref, mesh_i)) return fail("glTF: mesh reference is not a non-negative integer");
+            const Json *mesh = item("meshes", mesh_i);
             const Json *prims = mesh ? mesh->get("primitives") : nullptr;
             if (!prims || prims->kind != Json::kArr) return fail("glTF: mesh without primitives");
             for (const Json &pr : prims->arr) {                     // one assimp mesh per primitive
-                const long mode = (long)pr.number("mode", 4);
+                size_t mode = 4, pos_i = 0, ind_i = 0;
+                if (!pr.index("mode", 4, mode)) return fail("glTF: primitive mode is not a non-negative integer");
                 const Json *attrs = pr.get("attributes");
                 const Json *pos = attrs ? attrs->get("POSITION") : nullptr;
-                if (!pos || pos->kind != Json::kNum) continue;
+                if (!pos) continue;
+                if (!json_index(*pos, pos_i)) return fail("glTF: POSITION is not an accessor index");
                 std::vector<double> pv, iv;
-                if (!accessor((long)pos->num, 3, pv)) return false;
+                if (!accessor(pos_i, 3, pv)) return false;
                 const size_t nv = pv.size() / 3;
                 const Json *ind = pr.get("indices");
-                if (ind && ind->kind == Json::kNum) { if (!accessor((long)ind->num, 1, iv)) return false; }
+                if (ind) { if (!json_index(*ind, ind_i)) return fail("glTF: indices is not an accessor index"); if (!accessor(ind_i, 1, iv)) return false; }
                 else { iv.resize(nv); for (size_t i = 0; i < nv; ++i) iv[i] = (double)i; }
                 std::vector<pr_vec3> verts(nv);
                 for (size_t i = 0; i < nv; ++i) verts[i] = pr_vec3{ (float)pv[3 * i], (float)pv[3 * i + 1], (float)pv[3 * i + 2] };
@@ -360,7 +382,7 @@ struct Gltf {
             }
         }
         const Json *kids = nd->get("children");
-        if (kids && kids->kind == Json::kArr) for (const Json &k : kids->arr) if (!node((long)k.num, m, depth + 1)) return false;
+        if (kids && kids->kind == Json::kArr) for (const Json &k : kids->arr) { size_t ki = 0; if (!json_index(k, ki)) return fail("glTF: child is not a node index"); if (!node(ki, m, depth + 1)) return false; }
         return true;
     }
 };
@@ -406,17 +428,18 @@ bool load_gltf(const char *path, Mesh &m, bool binary)
     m.has_box = true;
     for (int a = 0; a < 3; ++a) { m.lo[a] = 1e10f; m.hi[a] = -1e10f; }     // renderer.cpp:147-148
     const Json *scenes = g.root.get("scenes");
-    const long scene_i = (long)g.root.number("scene", 0);
+    size_t scene_i = 0;
+    if (!g.root.index("scene", 0, scene_i)) { m.error = "glTF: scene is not a non-negative integer"; return false; }
     const Json *scene = g.item("scenes", scene_i);
     if (scenes && scene) {
         const Json *roots = scene->get("nodes");
-        if (roots && roots->kind == Json::kArr) for (const Json &r : roots->arr) if (!g.node((long)r.num, mat4_identity(), 0)) return false;
+        if (roots && roots->kind == Json::kArr) for (const Json &r : roots->arr) { size_t ri = 0; if (!json_index(r, ri)) { m.error = "glTF: scene root is not a node index"; return false; } if (!g.node(ri, mat4_identity(), 0)) return false; }
     } else {                                                      // no scene: every node that is nobody's child is a root
         const Json *nodes = g.root.get("nodes");
         if (nodes && nodes->kind == Json::kArr) {
             std::vector<char> is_child(nodes->arr.size(), 0);
-            for (const Json &n : nodes->arr) { const Json *k = n.get("children"); if (k && k->kind == Json::kArr) for (const Json &c : k->arr) if (c.num >= 0 && (size_t)c.num < is_child.size()) is_child[(size_t)c.num] = 1; }
-            for (size_t i = 0; i < nodes->arr.size(); ++i) if (!is_child[i] && !g.node((long)i, mat4_identity(), 0)) return false;
+            for (const Json &n : nodes->arr) { const Json *k = n.get("children"); if (k && k->kind == Json::kArr) for (const Json &c : k->arr) { size_t ci = 0; if (json_index(c, ci) && ci < is_child.size()) is_child[ci] = 1; } }
+            for (size_t i = 0; i < nodes->arr.size(); ++i) if (!is_child[i] && !g.node(i, mat4_identity(), 0)) return false;
         }
     }
     return m.error.empty();
