@@ -139,15 +139,38 @@ def test_first_pass_sums_bit_exact(gpu, scenario, gscenes, kind):
 
 
 def test_host_and_device_solve_agree_bitwise(gpu, scenario, gscenes):
+    """Host solve (sums finalized in the tail of the pass and stored into pinned host memory, or by the separate finalize launch + copy:
+    fused_solve 1 / 0) and device solve (fused tail / separate finalize+solve launch): same sums in the same order, same solver source."""
     out = []
-    for solve in (api.SOLVE_HOST, api.SOLVE_DEVICE):
-        api.set_option("solve", solve)
-        dev = api.DeviceVector.from_host(scenario["cloud"].reshape(-1))
-        r = api.ICP_Point2Plane(dev, gscenes["proj"], api.ICPConvergenceCriteria(0.0, 0.0, 20))
-        out.append((r.transformation_.copy(), r.fitness_, r.inlier_rmse_, dev.to_host()))
-    api.set_option("solve", api.SOLVE_HOST)
-    assert np.array_equal(out[0][0], out[1][0]) and out[0][1] == out[1][1] and out[0][2] == out[1][2]
-    assert np.array_equal(out[0][3], out[1][3])
+    try:
+        for solve, fused in ((api.SOLVE_HOST, 1), (api.SOLVE_HOST, 0), (api.SOLVE_DEVICE, 1), (api.SOLVE_DEVICE, 0)):
+            api.set_option("solve", solve); api.set_option("fused_solve", fused)
+            dev = api.DeviceVector.from_host(scenario["cloud"].reshape(-1))
+            r = api.ICP_Point2Plane(dev, gscenes["proj"], api.ICPConvergenceCriteria(0.0, 0.0, 20))
+            out.append((r.transformation_.copy(), r.fitness_, r.inlier_rmse_, dev.to_host()))
+    finally:
+        api.set_option("solve", api.SOLVE_HOST); api.set_option("fused_solve", 1)
+    for o in out[1:]:
+        assert np.array_equal(out[0][0], o[0]) and out[0][1] == o[1] and out[0][2] == o[2]
+        assert np.array_equal(out[0][3], o[3])
+
+
+@pytest.mark.parametrize("kind,P,groups", [("proj", 70, 2), ("proj", 130, 4), ("nn", 66, 2)])
+def test_host_solve_pose_groups_agree_bitwise(gpu, model, scenario, gscenes, kind, P, groups):
+    """The host-solve loop runs the batch as software-pipelined pose groups; records must not depend on the grouping, on where the
+    sums are finalized, or (early-exit criteria) on groups finishing at different iterations."""
+    poses = synth.hypotheses(P, seed=5)
+    poses[3] = poses[3].copy(); poses[3].reshape(4, 4)[0, 3] += 1.0e6          # an empty cloud in the first group
+    try:
+        for crit in ((0.0, 0.0, 20), (1e-5, 1e-5, 30)):
+            out = []
+            for g, fused in ((1, 0), (groups, 1), (groups, 0)):
+                api.set_option("pose_groups", g); api.set_option("fused_solve", fused)
+                out.append(api.refine_batch(model, poses, W, H, scenario["proj"], scenario["K"], gscenes[kind], api.ICPConvergenceCriteria(*crit)))
+            for o in out[1:]:
+                assert np.array_equal(out[0][1], o[1]) and out[0][0].tobytes() == o[0].tobytes(), crit
+    finally:
+        api.set_option("pose_groups", 2); api.set_option("fused_solve", 1)
 
 
 # ---- edge cases -----------------------------------------------------------------------------------
