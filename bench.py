@@ -51,7 +51,7 @@ BYTES_PER_POINT_PASS0, BYTES_PER_POINT_PASSK = 36.0, 48.0
 # L2s fetch from the fabric, Infinity-Cache hits included (guide, HBM section): the counter figure is FABRIC traffic, an upper bound of DRAM
 # traffic -- with <= 512 hypotheses per sub-batch the clouds are Infinity-Cache resident by design.
 PMC_TRAFFIC_BYTES_PER_POINT = {"proj": 25.2, "nn": 69.0}       # P = 1024 as ONE sub-batch (clouds spill the Infinity Cache): 23.9 B/point -- the same: it is the cloud read + write-back
-PMC_VALU_WAVE_INSTR_PER_POINT = {"proj": 2.079, "nn": None}
+PMC_VALU_WAVE_INSTR_PER_POINT = {"proj": 2.085, "nn": None}
 PMC_TRAFFIC_SOURCE = {"proj": "profiles/r03/pmc_proj_FETCH_SIZE.md + pmc_proj_WRITE_SIZE.md + sq_proj_SQ_INSTS_VALU*.md (icp_pass_kernel<SceneProjPacked>)",
                       "nn": "profiles/r03/pmc_nn_FETCH_SIZE.md + pmc_nn_WRITE_SIZE.md (search 39.7 + bound 6.3 + task walk 4.9 + winners pass 18.1 B/point)"}
 
