@@ -245,3 +245,50 @@ def test_deep_tree_runs_the_24_entry_stacks_and_every_dataflow_form(gpu, scenari
         for k, v in zip(names, (1, 1, 1, 1, 0)):
             api.set_option(k, v)
         api.set_option("scene_cache", 1)
+
+
+def _pathological(base):
+    p = base.copy().reshape(-1, 4, 4)
+    p[1, 0, 0] = np.nan
+    p[3, 2, 3] = np.inf
+    p[5] = 0.0
+    p[7, :3, 3] = [1e30, -1e30, 1e30]
+    p[9, :3, :3] *= -1.0                      # mirrored
+    p[11, 2, 3] = 1e-6                        # the camera inside the object
+    p[13, 2, 3] = -700.0                      # the object behind the camera
+    p[15, :3, :3] *= 1e6                      # a giant
+    p[17, :3, :3] *= 1e-9                     # a speck
+    p[19, 0, 3] = -np.inf
+    p[21, :3, :3] = np.nan
+    p[23, 3, :] = [1, 2, 3, 4]                # a last row that is not 0 0 0 1 (the renderer never reads it)
+    return p.reshape(base.shape), [1, 3, 5, 7, 9, 11, 13, 15, 17, 19, 21, 23]
+
+
+def test_pathological_hypotheses_do_no_harm(gpu, model, scenario, gscenes):
+    """Hypotheses with NaN / infinite / zero / mirrored / astronomically scaled matrices in a batch: nothing faults, the other hypotheses
+    of the batch are refined bit for bit as without them (synchronous path, both solves, both scenes, and on the asynchronous slots), and
+    the render of the finite oddities equals the oracle's (a mirrored object, one behind the camera, a speck, a foreign last row)."""
+    good = synth.hypotheses(40, seed=3)
+    bad, idx_bad = _pathological(good)
+    idx_ok = [i for i in range(40) if i not in idx_bad]
+    crit = api.ICPConvergenceCriteria(0.0, 0.0, 6)
+    try:
+        for solve in (api.SOLVE_DEVICE, api.SOLVE_HOST):
+            api.set_option("solve", solve)
+            for kind in ("proj", "nn"):
+                ref = api.refine_batch(model, good, W, H, scenario["proj"], scenario["K"], gscenes[kind], crit)
+                out = api.refine_batch(model, bad, W, H, scenario["proj"], scenario["K"], gscenes[kind], crit)
+                assert all(ref[0][i].tobytes() == out[0][i].tobytes() and ref[1][i] == out[1][i] for i in idx_ok), (solve, kind)
+                if solve == api.SOLVE_DEVICE:
+                    for b in (0, 1):
+                        api.refine_submit(b, model, bad, W, H, scenario["proj"], scenario["K"], gscenes[kind], crit)
+                    for b in (0, 1):
+                        o2 = api.refine_wait(b)
+                        assert all(o2[0][i].tobytes() == ref[0][i].tobytes() for i in idx_ok), (kind, b)
+    finally:
+        api.set_option("solve", api.SOLVE_DEVICE)
+    finite = [9, 13, 17, 23]
+    got = api.render_host(model, bad[finite], W, H, scenario["proj"])
+    want = O.render(scenario["tris"], bad[finite], W, H, scenario["proj"])
+    assert np.array_equal(got, want)
+    assert (got[0] > 0).sum() > 20000 and (got[3] > 0).sum() > 20000      # the mirrored object and the foreign last row do render
