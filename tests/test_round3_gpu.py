@@ -292,3 +292,34 @@ def test_pathological_hypotheses_do_no_harm(gpu, model, scenario, gscenes):
     want = O.render(scenario["tris"], bad[finite], W, H, scenario["proj"])
     assert np.array_equal(got, want)
     assert (got[0] > 0).sum() > 20000 and (got[3] > 0).sum() > 20000      # the mirrored object and the foreign last row do render
+
+
+@pytest.mark.parametrize("kind", ["proj", "nn"])
+def test_cloud_with_non_finite_and_absurd_points_matches_the_oracle(gpu, scenario, gscenes, kind):
+    """400 of the cloud's points replaced by NaN, infinities, 1e30, zero depth, negative depth, the origin and denormal-small values: the
+    reference's rules decide each of them (a projection that is NaN or out of range is rejected, common.h:63-73 / depth_scene.h:38-45; a
+    kd-tree query that finds nothing within max_dist is no correspondence) -- same inlier counts and transforms as the CPU oracle, per
+    cloud and inside a ragged batch, nothing faults."""
+    cloud = scenario["cloud"]
+    bad = cloud.copy()
+    ix = np.random.default_rng(0).choice(len(bad), 400, replace=False)
+    bad[ix[:50]] = np.nan
+    bad[ix[50:100], 2] = np.inf
+    bad[ix[100:150]] = [1e30, -1e30, 1e30]
+    bad[ix[150:200], 2] = 0.0
+    bad[ix[200:250], 2] = -0.5
+    bad[ix[250:300]] = 0.0
+    bad[ix[300:350], 0] = -np.inf
+    bad[ix[350:400]] *= 1e-30
+    crit = (0.0, 0.0, 1)                                          # two passes: the non-finite points go through one rigid update as well
+    ppb = api.get_option("points_per_block")
+    want, _, _, _ = O.icp(bad, scenario["proj_scene" if kind == "proj" else "nn_scene"], crit, O.SUM_CANONICAL, ppb)
+    dev = api.DeviceVector.from_host(bad.reshape(-1))
+    r = api.ICP_Point2Plane(dev, gscenes[kind], api.ICPConvergenceCriteria(*crit))
+    assert r.fitness_ == want["fitness"] and 0.5 < r.fitness_ < 1.0
+    assert np.allclose(r.transformation_.reshape(-1), want["T"], rtol=0, atol=1e-4)
+    offs = np.array([0, len(bad), len(bad) + len(cloud)], np.uint32)
+    both = api.DeviceVector.from_host(np.concatenate([bad, cloud]).reshape(-1))
+    res = api.ICP_Point2Plane_batch(both, offs, gscenes[kind], api.ICPConvergenceCriteria(*crit))
+    clean, _, _, _ = O.icp(cloud, scenario["proj_scene" if kind == "proj" else "nn_scene"], crit, O.SUM_CANONICAL, ppb)
+    assert res[0]["fitness"] == want["fitness"] and res[1]["fitness"] == clean["fitness"]
