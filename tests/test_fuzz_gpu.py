@@ -249,3 +249,33 @@ def test_arrival_protocol_stress_tiny_clouds(gpu):
     finally:
         api.set_option("profile", 0); api.set_option("fused_solve", 1); api.set_option("pose_groups", 2)
         api.set_option("solve", api.SOLVE_HOST)
+
+
+@pytest.mark.parametrize("seed,W,H", [(21, 97, 61), (22, 160, 120)])
+def test_render_mesh_with_non_finite_and_absurd_vertices(gpu, seed, W, H):
+    """Triangles with NaN, infinite, 1e30 and denormal-small vertices among ordinary ones: the image equals the oracle's (the loop
+    bounds of renderer.cu:100-125 decide what such a triangle touches), with and without an ROI, and through the fused path."""
+    rng = np.random.default_rng(seed)
+    K = np.array([1.1 * W, 0, W / 2, 0, 1.1 * W, H / 2, 0, 0, 1], np.float32)
+    tris = random_mesh(rng, 300, 40.0)
+    tris[10, 0, 0] = np.nan
+    tris[11, 1] = np.nan
+    tris[12, 2, 2] = np.inf
+    tris[13, 0] = [np.inf, -np.inf, np.inf]
+    tris[14] *= 1e30
+    tris[15, 1] = [1e30, 1e30, 1e30]
+    tris[16] *= 1e-38
+    tris[17, 2, 1] = -np.inf
+    tris[18] = 0.0
+    poses = np.stack([random_pose(rng, d) for d in (300.0, 120.0, 60.0)])
+    proj = O.compute_proj(K, W, H)
+    ref = O.render(tris, poses, W, H, proj)
+    assert (ref > 0).sum() > 100
+    model = api.Model(tris=tris)
+    assert np.array_equal(api.render_host(model, poses, W, H, proj), ref)
+    roi = (W // 5, H // 4, W // 2, H // 2)
+    assert np.array_equal(api.render_host(model, poses, W, H, proj, roi), O.render(tris, poses, W, H, proj, roi))
+    # fused path (per-pose pixel boxes from the mesh's box -- which is not finite here): cloud sizes as the oracle renders them
+    scene = api.Scene_projective().init_Scene_projective_cuda(ref[0], K)
+    _, sizes = api.refine_batch(model, poses, W, H, proj, K, scene, api.ICPConvergenceCriteria(0.0, 0.0, 2))
+    assert [int(s) for s in sizes] == [int((r > 0).sum()) for r in ref]
