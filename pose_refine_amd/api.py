@@ -329,6 +329,10 @@ class Scene_projective:
                                    max_dist_diff: float = 0.1):
         if scene_depth.dtype not in (np.uint16, np.int32):          # depth_scene.cpp:11-12 assert
             raise ValueError("scene depth must be CV_16U or CV_32S")
+        # the reference reads scene_depth.at(r, c) for r < height, c < width (depth_scene.cpp:17-30) and trusts the caller; an image
+        # of another size than the (width, height) given -- the defaults are 640 x 480 as in depth_scene.h -- is an error here
+        if scene_depth.ndim != 2 or scene_depth.shape != (height, width):
+            raise ValueError(f"scene depth is {scene_depth.shape}, expected ({height}, {width}): pass width / height of the image")
         self.width, self.height, self.max_dist_diff = width, height, max_dist_diff
         self.K = _f32(scene_K, -1)
         d = np.ascontiguousarray(scene_depth)
@@ -346,6 +350,8 @@ class Scene_projective:
         preparation (back-projection + normals) done by a kernel -- no CPU work, no PCIe traffic."""
         if scene_depth_dev.dtype not in (np.uint16, np.int32):
             raise ValueError("scene depth must be CV_16U or CV_32S")
+        if scene_depth_dev.size() != width * height:
+            raise ValueError(f"scene depth holds {scene_depth_dev.size()} values, expected {width} x {height}: pass width / height of the image")
         self.width, self.height, self.max_dist_diff = width, height, max_dist_diff
         self.K = _f32(scene_K, -1)
         self.pcd_buffer = DeviceVector(width * height * 3, np.float32)
@@ -418,6 +424,8 @@ class Scene_nn:
         """normals, valid-pixel gather and the level-order kd-tree build all on the device."""
         k = _f32(scene_K, -1)
         px = width * height
+        if scene_depth_dev.size() != px:
+            raise ValueError(f"scene depth holds {scene_depth_dev.size()} values, expected {width} x {height}")
         self.pcd_buffer = DeviceVector(px * 3, np.float32)
         self.normal_buffer = DeviceVector(px * 3, np.float32)
         self.nodes = DeviceVector(2 * px + 1, KDNODE)

@@ -276,6 +276,32 @@ def test_render_mesh_with_non_finite_and_absurd_vertices(gpu, seed, W, H):
     roi = (W // 5, H // 4, W // 2, H // 2)
     assert np.array_equal(api.render_host(model, poses, W, H, proj, roi), O.render(tris, poses, W, H, proj, roi))
     # fused path (per-pose pixel boxes from the mesh's box -- which is not finite here): cloud sizes as the oracle renders them
-    scene = api.Scene_projective().init_Scene_projective_cuda(ref[0], K)
+    scene = api.Scene_projective().init_Scene_projective_cuda(ref[0], K, W, H)
     _, sizes = api.refine_batch(model, poses, W, H, proj, K, scene, api.ICPConvergenceCriteria(0.0, 0.0, 2))
     assert [int(s) for s in sizes] == [int((r > 0).sum()) for r in ref]
+
+
+@pytest.mark.parametrize("W,H", [(8192, 2048), (2048, 8192), (4096, 4096)])
+def test_largest_frames(gpu, W, H):
+    """The largest frames the pixel packing admits (8192 on a side, 2^24 pixels): render against the oracle bit for bit, and the fused
+    path's clouds and first pass against it (projective scene made from the render)."""
+    rng = np.random.default_rng(W + H)
+    f = 0.9 * max(W, H)
+    K = np.array([f, 0, W / 2, 0, f, H / 2, 0, 0, 1], np.float32)
+    tris = random_mesh(rng, 300, 40.0)
+    poses = np.stack([random_pose(rng, d) for d in (160.0, 110.0)])
+    proj = O.compute_proj(K, W, H)
+    ref = O.render(tris, poses, W, H, proj)
+    assert (ref[0] > 0).sum() > 100000
+    model = api.Model(tris=tris)
+    got = api.render_host(model, poses, W, H, proj)
+    assert np.array_equal(got, ref)
+    scene = api.Scene_projective().init_Scene_projective_cuda(ref[0], K, W, H)
+    crit = (0.0, 0.0, 1)
+    res, sizes = api.refine_batch(model, poses, W, H, proj, K, scene, api.ICPConvergenceCriteria(*crit))
+    assert [int(s) for s in sizes] == [int((r > 0).sum()) for r in ref]
+    oscene = O.ProjScene(ref[0], K)
+    ppb = api.get_option("points_per_block")
+    for i in range(2):
+        want, _, _, _ = O.icp(O.depth2cloud(ref[i], K), oscene, crit, O.SUM_CANONICAL, ppb)
+        assert res[i]["fitness"] == want["fitness"] and np.allclose(res[i]["T"], want["T"], rtol=0, atol=1e-4)
