@@ -1737,7 +1737,17 @@ int pr_icp_batch(pr_vec3 *clouds_dev, const uint32_t *offsets_host, uint32_t n_c
         if (offsets_host[i + 1] < offsets_host[i]) { set_error("pr_icp_batch: offsets must be non-decreasing"); return PR_ERR_INVALID; }
         start[i] = offsets_host[i]; count[i] = offsets_host[i + 1] - offsets_host[i];
     }
-    return icp_drive(clouds_dev, start.data(), count.data(), n_clouds, sc, crit, results_host, nullptr);
+    // the hypothesis index is the y dimension of every launch of the loop (65 535 at most): longer lists run in pieces, one after the other
+    // (the clouds are independent of each other, so the pieces are)
+#ifndef PR_MAX_CLOUDS_PER_RUN
+#define PR_MAX_CLOUDS_PER_RUN 32768                               // (a larger value in an experiment build exercises the launchers' own split)
+#endif
+    constexpr uint32_t kMaxCloudsPerRun = PR_MAX_CLOUDS_PER_RUN;
+    for (uint32_t c0 = 0; c0 < n_clouds; c0 += kMaxCloudsPerRun) {
+        const uint32_t nc = std::min(kMaxCloudsPerRun, n_clouds - c0);
+        PR_TRY(icp_drive(clouds_dev, start.data() + c0, count.data() + c0, nc, sc, crit, results_host + c0, nullptr));
+    }
+    return PR_OK;
 }
 
 int pr_icp_proj(pr_vec3 *cloud_dev, uint32_t n_points, const pr_scene_proj *scene, pr_criteria crit, pr_result *result_out)
@@ -1949,7 +1959,7 @@ int pr_set_option(const char *name, int value)
     else if (n == "graph") opt.use_graph = value ? 1 : 0;
     else if (n == "icp_flow") opt.icp_flow = value ? 1 : 0;
     else if (n == "fused_solve") opt.fused_solve = value ? 1 : 0;
-    else if (n == "sub_batch") opt.sub_batch = std::max(32, value);
+    else if (n == "sub_batch") opt.sub_batch = std::min(32768, std::max(32, value));    // (the hypothesis index is the y dimension of the launches)
     else if (n == "overlap_pass") opt.overlap_pass = std::max(-1, value);
     else if (n == "pose_groups") opt.pose_groups = std::min(4, std::max(1, value));
     else if (n == "eager_streams") opt.eager_streams = value ? 1 : 0;

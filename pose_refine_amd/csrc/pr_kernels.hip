@@ -3452,6 +3452,10 @@ static hipError_t launch_pass(const IcpBatch &b, const Scene &sc, uint32_t n_pos
         IcpBatch bb = b;
         bb.meta += p0;
         bb.partial += (size_t)p0 * b.nblk * kAccStride;
+        if (bb.st) bb.st += p0;                                  // everything indexed by the hypothesis moves with the piece
+        if (bb.arrive) bb.arrive += p0;
+        if (bb.sums_out) bb.sums_out += (size_t)p0 * kAccStride;
+        if (bb.nn_qcount) bb.nn_qcount += kQCountStride * (size_t)p0;
         hipLaunchKernelGGL(HIP_KERNEL_NAME(icp_pass_kernel<Scene, kNN, kStack>), dim3(b.grid_x ? b.grid_x : b.nblk, np), dim3(kBlockThreads), lds_bytes, s, bb, sc);
     }
     return hipGetLastError();

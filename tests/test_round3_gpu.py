@@ -323,3 +323,27 @@ def test_cloud_with_non_finite_and_absurd_points_matches_the_oracle(gpu, scenari
     res = api.ICP_Point2Plane_batch(both, offs, gscenes[kind], api.ICPConvergenceCriteria(*crit))
     clean, _, _, _ = O.icp(cloud, scenario["proj_scene" if kind == "proj" else "nn_scene"], crit, O.SUM_CANONICAL, ppb)
     assert res[0]["fitness"] == want["fitness"] and res[1]["fitness"] == clean["fitness"]
+
+
+@pytest.mark.parametrize("kind", ["proj", "nn"])
+def test_more_clouds_than_a_launch_has_rows(gpu, scenario, gscenes, kind):
+    """70 000 clouds in one ICP_Point2Plane_batch call (the hypothesis index is the y dimension of the launches: the list runs in
+    pieces): every spot-checked cloud equals the same cloud refined on its own, host and device solve give the same records."""
+    cloud = scenario["cloud"]
+    n_clouds, per = 70000, 8
+    starts = np.random.default_rng(1).integers(0, len(cloud) - per, n_clouds)
+    cl = np.concatenate([cloud[s:s + per] for s in starts])
+    offs = (np.arange(n_clouds + 1) * per).astype(np.uint32)
+    crit = api.ICPConvergenceCriteria(0.0, 0.0, 3)
+    got = {}
+    try:
+        for solve in (api.SOLVE_DEVICE, api.SOLVE_HOST):
+            api.set_option("solve", solve)
+            res = api.ICP_Point2Plane_batch(api.DeviceVector.from_host(cl.reshape(-1)), offs, gscenes[kind], crit)
+            got[solve] = res.tobytes()
+            for i in (0, 1, 32767, 32768, 40001, 65535, 65536, n_clouds - 1):
+                one = api.ICP_Point2Plane(api.DeviceVector.from_host(cl[i * per:(i + 1) * per].reshape(-1)), gscenes[kind], crit)
+                assert one.fitness_ == res[i]["fitness"] and np.array_equal(one.transformation_.reshape(-1), res[i]["T"]), (solve, i)
+    finally:
+        api.set_option("solve", api.SOLVE_DEVICE)
+    assert got[api.SOLVE_DEVICE] == got[api.SOLVE_HOST]
