@@ -861,7 +861,7 @@ bool frame_size_ok(size_t W, size_t H)
 int render_impl(const pr_triangle *tris_dev, size_t n_tris, const pr_mat4 *poses_host, size_t P, size_t W, size_t H,
                 const pr_mat4 *proj, pr_roi roi, int32_t *depth_dev, bool zero_empty)
 {
-    if (!tris_dev || !poses_host || !proj || !depth_dev || W == 0 || H == 0) { set_error("pr_render: bad arguments"); return PR_ERR_INVALID; }
+    if ((!tris_dev && n_tris > 0) || !poses_host || !proj || !depth_dev || W == 0 || H == 0) { set_error("pr_render: bad arguments"); return PR_ERR_INVALID; }   // (an empty model has no array)
     if (!frame_size_ok(W, H)) return PR_ERR_INVALID;
     size_t rw = W, rh = H;
     if (roi.width > 0 && roi.height > 0) {
@@ -1144,7 +1144,7 @@ int refine_submit(int slot, const pr_triangle *tris_dev, size_t n_tris, const pr
     if (slot < 0 || slot >= kSlots) { set_error("slot must be 0..%d", kSlots - 1); return PR_ERR_INVALID; }
     Slot &sl = g->slots[slot];
     if (sl.pending) { set_error("pr_refine_submit: slot %d still holds an unfinished batch (call pr_refine_wait)", slot); return PR_ERR_INVALID; }
-    if (!tris_dev || !poses_host || !proj || !K || W == 0 || H == 0 || (!results_host && !results_dev)) { set_error("pr_refine_submit: bad arguments"); return PR_ERR_INVALID; }
+    if ((!tris_dev && n_tris > 0) || !poses_host || !proj || !K || W == 0 || H == 0 || (!results_host && !results_dev)) { set_error("pr_refine_submit: bad arguments"); return PR_ERR_INVALID; }
     if (crit.max_iteration < 0) { set_error("max_iteration must be >= 0"); return PR_ERR_INVALID; }
     if (!frame_size_ok(W, H) || !roi_ok(roi, W, H)) return PR_ERR_INVALID;
     sl.P = P; sl.user_results_host = results_host; sl.user_sizes = sizes_host; sl.delivered = false;

@@ -305,3 +305,62 @@ def test_largest_frames(gpu, W, H):
     for i in range(2):
         want, _, _, _ = O.icp(O.depth2cloud(ref[i], K), oscene, crit, O.SUM_CANONICAL, ppb)
         assert res[i]["fitness"] == want["fitness"] and np.allclose(res[i]["T"], want["T"], rtol=0, atol=1e-4)
+
+
+def test_more_hypotheses_than_a_launch_has_rows_and_empty_models(gpu):
+    """On a 48 x 32 frame: 70 000 hypotheses in one render call and 40 000 / 6 000 in one refinement call (projective / kd-tree; the
+    hypothesis index is the y dimension of the launches, so such calls run in pieces) -- spot checks against the oracle's render and
+    against the same hypotheses refined in a call of their own; a model of no triangles (no array at all) and of one triangle."""
+    rng = np.random.default_rng(5)
+    W, H = 48, 32
+    K = np.array([1.1 * W, 0, W / 2, 0, 1.1 * W, H / 2, 0, 0, 1], np.float32)
+    proj = O.compute_proj(K, W, H)
+    tris = random_mesh(rng, 200, 40.0)
+    model = api.Model(tris=tris)
+    base = [random_pose(rng, d) for d in (300.0, 150.0, 220.0)]
+    P = 70000
+    poses = np.stack([base[i % 3] for i in range(P)]).copy()
+    poses[:, 0, 3] += (np.arange(P) % 97).astype(np.float32) * 0.5
+    d = api.render_host(model, poses, W, H, proj)
+    for i in (0, 1, 32767, 32768, 65535, 65536, P - 1):
+        assert np.array_equal(d[i], O.render(tris, poses[i:i + 1], W, H, proj)[0]), i
+    scene_depth = O.render(tris, np.stack(base[:1]), W, H, proj)[0]
+    crit = api.ICPConvergenceCriteria(0.0, 0.0, 3)
+    try:
+        for kind, Pn in (("proj", 40000), ("nn", 6000)):
+            scene = api.Scene_projective().init_Scene_projective_cuda(scene_depth, K, W, H) if kind == "proj" else api.Scene_nn().init_Scene_nn_cuda(scene_depth, K)
+            for solve in (api.SOLVE_DEVICE, api.SOLVE_HOST):
+                api.set_option("solve", solve)
+                out = api.refine_batch(model, poses[:Pn], W, H, proj, K, scene, crit)
+                for i0 in (0, 511, 512, 20000 % Pn, Pn - 3):
+                    ref = api.refine_batch(model, poses[i0:i0 + 3], W, H, proj, K, scene, crit)
+                    assert out[0][i0:i0 + 3].tobytes() == ref[0].tobytes() and np.array_equal(out[1][i0:i0 + 3], ref[1]), (kind, solve, i0)
+    finally:
+        api.set_option("solve", api.SOLVE_HOST)
+    scene = api.Scene_projective().init_Scene_projective_cuda(scene_depth, K, W, H)
+    for n in (0, 1):
+        m = api.Model(tris=tris[:n])
+        assert np.array_equal(api.render_host(m, poses[:5], W, H, proj), O.render(tris[:n], poses[:5], W, H, proj) if n else np.zeros((5, H, W), np.int32))
+        res, sizes = api.refine_batch(m, poses[:5], W, H, proj, K, scene, crit)
+        assert [int(s) for s in sizes] == [int((r > 0).sum()) for r in O.render(tris[:n], poses[:5], W, H, proj)] if n else not sizes.any()
+
+
+@pytest.mark.parametrize("name,Kd", [("zero", [0] * 9), ("nan", [np.nan] * 9), ("mirrored", [-50, 0, 24, 0, -50, 16, 0, 0, 1])])
+def test_degenerate_intrinsics(gpu, name, Kd):
+    """Intrinsics that are all zero, NaN or negative: the render equals the oracle's (compute_proj and the viewport arithmetic decide),
+    scenes can be made from them and refinement runs to the end -- nothing faults."""
+    rng = np.random.default_rng(6)
+    W, H = 48, 32
+    K = np.array([1.1 * W, 0, W / 2, 0, 1.1 * W, H / 2, 0, 0, 1], np.float32)
+    tris = random_mesh(rng, 200, 40.0)
+    model = api.Model(tris=tris)
+    poses = np.stack([random_pose(rng, d) for d in (300.0, 150.0, 220.0, 90.0)])
+    scene_depth = O.render(tris, poses[:1], W, H, O.compute_proj(K, W, H))[0]
+    Kd = np.array(Kd, np.float32)
+    pj = api.compute_proj(Kd, W, H)
+    assert np.array_equal(pj, O.compute_proj(Kd, W, H), equal_nan=True)
+    assert np.array_equal(api.render_host(model, poses, W, H, pj), O.render(tris, poses, W, H, O.compute_proj(Kd, W, H)))
+    crit = api.ICPConvergenceCriteria(0.0, 0.0, 3)
+    for scene in (api.Scene_projective().init_Scene_projective_cuda(scene_depth, Kd, W, H), api.Scene_nn().init_Scene_nn_cuda(scene_depth, Kd)):
+        res, sizes = api.refine_batch(model, poses, W, H, pj, Kd, scene, crit)
+        assert len(res) == 4
