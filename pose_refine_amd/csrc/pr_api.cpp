@@ -1248,12 +1248,14 @@ int refine_submit_async(Slot &sl, const pr_triangle *tris_dev, size_t n_tris, ui
     // grid: one workgroup per block of the largest cloud of the previous batch (workgroups loop if this batch's clouds are
     // larger, surplus workgroups exit at once); the box bound itself would launch ~60 % empty workgroups (-2.5 % poses/s)
     const uint32_t grid_x = g->cloud_hint ? std::min(nblk, (g->cloud_hint + ppb - 1) / ppb) : nblk;
-    if (cstride * (size_t)std::min<size_t>(P, (size_t)std::max(32, opt.sub_batch)) > 0xffffffffull) { set_error("pr_refine_submit: batch too large for 32-bit cloud offsets"); return PR_ERR_INVALID; }
 
     // Large batches run as consecutive sub-batches that reuse the same depth / cloud / partial-sum memory: the clouds of
     // <= 512 hypotheses (~140 MB touched) stay in the 256 MiB Infinity Cache over their 21 passes (1024 poses as one batch:
     // 199 k poses/s, as 2 x 512: see DESIGN.md)
-    const uint32_t sub_cap = (uint32_t)std::max(32, opt.sub_batch);
+    // ... and, for large frames, small enough that the depth workspace of a sub-batch stays within ~4 GiB (as the synchronous path
+    // bounds its chunks) and the clouds within 2^30 points (offsets are 32-bit): 64 hypotheses per sub-batch at 4096 x 4096, all 512 up to 2 M pixels
+    uint32_t sub_cap = (uint32_t)std::max(32, opt.sub_batch);
+    sub_cap = (uint32_t)std::max<size_t>(1, std::min<size_t>({ (size_t)sub_cap, ((size_t)4 << 30) / (img * sizeof(int32_t)), ((size_t)1 << 30) / cstride }));     // (2^30 cloud points per sub-batch: 12 GiB of clouds, 24 GiB of kd-tree search state at most)
     const uint32_t n_sub = (P + sub_cap - 1) / sub_cap;
     const uint32_t sub = (P + n_sub - 1) / n_sub;
     PR_TRY(sl.depth.ensure(sizeof(int32_t) * img * sub));

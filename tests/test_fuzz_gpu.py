@@ -305,6 +305,16 @@ def test_largest_frames(gpu, W, H):
     for i in range(2):
         want, _, _, _ = O.icp(O.depth2cloud(ref[i], K), oscene, crit, O.SUM_CANONICAL, ppb)
         assert res[i]["fitness"] == want["fitness"] and np.allclose(res[i]["T"], want["T"], rtol=0, atol=1e-4)
+    # the asynchronous path (device solve) sizes its sub-batches so that the workspace of one stays within a few GiB: 150 hypotheses
+    # of a 16 M-pixel frame run as three sub-batches of 50..64; the first and the last equal the synchronous records
+    if W * H == 1 << 24:
+        many = np.concatenate([poses] * 75)
+        api.set_option("solve", api.SOLVE_DEVICE)
+        try:
+            res2, sizes2 = api.refine_batch(model, many, W, H, proj, K, scene, api.ICPConvergenceCriteria(*crit))
+        finally:
+            api.set_option("solve", api.SOLVE_HOST)
+        assert res2[:2].tobytes() == res.tobytes() and res2[-2:].tobytes() == res.tobytes() and np.array_equal(sizes2[-2:], sizes)
 
 
 def test_more_hypotheses_than_a_launch_has_rows_and_empty_models(gpu):
