@@ -347,3 +347,69 @@ def test_more_clouds_than_a_launch_has_rows(gpu, scenario, gscenes, kind):
     finally:
         api.set_option("solve", api.SOLVE_DEVICE)
     assert got[api.SOLVE_DEVICE] == got[api.SOLVE_HOST]
+
+
+@pytest.mark.parametrize("kind", ["proj", "nn"])
+def test_six_hundred_iterations(gpu, scenario, gscenes, kind):
+    """max_iteration = 600 with zero thresholds (601 passes, a long captured loop): host and device solve agree bit for bit and with the oracle."""
+    cl = scenario["cloud"][:6000]
+    crit = (0.0, 0.0, 600)
+    out = []
+    try:
+        for solve in (api.SOLVE_DEVICE, api.SOLVE_HOST):
+            api.set_option("solve", solve)
+            r = api.ICP_Point2Plane(api.DeviceVector.from_host(cl.reshape(-1)), gscenes[kind], api.ICPConvergenceCriteria(*crit))
+            out.append((r.transformation_.tobytes(), r.fitness_, r.inlier_rmse_))
+    finally:
+        api.set_option("solve", api.SOLVE_DEVICE)
+    assert out[0] == out[1]
+    want, _, _, _ = O.icp(cl, scenario["proj_scene" if kind == "proj" else "nn_scene"], crit, O.SUM_CANONICAL, api.get_option("points_per_block"))
+    assert out[0][1] == want["fitness"] and np.allclose(np.frombuffer(out[0][0], np.float32), want["T"], rtol=0, atol=1e-4)
+
+
+def test_reduction_tree_and_grouping_options_at_their_extremes(gpu, model, scenario, gscenes):
+    """points_per_block 1024 / 65 536 (one point step per workgroup / one workgroup per cloud), 1 and 4 pose groups, sub-batches of 32 on a
+    batch of 33: every combination equals the oracle in the tree that points_per_block selects."""
+    poses = synth.hypotheses(33, seed=2)
+    crit = (0.0, 0.0, 5)
+    cl = O.depth2cloud(O.render(scenario["tris"], poses[32:33], W, H, scenario["proj"])[0], scenario["K"])
+    try:
+        for ppb in (1024, 65536):
+            api.set_option("points_per_block", ppb)
+            want, _, _, _ = O.icp(cl, scenario["proj_scene"], crit, O.SUM_CANONICAL, ppb)
+            for groups, sub in ((1, 32), (4, 32), (3, 512)):
+                api.set_option("pose_groups", groups); api.set_option("sub_batch", sub)
+                res, sizes = api.refine_batch(model, poses, W, H, scenario["proj"], scenario["K"], gscenes["proj"], api.ICPConvergenceCriteria(*crit))
+                assert sizes[32] == len(cl) and res[32]["fitness"] == want["fitness"] and np.allclose(res[32]["T"], want["T"], rtol=0, atol=1e-4), (ppb, groups, sub)
+    finally:
+        api.set_option("points_per_block", 3072); api.set_option("pose_groups", 2); api.set_option("sub_batch", 512)
+
+
+def test_four_host_threads_on_the_shared_context(gpu, model, scenario, gscenes):
+    """Calls of different kinds from four threads at once on the process' shared context: every result equals the one computed alone."""
+    import threading
+    poses = synth.hypotheses(24, seed=8)
+    crit = api.ICPConvergenceCriteria(0.0, 0.0, 5)
+    cloud = scenario["cloud"]
+
+    def run(what):
+        if what == "refine":
+            return api.refine_batch(model, poses, W, H, scenario["proj"], scenario["K"], gscenes["proj"], crit)[0].tobytes()
+        if what == "nn":
+            return api.refine_batch(model, poses[:8], W, H, scenario["proj"], scenario["K"], gscenes["nn"], crit)[0].tobytes()
+        if what == "render":
+            return api.render_host(model, poses[:4], W, H, scenario["proj"]).tobytes()
+        return api.ICP_Point2Plane(api.DeviceVector.from_host(cloud.reshape(-1)), gscenes["proj"], crit).transformation_.tobytes()
+    kinds = ("refine", "nn", "render", "icp")
+    alone = {k: run(k) for k in kinds}
+    bad = []
+
+    def worker(tid):
+        for k in range(10):
+            what = kinds[(tid + k) % 4]
+            if run(what) != alone[what]:
+                bad.append((tid, k, what))
+    ts = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not bad
