@@ -413,3 +413,47 @@ def test_four_host_threads_on_the_shared_context(gpu, model, scenario, gscenes):
     [t.start() for t in ts]
     [t.join() for t in ts]
     assert not bad
+
+
+@pytest.mark.parametrize("name", ["identical", "line", "clusters", "one", "two", "eleven"])
+@pytest.mark.parametrize("max_leaf", [1, 10])
+def test_kdtree_build_on_degenerate_point_sets(gpu, name, max_leaf):
+    """A thousand identical points, points on a line, two clusters of exact duplicates, one / two / eleven points: the host build, the
+    device build and the oracle's give the same nodes and the same permutation (the alternating tie rule of pcd_scene.cpp decides)."""
+    rng = np.random.default_rng(3)
+    pts = {"identical": np.tile(np.array([[0.1, 0.2, 0.7]], np.float32), (1000, 1)),
+           "line": np.stack([np.linspace(0, 1, 777, dtype=np.float32), np.zeros(777, np.float32), np.full(777, 0.5, np.float32)], 1),
+           "clusters": np.concatenate([np.tile(np.array([[0, 0, 1]], np.float32), (300, 1)), np.tile(np.array([[1, 1, 1]], np.float32), (301, 1))]),
+           "one": np.array([[0.5, 0.5, 0.5]], np.float32), "two": np.array([[0.5, 0.5, 0.5], [0.1, 0.1, 0.1]], np.float32),
+           "eleven": rng.normal(size=(11, 3)).astype(np.float32)}[name]
+    n = len(pts)
+    nrm = rng.normal(size=(n, 3)).astype(np.float32)
+    lib = _lib.load()
+    hp, hn = pts.copy(), nrm.copy()
+    hnodes = np.zeros(2 * n + 1, _lib.KDNODE); cnt = C.c_uint32()
+    _lib.check(lib.pr_kdtree_build(hp.ctypes.data, hn.ctypes.data, n, max_leaf, hnodes.ctypes.data, len(hnodes), C.byref(cnt)))
+    op, on = pts.copy(), nrm.copy()
+    onodes = np.zeros(2 * n + 1, O.KDNODE)
+    ocnt = O.lib().po_kd_build(op.reshape(-1), on.reshape(-1), n, max_leaf, onodes.ctypes.data, len(onodes))
+    assert ocnt == cnt.value and onodes[:ocnt].tobytes() == hnodes[:ocnt].tobytes() and np.array_equal(op, hp) and np.array_equal(on, hn)
+    dp, dn = api.DeviceVector.from_host(pts.reshape(-1)), api.DeviceVector.from_host(nrm.reshape(-1))
+    dnodes = api.DeviceVector(2 * n + 1, _lib.KDNODE); dcnt = C.c_uint32()
+    _lib.check(lib.pr_kdtree_build_dev(dp.data(), dn.data(), n, max_leaf, dnodes.data(), 2 * n + 1, C.byref(dcnt)))
+    assert dcnt.value == cnt.value and dnodes.to_host()[:cnt.value].tobytes() == hnodes[:cnt.value].tobytes()
+    assert np.array_equal(dp.to_host().reshape(-1, 3), hp) and np.array_equal(dn.to_host().reshape(-1, 3), hn)
+
+
+@pytest.mark.parametrize("W,H,stride,tlx,tly,dt", [(97, 61, 3, 0, 0, np.int32), (101, 57, 7, 5, 9, np.uint16), (64, 48, 64, 0, 0, np.int32), (33, 2, 5, 1, 1, np.int32), (1, 1, 1, 0, 0, np.uint16)])
+def test_depth2cloud_strides_that_do_not_divide_the_frame(gpu, W, H, stride, tlx, tly, dt):
+    rng = np.random.default_rng(W * H + stride)
+    d = (rng.integers(0, 3, size=(H, W)) * rng.integers(200, 900, size=(H, W))).astype(dt)
+    K = np.array([80, 0, W / 2, 0, 82, H / 2, 0, 0, 1], np.float32)
+    got = api.depth2cloud(api.DeviceVector.from_host(d.reshape(-1)), W, H, K, stride, tlx, tly, dtype=dt).to_host().reshape(-1, 3)
+    want = O.depth2cloud(d, K, stride, tlx, tly)
+    assert got.shape == want.shape and np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("roi", [(0, 0, 1, 1), (639, 479, 1, 1), (320, 240, 1, 1), (0, 0, 640, 1), (0, 0, 1, 480), (300, 200, 37, 53)])
+def test_render_roi_extremes(gpu, model, scenario, roi):
+    poses = synth.hypotheses(3, seed=1)
+    assert np.array_equal(api.render_host(model, poses, W, H, scenario["proj"], roi), O.render(scenario["tris"], poses, W, H, scenario["proj"], roi))
