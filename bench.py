@@ -249,12 +249,14 @@ def main():
     for _ in range(args.warmup):
         step()
     cpu0 = time.process_time()
-    # Roofline samples: the LAST n_samples steps of the timed region run with profile 1 -- synchronously, as one pose group, with the
-    # other slot drained, HIP events around every correspondence launch -- so that the timed launches have the chip to themselves.
-    # A synchronous step costs ~0.45 ms more than a pipelined one and counts against `value`; at the end of the region the drain
-    # it needs is the drain the closing fence needs anyway (sampled in the middle, every sample also cost an empty pipeline
-    # afterwards: -3 % at 100 steps, -6 % at the driver's 20).  Four sampled steps (84 launches) from 40 steps up, one (21 launches: the
-    # very last step, whose tail has nothing left to overlap with anyway) below.
+    # Roofline samples: the LAST n_samples steps of the timed region run with profile 3 -- as one pose group, their loop starting when the
+    # other slot's batch is complete, HIP events around every correspondence launch -- so that the timed launches have the chip to
+    # themselves.  Such a step costs more than a pipelined one (its loop overlaps with nothing) and counts against `value`; at the end of the
+    # region the drain it needs is the drain the closing fence needs anyway (sampled in the middle, every sample also cost an empty
+    # pipeline afterwards: -3 % at 100 steps, -6 % at the driver's 20).  The batch itself stays asynchronous (its render runs under the previous
+    # step's loop, no host round trip): against the synchronous timed call of profile 1 that is +1-5 % at 20 steps, and it keeps the
+    # synchronous path's first-use allocations (hundreds of MB, 1-8 ms depending on the box) out of the timed region.  Four sampled steps
+    # (84 launches) from 40 steps up, one (21 launches: the very last step, whose tail has nothing left to overlap with anyway) below.
     n_samples = min(args.steps, 4 if args.steps >= 40 else 1)
     api.set_option("profile", 1 if args.sequential else 0)
     api.profile_reset()
@@ -262,7 +264,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         if i == args.steps - n_samples and not args.sequential:
-            api.set_option("profile", 1)
+            api.set_option("profile", int(os.environ.get("PR_BENCH_SAMPLE_PROFILE", "3")))
         step()
     fence()
     elapsed = time.perf_counter() - t0
@@ -344,7 +346,7 @@ def main():
                          "algorithmic_bytes_per_launch": bytes_per_launch, "points_per_launch": pts_per_launch,
                          "timing": ("HIP events on the library stream around every launch (--sequential: synchronous single-group steps)" if args.sequential else
                                     f"HIP events on the library stream around every launch of the last {n_samples} steps of the timed region; "
-                                    "a timed step runs synchronously as one pose group (other slot drained) so the launch has the chip to itself")},
+                                    "a timed step stays an asynchronous batch but its loop runs as one pose group and only once the other slot's batch is complete (option profile = 3), so the launch has the chip to itself")},
             "gather": ("none (1 rank)" if not multi else ("pr_gather_results: grouped ncclSend/ncclRecv on the library stream (C ABI over RCCL)" if gather_mode == "cabi" else
                                                             ("torch.distributed.gather (gloo, host copies: ranks share one device)" if share_device else "torch.distributed.gather (RCCL)"))),
             "gather_note": gather_note,

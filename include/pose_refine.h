@@ -296,7 +296,10 @@ int pr_gather_results(const pr_result *send_dev, uint32_t n_local, uint32_t n_to
 int  pr_set_option(const char *name, int value);
 int  pr_get_option(const char *name, int *value);
 /* HIP-event timing of the correspondence kernel on the library stream: option "profile" = 1 times every launch (all calls run
- * synchronously as one pose group), 2 does so for one call in `sample_period` (the other calls are unaffected).
+ * synchronously as one pose group), 2 does so for one call in `sample_period` (the other calls are unaffected), 3 times every launch
+ * of pr_refine_submit batches WITHOUT making them synchronous: a timed batch renders under the other slot's loop as usual, its own loop
+ * waits until the other slot's batch is complete, runs as one pose group and holds the other slot's next render back until it has
+ * finished -- the timed launches have the chip to themselves, the figures appear with that batch's pr_refine_wait.
  * Accumulated since the last reset: launches timed, model points they processed, and their algorithmic bytes (36 B/point on
  * the first pass of a cloud and on the score-only last pass, 48 B/point in between). */
 /* Work counters of the kd-tree search kernel, collected while option "nn_count" is 1 (instrumented runs; SURVEY 8d "count its own

@@ -176,6 +176,13 @@ struct Slot {
     uint32_t P = 0;
     pr_result *user_results_host = nullptr;
     uint32_t *user_sizes = nullptr;
+    // a TIMED asynchronous batch (option profile = 3): HIP events on the slot's stream around its render, its cloud emit and every
+    // correspondence pass (start / stop pairs in enqueue order), read by pr_refine_wait
+    bool timed = false;
+    std::vector<hipEvent_t> t_events;            // pool, reused from batch to batch
+    size_t t_used = 0;
+    struct TSpan { size_t e0, e1; int kind; uint32_t q0, nq; bool edge; };   // edge: first or last pass (36 B / point instead of 48)
+    std::vector<TSpan> t_spans;
 };
 
 // ---- hipGraph cache for the device-solve iteration loop ------------------------------------------
@@ -1041,6 +1048,8 @@ void slot_release(Slot &sl)
     sl.progress = nullptr; sl.progress_valid = false;
     if (sl.stream) hipStreamDestroy(sl.stream);
     sl.fork = sl.done = sl.scene_ready = nullptr; sl.stream = nullptr; sl.pending = false;
+    for (hipEvent_t e : sl.t_events) (void)hipEventDestroy(e);
+    sl.t_events.clear(); sl.t_used = 0; sl.t_spans.clear(); sl.timed = false;
 }
 
 // Host-side copy of a triangle buffer's box, once per (pointer, size): it feeds the per-pose pixel boxes computed on the host,
@@ -1128,6 +1137,21 @@ int refine_wait(int slot)
     uint32_t largest = 1;
     for (uint32_t i = 0; i < sl.P; ++i) largest = std::max(largest, h_counts[i]);
     g->cloud_hint = largest;
+    if (sl.timed) {                                              // the batch carried timing events: the same accounts as the synchronous timed path keeps
+        for (const Slot::TSpan &t : sl.t_spans) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, sl.t_events[t.e0], sl.t_events[t.e1]) != hipSuccess) continue;
+            if (t.kind == kSpanRender) g->render_ms += ms;
+            else if (t.kind == kSpanCloud) g->cloud_ms += ms;
+            else {
+                uint64_t pts = 0;
+                for (uint32_t i = t.q0; i < t.q0 + t.nq; ++i) pts += h_counts[i];
+                g->icp_ms += ms; g->icp_launches++;
+                g->icp_points += pts; g->icp_bytes += pts * (t.edge ? 36u : 48u);
+            }
+        }
+        sl.t_spans.clear(); sl.t_used = 0; sl.timed = false;
+    }
     if (sl.user_sizes) std::memcpy(sl.user_sizes, h_counts, sizeof(uint32_t) * sl.P);
     if (sl.user_results_host) std::memcpy(sl.user_results_host, h_out + (((size_t)sl.P * 4 + 63) & ~(size_t)63), sizeof(pr_result) * sl.P);
     return PR_OK;
@@ -1153,8 +1177,9 @@ int refine_submit(int slot, const pr_triangle *tris_dev, size_t n_tris, const pr
     const bool sample_call = (opt.profile == 2) && (g->sample_clock % period == 0);
     const bool proj_scene = (scene_kind == PR_SCENE_PROJ || scene_kind == PR_SCENE_PROJ_CROP);
     const bool nn_scene = (scene_kind == PR_SCENE_NN) && !opt.nn_count;     // (an instrumented kd-tree run stays synchronous)
+    (void)img;                                                   // (large frames: the asynchronous path sizes its sub-batches to its workspace bound)
     const bool async_ok = P > 0 && opt.solve_mode == PR_SOLVE_DEVICE && !opt.icp_flow && opt.raster_mode == 0 && (proj_scene || nn_scene)
-                          && img * sizeof(int32_t) * std::min<size_t>(P, (size_t)std::max(32, opt.sub_batch)) <= ((size_t)4 << 30) && (opt.profile == 0 || (opt.profile == 2 && !sample_call));
+                          && (opt.profile == 0 || opt.profile == 3 || (opt.profile == 2 && !sample_call));
     if (!async_ok) {
         // the synchronous path (host solve, timed calls, oversized batches): let the other slot drain first so
         // that a timed launch has the chip to itself, then run to completion; pr_refine_wait has nothing left to do
@@ -1283,6 +1308,18 @@ int refine_submit_async(Slot &sl, const pr_triangle *tris_dev, size_t n_tris, ui
     }
 
     hipStream_t st = sl.stream;
+    // A TIMED batch (profile 3) stays asynchronous: its render runs under the other slot's loop like any other, but its own loop waits
+    // until the other slot's batch is complete, runs as ONE pose group, lets the other slot's next render start only when it has
+    // finished, and carries HIP events around every launch -- the timed launches have the chip to themselves as in the synchronous timed
+    // path (profile 1), without that path's host round trips and its idle render.
+    const bool timed = (opt.profile == 3);
+    sl.timed = timed; sl.t_used = 0; sl.t_spans.clear();
+    auto t_event = [&]() -> size_t {
+        if (sl.t_used == sl.t_events.size()) { hipEvent_t e = nullptr; (void)hipEventCreate(&e); sl.t_events.push_back(e); }
+        return sl.t_used++;
+    };
+    auto t_begin = [&]() -> size_t { const size_t e = t_event(); (void)hipEventRecord(sl.t_events[e], st); return e; };
+    auto t_end = [&](size_t e0, int kind, uint32_t q0, uint32_t nq, bool edge) { const size_t e1 = t_event(); (void)hipEventRecord(sl.t_events[e1], st); sl.t_spans.push_back({ e0, e1, kind, q0, nq, edge }); };
     pr_mat4 *d_poses = sl.poses_bbox.as<pr_mat4>();
     int4 *d_box = reinterpret_cast<int4 *>(d_poses + P);
     // Both phases are bound by the same units, so a batch that renders while the other slot is in the middle of its ICP loop
@@ -1299,15 +1336,20 @@ int refine_submit_async(Slot &sl, const pr_triangle *tris_dev, size_t n_tris, ui
         prk::PoseMeta *meta = sl.meta.as<prk::PoseMeta>() + q0;
         prk::DevIcpState *dstate = sl.dstate.as<prk::DevIcpState>() + q0;
         uint32_t *arrive = sl.arrive.as<uint32_t>() + q0;
+        size_t te = timed ? t_begin() : 0;
         HIP_TRY(prk::launch_render_boxes(tris_dev, (uint32_t)n_tris, d_poses + q0, nq, nullptr, d_box + q0, sl.depth.as<int32_t>(),
                                          sl.row_count.as<uint32_t>(), sl.row_off.as<uint32_t>(), sl.counts.as<uint32_t>() + q0, W, H, *proj, none, st,
                                          /*compute_boxes=*/false, meta, dstate, arrive, (uint32_t)cstride));
+        if (timed) { t_end(te, kSpanRender, q0, nq, false); te = t_begin(); }
         HIP_TRY(prk::launch_emit_box(sl.depth.as<int32_t>(), nq, W, H, d_box + q0, K[0], K[4], K[2], K[5], sl.row_count.as<uint32_t>(),
                                      sl.row_off.as<uint32_t>(), sl.cloud.as<pr_vec3>(), cstride, st));
+        if (timed) t_end(te, kSpanCloud, q0, nq, false);
         if (q0 == 0) HIP_TRY(hipStreamWaitEvent(st, sl.scene_ready, 0));
+        if (timed && q0 == 0)                                     // the timed loop starts when the other slot's batch is complete
+            for (Slot &o : g->slots) if (&o != &sl && o.pending && !o.delivered && o.done) HIP_TRY(hipStreamWaitEvent(st, o.done, 0));
 
         // the iteration loop: (max_iteration+1) x [pass (+ fused finalize/solve)], pose groups on the slot's side streams
-        const uint32_t n_groups = std::max(1u, std::min({ (uint32_t)std::max(1, opt.pose_groups), 4u, nq / 32u }));
+        const uint32_t n_groups = timed ? 1u : std::max(1u, std::min({ (uint32_t)std::max(1, opt.pose_groups), 4u, nq / 32u }));
         auto group_begin = [&](uint32_t grp) { return (uint32_t)(((uint64_t)nq * grp) / n_groups); };
         if (nn_prev) HIP_TRY(hipMemsetAsync(nn_prev + 6 * nn_span, 0, sizeof(uint32_t) * prk::kQCountStride * nq, st));
         if (n_groups > 1) {
@@ -1343,10 +1385,14 @@ int refine_submit_async(Slot &sl, const pr_triangle *tris_dev, size_t n_tris, ui
                 bb.iter = it;
                 if (fused) { bb.fused = 1; bb.crit = crit; bb.st = dstate + p0; bb.arrive = arrive + p0; }
                 bb.score_only = (it == (uint32_t)crit.max_iteration) ? 1u : 0u;
-                HIP_TRY(launch_pass(bb, sc, np, gs));
+                if (timed) {                                         // (one group: gs == st)
+                    const size_t e0 = t_begin();
+                    HIP_TRY(launch_pass(bb, sc, np, gs));
+                    t_end(e0, kSpanIcp, q0 + p0, np, it == 0 || it == (uint32_t)crit.max_iteration);
+                } else HIP_TRY(launch_pass(bb, sc, np, gs));
                 if (!fused) HIP_TRY(prk::launch_icp_finalize_solve(bb.partial, meta + p0, nblk, steps, dstate + p0, crit, it, np, gs));
             }
-            if (q0 + sub >= P && it == std::min<uint32_t>((uint32_t)crit.max_iteration, opt.overlap_pass >= 0 ? (uint32_t)opt.overlap_pass : auto_overlap)) {
+            if (q0 + sub >= P && it == (timed ? (uint32_t)crit.max_iteration : std::min<uint32_t>((uint32_t)crit.max_iteration, opt.overlap_pass >= 0 ? (uint32_t)opt.overlap_pass : auto_overlap))) {
                 HIP_TRY(hipEventRecord(sl.progress, st));
                 sl.progress_valid = true;
             }
@@ -1944,7 +1990,7 @@ int pr_set_option(const char *name, int value)
     const std::string n(name);
     if (n == "solve") { if (value != PR_SOLVE_HOST && value != PR_SOLVE_DEVICE) { set_error("solve must be 0 or 1"); return PR_ERR_INVALID; } opt.solve_mode = value; }
     else if (n == "points_per_block") { if (value < 1024 || value % 1024) { set_error("points_per_block must be a multiple of 1024"); return PR_ERR_INVALID; } opt.steps = value / 1024; }
-    else if (n == "profile") { if (value < 0 || value > 2) { set_error("profile must be 0, 1 (every launch) or 2 (every launch of one call in sample_period)"); return PR_ERR_INVALID; } opt.profile = value; }
+    else if (n == "profile") { if (value < 0 || value > 3) { set_error("profile must be 0, 1 (every launch, synchronous calls), 2 (every launch of one call in sample_period) or 3 (every launch, asynchronous batches stay asynchronous)"); return PR_ERR_INVALID; } opt.profile = value; }
     else if (n == "sample_period") opt.sample_period = std::max(1, value);
     else if (n == "scene_cache") opt.scene_cache = value ? 1 : 0;
     else if (n == "nn_lds_nodes") opt.nn_lds_nodes = std::max(0, value);

@@ -457,3 +457,38 @@ def test_depth2cloud_strides_that_do_not_divide_the_frame(gpu, W, H, stride, tlx
 def test_render_roi_extremes(gpu, model, scenario, roi):
     poses = synth.hypotheses(3, seed=1)
     assert np.array_equal(api.render_host(model, poses, W, H, scenario["proj"], roi), O.render(scenario["tris"], poses, W, H, scenario["proj"], roi))
+
+
+@pytest.mark.parametrize("kind,P", [("proj", 96), ("nn", 40)])
+def test_timed_asynchronous_batches(gpu, model, scenario, gscenes, kind, P):
+    """Option profile = 3: batches submitted on the slots carry HIP events around their launches and stay asynchronous.  Results equal the
+    untimed ones bit for bit; the accounts read after pr_refine_wait hold one entry per pass and sub-batch, the points of every cloud
+    per pass, and 36 / 48 algorithmic bytes per point on edge / inner passes -- as the synchronous timed path (profile 1) reports them."""
+    poses_a, poses_b = synth.hypotheses(P, seed=21), synth.hypotheses(P, seed=22)
+    crit = api.ICPConvergenceCriteria(0.0, 0.0, 6)
+    api.set_option("sub_batch", 64)                               # P = 96 runs as two sub-batches
+    try:
+        api.set_option("profile", 0)
+        ref_a = api.refine_batch(model, poses_a, W, H, scenario["proj"], scenario["K"], gscenes[kind], crit)
+        ref_b = api.refine_batch(model, poses_b, W, H, scenario["proj"], scenario["K"], gscenes[kind], crit)
+        api.set_option("profile", 1)
+        api.profile_reset()
+        api.refine_batch(model, poses_a, W, H, scenario["proj"], scenario["K"], gscenes[kind], crit)
+        sync = api.profile_read()
+        api.set_option("profile", 3)
+        api.profile_reset()
+        api.refine_submit(0, model, poses_a, W, H, scenario["proj"], scenario["K"], gscenes[kind], crit)
+        api.refine_submit(1, model, poses_b, W, H, scenario["proj"], scenario["K"], gscenes[kind], crit)     # timed as well: runs after slot 0's batch
+        got_a = api.refine_wait(0)
+        one = api.profile_read()
+        got_b = api.refine_wait(1)
+        both = api.profile_read()
+    finally:
+        api.set_option("profile", 0); api.set_option("sub_batch", 512)
+    assert got_a[0].tobytes() == ref_a[0].tobytes() and np.array_equal(got_a[1], ref_a[1])
+    assert got_b[0].tobytes() == ref_b[0].tobytes() and np.array_equal(got_b[1], ref_b[1])
+    n_sub = (P + 63) // 64
+    assert one["icp_launches"] == 7 * n_sub and sync["icp_launches"] == 7        # (the synchronous path does not split 96 hypotheses)
+    assert one["icp_points"] == 7 * int(ref_a[1].sum()) == sync["icp_points"] and one["icp_bytes"] == sync["icp_bytes"] == int(ref_a[1].sum()) * (2 * 36 + 5 * 48)
+    assert both["icp_launches"] == 14 * n_sub and both["icp_points"] == 7 * int(ref_a[1].sum() + ref_b[1].sum())
+    assert 0 < one["icp_kernel_ms"] < 50 and one["render_ms"] > 0 and one["cloud_ms"] > 0
