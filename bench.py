@@ -255,9 +255,11 @@ def main():
     # region the drain it needs is the drain the closing fence needs anyway (sampled in the middle, every sample also cost an empty
     # pipeline afterwards: -3 % at 100 steps, -6 % at the driver's 20).  The batch itself stays asynchronous (its render runs under the previous
     # step's loop, no host round trip): against the synchronous timed call of profile 1 that is +1-5 % at 20 steps, and it keeps the
-    # synchronous path's first-use allocations (hundreds of MB, 1-8 ms depending on the box) out of the timed region.  Four sampled steps
-    # (84 launches) from 40 steps up, one (21 launches: the very last step, whose tail has nothing left to overlap with anyway) below.
-    n_samples = min(args.steps, 4 if args.steps >= 40 else 1)
+    # synchronous path's first-use allocations (hundreds of MB, 1-8 ms depending on the box) out of the timed region.  One sampled step
+    # (21 launches): the very last one, whose tail has nothing left to overlap with anyway.
+    # (one step: a timed loop that has another submitted batch waiting behind it on the other slot's queue runs its launches 2-3 us slower
+    # -- 41.1 / 41.0 / 42.0 / 38.7 us over four consecutive timed steps, only the last of which has nothing queued behind it)
+    n_samples = min(args.steps, 1)
     api.set_option("profile", 1 if args.sequential else 0)
     api.profile_reset()
     fence()

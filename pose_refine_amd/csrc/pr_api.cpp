@@ -666,7 +666,7 @@ int icp_drive(pr_vec3 *cloud_base, const uint32_t *start_h, const uint32_t *coun
         // Pose groups: the batch is split over up to four streams so that one group's serial solve tail (and the ragged end
         // of its pass) overlaps another group's pass.  Timed launches (profile 1, the sampled call of profile 2) run as a
         // single group so that the measured kernel has the chip to itself.
-        const bool timed_call = (opt.profile == 1) || sample_call;
+        const bool timed_call = (opt.profile == 1 || opt.profile == 3) || sample_call;   // (profile 3 only keeps SUBMITTED batches asynchronous: whatever runs here is a synchronous timed call)
         const uint32_t n_groups = timed_call ? 1u : std::max(1u, std::min({ (uint32_t)std::max(1, opt.pose_groups), 4u, P / 32u }));
         // the fixed sequence: state upload, (max_iteration+1) x [correspondence pass, finalize+solve], result pack
         auto enqueue_all = [&](std::vector<hipEvent_t> *, bool host_checks) -> int {
@@ -690,7 +690,7 @@ int icp_drive(pr_vec3 *cloud_base, const uint32_t *start_h, const uint32_t *coun
                     bb.iter = it;
                     if (fused) { bb.fused = 1; bb.crit = crit; bb.st = g->dstate.as<prk::DevIcpState>() + p0; bb.arrive = g->arrive.as<uint32_t>() + p0; }
                     bb.score_only = (it == (uint32_t)crit.max_iteration) ? 1u : 0u;
-                    if (grp == 0 && (opt.profile == 1 || sample_call)) {           // a timed call times every launch of its loop
+                    if (grp == 0 && timed_call) {           // a timed call times every launch of its loop
                         SpanGuard sp(kSpanIcp); HIP_TRY(launch_pass(bb, sc, np, st));
                         uint64_t pts = 0; for (uint32_t i = p0; i < p0 + np; ++i) pts += count_h[i];
                         // algorithmic bytes per point: 12 read + 24 gathered, + 12 written back once a transform is
@@ -762,7 +762,7 @@ int icp_drive(pr_vec3 *cloud_base, const uint32_t *start_h, const uint32_t *coun
     // 160 ns per 6x6 solve) is as long as the pass itself, and a single group leaves the GPU idle for all of it.  Results per
     // hypothesis do not depend on the grouping (sums, solve and state are per hypothesis).  A timed call (profile 1) is one group.
     const uint32_t host_sample_it = (uint32_t)((g->sample_clock++ * 5 + 1) % (uint64_t)(crit.max_iteration + 1));
-    const uint32_t n_groups = (opt.profile == 1) ? 1u : std::max(1u, std::min({ (uint32_t)std::max(1, opt.pose_groups), 4u, P / 32u }));
+    const uint32_t n_groups = (opt.profile == 1 || opt.profile == 3) ? 1u : std::max(1u, std::min({ (uint32_t)std::max(1, opt.pose_groups), 4u, P / 32u }));
     auto group_begin = [&](uint32_t grp) { return (uint32_t)(((uint64_t)P * grp) / n_groups); };
     if (opt.fused_solve) { PR_TRY(g->arrive.ensure(sizeof(uint32_t) * P)); HIP_TRY(hipMemsetAsync(g->arrive.p, 0, sizeof(uint32_t) * P, g->stream)); }
     if (n_groups > 1) {
@@ -795,7 +795,7 @@ int icp_drive(pr_vec3 *cloud_base, const uint32_t *start_h, const uint32_t *coun
         bb.meta += p0; bb.partial += (size_t)p0 * nblk * prk::kAccStride; if (bb.nn_qcount) bb.nn_qcount += prk::kQCountStride * (size_t)p0;
         bb.iter = it;
         if (host_fused) { bb.fused = 2; bb.arrive = g->arrive.as<uint32_t>() + p0; bb.sums_out = sums_dev + (size_t)p0 * prk::kAccStride; }
-        if (opt.profile == 1 || (opt.profile == 2 && it == host_sample_it && grp == 0 && n_groups == 1)) {
+        if (opt.profile == 1 || opt.profile == 3 || (opt.profile == 2 && it == host_sample_it && grp == 0 && n_groups == 1)) {
             SpanGuard sp(kSpanIcp); HIP_TRY(launch_pass(bb, sc, np, st));
             for (uint32_t i = p0; i < p0 + np; ++i) if (h_meta[i].state != prk::kSkip) { g->icp_points += count_h[i]; g->icp_bytes += (uint64_t)count_h[i] * (it == 0 ? 36u : 48u); }
         } else HIP_TRY(launch_pass(bb, sc, np, st));
@@ -1223,6 +1223,9 @@ int refine_submit_async(Slot &sl, const pr_triangle *tris_dev, size_t n_tris, ui
     for (uint32_t k = 1; k < groups_hint; ++k) PR_TRY(ensure_stream(sl.side[k - 1], &sl.join[k - 1]));
     hipStream_t scene_stream = groups_hint > 1 ? sl.side[0] : sl.stream;
     const Camera cam{ W, H, K[0], K[4], K[2], K[5] };            // kd-tree scenes: the pixel grid of the scene points under this camera
+    // nothing of this batch may run beside the loop of a TIMED batch on the other slot -- not even the small checks on the scene stream
+    if (scene_stream != sl.stream)
+        for (Slot &o : g->slots) if (&o != &sl && o.pending && !o.delivered && o.timed && o.progress_valid) HIP_TRY(hipStreamWaitEvent(scene_stream, o.progress, 0));
     PR_TRY(make_scene(scene_kind, scene, /*want_packed=*/true, sc, &sl.packed, scene_stream, scene_kind == PR_SCENE_NN ? &cam : nullptr, /*verify_now=*/false));
 
     PR_TRY(ensure_model_box(tris_dev, n_tris));                 // once per triangle buffer ...
