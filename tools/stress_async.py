@@ -2,7 +2,7 @@
 """Stress of the asynchronous slots: random batch sizes / poses alternate over the two slots (growing and shrinking
 workspaces, changing grid hints, sub-batches, empty clouds) and every batch is compared bit for bit with the synchronous path.
 
-    python tools/stress_async.py [jobs] [kd-tree fraction]
+    [PR_STRESS_TIMED=1] python tools/stress_async.py [jobs] [kd-tree fraction]      (PR_STRESS_TIMED: every third batch is a timed one, profile 3)
 
 With a kd-tree fraction > 0 some jobs run against one of TWO kd-tree scenes: the search records and the pixel grid are shared by
 both slots and hold one scene at a time, so alternating scenes forces rebuilds while the other slot has a batch in flight."""
@@ -43,7 +43,10 @@ for i, (p, c, sc) in enumerate(jobs):
     b = i & 1
     if infl[b] is not None:
         got[infl[b]] = api.refine_wait(b)
+    timed = os.environ.get("PR_STRESS_TIMED") and (i % 3 == 1)            # every third batch a TIMED asynchronous one (profile 3)
+    if timed: api.set_option("profile", 3)
     api.refine_submit(b, model, p, W, H, proj, K, sc, c)
+    if timed: api.set_option("profile", 0)
     infl[b] = i
 for b in (0, 1):
     if infl[b] is not None:
