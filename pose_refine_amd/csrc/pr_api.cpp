@@ -117,8 +117,8 @@ WriteLog g_writes;
 // ---- process-wide options (pr_set_option): plain ints, shared by every context ---------------------
 constexpr int kSlots = 2;
 struct Options {
-    int pose_groups = 2;             // PR_SOLVE_DEVICE: split the batch over this many streams (1..4); 2 measured best (1.31 vs 1.45 ms/step at
-                                     // 256 poses); launches of different groups overlap, so timed calls fall back to one group
+    int pose_groups = 0;             // split the batch over this many streams (1..4); 0 = by scene: 2 for projective scenes (1.31 vs 1.45 ms/step at
+                                     // 256 poses), 3 for kd-tree scenes; launches of different groups overlap, so timed calls fall back to one group
     int solve_mode = PR_SOLVE_HOST;
     int steps = 3;                   // 1024-point steps per workgroup -> 3072 points per workgroup (9 workgroups per 26 k-point cloud: measured 3-5 % faster than 2048 / 4096)
     int profile = 0;
@@ -131,7 +131,7 @@ struct Options {
     int nn_wide = 1;                 // queued tree searches: order-free walk over 128-byte lines (eight subtree boxes per wide node, one line per leaf); ties go to the binary walk
     int nn_stack = 1;                // kd-tree query: per-lane LDS stack (1) or the reference's stackless walk (0)
     int nn_split = 1;                // kd-tree scenes on compact records: search kernel (runs of consecutive points, grid window) + winners pass
-    int nn_run = 1;                  // 256-point chunks a workgroup of the search kernel takes (lane t of chunk k: point 256 k + t)
+    int nn_run = 2;                  // 256-point chunks a workgroup of the search kernel takes (lane t of chunk k: point 256 k + t); 2: +1-2 % over 1 on configs[2]
     int nn_grid = 1;                 // fused path: pixel grid of the scene points (seeds + window search); 0 = tree only
     int nn_count = 0;                // instrumented runs: the search kernel counts its work per pass (pr_nn_counters)
     int overlap_pass = -1;           // asynchronous path: the other slot's render may start once this slot has issued this pass of its loop (-1: chosen per batch, see refine_submit_async)
@@ -148,6 +148,9 @@ struct Options {
     int scene_cache = 1;             // keep the packed projective scene / kd traversal records of the latest scene between calls (pr_scene_invalidate)
 };
 Options opt;
+// streams a batch is split over: the option, or by scene -- 2 for projective scenes, 3 for kd-tree scenes (a kd-tree pass is a chain of four
+// launches with a latency-bound tail each: a third group fills what two leave idle, +1.5 % on configs[2]; a fourth loses 14 %)
+inline uint32_t pose_groups_for(int scene_kind) { return opt.pose_groups > 0 ? (uint32_t)opt.pose_groups : (scene_kind == PR_SCENE_NN ? 3u : 2u); }
 
 // packed projective scene (one 16-byte record per pixel + the two back-projection tables) of the latest scene it was built for
 struct PackedCache {
@@ -667,7 +670,7 @@ int icp_drive(pr_vec3 *cloud_base, const uint32_t *start_h, const uint32_t *coun
         // of its pass) overlaps another group's pass.  Timed launches (profile 1, the sampled call of profile 2) run as a
         // single group so that the measured kernel has the chip to itself.
         const bool timed_call = (opt.profile == 1 || opt.profile == 3) || sample_call;   // (profile 3 only keeps SUBMITTED batches asynchronous: whatever runs here is a synchronous timed call)
-        const uint32_t n_groups = timed_call ? 1u : std::max(1u, std::min({ (uint32_t)std::max(1, opt.pose_groups), 4u, P / 32u }));
+        const uint32_t n_groups = timed_call ? 1u : std::max(1u, std::min({ pose_groups_for(sc.kind), 4u, P / 32u }));
         // the fixed sequence: state upload, (max_iteration+1) x [correspondence pass, finalize+solve], result pack
         auto enqueue_all = [&](std::vector<hipEvent_t> *, bool host_checks) -> int {
             HIP_TRY(hipMemcpyAsync(g->dstate.p, init, sizeof(prk::DevIcpState) * P, hipMemcpyHostToDevice, g->stream));
@@ -720,7 +723,7 @@ int icp_drive(pr_vec3 *cloud_base, const uint32_t *start_h, const uint32_t *coun
         if (opt.use_graph && n_groups == 1 && (opt.profile == 0 || (opt.profile == 2 && !sample_call))) {   // HIP events recorded inside a captured graph cannot be timed
             GraphKey key;
             key.add(P); key.add(nblk); key.add(steps); key.add(crit); key.add(sc); key.add(cloud_base); key.add(g->meta.p); key.add(g->partial.p);
-            key.add(g->dstate.p); key.add(dres); key.add(results_host != nullptr); key.add(res); key.add(h_meta); key.add(init); key.add(opt.profile); key.add(opt.pose_groups); key.add(opt.fused_solve); key.add(g->arrive.p); key.add(b.nn_prev);
+            key.add(g->dstate.p); key.add(dres); key.add(results_host != nullptr); key.add(res); key.add(h_meta); key.add(init); key.add(opt.profile); key.add(pose_groups_for(sc.kind)); key.add(opt.fused_solve); key.add(g->arrive.p); key.add(b.nn_prev);
             key.add(b.nn_slack); key.add(b.nn_queue); key.add(b.nn_queue2); key.add(b.nn_qcount);    // laid out behind nn_prev at multiples of `span` (max start+count): same P / max_n, other offsets => other addresses
             CachedGraph *hit = nullptr;
             for (auto &c : g->graphs) if (c.exec && c.key == key) { hit = &c; break; }
@@ -762,7 +765,7 @@ int icp_drive(pr_vec3 *cloud_base, const uint32_t *start_h, const uint32_t *coun
     // 160 ns per 6x6 solve) is as long as the pass itself, and a single group leaves the GPU idle for all of it.  Results per
     // hypothesis do not depend on the grouping (sums, solve and state are per hypothesis).  A timed call (profile 1) is one group.
     const uint32_t host_sample_it = (uint32_t)((g->sample_clock++ * 5 + 1) % (uint64_t)(crit.max_iteration + 1));
-    const uint32_t n_groups = (opt.profile == 1 || opt.profile == 3) ? 1u : std::max(1u, std::min({ (uint32_t)std::max(1, opt.pose_groups), 4u, P / 32u }));
+    const uint32_t n_groups = (opt.profile == 1 || opt.profile == 3) ? 1u : std::max(1u, std::min({ pose_groups_for(sc.kind), 4u, P / 32u }));
     auto group_begin = [&](uint32_t grp) { return (uint32_t)(((uint64_t)P * grp) / n_groups); };
     if (opt.fused_solve) { PR_TRY(g->arrive.ensure(sizeof(uint32_t) * P)); HIP_TRY(hipMemsetAsync(g->arrive.p, 0, sizeof(uint32_t) * P, g->stream)); }
     if (n_groups > 1) {
@@ -1219,7 +1222,7 @@ int refine_submit_async(Slot &sl, const pr_triangle *tris_dev, size_t n_tris, ui
     std::memset(static_cast<void *>(&sc), 0, sizeof sc);
     // the packed copy of the scene does not depend on the render: when it has to be (re)built that happens on the first side
     // stream (idle until the loop forks), the loop waits for it; batches without pose groups build it in line
-    const uint32_t groups_hint = std::max(1u, std::min({ (uint32_t)std::max(1, opt.pose_groups), 4u, std::min<uint32_t>(P, (uint32_t)std::max(32, opt.sub_batch)) / 32u }));
+    const uint32_t groups_hint = std::max(1u, std::min({ pose_groups_for(scene_kind), 4u, std::min<uint32_t>(P, (uint32_t)std::max(32, opt.sub_batch)) / 32u }));
     for (uint32_t k = 1; k < groups_hint; ++k) PR_TRY(ensure_stream(sl.side[k - 1], &sl.join[k - 1]));
     hipStream_t scene_stream = groups_hint > 1 ? sl.side[0] : sl.stream;
     const Camera cam{ W, H, K[0], K[4], K[2], K[5] };            // kd-tree scenes: the pixel grid of the scene points under this camera
@@ -1352,7 +1355,7 @@ int refine_submit_async(Slot &sl, const pr_triangle *tris_dev, size_t n_tris, ui
             for (Slot &o : g->slots) if (&o != &sl && o.pending && !o.delivered && o.done) HIP_TRY(hipStreamWaitEvent(st, o.done, 0));
 
         // the iteration loop: (max_iteration+1) x [pass (+ fused finalize/solve)], pose groups on the slot's side streams
-        const uint32_t n_groups = timed ? 1u : std::max(1u, std::min({ (uint32_t)std::max(1, opt.pose_groups), 4u, nq / 32u }));
+        const uint32_t n_groups = timed ? 1u : std::max(1u, std::min({ pose_groups_for(scene_kind), 4u, nq / 32u }));
         auto group_begin = [&](uint32_t grp) { return (uint32_t)(((uint64_t)nq * grp) / n_groups); };
         if (nn_prev) HIP_TRY(hipMemsetAsync(nn_prev + 6 * nn_span, 0, sizeof(uint32_t) * prk::kQCountStride * nq, st));
         if (n_groups > 1) {
@@ -2012,7 +2015,7 @@ int pr_set_option(const char *name, int value)
     else if (n == "fused_solve") opt.fused_solve = value ? 1 : 0;
     else if (n == "sub_batch") opt.sub_batch = std::min(32768, std::max(32, value));    // (the hypothesis index is the y dimension of the launches)
     else if (n == "overlap_pass") opt.overlap_pass = std::max(-1, value);
-    else if (n == "pose_groups") opt.pose_groups = std::min(4, std::max(1, value));
+    else if (n == "pose_groups") opt.pose_groups = std::min(4, std::max(0, value));
     else if (n == "eager_streams") opt.eager_streams = value ? 1 : 0;
     else if (n == "raster_mode") { if (value < 0 || value > 1) { set_error("raster_mode must be 0 or 1"); return PR_ERR_INVALID; } opt.raster_mode = value; }
     else { set_error("unknown option %s", name); return PR_ERR_INVALID; }

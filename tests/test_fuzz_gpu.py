@@ -247,7 +247,7 @@ def test_arrival_protocol_stress_tiny_clouds(gpu):
             assert np.array_equal(sa, ref_sizes) and a.tobytes() == ref.tobytes(), rep
             assert np.array_equal(sb, ref_sizes[::-1]) and b.tobytes() == ref[::-1].tobytes(), rep
     finally:
-        api.set_option("profile", 0); api.set_option("fused_solve", 1); api.set_option("pose_groups", 2)
+        api.set_option("profile", 0); api.set_option("fused_solve", 1); api.set_option("pose_groups", 0)
         api.set_option("solve", api.SOLVE_HOST)
 
 

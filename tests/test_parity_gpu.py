@@ -170,7 +170,7 @@ def test_host_solve_pose_groups_agree_bitwise(gpu, model, scenario, gscenes, kin
             for o in out[1:]:
                 assert np.array_equal(out[0][1], o[1]) and out[0][0].tobytes() == o[0].tobytes(), crit
     finally:
-        api.set_option("pose_groups", 2); api.set_option("fused_solve", 1)
+        api.set_option("pose_groups", 0); api.set_option("fused_solve", 1)
 
 
 # ---- edge cases -----------------------------------------------------------------------------------

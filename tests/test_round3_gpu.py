@@ -103,7 +103,7 @@ def test_graph_cache_keeps_kdtree_batches_of_equal_shape_apart(gpu, scenario, gs
             got[graph] = res
         assert got[1] == got[0]
     finally:
-        api.set_option("graph", 1); api.set_option("pose_groups", 2)
+        api.set_option("graph", 1); api.set_option("pose_groups", 0)
 
 
 def test_synchronous_call_while_slot_0_is_pending(gpu, model, scenario, gscenes):
@@ -382,7 +382,7 @@ def test_reduction_tree_and_grouping_options_at_their_extremes(gpu, model, scena
                 res, sizes = api.refine_batch(model, poses, W, H, scenario["proj"], scenario["K"], gscenes["proj"], api.ICPConvergenceCriteria(*crit))
                 assert sizes[32] == len(cl) and res[32]["fitness"] == want["fitness"] and np.allclose(res[32]["T"], want["T"], rtol=0, atol=1e-4), (ppb, groups, sub)
     finally:
-        api.set_option("points_per_block", 3072); api.set_option("pose_groups", 2); api.set_option("sub_batch", 512)
+        api.set_option("points_per_block", 3072); api.set_option("pose_groups", 0); api.set_option("sub_batch", 512)
 
 
 def test_four_host_threads_on_the_shared_context(gpu, model, scenario, gscenes):
