@@ -376,7 +376,7 @@ def main():
         dist.destroy_process_group()
 
 
-def kdtree_extra(args, api, model, poses, scene_depth, W, H, proj, K, steps=8):
+def kdtree_extra(args, api, model, poses, scene_depth, W, H, proj, K, steps=20):
     """BASELINE.json configs[2] next to the headline: the same 256-hypothesis batch against the kd-tree scene (Scene_nn), a
     few steps through the two asynchronous slots, plus one instrumented (synchronous) batch whose work counters give the LOGICAL bytes of the
     search (wide nodes x 128 B + leaf points x 16 B + window cells x 16 B + 28 B per query for cloud and winner)."""
