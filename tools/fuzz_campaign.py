@@ -12,7 +12,7 @@ t0 = time.time()
 bad = []
 n = 0
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
-seed = 1000
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 while time.time() - t0 < budget:
     rng = np.random.default_rng(seed)
     W, H = int(rng.integers(16, 400)), int(rng.integers(16, 300))

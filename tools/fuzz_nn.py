@@ -9,7 +9,7 @@ import test_round3_gpu as R
 import test_parity_gpu as Pg
 api.init(0); api.set_option("solve", api.SOLVE_DEVICE)
 t0 = time.time(); budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
-bad = []; n = 0; seed = 5000
+bad = []; n = 0; seed = int(sys.argv[2]) if len(sys.argv) > 2 else 5000
 while time.time() - t0 < budget:
     rng = np.random.default_rng(seed)
     npts = int(rng.choice([1, 2, 7, 40, 300, 2500, 9000, 30000, 70000]))
