@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <new>
 #include <numeric>
 #include <sstream>
 #include <string>
@@ -82,6 +83,9 @@ bool load_ply(const char *path, Mesh &m)
 {
     std::ifstream in(path, std::ios::binary);
     if (!in) { m.error = std::string("cannot open ") + path; return false; }
+    in.seekg(0, std::ios::end);
+    const size_t file_size = (size_t)std::max<std::streamoff>(0, in.tellg());   // no element can have more entries than the file has bytes
+    in.seekg(0, std::ios::beg);
     std::string line;
     if (!std::getline(in, line) || line.compare(0, 3, "ply") != 0) { m.error = "not a PLY file"; return false; }
     bool ascii = false, big = false, header_ok = false;
@@ -93,7 +97,12 @@ bool load_ply(const char *path, Mesh &m)
         ss >> tok;
         if (tok == "end_header") { header_ok = true; break; }
         if (tok == "format") { std::string f; ss >> f; ascii = (f == "ascii"); big = (f == "binary_big_endian"); if (!ascii && !big && f != "binary_little_endian") { m.error = "unknown PLY format " + f; return false; } }
-        else if (tok == "element") { PlyElement e; ss >> e.name >> e.count; elems.push_back(e); }
+        else if (tok == "element") {
+            PlyElement e; double cnt = -1;
+            ss >> e.name >> cnt;
+            if (!(cnt >= 0) || cnt > (double)file_size) { m.error = "PLY element count that the file cannot hold: " + line; return false; }
+            e.count = (size_t)cnt; elems.push_back(e);
+        }
         else if (tok == "property" && !elems.empty()) {
             PlyProp p; std::string t; ss >> t;
             if (t == "list") { std::string ct, it; ss >> ct >> it >> p.name; p.is_list = true; p.count_type = ply_type(ct); p.type = ply_type(it); if (p.count_type == kBad) { m.error = "unknown PLY type " + ct; return false; } }
@@ -132,7 +141,11 @@ bool load_ply(const char *path, Mesh &m)
                     const double cnt = next(p.count_type);
                     if (!ok || cnt < 0 || cnt > 1e6) { m.error = "bad PLY list"; return false; }
                     poly.clear();
-                    for (long j = 0; j < (long)cnt; ++j) { const double v = next(p.type); if (!ok) { m.error = "truncated PLY body"; return false; } poly.push_back((long)v); }
+                    for (long j = 0; j < (long)cnt; ++j) {
+                        const double v = next(p.type);
+                        if (!ok) { m.error = "truncated PLY body"; return false; }
+                        poly.push_back((v >= 0 && v < 9.0e15) ? (long)v : -1L);      // (a negative, NaN or absurd index is refused by add_polygon)
+                    }
                     if (is_face && (int)k == ilist) { add_polygon(m, poly, n_vertices); if (!m.error.empty()) return false; }
                 }
             }
@@ -473,10 +486,20 @@ inline pr_vec3 back_project(size_t col, size_t row, float depth_mm, bool zero, c
 extern "C" {
 
 // Model::Model(fileName) / LoadModel (cuda_renderer/renderer.cpp:11-58)
+// load_mesh behind the C boundary: whatever a malformed file makes the containers throw becomes an error code
+static bool load_mesh_noexcept(const char *path, Mesh &m)
+{
+    try { return load_mesh(path, m); }
+    catch (const std::bad_alloc &) { m.error = "out of memory while reading the file (a count in it is absurd?)"; }
+    catch (const std::exception &e) { m.error = std::string("malformed file: ") + e.what(); }
+    catch (...) { m.error = "malformed file"; }
+    return false;
+}
 int pr_mesh_count(const char *path, size_t *n_triangles, size_t *n_vertices)
 {
     Mesh m;
-    if (!load_mesh(path, m)) { prh::set_error("pr_mesh_count: %s", m.error.c_str()); return PR_ERR_IO; }
+    if (!path) { prh::set_error("pr_mesh_count: null path"); return PR_ERR_INVALID; }
+    if (!load_mesh_noexcept(path, m)) { prh::set_error("pr_mesh_count: %s", m.error.c_str()); return PR_ERR_IO; }
     if (n_triangles) *n_triangles = m.faces.size() / 3;
     if (n_vertices) *n_vertices = m.vertices.size();
     return PR_OK;
@@ -486,7 +509,8 @@ int pr_mesh_load(const char *path, pr_triangle *tris_out, size_t cap_triangles, 
                  float bbox_min[3], float bbox_max[3])
 {
     Mesh m;
-    if (!load_mesh(path, m)) { prh::set_error("pr_mesh_load: %s", m.error.c_str()); return PR_ERR_IO; }
+    if (!path) { prh::set_error("pr_mesh_load: null path"); return PR_ERR_INVALID; }
+    if (!load_mesh_noexcept(path, m)) { prh::set_error("pr_mesh_load: %s", m.error.c_str()); return PR_ERR_IO; }
     const size_t nt = m.faces.size() / 3;
     for (size_t t = 0; t < nt && t < cap_triangles; ++t) {
         const int32_t *f = &m.faces[3 * t];
