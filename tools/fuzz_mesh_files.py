@@ -5,7 +5,7 @@ crash, hang or return triangles that index outside their vertices.   python tool
 
 With PR_MESH_HARNESS=<binary> the files go through a sanitizer build of the importers instead (AddressSanitizer + UBSan):
     g++ -std=c++17 -O1 -g -fsanitize=address,undefined -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude -Ipose_refine_amd/csrc \
-        harness.cpp pose_refine_amd/csrc/pr_host.cpp -o mesh_asan
+        tools/mesh_sanitize.cpp pose_refine_amd/csrc/pr_host.cpp -o mesh_asan
 (harness.cpp = tools/mesh_sanitize.cpp: pr_mesh_count / pr_mesh_load on every argv file, prints "ok N refused M", prh::set_error a stub)."""
 import os, sys, json, struct, subprocess, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
