@@ -492,3 +492,33 @@ def test_timed_asynchronous_batches(gpu, model, scenario, gscenes, kind, P):
     assert one["icp_points"] == 7 * int(ref_a[1].sum()) == sync["icp_points"] and one["icp_bytes"] == sync["icp_bytes"] == int(ref_a[1].sum()) * (2 * 36 + 5 * 48)
     assert both["icp_launches"] == 14 * n_sub and both["icp_points"] == 7 * int(ref_a[1].sum() + ref_b[1].sum())
     assert 0 < one["icp_kernel_ms"] < 50 and one["render_ms"] > 0 and one["cloud_ms"] > 0
+
+
+@pytest.mark.parametrize("kind", ["proj", "nn"])
+def test_host_solve_batches_from_two_threads_with_private_contexts(gpu, model, scenario, gscenes, kind):
+    """The reference's way of feeding the GPU (README.md:15): host threads, each with its own context, issue whole batches with the solve on
+    the host.  Every batch equals the one computed alone."""
+    import threading
+    poses = synth.hypotheses(70, seed=31)
+    crit = api.ICPConvergenceCriteria(0.0, 0.0, 6)
+    api.set_option("solve", api.SOLVE_HOST)
+    try:
+        alone = api.refine_batch(model, poses, W, H, scenario["proj"], scenario["K"], gscenes[kind], crit)
+        bad, errs = [], []
+
+        def work():
+            try:
+                api.thread_context(True)
+                for _ in range(6):
+                    out = api.refine_batch(model, poses, W, H, scenario["proj"], scenario["K"], gscenes[kind], crit)
+                    if out[0].tobytes() != alone[0].tobytes() or not np.array_equal(out[1], alone[1]):
+                        bad.append(1)
+                api.thread_context(False)
+            except Exception as e:                               # noqa: BLE001
+                errs.append(e)
+        ts = [threading.Thread(target=work) for _ in range(2)]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+    finally:
+        api.set_option("solve", api.SOLVE_DEVICE)
+    assert not errs and not bad, (errs, len(bad))
