@@ -33,8 +33,9 @@ import time
 
 # The pipelined loop keeps four streams busy side by side (two slots x two pose groups).  The HIP runtime maps every stream of
 # the process onto GPU_MAX_HW_QUEUES hardware queues (default 4, shared with torch's and RCCL's streams) and streams that share
-# a queue serialise, so ask for 8 -- before torch initialises the runtime.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# a queue serialise, so ask for 16 (the slots' four, a third pose group for kd-tree scenes, the private contexts of the host-solve threads, torch's
+# and RCCL's own) -- before torch initialises the runtime.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)

@@ -1572,7 +1572,9 @@ static void hw_queues_hint()
     // streams of a process onto GPU_MAX_HW_QUEUES hardware queues (default 4, shared with every other stream of the process),
     // and streams that share a queue serialise.  This only takes effect if the HIP runtime has not been initialised yet --
     // hosts that initialise it earlier (PyTorch) set the variable themselves, as bench.py does.
-    setenv("GPU_MAX_HW_QUEUES", "8", /*overwrite=*/0);
+    // 16: the slots' four streams, the third pose group of kd-tree batches and the streams of private contexts (host threads issuing batches
+    // of their own) all get a queue to themselves -- with 8, two such threads beside the slots ran at 166-198 k poses/s instead of 236-240 k.
+    setenv("GPU_MAX_HW_QUEUES", "16", /*overwrite=*/0);
 }
 
 int pr_init(int device)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """A/B of one library option in the pipelined (two-slot) loop: tools/ab_option.py <option> <v1,v2,...> [poses]"""
 import os, sys, time
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch

@@ -2,7 +2,7 @@
 """PR_SOLVE_HOST (north_star's "solve on host") as a function of the number of pose groups of its software pipeline:
 tools/host_solve_groups.py [poses] [nn]"""
 import os, sys, time
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np

@@ -3,7 +3,7 @@
 threads with private contexts (pr_thread_context) take the 256-hypothesis batches in turn, every call synchronous -- one thread's render and
 host work run under another thread's passes.   python tools/host_solve_threads.py [poses] [batches per thread]"""
 import os, sys, time, threading
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
