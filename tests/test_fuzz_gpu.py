@@ -374,3 +374,32 @@ def test_degenerate_intrinsics(gpu, name, Kd):
     for scene in (api.Scene_projective().init_Scene_projective_cuda(scene_depth, Kd, W, H), api.Scene_nn().init_Scene_nn_cuda(scene_depth, Kd)):
         res, sizes = api.refine_batch(model, poses, W, H, pj, Kd, scene, crit)
         assert len(res) == 4
+
+
+@pytest.mark.parametrize("W,H", [(1024, 768), (2048, 1536)])
+def test_large_kdtree_scenes(gpu, W, H):
+    """kd-tree scenes of 240 k and 900 k points (a frame of 0.8 / 3 M pixels): the tree built on the host, the one built on the device and the
+    oracle's are the same; a 200 k-point cloud refined against them equals the oracle's result; the fused path takes the scene as well."""
+    rng = np.random.default_rng(W)
+    f = 0.9 * W
+    K = np.array([f, 0, W / 2, 0, f, H / 2, 0, 0, 1], np.float32)
+    tris = random_mesh(rng, 300, 40.0)
+    poses = np.stack([random_pose(rng, 160.0)] * 2)
+    poses[1] = poses[0]; poses[1][0, 3] += 0.8; poses[1][2, 3] += 1.5
+    proj = O.compute_proj(K, W, H)
+    ref = O.render(tris, poses, W, H, proj)
+    scene = api.Scene_nn().init_Scene_nn_cuda(ref[0], K)
+    oscene = O.NNScene(ref[0], K)
+    assert len(scene.pcd_host) == len(oscene.pcd) > 200000 and scene.nodes_host.tobytes() == oscene.nodes.tobytes()
+    dscene = api.Scene_nn().init_Scene_nn_device(api.DeviceVector.from_host(ref[0].reshape(-1)), K, W, H)
+    assert (dscene._n_points, dscene._n_nodes) == (len(oscene.pcd), len(oscene.nodes))
+    assert dscene.nodes.to_host()[:len(oscene.nodes)].tobytes() == oscene.nodes.tobytes()
+    crit = (0.0, 0.0, 2)
+    cl = O.depth2cloud(ref[1], K)[::7][:200000]
+    want, _, _, _ = O.icp(cl, oscene, crit, O.SUM_CANONICAL, api.get_option("points_per_block"))
+    for sc in (scene, dscene):
+        r = api.ICP_Point2Plane(api.DeviceVector.from_host(cl.reshape(-1)), sc, api.ICPConvergenceCriteria(*crit))
+        assert r.fitness_ == want["fitness"] and np.allclose(r.transformation_.reshape(-1), want["T"], rtol=0, atol=1e-4)
+    model = api.Model(tris=tris)
+    res, sizes = api.refine_batch(model, poses, W, H, proj, K, scene, api.ICPConvergenceCriteria(*crit))
+    assert [int(s) for s in sizes] == [int((x > 0).sum()) for x in ref] and res["fitness"][0] == 1.0
