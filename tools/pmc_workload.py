@@ -16,6 +16,7 @@ sd = api.render_host(model, synth.scene_pose()[None], 640, 480, proj)[0]
 scene = api.Scene_projective().init_Scene_projective_cuda(sd, K) if scene_kind == "proj" else api.Scene_nn().init_Scene_nn_cuda(sd, K)
 poses = synth.hypotheses(P)
 for _ in range(3):
-    api.refine_batch(model, poses, 640, 480, proj, K, scene, api.ICPConvergenceCriteria(0.0, 0.0, 20))
+    _, sizes = api.refine_batch(model, poses, 640, 480, proj, K, scene, api.ICPConvergenceCriteria(0.0, 0.0, 20))
+print("points per batch:", int(sizes.sum()))
 d = api.render(model, poses, 640, 480, proj)      # fill: P*1228800 B written; max2zero: same read + written
 print("calibration bytes per fill/max2zero:", P * 640 * 480 * 4)
