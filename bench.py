@@ -120,6 +120,7 @@ def main():
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="library option (pr_set_option), repeatable -- tuning runs")
     ap.add_argument("--blocking-wait", type=int, default=-1, help="1: pr_refine_wait sleeps instead of spinning (default: 1 when more than one rank shares the host, else 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--burn-in", type=int, default=25, help="untimed steps BEFORE the --warmup steps that bring the device's clocks up from idle (reported as burn_in_steps; 0 = none)")
     ap.add_argument("--no-live-pmc", action="store_true", help="roofline.traffic from the committed counter passes instead of two rocprofv3 --pmc passes run by this process (rank 0, N = 1)")
     ap.add_argument("--no-kdtree-extra", action="store_true", help="skip the short configs[2] (kd-tree association) measurement appended to the line")
     ap.add_argument("--cpu-poses", type=int, default=0, help="CPU baseline sample size (0 = auto)")
@@ -248,6 +249,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Device power state: the first tens of milliseconds of load after process start run at lower clocks on part of the pool's boxes (a 20-step
+    # run after 5 warm-up steps: 236-248 k poses/s, after 20 or more: 252-255 k, same box, tools sweep in DESIGN.md section 5).  The
+    # --warmup steps the caller asks for stay what they are; these steps come before them, are never timed and are reported in the line.
+    for _ in range(max(0, args.burn_in)):
+        step()
     for w in range(args.warmup):
         # the first warm-up step is a timed one: the slot creates its HIP events (46 of them, several microseconds each) on first use, and
         # that belongs to the warm-up like every other first use, not into the timed region's sampled step
@@ -272,12 +278,16 @@ def main():
     api.profile_reset()
     fence()
     t0 = time.perf_counter()
+    marks = []
     for i in range(args.steps):
         if i == args.steps - n_samples and not args.sequential:
             api.set_option("profile", int(os.environ.get("PR_BENCH_SAMPLE_PROFILE", "3")))
         step()
+        marks.append(time.perf_counter() - t0)
     fence()
     elapsed = time.perf_counter() - t0
+    if os.environ.get("PR_BENCH_MARKS") and rank == 0:             # where a run's time went: cumulative ms after every step's submit + previous wait, and the closing fence
+        print("[bench] marks ms:", " ".join(f"{1e3 * m:.2f}" for m in marks), "| fence", f"{1e3 * (elapsed - marks[-1]):.2f}", file=sys.stderr, flush=True)
     host_cpu_s = time.process_time() - cpu0                          # CPU time of ALL threads of this process (timed region + the fence before it)
     sizes = last_sizes[0]
     api.set_option("profile", 0)
@@ -319,6 +329,7 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            "burn_in_steps": max(0, args.burn_in),                   # untimed, before the warm-up steps: device clocks up from idle
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True,
             "scaling": args.scaling,
