@@ -21,7 +21,9 @@
  * devices run side by side, which is how a C++ host drives N GPUs: one thread per device, pr_set_device(d) first.  Threads
  * that each refine their own hypotheses on the SAME device (the reference's usage, README.md:15 / icp.cu:170 per-thread
  * streams) call pr_thread_context(1) once to get a private context (own stream and workspaces) instead of queueing on the
- * shared one.  Options (pr_set_option) are process-wide.
+ * shared one (once per thread, for the thread's life: the runtime hands out hardware queues in the order streams are created, and a
+ * process that keeps creating and releasing contexts ends up with streams that share a queue -- two host-solve threads 235 k poses/s on
+ * fresh contexts, 154 k on the twelfth pair).  Options (pr_set_option) are process-wide.
  *
  * Caches and caller-owned memory.  Derived data is cached by the address of the buffers it was derived from: the packed copy
  * of a projective scene (pcd / normal arrays), the traversal records of a kd-tree scene (pcd / nodes arrays) and the model box
