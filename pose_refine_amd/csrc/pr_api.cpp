@@ -40,6 +40,7 @@ using prh::set_error;
         hipError_t e_ = (expr);                                                                 \
         if (e_ != hipSuccess) {                                                                 \
             set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            (void)hipGetLastError();          /* the runtime's sticky copy of this error must not be found by the next launch's check */ \
             return PR_ERR_HIP;                                                                  \
         }                                                                                       \
     } while (0)
@@ -1693,6 +1694,7 @@ int pr_memcpy_d2d(void *d, const void *s, size_t n) { return copy_sync(d, s, n, 
 int pr_fill_i32(int32_t *dev_dst, size_t count, int32_t value)
 {
     PR_ENTER();
+    if (!dev_dst && count) { set_error("pr_fill_i32: null destination"); return PR_ERR_INVALID; }
     g_writes.note(dev_dst, count * sizeof(int32_t));
     HIP_TRY(prk::launch_fill_i32(dev_dst, count, value, g->stream));
     HIP_TRY(hipStreamSynchronize(g->stream));

@@ -522,3 +522,20 @@ def test_host_solve_batches_from_two_threads_with_private_contexts(gpu, model, s
     finally:
         api.set_option("solve", api.SOLVE_DEVICE)
     assert not errs and not bad, (errs, len(bad))
+
+
+def test_misused_entry_points_return_codes_and_leave_no_trace(gpu):
+    """Null and foreign pointers, a double free, unknown options and slots: error codes (a null destination of pr_fill_i32 used to reach the
+    kernel and fault the GPU), and the call after a refused one works (the runtime's sticky copy of an error is not found by the next launch)."""
+    lib = _lib.load()
+    assert lib.pr_fill_i32(None, 10, 5) == -3
+    assert lib.pr_malloc(None, 16) == -3
+    host = np.zeros(16, np.float32)
+    assert lib.pr_memcpy_h2d(None, host.ctypes.data, 64) != 0          # refused by the runtime ...
+    d = api.DeviceVector(64, np.int32)
+    assert lib.pr_fill_i32(d.data(), 64, 7) == 0                          # ... and the next launch does not inherit that error
+    assert np.array_equal(d.to_host(), np.full(64, 7, np.int32))
+    q = C.c_void_p()
+    assert lib.pr_malloc(C.byref(q), 1024) == 0 and lib.pr_free(q) == 0 and lib.pr_free(q) != 0 and lib.pr_free(None) == 0
+    assert lib.pr_fill_i32(d.data(), 64, 9) == 0 and int(d.to_host()[0]) == 9
+    assert lib.pr_set_option(None, 1) == -3 and lib.pr_set_option(b"nonsense", 1) == -3 and lib.pr_refine_wait(7) == -3 and lib.pr_refine_wait(-1) == -3
