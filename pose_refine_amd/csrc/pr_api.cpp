@@ -872,7 +872,7 @@ bool frame_size_ok(size_t W, size_t H)
 int render_impl(const pr_triangle *tris_dev, size_t n_tris, const pr_mat4 *poses_host, size_t P, size_t W, size_t H,
                 const pr_mat4 *proj, pr_roi roi, int32_t *depth_dev, bool zero_empty)
 {
-    if ((!tris_dev && n_tris > 0) || !poses_host || !proj || !depth_dev || W == 0 || H == 0) { set_error("pr_render: bad arguments"); return PR_ERR_INVALID; }   // (an empty model has no array)
+    if ((!tris_dev && n_tris > 0) || (P && (!poses_host || !depth_dev)) || !proj || W == 0 || H == 0) { set_error("pr_render: bad arguments"); return PR_ERR_INVALID; }   // (an empty model has no array, no hypotheses need none)
     if (!frame_size_ok(W, H)) return PR_ERR_INVALID;
     size_t rw = W, rh = H;
     if (roi.width > 0 && roi.height > 0) {
@@ -1775,8 +1775,8 @@ int pr_scene_nn_prepare_dev(const void *depth_dev, int depth_is_i32, const float
 int pr_raw2depth_mask(const int32_t *raw_dev, size_t count, uint16_t *depth_host_out, uint8_t *mask_host_out)
 {
     PR_ENTER();
+    if (count == 0) return PR_OK;                                  // (an empty render stack has no array)
     if (!raw_dev || (!depth_host_out && !mask_host_out)) { set_error("pr_raw2depth_mask: bad arguments"); return PR_ERR_INVALID; }
-    if (count == 0) return PR_OK;
     if (depth_host_out) PR_TRY(g->conv16.ensure(count * sizeof(uint16_t) + 16));
     if (mask_host_out) PR_TRY(g->conv8.ensure(count + 16));
     HIP_TRY(prk::launch_raw2depth_mask(raw_dev, count, depth_host_out ? g->conv16.as<uint16_t>() : nullptr, mask_host_out ? g->conv8.as<uint8_t>() : nullptr, g->stream));
@@ -1791,7 +1791,15 @@ int pr_icp_batch(pr_vec3 *clouds_dev, const uint32_t *offsets_host, uint32_t n_c
                  pr_criteria crit, pr_result *results_host)
 {
     PR_ENTER();
-    if (!clouds_dev || !offsets_host || !results_host) { set_error("pr_icp_batch: bad arguments"); return PR_ERR_INVALID; }
+    if (!offsets_host || (n_clouds && !results_host)) { set_error("pr_icp_batch: bad arguments"); return PR_ERR_INVALID; }
+    if (n_clouds == 0) return PR_OK;
+    if (!clouds_dev) {                                            // clouds without a single point come without an array (an empty device_vector):
+        if (offsets_host[n_clouds] != offsets_host[0]) { set_error("pr_icp_batch: null cloud array"); return PR_ERR_INVALID; }
+        for (uint32_t i = 0; i < n_clouds; ++i) {                 // count == 0 -> identity, fitness 0, rmse 0 (icp.cu:183), like any empty cloud
+            identity16(results_host[i].T); results_host[i].fitness = 0.0f; results_host[i].inlier_rmse = 0.0f;
+        }
+        return PR_OK;
+    }
     SceneSel sc;
     std::memset(static_cast<void *>(&sc), 0, sizeof sc);
     PR_TRY(make_scene(scene_kind, scene, /*want_packed=*/false, sc));

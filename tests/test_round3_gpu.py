@@ -539,3 +539,28 @@ def test_misused_entry_points_return_codes_and_leave_no_trace(gpu):
     assert lib.pr_malloc(C.byref(q), 1024) == 0 and lib.pr_free(q) == 0 and lib.pr_free(q) != 0 and lib.pr_free(None) == 0
     assert lib.pr_fill_i32(d.data(), 64, 9) == 0 and int(d.to_host()[0]) == 9
     assert lib.pr_set_option(None, 1) == -3 and lib.pr_set_option(b"nonsense", 1) == -3 and lib.pr_refine_wait(7) == -3 and lib.pr_refine_wait(-1) == -3
+
+
+def test_empty_inputs_come_without_arrays(gpu, model, scenario, gscenes):
+    """What an empty device_vector hands over is a null pointer and a zero count: a render of no hypotheses, a cloud of no points (alone, in a
+    list of such, a list of none), an empty render stack for raw2depth -- the reference's answers (nothing / the identity with fitness 0,
+    icp.cu:183), not 'bad arguments'."""
+    e0 = np.zeros((0, 16), np.float32)
+    assert api.render(model, e0, W, H, scenario["proj"]).size() == 0
+    assert api.render_host(model, e0, W, H, scenario["proj"]).shape == (0, H, W)
+    crit = api.ICPConvergenceCriteria(0.0, 0.0, 3)
+    try:
+        for solve in (api.SOLVE_HOST, api.SOLVE_DEVICE):
+            api.set_option("solve", solve)
+            for sc in (gscenes["proj"], gscenes["nn"]):
+                r = api.ICP_Point2Plane(api.DeviceVector(0, np.float32), sc, crit)
+                assert r.fitness_ == 0.0 and r.inlier_rmse_ == 0.0 and np.array_equal(r.transformation_, np.eye(4, dtype=np.float32))
+                res = api.ICP_Point2Plane_batch(api.DeviceVector(0, np.float32), np.zeros(4, np.uint32), sc, crit)
+                assert len(res) == 3 and not res["fitness"].any() and all(np.array_equal(t.reshape(4, 4), np.eye(4, dtype=np.float32)) for t in res["T"])
+                assert len(api.ICP_Point2Plane_batch(api.DeviceVector(0, np.float32), np.zeros(1, np.uint32), sc, crit)) == 0
+                out = api.refine_batch(model, e0, W, H, scenario["proj"], scenario["K"], sc, crit)
+                assert len(out[0]) == 0 and len(out[1]) == 0
+    finally:
+        api.set_option("solve", api.SOLVE_DEVICE)
+    d16, m8 = api.raw2depth_mask(api.DeviceVector(0, np.int32))
+    assert d16.size == 0 and m8.size == 0
