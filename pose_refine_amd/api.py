@@ -307,6 +307,8 @@ def depth2cloud(depth_dev, width: int, height: int, K, stride: int = 1, tl_x: in
     ``depth_dev`` is a DeviceVector (or raw device address); offset_elems selects an image of a stack."""
     base = depth_dev.data() if isinstance(depth_dev, DeviceVector) else int(depth_dev)
     dt = np.dtype(dtype)
+    if isinstance(depth_dev, DeviceVector) and (offset_elems + width * height) * dt.itemsize > depth_dev.size() * depth_dev.dtype.itemsize:
+        raise ValueError(f"depth buffer of {depth_dev.size()} {depth_dev.dtype} values holds no {width} x {height} {dt} image at element {offset_elems}")
     k = _f32(K, -1)
     out, n = C.c_void_p(), C.c_uint32()
     fn = _lib.load().pr_depth2cloud_u16 if dt == np.uint16 else _lib.load().pr_depth2cloud_i32
@@ -462,6 +464,10 @@ def ICP_Point2Plane(model_pcd: DeviceVector, scene, criteria: ICPConvergenceCrit
 def ICP_Point2Plane_batch(clouds: DeviceVector, offsets, scene, criteria: ICPConvergenceCriteria = ICPConvergenceCriteria()) -> np.ndarray:
     """Many clouds against one scene (one launch per iteration).  offsets: P+1 point offsets."""
     offsets = np.ascontiguousarray(offsets, np.uint32)
+    if len(offsets) == 0:
+        raise ValueError("offsets: P + 1 point offsets (at least one)")
+    if int(offsets[-1]) * 3 > clouds.size():
+        raise ValueError(f"offsets end at point {int(offsets[-1])}, the cloud buffer holds {clouds.size() // 3}")
     res = np.zeros(len(offsets) - 1, RESULT)
     d = scene.desc()
     check(_lib.load().pr_icp_batch(clouds.data(), ptr(offsets), len(offsets) - 1, scene.kind, C.addressof(d), criteria.c(), ptr(res)))
