@@ -121,3 +121,19 @@ def test_cpp_host_shards_over_all_visible_gpus(golden_dir):
     assert r.returncode == 0, r.stdout + r.stderr
     got = json.loads(r.stdout[r.stdout.rindex("{"):])
     assert got["failures"] == 0 and got["devices"] >= 1 and got["mean_fitness"] > 0.3
+
+
+@pytest.mark.gpu
+def test_adapters_at_their_edges(golden_dir):
+    """No hypotheses, an image in which nothing is visible, clouds without points, holders that never held memory -- through the C++ adapters:
+    empty vectors and identity results (icp.cu:183), no error exit."""
+    from pose_refine_amd import build
+    build.build()
+    lib_dir = os.path.join(ROOT, "pose_refine_amd", "lib")
+    exe = os.path.join(ROOT, "tests", "cpp", "edge_cases_test")
+    subprocess.run(["g++", "-std=c++14", "-O2", "-Wall", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "edge_cases_test.cpp"),
+                    "-o", exe, "-L" + lib_dir, "-lpose_refine_hip", "-Wl,-rpath," + lib_dir], check=True)
+    out = subprocess.run([exe, golden_dir + "/"], check=True, capture_output=True, text=True).stdout
+    got = json.loads(out[out.index("{\"render_none\""):])
+    assert got["render_none"] == 0 and got["keep_none"] == 0 and got["empty_cloud"] == 0 and got["pose_renderer_none"] == 0
+    assert got["full_cloud"] > 20000 and got["identity"] == [1, 1, 1, 1] and got["full_fitness"] == 1.0
