@@ -712,6 +712,7 @@ void pr_shard_range(uint32_t n_items, uint32_t rank, uint32_t world, uint32_t *f
 {
     // contiguous blocks; the first (n % world) ranks take one extra item
     if (world == 0) world = 1;
+    if (rank >= world) { if (first) *first = n_items; if (count) *count = 0; return; }      // no such rank: an empty block behind the last one
     const uint32_t base = n_items / world, extra = n_items % world;
     const uint32_t f = rank * base + (rank < extra ? rank : extra);
     if (first) *first = f;

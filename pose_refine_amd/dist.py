@@ -15,6 +15,8 @@ def shard_bounds(n_items: int, rank: int, world: int) -> Tuple[int, int]:
     """Contiguous block of rank `rank`: (first, count); the first n_items % world ranks get one extra.
     Same rule as pr_shard_range in the C ABI."""
     world = max(1, world)
+    if rank >= world:
+        return n_items, 0                                          # no such rank: an empty block behind the last one
     base, extra = divmod(n_items, world)
     first = rank * base + min(rank, extra)
     return first, base + (1 if rank < extra else 0)
