@@ -46,7 +46,8 @@ VALU_PEAK = 256 * 4 * 2.4e9 / 4         # wave-instructions/s: 256 CUs x 4 SIMDs
 # destination/normal gather, + 12 B write-back on every pass after the first:
 # N*(21*36 + 20*12) = 996 N bytes per pose over 21 launches.
 BYTES_PER_POINT_PASS0, BYTES_PER_POINT_PASSK = 36.0, 48.0
-# Committed rocprofv3 PMC measurements of the correspondence kernel (bench.py cannot collect counters itself -- they need rocprofv3 passes
+# Committed rocprofv3 PMC measurements of the correspondence kernel: the fallback of live_pmc_traffic(), which collects the same two counters in
+# child passes of this run (counters need rocprofv3 passes
 # of their own): fabric-side bytes per point (FETCH_SIZE x2 per the gfx950 correction of MI355X_MICROARCH.md + WRITE_SIZE, both calibrated on
 # max2zero_kernel, which moves a known number of bytes) and VALU wave-instructions per point (SQ_INSTS_VALU).  FETCH_SIZE counts what the
 # L2s fetch from the fabric, Infinity-Cache hits included (guide, HBM section): the counter figure is FABRIC traffic, an upper bound of DRAM
