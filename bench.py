@@ -121,7 +121,7 @@ def main():
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="library option (pr_set_option), repeatable -- tuning runs")
     ap.add_argument("--blocking-wait", type=int, default=-1, help="1: pr_refine_wait sleeps instead of spinning (default: 1 when more than one rank shares the host, else 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--burn-in", type=int, default=25, help="untimed steps BEFORE the --warmup steps that bring the device's clocks up from idle (reported as burn_in_steps; 0 = none)")
+    ap.add_argument("--burn-in", type=int, default=0, help="experiments: untimed steps BEFORE the --warmup steps (device clocks up from idle; reported as burn_in_steps).  Default 0: W warm-up steps, K timed steps, nothing else")
     ap.add_argument("--no-live-pmc", action="store_true", help="roofline.traffic from the committed counter passes instead of two rocprofv3 --pmc passes run by this process (rank 0, N = 1)")
     ap.add_argument("--no-kdtree-extra", action="store_true", help="skip the short configs[2] (kd-tree association) measurement appended to the line")
     ap.add_argument("--cpu-poses", type=int, default=0, help="CPU baseline sample size (0 = auto)")
@@ -250,9 +250,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # Device power state: the first tens of milliseconds of load after process start run at lower clocks on part of the pool's boxes (a 20-step
-    # run after 5 warm-up steps: 236-248 k poses/s, after 20 or more: 252-255 k, same box, tools sweep in DESIGN.md section 5).  The
-    # --warmup steps the caller asks for stay what they are; these steps come before them, are never timed and are reported in the line.
+    # Device power state (experiments only, --burn-in N; default none): the first tens of milliseconds of load after process start run at lower
+    # clocks on part of the pool's boxes (a 20-step run after 5 warm-up steps: 236-248 k poses/s, after 20 or more: 252-255 k, same box,
+    # DESIGN.md section 5).  Such steps would come before the caller's --warmup steps, are never timed and are reported in the line.
     for _ in range(max(0, args.burn_in)):
         step()
     for w in range(args.warmup):
