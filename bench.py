@@ -430,7 +430,7 @@ def live_pmc_traffic(scene_kind):
                 cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", d, "-o", counter, "--", sys.executable, os.path.join(ROOT, "tools", "pmc_workload.py"), "256"]
                 if scene_kind != "proj":
                     cmd.append("nn")
-                r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+                r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=90)
                 for line in r.stdout.splitlines():
                     if line.startswith("points per batch:"):
                         points = int(line.split(":")[1])
