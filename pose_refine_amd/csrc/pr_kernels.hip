@@ -2317,6 +2317,9 @@ __global__ __launch_bounds__(256, PR_WIDE_WAVES) void nn_tree_wide_kernel(IcpBat
                 for (uint32_t i = 0; i < kPer; ++i) {
                     const bool v = r[i].w != kWideEmpty;
                     lb[i] = wide_box_lb(sx, sy, sz, r[i].x, r[i].y, r[i].z, scene);
+#ifdef PR_BOX_TWICE                                                 // experiment: what the box test's share of the step is (same result, computed twice)
+                    { float sx2 = sx; asm volatile("" : "+v"(sx2)); lb[i] = min_f32(lb[i], wide_box_lb(sx2, sy, sz, r[i].x, r[i].y, r[i].z, scene)); }
+#endif
                     keep[i] = v && lb[i] <= bnd;
                     leaf[i] = (r[i].w & kWideLeaf) != 0u;
                     if (v && !keep[i]) sec_l = min_f32(sec_l, lb[i]);
