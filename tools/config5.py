@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """BASELINE.json configs[4]: 1M-triangle synthetic mesh, 1280x720, per-GPU share of 1024 poses (128).
-Checks one pose against the CPU oracle (render + cloud + ICP) and times the batch."""
+Checks two poses against the CPU oracle (render + cloud + ICP) and times the batch.   tools/config5.py [poses] [--check] [--nn]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -20,7 +20,8 @@ proj = api.compute_proj(K, W, H)
 poses = synth.hypotheses(P)
 sd = api.render_host(model, synth.scene_pose()[None], W, H, proj)[0]
 print("scene valid px", int((sd > 0).sum()), "depth range", int(sd[sd > 0].min()), int(sd.max()))
-scene = api.Scene_projective().init_Scene_projective_cuda(sd, K, W, H)
+kd = "--nn" in sys.argv                                             # the same workload against the kd-tree scene (165 k scene points)
+scene = api.Scene_nn().init_Scene_nn_cuda(sd, K) if kd else api.Scene_projective().init_Scene_projective_cuda(sd, K, W, H)
 crit = api.ICPConvergenceCriteria(0.0, 0.0, 20)
 res, sizes = api.refine_batch(model, poses, W, H, proj, K, scene, crit)
 t0 = time.perf_counter(); n = 3
@@ -32,7 +33,7 @@ if check:
     oproj = O.compute_proj(K, W, H)
     osd = O.render(tris, synth.scene_pose()[None], W, H, oproj)[0]
     assert np.array_equal(osd, sd), "scene render differs from oracle"
-    oscene = O.ProjScene(sd, K)
+    oscene = O.NNScene(sd, K) if kd else O.ProjScene(sd, K)
     ores, osizes, _ = O.refine_batch(tris, poses[:2], W, H, oproj, K, oscene, (0.0, 0.0, 20), O.SUM_CANONICAL, api.get_option("points_per_block"))
     assert np.array_equal(osizes, sizes[:2]), (osizes, sizes[:2])
     assert np.array_equal(ores["fitness"], res["fitness"][:2]), (ores["fitness"], res["fitness"][:2])
