@@ -54,6 +54,12 @@ BYTES_PER_POINT_PASS0, BYTES_PER_POINT_PASSK = 36.0, 48.0
 # traffic -- with <= 512 hypotheses per sub-batch the clouds are Infinity-Cache resident by design.
 PMC_TRAFFIC_BYTES_PER_POINT = {"proj": 25.2, "nn": 69.0}       # P = 1024 as ONE sub-batch (clouds spill the Infinity Cache): 23.9 B/point -- the same: it is the cloud read + write-back
 PMC_VALU_WAVE_INSTR_PER_POINT = {"proj": 2.085, "nn": None}
+# what DRAM carries when the clouds do NOT fit the Infinity Cache (1024 hypotheses as one sub-batch): committed fallback of the run's own passes
+PMC_DRAM_FRAC = {"proj": 0.46, "nn": None}
+PMC_DRAM_SOURCE = "committed: profiles/r03/pmc_proj_p1024_onebatch_*.md + kernel_stats_p1024_onebatch.md (537 MB per 147.1 us launch = 3.65 TB/s)"
+# committed SQ counter pass of the kd-tree task walk (profiles/r03/sq_nn_SQ_ACTIVE_INST_VALU_SQ_WAVE_CYCLES_SQ_WAIT_INST_ANY.md): share of wave-cycles with a VALU instruction active
+NN_WALK_VALU_ACTIVE_FRAC = 0.27
+NN_WALK_HBM_BYTES_PER_POINT = 4.9                                  # profiles/r03/pmc_nn_*.md: the walk reads queue entries + cloud points, writes winners
 PMC_TRAFFIC_SOURCE = {"proj": "profiles/r03/pmc_proj_FETCH_SIZE.md + pmc_proj_WRITE_SIZE.md + sq_proj_SQ_INSTS_VALU*.md (icp_pass_kernel<SceneProjPacked>)",
                       "nn": "profiles/r03/pmc_nn_FETCH_SIZE.md + pmc_nn_WRITE_SIZE.md (search 39.7 + bound 6.3 + task walk 4.9 + winners pass 18.1 B/point)"}
 
@@ -100,15 +106,91 @@ def flush_c_stdio():
         pass
 
 
-def main():
+# ---- the job's control plane: barrier, max over ranks, small objects to everybody ------------------------------------------------
+class SoloGroup:
+    """One rank."""
+    world, rank, kind = 1, 0, "solo"
+
+    def barrier(self):
+        pass
+
+    def all_gather(self, obj):
+        return [obj]
+
+    def destroy(self):
+        pass
+
+
+class TorchGroup:
+    """One process per GPU (the contract's launch): torch.distributed on RCCL, gloo when the ranks share one device (test mode)."""
+    kind = "processes"
+
+    def __init__(self, rank, world, local_rank, share_device):
+        import torch
+        import torch.distributed as dist
+        self.dist, self.world, self.rank = dist, world, rank
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if share_device:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    def barrier(self):
+        self.dist.barrier()
+
+    def all_gather(self, obj):
+        out = [None] * self.world
+        self.dist.all_gather_object(out, obj)
+        return out
+
+    def destroy(self):
+        self.dist.barrier()
+        self.dist.destroy_process_group()
+
+
+class ThreadGroup:
+    """One process, one host thread per GPU (SURVEY 8e's launcher-free form, tests/cpp/shard_test.cpp in C++): the ranks meet at a
+    threading.Barrier and exchange small objects through a shared list."""
+    kind = "threads"
+
+    class Shared:
+        def __init__(self, world):
+            import threading
+            self.world, self.bar, self.box = world, threading.Barrier(world), [None] * world
+
+    def __init__(self, shared, rank):
+        self.sh, self.world, self.rank = shared, shared.world, rank
+
+    def barrier(self):
+        self.sh.bar.wait()
+
+    def all_gather(self, obj):
+        self.sh.box[self.rank] = obj
+        self.sh.bar.wait()
+        out = list(self.sh.box)
+        self.sh.bar.wait()
+        return out
+
+    def destroy(self):
+        pass
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=1, help="ranks of the job, one per GPU.  Without WORLD_SIZE in the environment and N > 1 this process "
+                                                          "starts the N ranks itself (--launcher)")
+    ap.add_argument("--launcher", choices=["processes", "threads"], default=os.environ.get("PR_BENCH_LAUNCHER", "processes"),
+                    help="how `bench.py --gpus N` (N > 1, no WORLD_SIZE) starts its ranks: processes = re-run under torch.distributed.run "
+                         "(one process per GPU, the contract's form); threads = one process, one host thread per GPU, pr_comm_init_all")
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--poses", type=int, default=256, help="hypotheses per GPU per step (weak scaling)")
     ap.add_argument("--global-poses", type=int, default=0, help="hypotheses per step over ALL GPUs (0: --poses x GPUs); BASELINE configs[3] = 4096 on 8 GPUs")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: per-GPU batch fixed (--poses, or --global-poses / N); strong: the global batch is fixed (--global-poses, default 4096) and split over the ranks")
+    ap.add_argument("--gather", choices=["job", "step"], default="job",
+                    help="N > 1: job = ONE exchange of all K x P result records after the last step (north_star's single gather); step = one exchange per step, under the next step")
+    ap.add_argument("--no-config3", action="store_true", help="N > 1: skip the BASELINE configs[3] measurement (4096 hypotheses over the N ranks) appended to the line")
     ap.add_argument("--scene", choices=["proj", "nn"], default="proj")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--solve", choices=["host", "device"], default=os.environ.get("PR_BENCH_SOLVE", "device"))
@@ -118,29 +200,126 @@ def main():
     ap.add_argument("--sequential", action="store_true",
                     help="every step through the synchronous single-group path with HIP events around EVERY correspondence launch "
                          "(profile 1): the mode in which rocprofv3's per-launch average and the event average measure the same thing")
+    ap.add_argument("--sample-in", choices=["after", "warmup", "timed"], default="after",
+                    help="where the roofline sample (one step with HIP events around every correspondence launch, its loop alone on the chip) is taken: "
+                         "after = one more, untimed step behind the closing fence of the timed region (default: the timed region holds pipelined steps only and "
+                         "the device is as warm as it gets); warmup = the last warm-up step; timed = the last step of the timed region (rounds 1-3)")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="library option (pr_set_option), repeatable -- tuning runs")
     ap.add_argument("--blocking-wait", type=int, default=-1, help="1: pr_refine_wait sleeps instead of spinning (default: 1 when more than one rank shares the host, else 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--burn-in", type=int, default=0, help="experiments: untimed steps BEFORE the --warmup steps (device clocks up from idle; reported as burn_in_steps).  Default 0: W warm-up steps, K timed steps, nothing else")
-    ap.add_argument("--no-live-pmc", action="store_true", help="roofline.traffic from the committed counter passes instead of two rocprofv3 --pmc passes run by this process (rank 0, N = 1)")
+    ap.add_argument("--no-live-pmc", action="store_true", help="roofline.traffic from the committed counter passes instead of rocprofv3 --pmc passes run by this process (rank 0, N = 1)")
     ap.add_argument("--no-kdtree-extra", action="store_true", help="skip the short configs[2] (kd-tree association) measurement appended to the line")
     ap.add_argument("--cpu-poses", type=int, default=0, help="CPU baseline sample size (0 = auto)")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def visible_devices():
+    """GPUs this process can see (through the library: pr_device_count; no torch needed)."""
+    from pose_refine_amd import api
+    return int(api.device_count())
+
+
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def check_device_budget(n_ranks, n_visible, share_device):
+    """`--gpus N` needs N devices -- unless PR_BENCH_SHARE_DEVICE=1 (test mode for one-GPU boxes: every rank on device 0)."""
+    if n_ranks > n_visible and not share_device:
+        raise SystemExit(f"bench.py --gpus {n_ranks}: only {n_visible} GPU(s) visible.  Run on a node with {n_ranks} GPUs, or set PR_BENCH_SHARE_DEVICE=1 "
+                         "(test mode: every rank uses device 0 and the gather runs on host copies) to exercise the N > 1 path on this box.")
+
+
+def launch_command(n_ranks, port, argv):
+    """The contract's launch line for N ranks on one node, for `bench.py <argv>`."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def has_result_line(text):
+    return any(l.startswith('{"metric"') for l in text.splitlines())
+
+
+def spawn_processes(args, argv):
+    """`python bench.py --gpus N` with no WORLD_SIZE: start the N ranks (one process per GPU) under torch.distributed.run and pass their
+    line through.  If that launch produces no line (no free port, torchrun missing, a rendezvous failure), the same job is run as N host
+    threads of this process (--launcher threads) and the line says so."""
+    import subprocess
+    cmd = launch_command(args.gpus, free_port(), argv)
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    env["PR_BENCH_LAUNCHED_BY"] = "bench.py (torch.distributed.run started by `bench.py --gpus N`)"
+    print("[bench] starting", " ".join(cmd[1:8]), "...", file=sys.stderr, flush=True)
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    if r.returncode == 0 and has_result_line(r.stdout):
+        sys.stdout.write(r.stdout)
+        sys.stdout.flush()
+        return 0
+    sys.stderr.write(r.stdout)
+    print(f"[bench] torch.distributed.run ended with code {r.returncode} and no result line; running the {args.gpus} ranks as host threads of this process", file=sys.stderr, flush=True)
+    return run_threads(args, note=f"torch.distributed.run failed (exit code {r.returncode}); fell back to --launcher threads")
+
+
+def run_threads(args, note=None):
+    """One process, one host thread per GPU: pr_comm_init_all(N), pr_set_device(d) per thread, contiguous shards, pr_gather_results."""
+    import threading
+    import torch                                                    # noqa: F401 -- first, so that torch's HIP runtime is the one in the process
+    from pose_refine_amd import api
+    n = args.gpus
+    share_device = os.environ.get("PR_BENCH_SHARE_DEVICE", "0") == "1"
+    check_device_budget(n, visible_devices(), share_device)
+    api.init(0)
+    comm_note = None
+    if not share_device and os.environ.get("PR_BENCH_GATHER", "cabi") != "host":
+        try:
+            api.comm_init_all(n)                                    # ncclCommInitAll: one communicator per device context
+        except Exception as e:                                      # noqa: BLE001 -- the measurement goes on with a host gather
+            comm_note = f"pr_comm_init_all({n}) failed: {e}"
+    shared = ThreadGroup.Shared(n)
+    outs, errs = [None] * n, [None] * n
+
+    def work(rank):
+        try:
+            outs[rank] = run_rank(args, ThreadGroup(shared, rank), local_dev=0 if share_device else rank, share_device=share_device,
+                                  launcher_note=note, comm_ready=(comm_note is None and not share_device), comm_note=comm_note)
+        except BaseException as e:                                  # noqa: BLE001
+            import traceback
+            errs[rank] = "".join(traceback.format_exception(type(e), e, e.__traceback__))
+            shared.bar.abort()
+    ts = [threading.Thread(target=work, args=(r,)) for r in range(n)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    bad = [e for e in errs if e and "BrokenBarrierError" not in e] or [e for e in errs if e]
+    if bad:
+        sys.stderr.write(bad[0])
+        return 1
+    flush_c_stdio()
+    print(json.dumps(outs[0]), flush=True)
+    return 0
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:            # `python bench.py --gpus N`: this process starts the ranks
+        if args.launcher == "threads":
+            return run_threads(args)
+        check_device_budget(args.gpus, visible_devices(), os.environ.get("PR_BENCH_SHARE_DEVICE", "0") == "1")
+        return spawn_processes(args, argv)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and "WORLD_SIZE" in os.environ and world > 1:
+        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE = {world}: the launcher's world size is used", file=sys.stderr, flush=True)
     # PR_BENCH_FORCE_COMM=1 (test mode for one-GPU boxes): run the whole N > 1 machinery -- process group on the RCCL backend, C-ABI communicator,
-    # pr_gather_results per step -- with a world of ONE rank, so that torch's RCCL and the library's use of it meet in one process
+    # the gather -- with a world of ONE rank, so that torch's RCCL and the library's use of it meet in one process
     multi = world > 1 or os.environ.get("PR_BENCH_FORCE_COMM", "0") == "1"
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-
-    # torch first: its bundled HIP runtime must be the one both torch and libpose_refine_hip.so use
-    import torch
-    import torch.distributed as dist
-    import numpy as np
-    from pose_refine_amd import api, synth
-    from pose_refine_amd import dist as prd
-
+    import torch                                                    # torch first: its bundled HIP runtime must be the one both torch and libpose_refine_hip.so use
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     # PR_BENCH_SHARE_DEVICE=1 is a TEST mode for boxes with one GPU: every rank uses device 0 and the gather runs over
@@ -148,33 +327,54 @@ def main():
     share_device = os.environ.get("PR_BENCH_SHARE_DEVICE", "0") == "1"
     if share_device:
         local_rank = 0
+    if multi and not share_device and local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: local rank {local_rank} but only {torch.cuda.device_count()} GPU(s) visible (PR_BENCH_SHARE_DEVICE=1 lets ranks share device 0: test mode)")
     torch.cuda.set_device(local_rank)
-    if multi:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    group = TorchGroup(rank, world, local_rank, share_device) if multi else SoloGroup()
+    out = run_rank(args, group, local_dev=local_rank, share_device=share_device, launcher_note=None, comm_ready=False, comm_note=None, force_multi=multi)
+    if out is not None:
+        flush_c_stdio()
+        print(json.dumps(out), flush=True)
+    group.destroy()
+    return 0
+
+
+def run_rank(args, group, local_dev, share_device, launcher_note, comm_ready, comm_note, force_multi=False):
+    """Everything one rank does; rank 0 returns the line (a dict), the others None."""
+    import numpy as np
+    from pose_refine_amd import api, synth
+    from pose_refine_amd import dist as prd
+
+    world, rank = group.world, group.rank
+    multi = world > 1 or force_multi
+    threads_mode = group.kind == "threads"
+    if threads_mode:
+        api.set_device(local_dev)
         if share_device:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    api.init(local_rank)
-    # the gather of the solved transforms: C ABI (RCCL directly) unless told otherwise or the communicator cannot be formed
-    gather_mode = "torch" if (share_device or os.environ.get("PR_BENCH_GATHER", "cabi") == "torch") else "cabi"
-    gather_note = None
-    if multi and gather_mode == "cabi":
+            api.thread_context(True)                                # ranks sharing device 0: a private context (stream, workspaces, slots) each
+    else:
+        api.init(local_dev)
+    # the gather of the solved transforms: C ABI (RCCL directly) unless told otherwise or the communicator cannot be formed;
+    # ranks that share one device (test mode) exchange host copies through the control plane
+    want = os.environ.get("PR_BENCH_GATHER", "cabi")
+    gather_mode = "host" if (share_device or want == "host") else ("torch" if (want == "torch" and not threads_mode) else "cabi")
+    gather_note = comm_note
+    if multi and gather_mode == "cabi" and threads_mode and not comm_ready:
+        gather_mode = "host"
+    if multi and gather_mode == "cabi" and not threads_mode:
         try:
-            ident = [api.comm_id() if rank == 0 else None]
-            dist.broadcast_object_list(ident, src=0)               # 128 bytes, once
-            api.comm_init_rank(ident[0], rank, world)
+            ident = group.all_gather(api.comm_id() if rank == 0 else None)[0]    # 128 bytes, once
+            api.comm_init_rank(ident, rank, world)
         except Exception as e:                                     # noqa: BLE001 -- a failed bootstrap must not cost the measurement
             print(f"[bench] rank {rank}: C-ABI communicator unavailable ({e}); falling back to torch.distributed.gather", file=sys.stderr, flush=True)
             gather_mode = "torch"
             gather_note = f"C-ABI bootstrap failed on rank {rank}: {e}"
-        notes = [None] * world
-        dist.all_gather_object(notes, gather_note)
+        notes = group.all_gather(gather_note)
         if any(notes):                                             # one rank without a communicator: every rank uses torch's gather, and the line says why
             gather_mode = "torch"
             gather_note = "; ".join(n for n in notes if n)
     if multi:
-        dist.barrier()                                              # every rank's communicators exist (and have printed what they print)
+        group.barrier()                                             # every rank's communicators exist (and have printed what they print)
     flush_c_stdio()
     api.set_option("blocking_wait", (1 if world > 1 else 0) if args.blocking_wait < 0 else args.blocking_wait)
     api.set_option("solve", api.SOLVE_DEVICE if args.solve == "device" else api.SOLVE_HOST)
@@ -187,225 +387,319 @@ def main():
         api.set_option(name, int(value))
 
     W, H, K = synth.WIDTH, synth.HEIGHT, synth.K_TEST
-    # this rank's shard: contiguous hypotheses [first, first + P) of the seeded stream (prd.shard_bounds == pr_shard_range of the C ABI)
-    if args.scaling == "strong":
-        global_poses = args.global_poses or 4096
-    else:
-        global_poses = args.global_poses or args.poses * world
-    first, P = prd.shard_bounds(global_poses, rank, world)
-    P_max = prd.shard_bounds(global_poses, 0, world)[1]
-    if P == 0:
-        raise SystemExit(f"rank {rank}: empty shard ({global_poses} hypotheses over {world} ranks)")
     model = api.Model(os.path.join(ROOT, "tests", "golden", "obj_06.ply"))
     proj = api.compute_proj(K, W, H)
     scene_depth = api.render_host(model, synth.scene_pose()[None], W, H, proj)[0]
     scene = (api.Scene_projective().init_Scene_projective_cuda(scene_depth, K) if args.scene == "proj"
              else api.Scene_nn().init_Scene_nn_cuda(scene_depth, K))
-    poses = synth.hypotheses(P, seed=6, first=first)             # this rank's shard of the global batch
     crit = api.ICPConvergenceCriteria(0.0, 0.0, args.iters)
+    sample_profile = int(os.environ.get("PR_BENCH_SAMPLE_PROFILE", "3"))
 
-    # P x RegistrationResult (72 B) on the device, double-buffered.  Step k is SUBMITTED on slot k&1 (everything enqueued, no
-    # host round trip) and only then is step k-1 waited for and its results handed to the gather -- the GPU always has the
-    # next batch queued, and the gather of step k-1 (RCCL's stream) overlaps step k.
-    results = [torch.zeros(P * 18, dtype=torch.float32, device="cuda") for _ in range(2)]
-    gathered = [torch.zeros(global_poses * 18, dtype=torch.float32, device="cuda") for _ in range(2)] if (multi and rank == 0 and gather_mode == "cabi") else [None, None]
-    pending = [None, None]                                       # gather handle per buffer
-    inflight = [False, False]                                    # submitted, not yet waited for
-    step_no = [0]
-    last_sizes = [None]
+    class Job:
+        """K steps of one global batch size: this rank's contiguous shard [first, first + P) of the seeded hypothesis stream
+        (prd.shard_bounds == pr_shard_range of the C ABI), refined through the two asynchronous slots -- step k is SUBMITTED on slot k & 1
+        (everything enqueued, no host round trip) and only then is step k-1 waited for -- with the results of step k going to record
+        block k of one device buffer.  The gather: ONE exchange of all K x P records after the last step (`job`), or one per step enqueued
+        behind its batch and overlapped with the next (`step`)."""
 
-    def retire(b):
-        if not inflight[b]:
-            return
-        _, sizes = api.refine_wait(b)
-        inflight[b] = False
-        last_sizes[0] = sizes
-        if multi and gather_mode == "cabi":                 # the single RCCL exchange of the job: P x 72 B per rank to rank 0,
-            api.gather_results(results[b].data_ptr(), P, global_poses, 0,   # enqueued on the library's stream behind this batch
-                               gathered[b].data_ptr() if rank == 0 else None)
-        elif multi:
-            pending[b] = prd.gather_results(results[b].cpu() if share_device else results[b], world, rank, dst=0, max_count=P_max, async_op=True)
+        def __init__(self, global_poses, steps, gather_when):
+            self.global_poses, self.steps = global_poses, max(1, steps)
+            self.first, self.P = prd.shard_bounds(global_poses, rank, world)
+            self.P_max = prd.shard_bounds(global_poses, 0, world)[1]
+            if self.P == 0:
+                raise SystemExit(f"rank {rank}: empty shard ({global_poses} hypotheses over {world} ranks)")
+            self.poses = synth.hypotheses(self.P, seed=6, first=self.first)
+            self.gather_when = gather_when
+            self.gather_why = None
+            if multi and gather_when == "job" and global_poses % world != 0:
+                # the K x P blocks of uneven shards are not the shards of K x global records: exchange per step instead
+                self.gather_when, self.gather_why = "step", f"{global_poses} hypotheses do not divide over {world} ranks evenly: one exchange per step"
+            self.res = api.DeviceVector(self.steps * self.P * 18, np.float32)           # K blocks of P x RegistrationResult (72 B)
+            n_recv = self.steps * global_poses if self.gather_when == "job" else 2 * global_poses
+            self.recv = api.DeviceVector(n_recv * 18, np.float32) if (multi and rank == 0 and gather_mode == "cabi") else None
+            self.inflight = [None, None]                              # slot -> step index submitted, not yet waited for
+            self.k = 0
+            self.last_sizes = None
+            self.gathers = 0
+            self.host_gathered = None
 
-    def step():
-        b = step_no[0] & 1
-        step_no[0] += 1
-        if pending[b] is not None:                              # buffer b was handed to a gather two steps ago
-            pending[b].wait()
-            torch.cuda.current_stream().synchronize()
-            pending[b] = None
-        api.refine_submit(b, model, poses, W, H, proj, K, scene, crit, results_dev=results[b].data_ptr())
-        inflight[b] = True
-        retire(1 - b)
+        def block(self, k):
+            return self.res.data() + (k % self.steps) * self.P * 72
 
-    def fence():
-        for b in (0, 1):
-            retire(b)
-        for b in (0, 1):
-            if pending[b] is not None:
-                pending[b].wait()
-                pending[b] = None
-        if multi and gather_mode == "cabi":
-            api.sync()                                           # the library stream carries the gathers
-        if multi:
-            dist.barrier()
-        torch.cuda.synchronize()
+        def exchange(self, send_ptr, n_local, n_total, recv_slot=0):
+            """One gather of n_local records per rank to rank 0."""
+            self.gathers += 1
+            if gather_mode == "cabi":
+                api.gather_results(send_ptr, n_local, n_total, 0, (self.recv.data() + recv_slot * n_total * 72) if rank == 0 else None)
+            elif gather_mode == "torch":
+                import torch
+                api.sync()
+                t = torch.empty(n_local * 18, dtype=torch.float32, device="cuda")
+                api._lib.check(api._lib.load().pr_memcpy_d2d(t.data_ptr(), send_ptr, n_local * 72))
+                prd.gather_results(t, world, rank, dst=0, max_count=max(prd.shard_bounds(n_total, r, world)[1] for r in range(world)))
+            else:                                                    # ranks share one device (test mode): host copies through the control plane
+                api.sync()
+                h = np.empty(n_local * 18, np.float32)
+                api._lib.check(api._lib.load().pr_memcpy_d2h(api.ptr(h), send_ptr, h.nbytes))
+                parts = group.all_gather(h)
+                if rank == 0:
+                    self.host_gathered = np.concatenate(parts)
 
-    # Device power state (experiments only, --burn-in N; default none): the first tens of milliseconds of load after process start run at lower
-    # clocks on part of the pool's boxes (a 20-step run after 5 warm-up steps: 236-248 k poses/s, after 20 or more: 252-255 k, same box,
-    # DESIGN.md section 5).  Such steps would come before the caller's --warmup steps, are never timed and are reported in the line.
-    for _ in range(max(0, args.burn_in)):
-        step()
-    for w in range(args.warmup):
-        # the first warm-up step is a timed one: the slot creates its HIP events (46 of them, several microseconds each) on first use, and
-        # that belongs to the warm-up like every other first use, not into the timed region's sampled step
-        if w == 0 and not args.sequential:
-            api.set_option("profile", int(os.environ.get("PR_BENCH_SAMPLE_PROFILE", "3")))
-        step()
-        if w == 0 and not args.sequential:
+        def retire(self, b):
+            k = self.inflight[b]
+            if k is None:
+                return
+            _, sizes = api.refine_wait(b)
+            self.inflight[b] = None
+            self.last_sizes = sizes
+            if multi and self.gather_when == "step":              # enqueued on the library's stream behind this batch (cabi), under the next step
+                self.exchange(self.block(k), self.P, self.global_poses, recv_slot=k & 1)
+
+        def step(self):
+            b = self.k & 1
+            api.refine_submit(b, model, self.poses, W, H, proj, K, scene, crit, results_dev=self.block(self.k))
+            self.inflight[b] = self.k
+            self.k += 1
+            self.retire(1 - b)
+
+        def fence(self, gather=True):
+            for b in (0, 1):
+                self.retire(b)
+            if multi and gather and self.gather_when == "job":  # the job's single exchange: every record of the K steps, 72 B each
+                self.exchange(self.res.data(), self.steps * self.P, self.steps * self.global_poses)
+            api.sync()                                           # the library stream carries the batches and the gathers
+            if multi:
+                group.barrier()
+
+        def sample(self):
+            """One step with HIP events around every correspondence launch, its loop alone on the chip (option profile = 3)."""
+            api.set_option("profile", sample_profile)
+            self.step()
+            self.fence(gather=False)
             api.set_option("profile", 0)
+
+        def run(self, warmup, burn_in=0, sample_in="warmup", sequential=False, marks_out=None):
+            """`warmup` untimed steps, then exactly `steps` timed ones between two fences (barrier + device drained on both sides).
+            Returns (elapsed seconds, profile of the sampled launches or None, launch durations of the sample)."""
+            prof, launches_us = None, None
+            for _ in range(max(0, burn_in)):
+                self.step()
+            if not sequential:
+                api.profile_reset()
+            for w in range(warmup):
+                # the first warm-up step is a timed one: a slot creates its HIP events (46 of them, several microseconds each) on first use, and
+                # that belongs to the warm-up like every other first use.  The LAST warm-up step is the roofline sample (--sample-in warmup).
+                if sequential or sample_in is None:
+                    self.step()
+                elif w == warmup - 1 and sample_in == "warmup":
+                    self.fence(gather=False)
+                    api.profile_reset()
+                    self.sample()
+                    prof, launches_us = api.profile_read(), api.profile_launches()
+                elif w == 0:
+                    self.sample()
+                else:
+                    self.step()
+            api.set_option("profile", 1 if sequential else 0)
+            if sequential or prof is None:
+                api.profile_reset()
+            self.fence()                                             # also warms the job's exchange up
+            self.k = 0
+            self.gathers = 0
+            t0 = time.perf_counter()
+            for i in range(self.steps):
+                if prof is None and sample_in in ("timed", "warmup") and not sequential and i == self.steps - 1:
+                    api.set_option("profile", sample_profile)        # --sample-in timed (or no warm-up step to sample): the last timed step
+                self.step()
+                if marks_out is not None:
+                    marks_out.append(time.perf_counter() - t0)
+            self.fence()
+            elapsed = time.perf_counter() - t0
+            api.set_option("profile", 0)
+            if sequential:
+                prof, launches_us = api.profile_read(), api.profile_launches()
+                self.sampled_in = "every step (--sequential)"
+            elif sample_in == "after":
+                api.profile_reset()
+                self.sample()                                        # one more step, untimed: same batch, same kernels and arguments as every timed step
+                prof, launches_us = api.profile_read(), api.profile_launches()
+                self.sampled_in = "after (one untimed step behind the timed region's closing fence)"
+            elif prof is None:
+                prof, launches_us = api.profile_read(), api.profile_launches()
+                self.sampled_in = "timed region (its last step)"
+            else:
+                self.sampled_in = "warmup (the last warm-up step)"
+            return elapsed, prof, launches_us
+
+    def over_ranks(elapsed, steps):
+        """max over ranks of the elapsed time, and every rank's own ms per step"""
+        mine = 1e3 * elapsed / steps
+        if not multi:
+            return elapsed, [mine]
+        both = group.all_gather((elapsed, mine))
+        return max(e for e, _ in both), [m for _, m in both]
+
+    if args.scaling == "strong":
+        global_poses = args.global_poses or 4096
+    else:
+        global_poses = args.global_poses or args.poses * world
+    job = Job(global_poses, args.steps, args.gather)
+    P, P_max = job.P, job.P_max
     cpu0 = time.process_time()
-    # Roofline samples: the LAST n_samples steps of the timed region run with profile 3 -- as one pose group, their loop starting when the
-    # other slot's batch is complete, HIP events around every correspondence launch -- so that the timed launches have the chip to
-    # themselves.  Such a step costs more than a pipelined one (its loop overlaps with nothing) and counts against `value`; at the end of the
-    # region the drain it needs is the drain the closing fence needs anyway (sampled in the middle, every sample also cost an empty
-    # pipeline afterwards: -3 % at 100 steps, -6 % at the driver's 20).  The batch itself stays asynchronous (its render runs under the previous
-    # step's loop, no host round trip): against the synchronous timed call of profile 1 that is +1-5 % at 20 steps, and it keeps the
-    # synchronous path's first-use allocations (hundreds of MB, 1-8 ms depending on the box) out of the timed region.  One sampled step
-    # (21 launches): the very last one, whose tail has nothing left to overlap with anyway.
-    # (one step: a timed loop that has another submitted batch waiting behind it on the other slot's queue runs its launches 2-3 us slower
-    # -- 41.1 / 41.0 / 42.0 / 38.7 us over four consecutive timed steps, only the last of which has nothing queued behind it)
-    n_samples = min(args.steps, 1)
-    api.set_option("profile", 1 if args.sequential else 0)
-    api.profile_reset()
-    fence()
-    t0 = time.perf_counter()
     marks = []
-    for i in range(args.steps):
-        if i == args.steps - n_samples and not args.sequential:
-            api.set_option("profile", int(os.environ.get("PR_BENCH_SAMPLE_PROFILE", "3")))
-        step()
-        marks.append(time.perf_counter() - t0)
-    fence()
-    elapsed = time.perf_counter() - t0
+    # Roofline sample: ONE step with profile 3 -- an asynchronous batch like every other (its render runs under the previous step's loop, no
+    # host round trip), but its loop runs as one pose group, starts when the other slot's batch is complete and carries HIP events around
+    # every correspondence launch, so the timed launches have the chip to themselves.  By default it is ONE MORE STEP BEHIND the timed region's
+    # closing fence: the same batch, the same kernels and arguments as every timed step, without its exclusive loop (which overlaps with
+    # nothing: ~0.5 ms) counting against `value` -- a 20-step region is 21 ms -- and on a device that has been under load for the whole run
+    # (sampled in the last warm-up step, 5 ms after the first launch, the same launches read 41.9 instead of 39.2 us: clocks still coming up).
+    # --sample-in timed puts it back into the timed region (its last step, as in rounds 1-3), --sample-in warmup into the last warm-up step.
+    elapsed, prof, launches_us = job.run(args.warmup, burn_in=args.burn_in, sample_in=args.sample_in, sequential=args.sequential, marks_out=marks)
     if os.environ.get("PR_BENCH_MARKS") and rank == 0:             # where a run's time went: cumulative ms after every step's submit + previous wait, and the closing fence
         print("[bench] marks ms:", " ".join(f"{1e3 * m:.2f}" for m in marks), "| fence", f"{1e3 * (elapsed - marks[-1]):.2f}", file=sys.stderr, flush=True)
-    host_cpu_s = time.process_time() - cpu0                          # CPU time of ALL threads of this process (timed region + the fence before it)
-    sizes = last_sizes[0]
-    api.set_option("profile", 0)
-    prof = api.profile_read()
-
+    host_cpu_s = time.process_time() - cpu0                          # CPU time of ALL threads of this process (warm-up + timed region)
+    wall_s = elapsed
+    sizes = job.last_sizes
+    gathers_timed = job.gathers
     gather_ms, gather_n = (api.gather_profile() if (multi and gather_mode == "cabi") else (0.0, 0))
-    per_rank_ms = [1e3 * elapsed / args.steps]
-    if multi:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share_device else "cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        mine = 1e3 * elapsed / args.steps
-        per_rank_ms = [None] * world
-        dist.all_gather_object(per_rank_ms, mine)
-        elapsed = float(t.item())
+    elapsed, per_rank_ms = over_ranks(elapsed, args.steps)
+
+    # BASELINE configs[3] next to the weak-scaling line: 4096 hypotheses per step over the N ranks (512 per GPU on 8), same loop, same gather
+    config3 = None
+    if multi and world > 1 and not args.no_config3 and args.scene == "proj" and not args.sequential and global_poses != 4096:
+        k3 = min(args.steps, 20)
+        job3 = Job(4096, k3, args.gather)
+        e3, _, _ = job3.run(min(args.warmup, 3), sample_in=None)
+        e3, per3 = over_ranks(e3, k3)
+        config3 = {"workload": f"BASELINE configs[3]: obj_06.ply, 4096 hypotheses per step sharded over {world} GPUs ({job3.P_max} per GPU), projective, {args.iters} ICP iterations, "
+                               f"{'ONE gather of all ' + str(k3) + ' x 4096 records' if job3.gather_when == 'job' else 'one gather per step'}",
+                   "value": 4096 * k3 / e3, "unit": "poses/s", "ms_per_step": 1e3 * e3 / k3, "steps": k3, "scaling": "strong", "global_batch": 4096,
+                   "poses_per_gpu": job3.P_max, "per_rank_ms_per_step": per3, "gathers": job3.gathers}
 
     flush_c_stdio()
     if multi:
-        dist.barrier()                                              # nothing of any rank is left to be written before rank 0's line
-    if rank == 0:
-        total_poses = global_poses * args.steps
-        launches = max(1, prof["icp_launches"])
-        pts_per_launch = prof["icp_points"] / launches
-        bytes_per_launch = prof["icp_bytes"] / launches          # 36 B/point on pass 0, 48 B/point afterwards
-        avg_launch_s = prof["icp_kernel_ms"] * 1e-3 / launches
-        achieved = bytes_per_launch / avg_launch_s if avg_launch_s > 0 else 0.0
-        traffic = PMC_TRAFFIC_BYTES_PER_POINT[args.scene] * pts_per_launch if PMC_TRAFFIC_BYTES_PER_POINT[args.scene] else None
-        traffic_source = ("committed rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE passes, "
-                          + PMC_TRAFFIC_SOURCE[args.scene] + f": {PMC_TRAFFIC_BYTES_PER_POINT[args.scene]} B/point x points of a launch")
-        live = None
-        if world == 1 and not args.no_live_pmc and not args.sequential:
-            live = live_pmc_traffic(args.scene)                     # two counter passes of the same kernels, run now
-        if live:
-            traffic = live["bytes_per_point"] * pts_per_launch
-            traffic_source = live["source"]
-        out = {
-            "metric": "refined poses/sec (640x480, 20 ICP iters)",
-            "value": total_poses / elapsed,
-            "unit": "poses/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "burn_in_steps": max(0, args.burn_in),                   # untimed, before the warm-up steps: device clocks up from idle
-            "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True,
-            "scaling": args.scaling,
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": f"obj_06.ply, {P_max}-pose batch per GPU, 640x480 synthetic depth, "
-                                   f"{'projective' if args.scene == 'proj' else 'kd-tree NN (exact search with the reference tie-breaks: keep-the-winner test and pixel-window scan where the bound allows, order-free task walk over 128-byte wide nodes otherwise, ties repeated by the ordered walk)'} association, "
-                                   f"{args.iters} ICP iterations (21 passes), solve on {args.solve}"
-                                   + (f", {args.pose_groups or (2 if args.scene == 'proj' else 3)} pose groups" if args.solve == "device" else ""),
-                       "poses_per_gpu": P_max, "global_batch": global_poses, "points_per_pose_mean": float(np.mean(sizes)),
-                       "parallelism": (f"pose-shard x{world}, no data-path collective, "
-                                       + ("no gather (1 rank)" if not multi else
-                                          ("1 RCCL gather per step (pr_gather_results)" if gather_mode == "cabi" else
-                                           ("1 gloo gather per step on host copies (ranks share one device: test mode)" if share_device else "1 torch.distributed gather per step (RCCL backend)"))))},
-            # `bound`: what the counters say limits this kernel.  `frac` is the contract's figure -- SURVEY 8d's ALGORITHMIC bytes over the launch
-            # time, against the HBM peak; it exceeds what HBM really carries (the packed 16-byte scene record, Infinity-Cache-resident clouds), so
-            # it is a throughput score, not a statement that the kernel sits on the HBM roof: the projective pass is VALU-bound (`valu_frac`).
-            "roofline": {"bound": ("valu" if args.scene == "proj" else "l1/lds + valu (cache-resident search: HBM carries only clouds and winners)"),
-                         "bound_contract_enum": "hbm",
-                         "kernel": ("icp_pass_kernel (correspondence + 29-term reduce" if args.scene == "proj" else
-                                                     "one correspondence pass = nn_search_kernel + nn_bound_kernel + nn_tree_wide_kernel + icp_pass_kernel<SceneNNWinners> (search, bound + window, task walk of the queued queries, 29-term reduce over the winners")
-                                                    + (" + finalize/solve tail)" if args.fused_solve and args.solve == "device" else ")"),
-                         "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK,
-                         # (`frac` can exceed 1: SURVEY 8d's algorithmic bytes charge the reference's 24-byte scene gather and a cloud
-                         # that streams from HBM; the packed 16-byte scene record and the cache-resident clouds move fewer real bytes)
-                         # two readings of the same launches: SURVEY 8d's ALGORITHMIC bytes (what `frac` is), and the HBM bytes the
-                         # PMC counters saw for this kernel.  At <= 512 hypotheses per sub-batch the clouds are Infinity-Cache
-                         # resident by design and the 16-byte scene records hit L2, so the counter figure is the lower one.
-                         "frac_algorithmic": achieved / HBM_PEAK,
-                         # committed counter figures x this run's points and launch time: fabric bytes (FETCH_SIZE counts Infinity-Cache hits
-                         # too, so this is an UPPER bound of DRAM traffic) and VALU issue slots (SQ_INSTS_VALU wave-instructions / 6.1e11 per s)
-                         "frac_fabric_counter": (traffic / avg_launch_s / HBM_PEAK) if (traffic and avg_launch_s > 0) else None,
-                         "valu_frac": (PMC_VALU_WAVE_INSTR_PER_POINT[args.scene] * pts_per_launch / avg_launch_s / VALU_PEAK)
-                                      if (PMC_VALU_WAVE_INSTR_PER_POINT[args.scene] and avg_launch_s > 0) else None,
-                         "valu_peak_wave_instr_per_s": VALU_PEAK,
-                         "traffic": traffic,
-                         "traffic_source": traffic_source,
-                         "traffic_live": live,
-                         "residency": "clouds of a sub-batch (<= 512 hypotheses) stay in the 256 MiB Infinity Cache over the 21 passes; scene records are L2-resident",
-                         "avg_launch_us": avg_launch_s * 1e6, "launches": int(launches),
-                         "algorithmic_bytes_per_launch": bytes_per_launch, "points_per_launch": pts_per_launch,
-                         "timing": ("HIP events on the library stream around every launch (--sequential: synchronous single-group steps)" if args.sequential else
-                                    f"HIP events on the library stream around every launch of the last {n_samples} steps of the timed region; "
-                                    "a timed step stays an asynchronous batch but its loop runs as one pose group and only once the other slot's batch is complete (option profile = 3), so the launch has the chip to itself")},
-            "gather": ("none (1 rank)" if not multi else ("pr_gather_results: grouped ncclSend/ncclRecv on the library stream (C ABI over RCCL)" if gather_mode == "cabi" else
-                                                            ("torch.distributed.gather (gloo, host copies: ranks share one device)" if share_device else "torch.distributed.gather (RCCL)"))),
-            "gather_note": gather_note,
-            "gather_event_us": (1e3 * gather_ms / gather_n) if gather_n else None,      # HIP events around the exchange on the library stream, sampled steps (rank 0)
-            "gather_events": int(gather_n),
-            "per_rank_ms_per_step": per_rank_ms,
-            "host_cpu_per_wall": host_cpu_s / elapsed if elapsed > 0 else None,   # rank 0: CPUs kept busy by this process during the timed region (spinning waits count)
-            "blocking_wait": bool(api.get_option("blocking_wait")),
-            "phase_ms_per_timed_step": {"render": prof["render_ms"] / max(1, launches // (args.iters + 1)),
-                                        "cloud": prof["cloud_ms"] / max(1, launches // (args.iters + 1))},
-        }
-        if world == 1 and args.scene == "proj" and args.solve == "device" and not args.sequential and not args.no_kdtree_extra:
-            out["solve_on_host"] = host_solve_extra(args, api, model, poses, W, H, proj, K, scene)
-        if world == 1 and args.scene == "proj" and not args.no_kdtree_extra and not args.sequential:
-            out["config2_kdtree"] = kdtree_extra(args, api, model, poses, scene_depth, W, H, proj, K)
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, args.scene, model.tris, scene_depth, K, W, H)
-            if "config2_kdtree" in out:
-                out["config2_kdtree"]["cpu_baseline"] = cpu_baseline(args, "nn", model.tris, scene_depth, K, W, H)
-        flush_c_stdio()
-        print(json.dumps(out), flush=True)
+        group.barrier()                                             # nothing of any rank is left to be written before rank 0's line
+    if rank != 0:
+        return None
 
-    if multi:
-        dist.barrier()
-        dist.destroy_process_group()
+    total_poses = global_poses * args.steps
+    launches = max(1, prof["icp_launches"])
+    pts_per_launch = prof["icp_points"] / launches
+    bytes_per_launch = prof["icp_bytes"] / launches          # 36 B/point on pass 0, 48 B/point afterwards (SURVEY 8d)
+    avg_launch_s = prof["icp_kernel_ms"] * 1e-3 / launches
+    achieved = bytes_per_launch / avg_launch_s if avg_launch_s > 0 else 0.0
+    traffic = PMC_TRAFFIC_BYTES_PER_POINT[args.scene] * pts_per_launch if PMC_TRAFFIC_BYTES_PER_POINT[args.scene] else None
+    traffic_source = ("committed rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE passes, "
+                      + PMC_TRAFFIC_SOURCE[args.scene] + f": {PMC_TRAFFIC_BYTES_PER_POINT[args.scene]} B/point x points of a launch")
+    live = dram = None
+    if world == 1 and not multi and not args.no_live_pmc and not args.sequential:
+        live = live_pmc_traffic(args.scene)                     # two counter passes of the same kernels, run now
+        if args.scene == "proj":
+            dram = live_pmc_traffic("proj", n_poses=1024, opts="sub_batch=1024,pose_groups=1", with_duration=True)
+    if live:
+        traffic = live["bytes_per_point"] * pts_per_launch
+        traffic_source = live["source"]
+    # what DRAM really carries: 1024 hypotheses as ONE sub-batch (270 MB of clouds: more than the 256 MiB Infinity Cache holds)
+    if dram and dram.get("launch_us"):
+        frac_dram = dram["bytes_per_point"] * dram["points_per_dispatch"] / (dram["launch_us"] * 1e-6) / HBM_PEAK
+        dram_note = (f"this run: 1024 hypotheses as one sub-batch (clouds exceed the Infinity Cache), {dram['bytes_per_point']:.1f} B/point x {dram['points_per_dispatch']} points "
+                     f"per {dram['launch_us']:.1f} us launch (rocprofv3 --kernel-trace pass of the same workload)")
+    else:
+        frac_dram, dram_note = PMC_DRAM_FRAC.get(args.scene), PMC_DRAM_SOURCE
+    lus = np.sort(np.asarray(launches_us, np.float64)) if launches_us is not None and len(launches_us) else None
+    n_samples = 1
+    out = {
+        "metric": "refined poses/sec (640x480, 20 ICP iters)",
+        "value": total_poses / elapsed,
+        "unit": "poses/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "burn_in_steps": max(0, args.burn_in),                   # untimed, before the warm-up steps: device clocks up from idle (see DESIGN.md section 5)
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True,
+        "scaling": args.scaling,
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"obj_06.ply, {P_max}-pose batch per GPU, 640x480 synthetic depth, "
+                               f"{'projective' if args.scene == 'proj' else 'kd-tree NN (exact search with the reference tie-breaks: keep-the-winner test and pixel-window scan where the bound allows, order-free task walk over 128-byte wide nodes otherwise, ties repeated by the ordered walk)'} association, "
+                               f"{args.iters} ICP iterations (21 passes), solve on {args.solve}"
+                               + (f", {args.pose_groups or (2 if args.scene == 'proj' else 3)} pose groups" if args.solve == "device" else ""),
+                   "poses_per_gpu": P_max, "global_batch": global_poses, "points_per_pose_mean": float(np.mean(sizes)),
+                   "parallelism": (f"pose-shard x{world}, no data-path collective, "
+                                   + ("no gather (1 rank)" if not multi else
+                                      (f"{'ONE gather of the job (all K x P records after the last step)' if job.gather_when == 'job' else '1 gather per step'}: "
+                                       + {"cabi": "pr_gather_results (RCCL)", "torch": "torch.distributed.gather (RCCL backend)",
+                                          "host": "host copies through the control plane (ranks share one device: test mode)"}[gather_mode])))},
+        "launcher": {"kind": group.kind,
+                     "how": (os.environ.get("PR_BENCH_LAUNCHED_BY") or
+                             {"solo": "one process, one GPU", "threads": "one process, one host thread per GPU (pr_comm_init_all + pr_set_device per thread)",
+                              "processes": "one process per GPU, started by the caller's launcher (torch.distributed.run / torchrun environment)"}[group.kind]),
+                     "note": launcher_note, "share_device_test_mode": share_device},
+        # `bound`: what the counters say limits this kernel.  `frac` is the contract's figure -- SURVEY 8d's ALGORITHMIC bytes over the launch
+        # time, against the HBM peak; it exceeds what HBM really carries (the packed 16-byte scene record, Infinity-Cache-resident clouds), so
+        # it is a throughput score, not a statement that the kernel sits on the HBM roof: the projective pass is VALU-bound (`valu_frac`).
+        "roofline": {"bound": ("valu" if args.scene == "proj" else "l1/lds + valu (cache-resident search: HBM carries only clouds and winners)"),
+                     "bound_contract_enum": "hbm",
+                     "kernel": ("icp_pass_kernel (correspondence + 29-term reduce" if args.scene == "proj" else
+                                                 "one correspondence pass = nn_search_kernel + nn_bound_kernel + nn_tree_wide_kernel + icp_pass_kernel<SceneNNWinners> (search, bound + window, task walk of the queued queries, 29-term reduce over the winners")
+                                                + (" + finalize/solve tail)" if args.fused_solve and args.solve == "device" else ")"),
+                     "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK,
+                     # (`frac` can exceed 1: SURVEY 8d's algorithmic bytes charge the reference's 24-byte scene gather and a cloud
+                     # that streams from HBM; the packed 16-byte scene record and the cache-resident clouds move fewer real bytes)
+                     # readings of the same launches: SURVEY 8d's ALGORITHMIC bytes (what `frac` is), the fabric bytes the PMC counters
+                     # saw for this kernel (Infinity-Cache hits included), and the DRAM figure of a batch that does not fit that cache
+                     "frac_algorithmic": achieved / HBM_PEAK,
+                     "frac_fabric_counter": (traffic / avg_launch_s / HBM_PEAK) if (traffic and avg_launch_s > 0) else None,
+                     "frac_dram_counter": frac_dram, "frac_dram_counter_source": dram_note, "dram_live": dram,
+                     "valu_frac": (PMC_VALU_WAVE_INSTR_PER_POINT[args.scene] * pts_per_launch / avg_launch_s / VALU_PEAK)
+                                  if (PMC_VALU_WAVE_INSTR_PER_POINT[args.scene] and avg_launch_s > 0) else None,
+                     "valu_peak_wave_instr_per_s": VALU_PEAK,
+                     "traffic": traffic,
+                     "traffic_source": traffic_source,
+                     "traffic_live": live,
+                     "residency": "clouds of a sub-batch (<= 512 hypotheses) stay in the 256 MiB Infinity Cache over the 21 passes; scene records are L2-resident",
+                     "avg_launch_us": avg_launch_s * 1e6, "launches": int(launches),
+                     # the sampled launches one by one: pass 0 and the score-only last pass move 36 B/point, the others 48
+                     "launch_us_spread": ({"min": float(lus[0]), "median": float(np.median(lus)), "max": float(lus[-1]), "n": int(len(lus))} if lus is not None else None),
+                     "algorithmic_bytes_per_launch": bytes_per_launch, "points_per_launch": pts_per_launch,
+                     "sampled_in": job.sampled_in,
+                     "timing": ("HIP events on the library stream around every launch (--sequential: synchronous single-group steps)" if args.sequential else
+                                f"HIP events on the library stream around every launch of {n_samples} step ({job.sampled_in}); "
+                                "the sampled step stays an asynchronous batch but its loop runs as one pose group and only once the other slot's batch is complete (option profile = 3), so the launch has the chip to itself")},
+        "gather": ("none (1 rank)" if not multi else {"cabi": "pr_gather_results: grouped ncclSend/ncclRecv on the library stream (C ABI over RCCL)",
+                                                        "torch": "torch.distributed.gather (RCCL)",
+                                                        "host": "host copies through the control plane (ranks share one device: test mode)"}[gather_mode]),
+        "gather_when": (job.gather_when if multi else None), "gather_when_note": job.gather_why, "gathers_in_timed_region": gathers_timed if multi else 0,
+        "gather_bytes_per_rank": (72 * P * (args.steps if job.gather_when == "job" else 1)) if multi else 0,
+        "gather_note": gather_note,
+        "gather_event_us": (1e3 * gather_ms / gather_n) if gather_n else None,      # HIP events around the exchange on the library stream, sampled steps (rank 0)
+        "gather_events": int(gather_n),
+        "per_rank_ms_per_step": per_rank_ms,
+        "host_cpu_per_wall": host_cpu_s / wall_s if wall_s > 0 else None,   # rank 0's process: CPU seconds (all threads, warm-up included) per second of the timed region
+        "blocking_wait": bool(api.get_option("blocking_wait")),
+        "phase_ms_per_timed_step": {"render": prof["render_ms"] / max(1, launches // (args.iters + 1)),
+                                    "cloud": prof["cloud_ms"] / max(1, launches // (args.iters + 1))},
+    }
+    if config3:
+        out["config3_4096_global"] = config3
+    solo = world == 1 and not multi
+    if solo and args.scene == "proj" and args.solve == "device" and not args.sequential and not args.no_kdtree_extra:
+        out["solve_on_host"] = host_solve_extra(args, api, model, job.poses, W, H, proj, K, scene)
+    if solo and args.scene == "proj" and not args.no_kdtree_extra and not args.sequential:
+        out["config2_kdtree"] = kdtree_extra(args, api, model, job.poses, scene_depth, W, H, proj, K)
+    if solo and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args, args.scene, model.tris, scene_depth, K, W, H)
+        if "config2_kdtree" in out:
+            out["config2_kdtree"]["cpu_baseline"] = cpu_baseline(args, "nn", model.tris, scene_depth, K, W, H)
+    return out
 
 
-def live_pmc_traffic(scene_kind):
-    """roofline.traffic measured by this run: two `rocprofv3 --kernel-trace --pmc <counter>` passes (FETCH_SIZE, WRITE_SIZE: one counter per
+def live_pmc_traffic(scene_kind, n_poses=256, opts="pose_groups=1", with_duration=False):
+    """(with_duration: a third child pass, `--kernel-trace` alone, gives the same kernels' average launch time for the same workload.)
+    roofline.traffic measured by this run: two `rocprofv3 --kernel-trace --pmc <counter>` passes (FETCH_SIZE, WRITE_SIZE: one counter per
     pass, as MI355X_MICROARCH.md prescribes) of tools/pmc_workload.py -- three 256-hypothesis batches of the same workload as ONE pose group, so
     that a dispatch covers every cloud of the batch -- in child processes, read back from the rocpd databases.  FETCH_SIZE is corrected by
     the factor this very pass shows on max2zero_kernel, which reads and writes a known number of bytes (2.0 on gfx950; outside 1.8-2.2 the
@@ -425,12 +719,29 @@ def live_pmc_traffic(scene_kind):
         calib = {}
         points = None
         with tempfile.TemporaryDirectory(dir="/tmp") as d:
-            env = dict(os.environ, TMPDIR="/tmp", PR_OPTS="pose_groups=1", PR_RASTER_MODE="0")
+            env = dict(os.environ, TMPDIR="/tmp", PR_OPTS=opts, PR_RASTER_MODE="0")
+            launch_us = None
+            if with_duration:
+                cmd = [exe, "--kernel-trace", "-d", d, "-o", "trace", "--", sys.executable, os.path.join(ROOT, "tools", "pmc_workload.py"), str(n_poses)] + ([] if scene_kind == "proj" else ["nn"])
+                r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=120)
+                dbs = glob.glob(os.path.join(d, "**", "trace_results.db"), recursive=True)
+                if r.returncode == 0 and dbs:
+                    con = sqlite3.connect(dbs[0])
+                    rows = list(con.execute("select name, (end - start) / 1000.0 from kernels"))
+                    con.close()
+                    tot = 0.0
+                    for k in kernels:
+                        v = [us for n, us in rows if k in n]
+                        if not v:
+                            tot = None
+                            break
+                        tot += sum(v) / len(v)
+                    launch_us = tot
             for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-                cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", d, "-o", counter, "--", sys.executable, os.path.join(ROOT, "tools", "pmc_workload.py"), "256"]
+                cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", d, "-o", counter, "--", sys.executable, os.path.join(ROOT, "tools", "pmc_workload.py"), str(n_poses)]
                 if scene_kind != "proj":
                     cmd.append("nn")
-                r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=90)
+                r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=120)
                 for line in r.stdout.splitlines():
                     if line.startswith("points per batch:"):
                         points = int(line.split(":")[1])
@@ -447,11 +758,11 @@ def live_pmc_traffic(scene_kind):
                         return None
                     total += sum(v for _, _, v in hit) / sum(c for _, c, _ in hit)
                 per_dispatch[counter] = total
-                # calibration: the workload's two max2zero launches (one scene image, then the 256 images of a public render call) read
-                # and write every pixel of 257 images of 640 x 480 int32 -- known bytes against the counter's sum over both
+                # calibration: the workload's two max2zero launches (one scene image, then the n_poses images of a public render call) read
+                # and write every pixel of n_poses + 1 images of 640 x 480 int32 -- known bytes against the counter's sum over both
                 cal = [v for n, c, v in rows if "max2zero_kernel" in n]
                 if cal and cal[0] > 0:
-                    calib[counter] = (257 * 640 * 480 * 4 / 1024.0) / cal[0]
+                    calib[counter] = ((n_poses + 1) * 640 * 480 * 4 / 1024.0) / cal[0]
         f_fetch = calib.get("FETCH_SIZE", 2.0)
         if not (1.8 <= f_fetch <= 2.2):
             f_fetch = 2.0
@@ -461,8 +772,8 @@ def live_pmc_traffic(scene_kind):
         kb = f_fetch * per_dispatch["FETCH_SIZE"] + f_write * per_dispatch["WRITE_SIZE"]
         bpp = kb * 1024.0 / points
         return {"bytes_per_point": bpp, "fetch_kb_per_dispatch": per_dispatch["FETCH_SIZE"], "write_kb_per_dispatch": per_dispatch["WRITE_SIZE"],
-                "fetch_correction": f_fetch, "write_correction": f_write, "points_per_dispatch": points,
-                "source": (f"this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (one pass each) of tools/pmc_workload.py 256 as one pose group -- "
+                "fetch_correction": f_fetch, "write_correction": f_write, "points_per_dispatch": points, "launch_us": launch_us, "hypotheses": n_poses, "options": opts,
+                "source": (f"this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (one pass each) of tools/pmc_workload.py {n_poses} ({opts}) -- "
                            f"({f_fetch:.3f} x {per_dispatch['FETCH_SIZE']:.0f} + {f_write:.3f} x {per_dispatch['WRITE_SIZE']:.0f}) KB per dispatch of {points} points = {bpp:.1f} B/point "
                            f"(fabric side: Infinity-Cache hits included), x points of a launch; both counters corrected by what max2zero_kernel (known bytes) shows in the same pass")}
     except Exception as e:                                         # noqa: BLE001 -- an extra: never at the cost of the line
@@ -486,6 +797,15 @@ def kdtree_extra(args, api, model, poses, scene_depth, W, H, proj, K, steps=20):
             api.refine_wait((k - 1) & 1)
     api.refine_wait((steps - 1) & 1)
     dt = (time.perf_counter() - t0) / steps
+    # the dominant kernel of this configuration by itself: ONE more batch with events between the four kernels of every pass (profile 3:
+    # asynchronous, one pose group, the chip to itself) -> pr_profile_nn
+    api.profile_reset()
+    api.set_option("profile", 3)
+    api.refine_submit(0, model, poses, W, H, proj, K, scene, crit)
+    _, sizes_t = api.refine_wait(0)
+    api.set_option("profile", 0)
+    part_ms, n_pass = api.profile_nn()
+    pass_us = api.profile_launches()
     api.set_option("nn_count", 1)
     api.nn_counters(args.iters + 1)
     api.refine_batch(model, poses, W, H, proj, K, scene, crit)
@@ -494,11 +814,31 @@ def kdtree_extra(args, api, model, poses, scene_depth, W, H, proj, K, steps=20):
     tot = c.sum(0)
     logical = tot[4] * 128 + tot[6] * 16 + tot[7] * 16 + tot[0] * 28          # wide nodes are 128-byte lines, leaf points 16-byte records
     hbm = PMC_TRAFFIC_BYTES_PER_POINT["nn"] * tot[0] if PMC_TRAFFIC_BYTES_PER_POINT["nn"] else None
+    roof = None
+    if n_pass:
+        names = ["nn_search_kernel", "nn_bound_kernel", "nn_tree_wide_kernel<2>", "icp_pass_kernel<SceneNNWinners>"]
+        step_ms = float(part_ms.sum())
+        k = int(np.argmax(part_ms))
+        pts = float(np.sum(sizes_t))                                 # cloud points of the batch = queries of one pass
+        walk_s = part_ms[2] * 1e-3 / n_pass
+        roof = {"kernel": names[k], "dominant_by": "HIP events between the four kernels of every pass of one timed batch (pr_profile_nn)",
+                "avg_launch_us": 1e3 * part_ms[k] / n_pass, "share_of_step": part_ms[k] / step_ms if step_ms > 0 else None,
+                "per_kernel_ms_per_step": {n: float(v) for n, v in zip(names, part_ms)}, "passes": int(n_pass), "one_group_step_ms": step_ms,
+                "first_passes_us": [float(v) for v in pass_us[:4]],
+                "bound": "lds-chain / latency (dependent LDS queue operations per step; VALU active 27 % of wave-cycles, HBM ~ 0)",
+                "valu_active_frac": NN_WALK_VALU_ACTIVE_FRAC,
+                "valu_active_frac_source": "committed: profiles/r03/sq_nn_SQ_ACTIVE_INST_VALU_SQ_WAVE_CYCLES_SQ_WAIT_INST_ANY.md (nn_tree_wide_kernel)",
+                # HBM side of the task walk alone: committed counter bytes per cloud point x this batch's points over this run's launch time
+                "hbm_GBps": (NN_WALK_HBM_BYTES_PER_POINT * pts / walk_s / 1e9) if walk_s > 0 else None,
+                "hbm_frac": (NN_WALK_HBM_BYTES_PER_POINT * pts / walk_s / HBM_PEAK) if walk_s > 0 else None,
+                "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                "note": "the kd-tree search is cache-resident by design (SURVEY 8d): no kernel of the pass is HBM-bound; hbm_frac is reported because BASELINE's metric asks for it"}
     return {"workload": f"obj_06.ply, {len(poses)}-pose batch, 640x480, kd-tree nearest-neighbour association (Scene_nn: exact search, "
                         "reference tie-breaks; search kernel = keep-the-winner test and pixel-window scan where the bound allows it, bound kernel = "
                         "descent through the representative points + window, task walk over 128-byte wide nodes for the rest, ties repeated by the ordered walk), "
                         f"{args.iters} ICP iterations, two asynchronous slots",
             "value": len(poses) / dt, "unit": "poses/s", "ms_per_step": dt * 1e3, "steps": steps,
+            "roofline": roof,
             "queries_per_step": tot[0], "settled_by_pixel_window_frac": tot[1] / max(tot[0], 1.0), "tree_searches_frac": tot[2] / max(tot[0], 1.0),
             "tree_nodes_per_tree_search": tot[4] / max(tot[2], 1.0), "leaf_points_per_tree_search": tot[6] / max(tot[2], 1.0),
             "logical_bytes_per_step": logical, "logical_GBps_over_step": logical / dt / 1e9,
@@ -599,4 +939,4 @@ def cpu_baseline(args, scene_kind, tris, scene_depth, K, W, H):
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

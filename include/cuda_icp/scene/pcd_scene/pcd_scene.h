@@ -103,5 +103,5 @@ public:
     }
     pr_scene_nn c_view() const { pr_scene_nn s; s.max_dist_diff = max_dist_diff; s.pcd = reinterpret_cast<const pr_vec3 *>(pcd_ptr); s.normal = reinterpret_cast<const pr_vec3 *>(normal_ptr);
         s.nodes = reinterpret_cast<const pr_kdnode *>(node_ptr); s.n_points = n_points; s.n_nodes = n_nodes;
-        s.cam_fx = cam_[0]; s.cam_fy = cam_[1]; s.cam_cx = cam_[2]; s.cam_cy = cam_[3]; s.cam_w = cam_w_; s.cam_h = cam_h_; return s; }
+        s.cam_fx = cam_[0]; s.cam_fy = cam_[1]; s.cam_cx = cam_[2]; s.cam_cy = cam_[3]; s.cam_w = cam_w_; s.cam_h = cam_h_; s.cam_magic = cam_w_ ? PR_SCENE_NN_CAM_MAGIC : 0u; return s; }
 };

@@ -91,7 +91,13 @@ typedef struct {
      * the fused path does; it is a HINT: the pixel grid is only used if every scene point really projects into a cell of its own. */
     float cam_fx, cam_fy, cam_cx, cam_cy;
     uint32_t cam_w, cam_h;
+    /* The hint is read only when cam_magic == PR_SCENE_NN_CAM_MAGIC: a caller that fills the reference's six members field by field and
+     * leaves the rest of the struct uninitialised (or zero) never triggers a grid build from garbage.  The struct has grown since round 2
+     * (it ends here; sizeof == 72): callers must be compiled against this header -- PR_ABI_VERSION / pr_abi_version() tell them apart. */
+    uint32_t cam_magic;
 } pr_scene_nn;
+#define PR_SCENE_NN_CAM_MAGIC 0x4d414350u   /* 'PCAM' */
+#define PR_ABI_VERSION 4                    /* bumped whenever a struct of this header changes size or layout */
 
 /* A Scene_projective whose arrays cover only a window of the frame: pcd2dep(src, K, tl_x, tl_y) / dep2pcd(x, y, d, K, tl_x, tl_y)
  * (common.h:47-73) with the offsets the reference declares but never passes.  view.width / view.height are
@@ -112,6 +118,7 @@ typedef struct {
 /* ---- library / device ------------------------------------------------------------------------ */
 const char *pr_last_error(void);
 const char *pr_version(void);
+int pr_abi_version(void);                        /* PR_ABI_VERSION the library was built with: compare with the header a caller was compiled against */
 int pr_device_count(void);                       /* number of visible HIP devices (0 if none)              */
 int pr_init(int device);                         /* bind the calling thread to the device's shared context, create its stream (test.cpp:12-20 warm-up) */
 int pr_set_device(int device);                   /* same (cudaSetDevice, which test.cpp:14 leaves commented out)                 */
@@ -311,6 +318,13 @@ int  pr_nn_counters(uint64_t *out, uint32_t passes);
 int  pr_profile_reset(void);
 int  pr_profile_read(double *kernel_ms, uint64_t *launches, uint64_t *points, uint64_t *algorithmic_bytes,
                      double *render_ms, double *cloud_ms);
+/* The timed launches one by one, in microseconds, in the order they were read back (at most 8192 since the last reset): *n = how many
+ * there are, the first min(*n, capacity) are copied.  What a min / median / max over the sampled launches is made from. */
+int  pr_profile_launches(float *launch_us, uint32_t capacity, uint32_t *n);
+/* A kd-tree correspondence pass is four kernels (search, bound + window, task walk, reduce over the winners: Scene_nn::query of
+ * pcd_scene.h:60-136 inside thrust__pcd2Ab, icp.h:128-209).  Timed asynchronous batches (profile 3) put events between them:
+ * part_ms[0..3] = accumulated time of each kernel, *passes = passes that contributed.  Reset by pr_profile_reset. */
+int  pr_profile_nn(double part_ms[4], uint64_t *passes);
 /* HIP-event time of the pr_gather_results exchanges issued while option "profile" was non-zero (events on the context's stream around
  * the grouped send / receive; accumulated since pr_profile_reset).  Waits for the stream.  New in this library -- the reference has
  * no multi-device code (test.cpp:14). */

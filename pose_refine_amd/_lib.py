@@ -49,10 +49,13 @@ class SceneProjCropDesc(C.Structure):
     _fields_ = [("view", SceneProjDesc), ("tl_x", C.c_uint32), ("tl_y", C.c_uint32)]
 
 
+SCENE_NN_CAM_MAGIC = 0x4d414350          # PR_SCENE_NN_CAM_MAGIC: the camera hint of a pr_scene_nn is read only with it
+
+
 class SceneNNDesc(C.Structure):
     _fields_ = [("max_dist_diff", C.c_float), ("pcd", C.c_void_p), ("normal", C.c_void_p), ("nodes", C.c_void_p),
                 ("n_points", C.c_uint32), ("n_nodes", C.c_uint32),
-                ("cam_fx", C.c_float), ("cam_fy", C.c_float), ("cam_cx", C.c_float), ("cam_cy", C.c_float), ("cam_w", C.c_uint32), ("cam_h", C.c_uint32)]
+                ("cam_fx", C.c_float), ("cam_fy", C.c_float), ("cam_cx", C.c_float), ("cam_cy", C.c_float), ("cam_w", C.c_uint32), ("cam_h", C.c_uint32), ("cam_magic", C.c_uint32)]
 
 
 # name -> (restype, argtypes); this table is also what tests/test_cabi_symbols.py checks against the header
@@ -60,6 +63,7 @@ _vp, _sz, _u32, _i32 = C.c_void_p, C.c_size_t, C.c_uint32, C.c_int
 SIGNATURES = {
     "pr_last_error": (C.c_char_p, []),
     "pr_version": (C.c_char_p, []),
+    "pr_abi_version": (_i32, []),
     "pr_device_count": (_i32, []),
     "pr_init": (_i32, [_i32]),
     "pr_set_device": (_i32, [_i32]),
@@ -116,6 +120,8 @@ SIGNATURES = {
     "pr_profile_read": (_i32, [C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
                                 C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "pr_gather_profile": (_i32, [C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
+    "pr_profile_launches": (_i32, [_vp, _u32, C.POINTER(_u32)]),
+    "pr_profile_nn": (_i32, [_vp, C.POINTER(C.c_uint64)]),
 }
 
 _lib = None

@@ -125,6 +125,24 @@ def profile_read():
                 render_ms=rms.value, cloud_ms=cms.value)
 
 
+def profile_launches() -> np.ndarray:
+    """``pr_profile_launches``: the timed correspondence launches since the last reset, one by one, in microseconds."""
+    n = C.c_uint32()
+    check(_lib.load().pr_profile_launches(None, 0, C.byref(n)))
+    out = np.zeros(n.value, np.float32)
+    if n.value:
+        check(_lib.load().pr_profile_launches(ptr(out), n.value, C.byref(n)))
+    return out
+
+
+def profile_nn():
+    """``pr_profile_nn``: accumulated time of the four kernels of the timed kd-tree passes -- (ms[4]: search, bound, task walk, winners pass; passes)."""
+    ms = np.zeros(4, np.float64)
+    n = C.c_uint64()
+    check(_lib.load().pr_profile_nn(ptr(ms), C.byref(n)))
+    return ms, n.value
+
+
 def gather_profile():
     """HIP-event time of the gathers issued while option ``profile`` was on: (total ms, count).  Waits for the library stream."""
     ms, n = C.c_double(), C.c_uint64()
@@ -445,7 +463,8 @@ class Scene_nn:
         n_pts = len(self.pcd_host) if self.pcd_host is not None else self._n_points
         n_nodes = len(self.nodes_host) if self.nodes_host is not None else self._n_nodes
         cam = self.camera if getattr(self, "camera", None) else (0.0, 0.0, 0.0, 0.0, 0, 0)
-        return SceneNNDesc(self.max_dist_diff, self.pcd_buffer.data(), self.normal_buffer.data(), self.nodes.data(), n_pts, n_nodes, *cam)
+        return SceneNNDesc(self.max_dist_diff, self.pcd_buffer.data(), self.normal_buffer.data(), self.nodes.data(), n_pts, n_nodes, *cam,
+                           _lib.SCENE_NN_CAM_MAGIC if cam[4] else 0)
 
 
 def ICP_Point2Plane(model_pcd: DeviceVector, scene, criteria: ICPConvergenceCriteria = ICPConvergenceCriteria()) -> RegistrationResult:

@@ -185,7 +185,7 @@ struct Slot {
     bool timed = false;
     std::vector<hipEvent_t> t_events;            // pool, reused from batch to batch
     size_t t_used = 0;
-    struct TSpan { size_t e0, e1; int kind; uint32_t q0, nq; bool edge; };   // edge: first or last pass (36 B / point instead of 48)
+    struct TSpan { size_t e0, e1; int kind; uint32_t q0, nq; bool edge; bool marks; size_t m[3]; };   // edge: first or last pass (36 B / point instead of 48); marks: events between the kernels of a kd-tree pass
     std::vector<TSpan> t_spans;
 };
 
@@ -235,6 +235,8 @@ struct Ctx {
     struct Span { size_t e0, e1; int kind; };
     std::vector<Span> spans;
     double icp_ms = 0, render_ms = 0, cloud_ms = 0; uint64_t icp_launches = 0, icp_points = 0, icp_bytes = 0, sample_clock = 0;
+    std::vector<float> icp_launch_us;                            // the timed launches one by one (pr_profile_launches), bounded
+    double nn_part_ms[4] = { 0, 0, 0, 0 }; uint64_t nn_part_n = 0;   // kd-tree pass by kernel: search, bound, task walk, winners pass (pr_profile_nn)
     Slot slots[kSlots];
     std::vector<CachedGraph> graphs;
     uint64_t graph_clock = 0;
@@ -324,12 +326,14 @@ struct SpanGuard {
     explicit SpanGuard(int k) : on(opt.profile != 0), kind(k) { if (on) { e0 = take_event(); hipEventRecord(g->ev_pool[e0], g->stream); } }
     ~SpanGuard() { if (on) { size_t e1 = take_event(); hipEventRecord(g->ev_pool[e1], g->stream); g->spans.push_back({ e0, e1, kind }); } }
 };
+constexpr size_t kLaunchSamples = 8192;
+inline void note_launch_us(float ms) { if (g->icp_launch_us.size() < kLaunchSamples) g->icp_launch_us.push_back(ms * 1e3f); }
 void drain_spans()                   // call after the stream has been synchronised
 {
     for (const auto &s : g->spans) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, g->ev_pool[s.e0], g->ev_pool[s.e1]) != hipSuccess) continue;
-        if (s.kind == kSpanIcp) { g->icp_ms += ms; g->icp_launches++; }
+        if (s.kind == kSpanIcp) { g->icp_ms += ms; g->icp_launches++; note_launch_us(ms); }
         else if (s.kind == kSpanRender) g->render_ms += ms;
         else g->cloud_ms += ms;
     }
@@ -490,7 +494,7 @@ int make_scene(int kind, const void *scene, bool want_packed, SceneSel &out, Pac
         }
         // a bare ICP call has no camera of its own: the scene's hint, if it carries one (pose_refine.h)
         Camera hinted;
-        if (!cam && s->cam_w && s->cam_h && s->cam_fx > 0.0f && s->cam_fy > 0.0f) { hinted = Camera{ s->cam_w, s->cam_h, s->cam_fx, s->cam_fy, s->cam_cx, s->cam_cy }; cam = &hinted; }
+        if (!cam && s->cam_magic == PR_SCENE_NN_CAM_MAGIC && s->cam_w && s->cam_h && s->cam_fx > 0.0f && s->cam_fy > 0.0f) { hinted = Camera{ s->cam_w, s->cam_h, s->cam_fx, s->cam_fy, s->cam_cx, s->cam_cy }; cam = &hinted; }
         // pixel grid of the scene points under the hypotheses' camera (fused paths), or under the camera the scene says it was made with.  Usable
         // when every scene point owns a cell -- a Scene_nn made from a depth image with these intrinsics -- else the tree alone.
         if (cam && opt.nn_grid && out.nn.rec32 && (size_t)cam->w * cam->h <= ((size_t)1 << 24)) {
@@ -520,12 +524,12 @@ int make_scene(int kind, const void *scene, bool want_packed, SceneSel &out, Pac
     return PR_ERR_INVALID;
 }
 
-hipError_t launch_pass(const prk::IcpBatch &b, const SceneSel &sc, uint32_t P, hipStream_t st = nullptr)
+hipError_t launch_pass(const prk::IcpBatch &b, const SceneSel &sc, uint32_t P, hipStream_t st = nullptr, hipEvent_t *nn_marks = nullptr)
 {
     if (!st) st = g->stream;
     if (sc.kind == PR_SCENE_NN) {
         if (sc.nn_split && b.nn_prev) {                            // search (applies the pending update, leaves the winners in nn_prev) ...
-            hipError_t e = prk::launch_nn_search(b, sc.nn, P, sc.nn_max_points, (uint32_t)std::max(1, opt.nn_run), st);
+            hipError_t e = prk::launch_nn_search(b, sc.nn, P, sc.nn_max_points, (uint32_t)std::max(1, opt.nn_run), st, nn_marks);
             if (e != hipSuccess) return e;
             prk::IcpBatch bb = b;                                   // ... then the canonical-order pass over the winners
             bb.pre_transformed = 1;
@@ -765,8 +769,12 @@ int icp_drive(pr_vec3 *cloud_base, const uint32_t *start_h, const uint32_t *coun
     // group, the correspondence pass of the next group is on the chip -- the host's share of an iteration (copy latency, wake-up,
     // 160 ns per 6x6 solve) is as long as the pass itself, and a single group leaves the GPU idle for all of it.  Results per
     // hypothesis do not depend on the grouping (sums, solve and state are per hypothesis).  A timed call (profile 1) is one group.
-    const uint32_t host_sample_it = (uint32_t)((g->sample_clock++ * 5 + 1) % (uint64_t)(crit.max_iteration + 1));
-    const uint32_t n_groups = (opt.profile == 1 || opt.profile == 3) ? 1u : std::max(1u, std::min({ pose_groups_for(sc.kind), 4u, P / 32u }));
+    // profile 2: one call in sample_period times ONE of its passes (a different iteration from call to call); that call runs as one pose
+    // group like the calls of profile 1 / 3, so that the timed launch has the chip to itself -- the other calls keep their pipeline
+    const uint64_t host_tick = g->sample_clock++;
+    const bool host_sample_call = (opt.profile == 2) && (host_tick % (uint64_t)std::max(1, opt.sample_period) == 0);
+    const uint32_t host_sample_it = (uint32_t)(((host_tick / (uint64_t)std::max(1, opt.sample_period)) * 5 + 1) % (uint64_t)(crit.max_iteration + 1));
+    const uint32_t n_groups = (opt.profile == 1 || opt.profile == 3 || host_sample_call) ? 1u : std::max(1u, std::min({ pose_groups_for(sc.kind), 4u, P / 32u }));
     auto group_begin = [&](uint32_t grp) { return (uint32_t)(((uint64_t)P * grp) / n_groups); };
     if (opt.fused_solve) { PR_TRY(g->arrive.ensure(sizeof(uint32_t) * P)); HIP_TRY(hipMemsetAsync(g->arrive.p, 0, sizeof(uint32_t) * P, g->stream)); }
     if (n_groups > 1) {
@@ -799,7 +807,7 @@ int icp_drive(pr_vec3 *cloud_base, const uint32_t *start_h, const uint32_t *coun
         bb.meta += p0; bb.partial += (size_t)p0 * nblk * prk::kAccStride; if (bb.nn_qcount) bb.nn_qcount += prk::kQCountStride * (size_t)p0;
         bb.iter = it;
         if (host_fused) { bb.fused = 2; bb.arrive = g->arrive.as<uint32_t>() + p0; bb.sums_out = sums_dev + (size_t)p0 * prk::kAccStride; }
-        if (opt.profile == 1 || opt.profile == 3 || (opt.profile == 2 && it == host_sample_it && grp == 0 && n_groups == 1)) {
+        if (opt.profile == 1 || opt.profile == 3 || (host_sample_call && it == host_sample_it)) {
             SpanGuard sp(kSpanIcp); HIP_TRY(launch_pass(bb, sc, np, st));
             for (uint32_t i = p0; i < p0 + np; ++i) if (h_meta[i].state != prk::kSkip) { g->icp_points += count_h[i]; g->icp_bytes += (uint64_t)count_h[i] * (it == 0 ? 36u : 48u); }
         } else HIP_TRY(launch_pass(bb, sc, np, st));
@@ -1150,8 +1158,14 @@ int refine_wait(int slot)
             else {
                 uint64_t pts = 0;
                 for (uint32_t i = t.q0; i < t.q0 + t.nq; ++i) pts += h_counts[i];
-                g->icp_ms += ms; g->icp_launches++;
+                g->icp_ms += ms; g->icp_launches++; note_launch_us(ms);
                 g->icp_points += pts; g->icp_bytes += pts * (t.edge ? 36u : 48u);
+                if (t.marks) {                                      // kd-tree pass: search | bound | task walk | winners pass
+                    const hipEvent_t ev[5] = { sl.t_events[t.e0], sl.t_events[t.m[0]], sl.t_events[t.m[1]], sl.t_events[t.m[2]], sl.t_events[t.e1] };
+                    float part[4]; bool ok = true;
+                    for (int k = 0; k < 4; ++k) ok = ok && hipEventElapsedTime(&part[k], ev[k], ev[k + 1]) == hipSuccess;
+                    if (ok) { for (int k = 0; k < 4; ++k) g->nn_part_ms[k] += part[k]; g->nn_part_n++; }
+                }
             }
         }
         sl.t_spans.clear(); sl.t_used = 0; sl.timed = false;
@@ -1331,7 +1345,7 @@ int refine_submit_async(Slot &sl, const pr_triangle *tris_dev, size_t n_tris, ui
         return sl.t_used++;
     };
     auto t_begin = [&]() -> size_t { const size_t e = t_event(); (void)hipEventRecord(sl.t_events[e], st); return e; };
-    auto t_end = [&](size_t e0, int kind, uint32_t q0, uint32_t nq, bool edge) { const size_t e1 = t_event(); (void)hipEventRecord(sl.t_events[e1], st); sl.t_spans.push_back({ e0, e1, kind, q0, nq, edge }); };
+    auto t_end = [&](size_t e0, int kind, uint32_t q0, uint32_t nq, bool edge) { const size_t e1 = t_event(); (void)hipEventRecord(sl.t_events[e1], st); sl.t_spans.push_back({ e0, e1, kind, q0, nq, edge, false, { 0, 0, 0 } }); };
     pr_mat4 *d_poses = sl.poses_bbox.as<pr_mat4>();
     int4 *d_box = reinterpret_cast<int4 *>(d_poses + P);
     // Both phases are bound by the same units, so a batch that renders while the other slot is in the middle of its ICP loop
@@ -1399,8 +1413,13 @@ int refine_submit_async(Slot &sl, const pr_triangle *tris_dev, size_t n_tris, ui
                 bb.score_only = (it == (uint32_t)crit.max_iteration) ? 1u : 0u;
                 if (timed) {                                         // (one group: gs == st)
                     const size_t e0 = t_begin();
-                    HIP_TRY(launch_pass(bb, sc, np, gs));
+                    // a kd-tree pass is four kernels: three more events between them give each kernel's own time (pr_profile_nn)
+                    const bool marks = sc.kind == PR_SCENE_NN && sc.nn_split && bb.nn_prev && np <= 32768u;
+                    size_t mi[3] = { 0, 0, 0 }; hipEvent_t me[3] = { nullptr, nullptr, nullptr };
+                    if (marks) for (int k = 0; k < 3; ++k) { mi[k] = t_event(); me[k] = sl.t_events[mi[k]]; }
+                    HIP_TRY(launch_pass(bb, sc, np, gs, marks ? me : nullptr));
                     t_end(e0, kSpanIcp, q0 + p0, np, it == 0 || it == (uint32_t)crit.max_iteration);
+                    if (marks) { Slot::TSpan &ts = sl.t_spans.back(); ts.marks = true; for (int k = 0; k < 3; ++k) ts.m[k] = mi[k]; }
                 } else HIP_TRY(launch_pass(bb, sc, np, gs));
                 if (!fused) HIP_TRY(prk::launch_icp_finalize_solve(bb.partial, meta + p0, nblk, steps, dstate + p0, crit, it, np, gs));
             }
@@ -1559,6 +1578,8 @@ extern "C" {
 
 const char *pr_last_error(void) { return prh::g_err.c_str(); }
 const char *pr_version(void) { return "pose_refine_amd 0.1 (gfx950)"; }
+int pr_abi_version(void) { return PR_ABI_VERSION; }
+static_assert(sizeof(pr_scene_nn) == 72, "pr_scene_nn layout (PR_ABI_VERSION)");
 
 int pr_device_count(void)
 {
@@ -2091,6 +2112,26 @@ int pr_profile_reset(void)
     std::lock_guard<std::mutex> lk(g->mu);
     g->icp_ms = g->render_ms = g->cloud_ms = 0; g->icp_launches = g->icp_points = g->icp_bytes = 0; g->sample_clock = 0;
     g->gather_ms = 0; g->gather_n = 0; g->gather_ev_used = 0;
+    g->icp_launch_us.clear();
+    for (double &v : g->nn_part_ms) v = 0;
+    g->nn_part_n = 0;
+    return PR_OK;
+}
+int pr_profile_launches(float *launch_us, uint32_t capacity, uint32_t *n)
+{
+    PR_TRY(bind_default());
+    std::lock_guard<std::mutex> lk(g->mu);
+    const uint32_t have = (uint32_t)g->icp_launch_us.size();
+    if (n) *n = have;
+    if (launch_us) std::memcpy(launch_us, g->icp_launch_us.data(), sizeof(float) * std::min(have, capacity));
+    return PR_OK;
+}
+int pr_profile_nn(double part_ms[4], uint64_t *passes)
+{
+    PR_TRY(bind_default());
+    std::lock_guard<std::mutex> lk(g->mu);
+    if (part_ms) for (int k = 0; k < 4; ++k) part_ms[k] = g->nn_part_ms[k];
+    if (passes) *passes = g->nn_part_n;
     return PR_OK;
 }
 int pr_profile_read(double *kernel_ms, uint64_t *launches, uint64_t *points, uint64_t *algorithmic_bytes, double *render_ms, double *cloud_ms)

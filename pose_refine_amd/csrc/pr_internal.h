@@ -176,7 +176,8 @@ hipError_t launch_icp_pass_proj_aos(const IcpBatch &b, const SceneProjAoS &sc, u
 hipError_t launch_icp_pass_proj_packed(const IcpBatch &b, const SceneProjPacked &sc, uint32_t n_poses, hipStream_t s);
 hipError_t launch_icp_pass_nn(const IcpBatch &b, const SceneNNDev &sc, uint32_t n_poses, hipStream_t s);
 // split form of the kd-tree pass: search (pending transform applied, winners written to b.nn_prev) + gather/accumulate pass
-hipError_t launch_nn_search(const IcpBatch &b, const SceneNNDev &sc, uint32_t n_poses, uint32_t max_points, uint32_t run, hipStream_t s);
+// marks (or null): three events recorded after the search, the bound and the walk kernel (timed batches; n_poses <= 32768)
+hipError_t launch_nn_search(const IcpBatch &b, const SceneNNDev &sc, uint32_t n_poses, uint32_t max_points, uint32_t run, hipStream_t s, hipEvent_t *marks = nullptr);
 hipError_t launch_icp_pass_nn_winners(const IcpBatch &b, const SceneNNWinners &sc, uint32_t n_poses, hipStream_t s);
 // info[0] = 1 when every scene point owns a grid cell (the grid may be used), 0 otherwise
 // grid: gw*gh cells followed by the three pyramid levels (nn_grid_cells(gw, gh) cells in all)

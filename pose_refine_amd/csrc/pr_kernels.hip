@@ -3156,7 +3156,12 @@ __global__ __launch_bounds__(kWideBuildThreads) void nn_wide_build_kernel(const 
     if (tid == 0) { wq[0] = 0u; s_bad = (info[1] == 1u) ? 0u : 1u; }
     __syncthreads();
     uint32_t begin = 0, end = 1;
-    for (int level = 0; level < 64 && begin < end && !s_bad; ++level) {
+    for (int level = 0; level < 64 && begin < end; ++level) {
+        // s_bad is read into a register BETWEEN two barriers (the one that ended the previous level and this one): stage (A) below sets it,
+        // and a thread still evaluating the loop condition while a faster one is already in (A) would leave the loop alone -- a divergent barrier
+        const bool bad_so_far = s_bad != 0u;
+        __syncthreads();
+        if (bad_so_far) break;
         // (A) frontiers; the words of the record hold binary node ids for now
         for (uint32_t k = begin + tid; k < end; k += kWideBuildThreads) {
             uint32_t fr[8]; float fsz[8]; int nf = 1;
@@ -3479,7 +3484,7 @@ hipError_t launch_icp_pass_nn(const IcpBatch &b, const SceneNNDev &sc, uint32_t 
 hipError_t launch_icp_pass_nn_winners(const IcpBatch &b, const SceneNNWinners &sc, uint32_t n_poses, hipStream_t s)
 { return launch_pass<SceneNNWinners, true, -1>(b, sc, n_poses, 0, s); }
 
-hipError_t launch_nn_search(const IcpBatch &b, const SceneNNDev &sc, uint32_t n_poses, uint32_t max_points, uint32_t run, hipStream_t s)
+hipError_t launch_nn_search(const IcpBatch &b, const SceneNNDev &sc, uint32_t n_poses, uint32_t max_points, uint32_t run, hipStream_t s, hipEvent_t *marks)
 {
     if (n_poses == 0 || max_points == 0) return hipSuccess;
     if (!sc.rec32 || (sc.stack_depth != 16 && sc.stack_depth != 24) || !b.nn_prev || !b.nn_slack || !b.nn_queue || !b.nn_queue2 || !b.nn_qcount) return hipErrorInvalidValue;
@@ -3500,8 +3505,11 @@ hipError_t launch_nn_search(const IcpBatch &b, const SceneNNDev &sc, uint32_t n_
         IcpBatch bb = b;
         bb.meta += p0; bb.nn_qcount += kQCountStride * p0;
         hipLaunchKernelGGL(nn_search_kernel, dim3(gx, np), dim3(kBlockThreads), 0, s, bb, sc, run);
+        if (marks) (void)hipEventRecord(marks[0], s);
+        if (!sc.wide && marks) (void)hipEventRecord(marks[1], s);
         if (sc.wide) {
             hipLaunchKernelGGL(nn_bound_kernel, dim3(tree_gx, np), dim3(kBlockThreads), 0, s, bb, sc);
+            if (marks) (void)hipEventRecord(marks[1], s);
             // a wavefront of the task walk takes 64 queries at a time -- unless the whole launch has too few to fill the chip that way (a single
             // cloud: 26 k queries = 103 workgroups of 4 x 64): then 16 at a time in four times as many workgroups
             uint32_t qbatch = 64u, walk_gx = tree_gx;
@@ -3510,6 +3518,7 @@ hipError_t launch_nn_search(const IcpBatch &b, const SceneNNDev &sc, uint32_t n_
         }
         else if (sc.stack_depth == 16) hipLaunchKernelGGL(HIP_KERNEL_NAME(nn_tree_kernel<16 + 0x100>), dim3(tree_gx, np), dim3(kBlockThreads), (size_t)16 * kBlockThreads * 8, s, bb, sc);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(nn_tree_kernel<24 + 0x100>), dim3(tree_gx, np), dim3(kBlockThreads), (size_t)24 * kBlockThreads * 8, s, bb, sc);
+        if (marks) (void)hipEventRecord(marks[2], s);
     }
     return hipGetLastError();
 }

@@ -1,0 +1,111 @@
+"""`python bench.py --gpus N` starts its N ranks itself.  CPU half: the launcher logic -- the
+command line it builds, the device-budget refusal, the fall-back from processes to threads, the thread control plane.
+GPU half (-m gpu): both launchers end to end with two ranks sharing the box's one GPU (PR_BENCH_SHARE_DEVICE=1)."""
+import json
+import os
+import subprocess
+import sys
+import threading
+import types
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def test_launch_command_is_the_contracts_line():
+    cmd = bench.launch_command(8, 29512, ["--gpus", "8", "--steps", "20", "--warmup", "5"])
+    assert cmd[0] == sys.executable and cmd[1:3] == ["-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29512"
+    i = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"]
+
+
+def test_more_ranks_than_devices_is_refused_with_a_clear_message():
+    with pytest.raises(SystemExit) as e:
+        bench.check_device_budget(8, 1, share_device=False)
+    assert "only 1 GPU(s) visible" in str(e.value) and "PR_BENCH_SHARE_DEVICE=1" in str(e.value)
+    bench.check_device_budget(8, 1, share_device=True)          # test mode: allowed
+    bench.check_device_budget(8, 8, share_device=False)
+
+
+def test_gpus_n_without_world_size_goes_to_the_launcher(monkeypatch):
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.delenv("PR_BENCH_SHARE_DEVICE", raising=False)
+    calls = []
+    monkeypatch.setattr(bench, "visible_devices", lambda: 8)
+    monkeypatch.setattr(bench, "spawn_processes", lambda args, argv: calls.append(("processes", args.gpus, list(argv))) or 0)
+    monkeypatch.setattr(bench, "run_threads", lambda args, note=None: calls.append(("threads", args.gpus, note)) or 0)
+    assert bench.main(["--gpus", "8", "--steps", "3"]) == 0
+    assert bench.main(["--gpus", "4", "--launcher", "threads"]) == 0
+    assert calls == [("processes", 8, ["--gpus", "8", "--steps", "3"]), ("threads", 4, None)]
+    monkeypatch.setattr(bench, "visible_devices", lambda: 1)
+    with pytest.raises(SystemExit) as e:
+        bench.main(["--gpus", "2"])
+    assert "only 1 GPU(s) visible" in str(e.value)
+
+
+def test_failed_process_launch_falls_back_to_threads(monkeypatch, capsys):
+    notes = []
+    monkeypatch.setattr(bench, "run_threads", lambda args, note=None: notes.append(note) or 0)
+    monkeypatch.setattr(subprocess, "run", lambda cmd, **kw: types.SimpleNamespace(returncode=1, stdout="rendezvous failed\n"))
+    args = bench.parse_args(["--gpus", "2"])
+    assert bench.spawn_processes(args, ["--gpus", "2"]) == 0
+    assert notes and "fell back to --launcher threads" in notes[0]
+    # a launch that printed its line is passed through untouched
+    line = json.dumps({"metric": "refined poses/sec (640x480, 20 ICP iters)", "n_gpus": 2})
+    monkeypatch.setattr(subprocess, "run", lambda cmd, **kw: types.SimpleNamespace(returncode=0, stdout="banner\n" + line + "\n"))
+    notes.clear()
+    assert bench.spawn_processes(args, ["--gpus", "2"]) == 0
+    assert not notes and capsys.readouterr().out.strip().splitlines()[-1] == line
+
+
+def test_thread_group_is_a_barrier_and_an_all_gather():
+    world = 4
+    shared = bench.ThreadGroup.Shared(world)
+    got = [None] * world
+
+    def work(r):
+        g = bench.ThreadGroup(shared, r)
+        a = g.all_gather(("first", r))
+        g.barrier()
+        b = g.all_gather(r * r)
+        got[r] = (a, b)
+    ts = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    for r in range(world):
+        assert got[r] == ([("first", i) for i in range(world)], [i * i for i in range(world)])
+
+
+def _run_bench(extra, env_extra):
+    env = dict(os.environ, PR_BENCH_SHARE_DEVICE="1", **env_extra)
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--no-config3"] + extra,
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(line) == 1, r.stdout[-2000:]
+    assert r.stdout.strip().splitlines()[-1] == line[0]         # the JSON line is the last thing printed
+    return json.loads(line[0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("launcher", ["processes", "threads"])
+def test_bench_starts_two_ranks_by_itself(launcher):
+    d = _run_bench(["--launcher", launcher], {})
+    assert d["n_gpus"] == 2 and len(d["per_rank_ms_per_step"]) == 2
+    assert d["launcher"]["kind"] == launcher and d["launcher"]["share_device_test_mode"] is True
+    assert d["gather_when"] == "job" and d["gathers_in_timed_region"] == 1
+    assert d["config"]["global_batch"] == 512 and d["value"] > 1000
+    assert "cpu_baseline" not in d
+
+
+@pytest.mark.gpu
+def test_bench_uneven_shards_gather_per_step():
+    d = _run_bench(["--launcher", "threads", "--global-poses", "301", "--gather", "job"], {})
+    assert d["gather_when"] == "step" and d["gathers_in_timed_region"] == 6 and "do not divide" in d["gather_when_note"]
+    assert d["config"]["poses_per_gpu"] == 151
