@@ -515,6 +515,7 @@ def run_rank(args, group, local_dev, share_device, launcher_note, comm_ready, co
                     marks_out.append(time.perf_counter() - t0)
             self.fence()
             elapsed = time.perf_counter() - t0
+            self.gathers_timed = self.gathers                        # exchanges inside the timed region (the sample step below is outside it)
             api.set_option("profile", 0)
             if sequential:
                 prof, launches_us = api.profile_read(), api.profile_launches()
@@ -560,7 +561,7 @@ def run_rank(args, group, local_dev, share_device, launcher_note, comm_ready, co
     host_cpu_s = time.process_time() - cpu0                          # CPU time of ALL threads of this process (warm-up + timed region)
     wall_s = elapsed
     sizes = job.last_sizes
-    gathers_timed = job.gathers
+    gathers_timed = job.gathers_timed
     gather_ms, gather_n = (api.gather_profile() if (multi and gather_mode == "cabi") else (0.0, 0))
     elapsed, per_rank_ms = over_ranks(elapsed, args.steps)
 
@@ -574,7 +575,7 @@ def run_rank(args, group, local_dev, share_device, launcher_note, comm_ready, co
         config3 = {"workload": f"BASELINE configs[3]: obj_06.ply, 4096 hypotheses per step sharded over {world} GPUs ({job3.P_max} per GPU), projective, {args.iters} ICP iterations, "
                                f"{'ONE gather of all ' + str(k3) + ' x 4096 records' if job3.gather_when == 'job' else 'one gather per step'}",
                    "value": 4096 * k3 / e3, "unit": "poses/s", "ms_per_step": 1e3 * e3 / k3, "steps": k3, "scaling": "strong", "global_batch": 4096,
-                   "poses_per_gpu": job3.P_max, "per_rank_ms_per_step": per3, "gathers": job3.gathers}
+                   "poses_per_gpu": job3.P_max, "per_rank_ms_per_step": per3, "gathers": job3.gathers_timed}
 
     flush_c_stdio()
     if multi:

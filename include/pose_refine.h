@@ -325,6 +325,19 @@ int  pr_profile_launches(float *launch_us, uint32_t capacity, uint32_t *n);
  * pcd_scene.h:60-136 inside thrust__pcd2Ab, icp.h:128-209).  Timed asynchronous batches (profile 3) put events between them:
  * part_ms[0..3] = accumulated time of each kernel, *passes = passes that contributed.  Reset by pr_profile_reset. */
 int  pr_profile_nn(double part_ms[4], uint64_t *passes);
+/* Audit entry: the 29 per-point terms of ONE correspondence pass -- thrust__pcd2Ab's Vec29f, icp.h:128-209: the 21
+ * upper-triangle products J_i J_j row by row, the 6 products J_i r, r^2, and 1 -- for every point of one cloud, zeros where the query
+ * found no correspondence.  update16 (a row-major 4x4, or NULL) is applied to the cloud first and written back, exactly as the fused pass
+ * applies the pending update of the previous iteration (transform_pcd_cuda, icp.cu:142-153).  want_packed != 0 looks the projective scene
+ * up through the packed 16-byte record the fused path uses.  contrib_host receives n_points x 29 floats.  A caller that adds the rows in
+ * point order reproduces the reference's single-thread summation (icp.cpp:139-148), which the product kernel replaces by its fixed tree. */
+int  pr_debug_contrib29(pr_vec3 *cloud_dev, uint32_t n_points, int scene_kind, const void *scene, const float *update16, int want_packed,
+                        float *contrib_host);
+/* Two things the library does silently for correctness, counted per context since it was created: asynchronous batches that
+ * pr_refine_wait ran a SECOND time because the device-side checks found a stale model box or a scene array that no longer matches its
+ * cached form (a caller who sees this grow writes to its buffers behind the library's back: pr_invalidate is the cheap cure), and timed
+ * spans / batches whose HIP-event timing was dropped because an event could not be created or recorded (the work itself ran). */
+int  pr_stats(uint64_t *batches_repeated, uint64_t *timings_dropped);
 /* HIP-event time of the pr_gather_results exchanges issued while option "profile" was non-zero (events on the context's stream around
  * the grouped send / receive; accumulated since pr_profile_reset).  Waits for the stream.  New in this library -- the reference has
  * no multi-device code (test.cpp:14). */

@@ -122,6 +122,8 @@ SIGNATURES = {
     "pr_gather_profile": (_i32, [C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "pr_profile_launches": (_i32, [_vp, _u32, C.POINTER(_u32)]),
     "pr_profile_nn": (_i32, [_vp, C.POINTER(C.c_uint64)]),
+    "pr_debug_contrib29": (_i32, [_vp, _u32, _i32, _vp, _vp, _i32, _vp]),
+    "pr_stats": (_i32, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
 }
 
 _lib = None

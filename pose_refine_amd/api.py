@@ -143,6 +143,13 @@ def profile_nn():
     return ms, n.value
 
 
+def stats():
+    """``pr_stats``: (asynchronous batches repeated by the stale-cache safety net, timings dropped after a failed event call)."""
+    a, b = C.c_uint64(), C.c_uint64()
+    check(_lib.load().pr_stats(C.byref(a), C.byref(b)))
+    return a.value, b.value
+
+
 def gather_profile():
     """HIP-event time of the gathers issued while option ``profile`` was on: (total ms, count).  Waits for the library stream."""
     ms, n = C.c_double(), C.c_uint64()
@@ -491,6 +498,16 @@ def ICP_Point2Plane_batch(clouds: DeviceVector, offsets, scene, criteria: ICPCon
     d = scene.desc()
     check(_lib.load().pr_icp_batch(clouds.data(), ptr(offsets), len(offsets) - 1, scene.kind, C.addressof(d), criteria.c(), ptr(res)))
     return res
+
+
+def debug_contrib29(model_pcd: DeviceVector, scene, update=None, packed: bool = False) -> np.ndarray:
+    """``pr_debug_contrib29``: the (n, 29) per-point terms of one correspondence pass; ``update`` (4x4 or None) is applied to the cloud first."""
+    n = model_pcd.size() // 3
+    out = np.zeros((n, 29), np.float32)
+    d = scene.desc()
+    u = _f32(update, -1) if update is not None else None
+    check(_lib.load().pr_debug_contrib29(model_pcd.data(), n, scene.kind, C.addressof(d), ptr(u) if u is not None else None, int(packed), ptr(out)))
+    return out
 
 
 def refine_batch(tris, poses, width: int, height: int, proj, K, scene,

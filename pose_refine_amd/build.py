@@ -15,14 +15,19 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "lib", "libpose_refine_hip.so")
-SOURCES = ["pr_kernels.hip", "pr_api.cpp", "pr_host.cpp"]
-DEPS = SOURCES + ["pr_internal.h", "pr_solver.inl", os.path.join(ROOT, "include", "pose_refine.h")]
+# one translation unit per stage of the path (kernels + their launchers), the C ABI and the host-side code; headers = shared device code
+SOURCES = ["raster.hip", "d2c.hip", "icp_pass.hip", "icp_flow.hip", "icp_debug.hip", "nn_search.hip", "nn_build.hip", "kd_build.hip", "scene_prep.hip",
+           "pr_api.cpp", "pr_host.cpp"]
+HEADERS = ["pr_internal.h", "pr_solver.inl", "pr_tuning.h", "pr_device.h", "pr_launch.h", "proj_query.h", "nn_query.h", "icp_accumulate.h",
+           "icp_solve_device.h"]
+DEPS = SOURCES + HEADERS + [os.path.join(ROOT, "include", "pose_refine.h")]
+OBJ_DIR = os.path.join(HERE, "lib", "obj")
 # -ffp-contract=off: no FMA contraction anywhere (bit-parity with the CPU restatement);
 # division and sqrt stay IEEE-correct (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt).
 # -fno-slp-vectorize: the SLP vectoriser packs the 29-term accumulation into v_pk_mul_f32 / v_pk_add_f32 plus ~230 v_mov to
 # arrange the pairs; on gfx950 packed f32 is no faster per element, so the unpacked code is ~8 % quicker (measured A/B).
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared",
-         "-Wno-unused-value", "-Wl,-rpath,/opt/rocm/lib"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-Wno-unused-value"]
+LINK_FLAGS = ["--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-rpath,/opt/rocm/lib"]
 
 
 def hipcc() -> str:
@@ -40,14 +45,34 @@ def is_stale() -> bool:
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile the translation units side by side (a unit is recompiled when it, a header or the flags changed), then link."""
     if not force and not is_stale():
         return OUT
-    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    from concurrent.futures import ThreadPoolExecutor
+    os.makedirs(OBJ_DIR, exist_ok=True)
     extra = os.environ.get("PR_EXTRA_FLAGS", "").split()
-    cmd = [hipcc()] + FLAGS + extra + ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC] + \
-          [os.path.join(CSRC, s) for s in SOURCES] + ["-o", OUT]
+    base = [hipcc()] + FLAGS + extra + ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+    stamp = os.path.join(OBJ_DIR, "flags.txt")
+    flags_now = " ".join(base)
+    flags_same = os.path.exists(stamp) and open(stamp).read() == flags_now
+    newest_header = max(os.path.getmtime(d if os.path.isabs(d) else os.path.join(CSRC, d)) for d in DEPS if d not in SOURCES)
+
+    def compile_one(name: str) -> str:
+        obj = os.path.join(OBJ_DIR, name.rsplit(".", 1)[0] + ".o")
+        src = os.path.join(CSRC, name)
+        if force or not flags_same or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), newest_header):
+            cmd = base + ["-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.run(cmd, check=True)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4)) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    open(stamp, "w").write(flags_now)
+    cmd = [hipcc()] + LINK_FLAGS + objs + ["-o", OUT]
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
     return OUT
 

@@ -1,0 +1,271 @@
+// nn_build.hip -- traversal records derived from the reference's Node_kdtree array: topology + tight boxes, 64- and 32-byte records, 128-byte wide records
+// gfx950 (CDNA4, wave64); compiled with -ffp-contract=off: every per-element value is bit-identical to the CPU restatement.
+#include "pr_launch.h"
+#include "nn_query.h"
+
+namespace prk {
+
+__global__ __launch_bounds__(256) void nn_accel_kernel(const pr_kdnode *__restrict__ nodes, uint32_t n_nodes,
+                                                       const pr_vec3 *__restrict__ pcd, uint32_t n_points,
+                                                       int4 *__restrict__ topo, float4 *__restrict__ bmin,
+                                                       float4 *__restrict__ bmax, float4 *__restrict__ pts)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n_points) pts[i] = make_float4(pcd[i].x, pcd[i].y, pcd[i].z, 0.0f);
+    if (i >= n_nodes) return;
+    const pr_kdnode nd = nodes[i];
+    const bool leaf = (nd.child1 < 0 || nd.child2 < 0);              // pcd_scene.h:21-24
+    const int pw = ((nd.parent + 1) & 0x3fffffff) | (int)((uint32_t)(nd.split_dim & 3) << 30);
+    if (leaf) {
+        float lo[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, hi[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
+        for (int k = nd.left; k < nd.right; ++k) {
+            const float c3[3] = { pcd[k].x, pcd[k].y, pcd[k].z };
+            for (int d = 0; d < 3; ++d) { lo[d] = fminf(lo[d], c3[d]); hi[d] = fmaxf(hi[d], c3[d]); }
+        }
+        topo[i] = make_int4(nd.left, nd.right, -1, pw);
+        bmin[i] = make_float4(lo[0], lo[1], lo[2], 0.0f);
+        bmax[i] = make_float4(hi[0], hi[1], hi[2], 0.0f);
+    } else {
+        topo[i] = make_int4(__float_as_int(nd.split_v), nd.child1, nd.child2, pw);
+        bmin[i] = make_float4(nd.bbox[0], nd.bbox[2], nd.bbox[4], 0.0f);
+        bmax[i] = make_float4(nd.bbox[1], nd.bbox[3], nd.bbox[5], 0.0f);
+    }
+}
+
+// 64-byte traversal records for the stack variant + the depth of the tree (longest root-to-node path)
+__global__ __launch_bounds__(256) void nn_records_kernel(const int4 *__restrict__ topo, const float4 *__restrict__ bmin,
+                                                         const float4 *__restrict__ bmax, uint32_t n_nodes,
+                                                         float4 *__restrict__ rec, uint32_t *__restrict__ max_depth)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_nodes) return;
+    const int4 t = topo[i];
+    float4 r0, r1 = make_float4(0, 0, 0, 0), r2 = r1, r3 = r1;
+    if (t.z < 0) r0 = make_float4(__int_as_float(t.x), __int_as_float(t.y), __int_as_float(-1), 0.0f);
+    else {
+        const int dim = (int)((uint32_t)t.w >> 30);
+        r0 = make_float4(__int_as_float(t.x), __int_as_float(t.y), __int_as_float(t.z), __int_as_float(dim));
+        const int y = ((uint32_t)t.y < n_nodes) ? t.y : 0, z = ((uint32_t)t.z < n_nodes) ? t.z : 0;   // malformed links are reported below
+        const float4 a0 = bmin[y], a1 = bmax[y], c0 = bmin[z], c1 = bmax[z];
+        r1 = make_float4(a0.x, a0.y, a0.z, a1.x);
+        r2 = make_float4(a1.y, a1.z, c0.x, c0.y);
+        r3 = make_float4(c0.z, c1.x, c1.y, c1.z);
+    }
+    rec[(size_t)i * 4] = r0; rec[(size_t)i * 4 + 1] = r1; rec[(size_t)i * 4 + 2] = r2; rec[(size_t)i * 4 + 3] = r3;
+    uint32_t depth = 0;
+    for (int p = (t.w & 0x3fffffff) - 1; p >= 0 && depth < 4096; p = (topo[p].w & 0x3fffffff) - 1) ++depth;
+    // The stack size is derived from this depth, which follows the PARENT links, while the search follows the CHILD links: the
+    // nodes are the caller's, so the two are cross-checked.  Any disagreement reports an impossible depth and the scene is
+    // searched with the reference's stackless walk instead (which uses both kinds of link exactly like pcd_scene.h:60-136).
+    if (t.z >= 0) {
+        const bool in_range = (uint32_t)t.y < n_nodes && (uint32_t)t.z < n_nodes && t.y > (int)i && t.z > (int)i;
+        if (!in_range || (topo[t.y].w & 0x3fffffff) - 1 != (int)i || (topo[t.z].w & 0x3fffffff) - 1 != (int)i) depth = 0x7fffffffu;
+    }
+    atomicMax(max_depth, depth);
+}
+
+// Compact traversal records: 32 bytes per node.
+//   word 0: split value (internal) | first point (leaf)
+//   word 1: child1 | dim << 30 (internal; child2 = child1 + 1, as KDTree_cpu::build_tree appends children pairwise) | end point | 3 << 30 (leaf)
+//   words 2..7: the boxes of child1 and child2 as 12 uint16 {lo.x lo.y lo.z hi.x hi.y hi.z} x 2, quantised in the frame of
+//   the root box and rounded OUTWARDS (checked with the very dequantisation arithmetic the query uses).  A looser box can
+//   only make the search visit a subtree it could have skipped -- a subtree whose every point is farther than the current
+//   best -- so winners, distances and tie-breaks are those of the exact boxes.
+__global__ void nn_frame_kernel(const float4 *__restrict__ bmin, const float4 *__restrict__ bmax, uint32_t *__restrict__ info)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const float lo[3] = { bmin[0].x, bmin[0].y, bmin[0].z }, hi[3] = { bmax[0].x, bmax[0].y, bmax[0].z };
+    for (int a = 0; a < 3; ++a) {
+        float sc = (hi[a] - lo[a]) / 65535.0f * 1.000001f;
+        if (!(sc > 1e-30f)) sc = 1e-30f;
+        info[2 + a] = __float_as_uint(lo[a]);
+        info[5 + a] = __float_as_uint(sc);
+    }
+    info[1] = 1u;
+}
+__global__ __launch_bounds__(256) void nn_records32_kernel(const int4 *__restrict__ topo, const float4 *__restrict__ bmin,
+                                                           const float4 *__restrict__ bmax, uint32_t n_nodes, uint4 *__restrict__ rec32,
+                                                           uint2 *__restrict__ desc, uint32_t *__restrict__ info)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_nodes) return;
+    const int4 t = topo[i];
+    uint32_t w[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    bool ok = true;
+    if (t.z < 0) { w[0] = (uint32_t)t.x; w[1] = (uint32_t)t.y | (3u << 30); ok = ((uint32_t)t.y < (1u << 30)); }
+    else {
+        const uint32_t dim = (uint32_t)t.w >> 30;
+        w[0] = (uint32_t)t.x; w[1] = (uint32_t)t.y | (dim << 30);
+        ok = (t.z == t.y + 1) && ((uint32_t)t.y < (1u << 30)) && dim < 3 && (uint32_t)t.z < n_nodes;
+        // the 8-byte descent skips a far side on (q - split)^2 alone, which needs left_max <= split <= right_min
+        // (pcd_scene.cpp:135 builds trees that way; other trees take the exact 64-byte records)
+        if (ok) {
+            const float lmax = (dim == 0) ? bmax[t.y].x : ((dim == 1) ? bmax[t.y].y : bmax[t.y].z);
+            const float rmin = (dim == 0) ? bmin[t.z].x : ((dim == 1) ? bmin[t.z].y : bmin[t.z].z);
+            const float split = __int_as_float(t.x);
+            if (!(lmax <= split && split <= rmin)) ok = false;
+        }
+        uint32_t q[12];
+        for (int c = 0; c < 2; ++c) {
+            const int ch = ok ? (c ? t.z : t.y) : 0;
+            const float lo[3] = { bmin[ch].x, bmin[ch].y, bmin[ch].z }, hi[3] = { bmax[ch].x, bmax[ch].y, bmax[ch].z };
+            for (int a = 0; a < 3; ++a) {
+                const float qmin = __uint_as_float(info[2 + a]), qs = __uint_as_float(info[5 + a]);
+                float fl = floorf((lo[a] - qmin) / qs) - 1.0f;
+                uint32_t ql = fl > 0.0f ? (fl < 65535.0f ? (uint32_t)fl : 65535u) : 0u;
+                while (ql > 0 && !(nn_deq(ql, qmin, qs) <= lo[a])) --ql;
+                if (!(nn_deq(ql, qmin, qs) <= lo[a])) ok = false;
+                float fh = ceilf((hi[a] - qmin) / qs) + 1.0f;
+                uint32_t qh = fh > 0.0f ? (fh < 65535.0f ? (uint32_t)fh : 65535u) : 0u;
+                while (qh < 65535u && !(nn_deq(qh, qmin, qs) >= hi[a])) ++qh;
+                if (!(nn_deq(qh, qmin, qs) >= hi[a])) ok = false;
+                q[c * 6 + a] = ql; q[c * 6 + 3 + a] = qh;
+            }
+        }
+        for (int k = 0; k < 6; ++k) w[2 + k] = q[2 * k] | (q[2 * k + 1] << 16);
+    }
+    rec32[(size_t)i * 2] = make_uint4(w[0], w[1], w[2], w[3]);
+    rec32[(size_t)i * 2 + 1] = make_uint4(w[4], w[5], w[6], w[7]);
+    desc[i] = make_uint2(w[0], w[1]);
+    if (!ok) info[1] = 0u;                                       // any node that does not fit: the 64-byte records are used instead
+}
+
+// ---- wide records (query_nn_wide) ---------------------------------------------------------------------------------------------
+// Box of a binary node as 6 uint16 in the root-box frame, rounded outwards and checked with the dequantisation the query uses.
+__device__ __forceinline__ bool wide_quant_box(const float4 lo4, const float4 hi4, const uint32_t *__restrict__ info, uint32_t (&u)[3])
+{
+    const float lo[3] = { lo4.x, lo4.y, lo4.z }, hi[3] = { hi4.x, hi4.y, hi4.z };
+    uint32_t q[6];
+    bool ok = true;
+    for (int a = 0; a < 3; ++a) {
+        const float qmin = __uint_as_float(info[2 + a]), qs = __uint_as_float(info[5 + a]);
+        const float fl = floorf((lo[a] - qmin) / qs) - 1.0f;
+        uint32_t ql = fl > 0.0f ? (fl < 65535.0f ? (uint32_t)fl : 65535u) : 0u;
+        while (ql > 0 && !(nn_deq_fma(ql, qmin, qs) <= lo[a])) --ql;
+        if (!(nn_deq_fma(ql, qmin, qs) <= lo[a])) ok = false;
+        const float fh = ceilf((hi[a] - qmin) / qs) + 1.0f;
+        uint32_t qh = fh > 0.0f ? (fh < 65535.0f ? (uint32_t)fh : 65535u) : 0u;
+        while (qh < 65535u && !(nn_deq_fma(qh, qmin, qs) >= hi[a])) ++qh;
+        if (!(nn_deq_fma(qh, qmin, qs) >= hi[a])) ok = false;
+        q[a] = ql; q[3 + a] = qh;
+    }
+    u[0] = q[0] | (q[1] << 16); u[1] = q[2] | (q[3] << 16); u[2] = q[4] | (q[5] << 16);
+    return ok;
+}
+// One workgroup builds the wide nodes level by level (a scene is prepared once; 6 287 binary nodes give 5 levels).  Per level:
+// (A) every wide node opens its binary root into a frontier of up to eight descendants -- repeatedly the internal frontier node
+// with the longest box diagonal -- and counts the internal ones, (B) an exclusive scan of those counts numbers the next level's
+// wide nodes (deterministic: a wide node's index does not depend on timing), (C) the records are written.  `wq[k]` = binary root
+// of wide node k, `cnt[k]` = scan scratch.  A tree whose links are out of order (child index <= parent index) clears info[8].
+constexpr uint32_t kWideBuildThreads = 1024;
+__global__ __launch_bounds__(kWideBuildThreads) void nn_wide_build_kernel(const int4 *__restrict__ topo, const float4 *__restrict__ bmin,
+                                                                           const float4 *__restrict__ bmax, uint32_t n_nodes, uint4 *__restrict__ wide,
+                                                                           uint32_t cap_wide, uint32_t *__restrict__ wq, uint32_t *__restrict__ cnt,
+                                                                           uint32_t n_points, uint32_t *__restrict__ info)
+{
+    __shared__ uint32_t part[kWideBuildThreads];
+    __shared__ uint32_t s_bad;
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) { wq[0] = 0u; s_bad = (info[1] == 1u) ? 0u : 1u; }
+    __syncthreads();
+    uint32_t begin = 0, end = 1;
+    for (int level = 0; level < 64 && begin < end; ++level) {
+        // s_bad is read into a register BETWEEN two barriers (the one that ended the previous level and this one): stage (A) below sets it,
+        // and a thread still evaluating the loop condition while a faster one is already in (A) would leave the loop alone -- a divergent barrier
+        const bool bad_so_far = s_bad != 0u;
+        __syncthreads();
+        if (bad_so_far) break;
+        // (A) frontiers; the words of the record hold binary node ids for now
+        for (uint32_t k = begin + tid; k < end; k += kWideBuildThreads) {
+            uint32_t fr[8]; float fsz[8]; int nf = 1;
+            fr[0] = wq[k];
+            auto size_of = [&](uint32_t n) -> float {              // -1 for a leaf (never opened)
+                if (topo[n].z < 0) return -1.0f;
+                const float4 a = bmin[n], b = bmax[n];
+                return (b.x - a.x) * (b.x - a.x) + (b.y - a.y) * (b.y - a.y) + (b.z - a.z) * (b.z - a.z);
+            };
+            fsz[0] = (topo[fr[0]].z < 0) ? -1.0f : FLT_MAX;        // the root of a wide node is always opened (unless the whole tree is one leaf)
+            while (nf < 8) {
+                int pick = -1;
+                for (int i = 0; i < nf; ++i) if (fsz[i] >= 0.0f && (pick < 0 || fsz[i] > fsz[pick])) pick = i;
+                if (pick < 0) break;
+                const uint32_t n = fr[pick];
+                const int4 t = topo[n];
+                if (!((uint32_t)t.y < n_nodes && (uint32_t)t.z < n_nodes && (uint32_t)t.y > n && (uint32_t)t.z > n)) { s_bad = 1u; fsz[pick] = -1.0f; continue; }
+                fr[pick] = (uint32_t)t.y; fsz[pick] = size_of((uint32_t)t.y);
+                fr[nf] = (uint32_t)t.z;   fsz[nf] = size_of((uint32_t)t.z);
+                ++nf;
+            }
+            uint32_t internal = 0;
+            for (int c = 0; c < 8; ++c) {                            // slot c = {box, reference}; internal children carry their BINARY id until (C)
+                uint32_t u[3] = { 0u, 0u, 0u }, ref = kWideEmpty;
+                if (c < nf) {
+                    const uint32_t n = fr[c];
+                    const int4 t = topo[n];
+                    if (!wide_quant_box(bmin[n], bmax[n], info, u)) s_bad = 1u;
+                    if (t.z < 0) {
+                        const int lo = t.x, hi = t.y;
+                        if (lo >= 0 && hi > lo && (uint32_t)(hi - lo) <= kWideMaxLeafPoints && (uint32_t)lo <= kWideFirstMask && (uint32_t)hi <= n_points)
+                            ref = kWideLeaf | ((uint32_t)(hi - lo) << 27) | (uint32_t)lo;
+                        else if (hi != lo) s_bad = 1u;               // (an empty leaf stays an empty slot)
+                    } else { ref = n; ++internal; if (n >= 0x7fffffffu) s_bad = 1u; }
+                }
+                wide[(size_t)k * 8 + c] = make_uint4(u[0], u[1], u[2], ref);
+            }
+            cnt[k] = internal;
+        }
+        __syncthreads();
+        // (B) exclusive scan of cnt[begin, end): contiguous chunk per thread, Hillis-Steele over the chunk sums
+        const uint32_t span = end - begin, chunk = (span + kWideBuildThreads - 1) / kWideBuildThreads;
+        const uint32_t c0 = begin + tid * chunk, c1 = (c0 + chunk < end) ? c0 + chunk : end;
+        uint32_t sum = 0;
+        for (uint32_t k = c0; k < c1 && k >= begin; ++k) sum += cnt[k];
+        part[tid] = sum;
+        __syncthreads();
+        for (uint32_t off = 1; off < kWideBuildThreads; off <<= 1) {
+            const uint32_t v = (tid >= off) ? part[tid - off] : 0u;
+            __syncthreads();
+            part[tid] += v;
+            __syncthreads();
+        }
+        const uint32_t total = part[kWideBuildThreads - 1];
+        uint32_t run = part[tid] - sum;                              // exclusive prefix of this thread's chunk
+        for (uint32_t k = c0; k < c1 && k >= begin; ++k) { const uint32_t v = cnt[k]; cnt[k] = run; run += v; }
+        if (tid == 0 && (size_t)end + total > (size_t)cap_wide) s_bad = 1u;
+        __syncthreads();
+        if (s_bad) break;
+        // (C) number the internal children: wide node k's go to end + cnt[k] ...
+        for (uint32_t k = begin + tid; k < end; k += kWideBuildThreads) {
+            uint32_t next = end + cnt[k];
+            for (int c = 0; c < 8; ++c) {
+                uint4 r = wide[(size_t)k * 8 + c];
+                if (r.w != kWideEmpty && !(r.w & kWideLeaf)) { wq[next] = r.w; r.w = next; ++next; wide[(size_t)k * 8 + c] = r; }
+            }
+        }
+        __syncthreads();
+        begin = end; end = end + total;
+    }
+    __syncthreads();
+    if (tid == 0) { info[8] = (s_bad || begin < end) ? 0u : 1u; info[9] = end; }
+}
+
+hipError_t launch_build_nn_accel(const pr_kdnode *nodes, uint32_t n_nodes, const pr_vec3 *pcd, uint32_t n_points,
+                                 int4 *topo, float4 *bmin, float4 *bmax, float4 *pts, float4 *rec, uint4 *rec32, uint2 *desc, uint32_t *info, hipStream_t s,
+                                 uint4 *wide, uint32_t *wide_scratch)
+{
+    const uint32_t m = (n_nodes > n_points) ? n_nodes : n_points;
+    if (m == 0) return hipSuccess;
+    hipLaunchKernelGGL(nn_accel_kernel, dim3((m + 255) / 256), dim3(256), 0, s, nodes, n_nodes, pcd, n_points, topo, bmin, bmax, pts);
+    hipError_t e = hipMemsetAsync(info, 0, 16 * sizeof(uint32_t), s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(nn_records_kernel, dim3((n_nodes + 255) / 256), dim3(256), 0, s, topo, bmin, bmax, n_nodes, rec, info);
+    hipLaunchKernelGGL(nn_frame_kernel, dim3(1), dim3(64), 0, s, bmin, bmax, info);
+    hipLaunchKernelGGL(nn_records32_kernel, dim3((n_nodes + 255) / 256), dim3(256), 0, s, topo, bmin, bmax, n_nodes, rec32, desc, info);
+    if (wide && wide_scratch) {
+        const uint32_t cap = (uint32_t)nn_wide_capacity(n_nodes);
+        hipLaunchKernelGGL(nn_wide_build_kernel, dim3(1), dim3(kWideBuildThreads), 0, s, topo, bmin, bmax, n_nodes, wide, cap, wide_scratch, wide_scratch + cap, n_points, info);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace prk

@@ -236,6 +236,7 @@ struct Ctx {
     std::vector<Span> spans;
     double icp_ms = 0, render_ms = 0, cloud_ms = 0; uint64_t icp_launches = 0, icp_points = 0, icp_bytes = 0, sample_clock = 0;
     std::vector<float> icp_launch_us;                            // the timed launches one by one (pr_profile_launches), bounded
+    uint64_t stat_repeated = 0, stat_timing_dropped = 0;         // pr_stats: batches run twice by the stale-cache safety net; timed spans lost to a failed event call
     double nn_part_ms[4] = { 0, 0, 0, 0 }; uint64_t nn_part_n = 0;   // kd-tree pass by kernel: search, bound, task walk, winners pass (pr_profile_nn)
     Slot slots[kSlots];
     std::vector<CachedGraph> graphs;
@@ -316,15 +317,27 @@ int require_ctx()
 
 // ---- profiling spans (HIP events on the library stream) ------------------------------------------
 enum { kSpanIcp = 0, kSpanRender = 1, kSpanCloud = 2 };
+// (a failed event call must not vanish: HIP_TRY clears the sticky error, so the span is dropped HERE and counted -- pr_stats)
+constexpr size_t kNoEvent = (size_t)-1;
 size_t take_event()
 {
-    if (g->ev_used == g->ev_pool.size()) { hipEvent_t e; hipEventCreate(&e); g->ev_pool.push_back(e); }
+    if (g->ev_used == g->ev_pool.size()) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess || !e) { (void)hipGetLastError(); g->stat_timing_dropped++; return kNoEvent; }
+        g->ev_pool.push_back(e);
+    }
     return g->ev_used++;
+}
+inline bool record_event(size_t e, hipStream_t st)
+{
+    if (e == kNoEvent) return false;
+    if (hipEventRecord(g->ev_pool[e], st) != hipSuccess) { (void)hipGetLastError(); g->stat_timing_dropped++; return false; }
+    return true;
 }
 struct SpanGuard {
     bool on; size_t e0 = 0; int kind;
-    explicit SpanGuard(int k) : on(opt.profile != 0), kind(k) { if (on) { e0 = take_event(); hipEventRecord(g->ev_pool[e0], g->stream); } }
-    ~SpanGuard() { if (on) { size_t e1 = take_event(); hipEventRecord(g->ev_pool[e1], g->stream); g->spans.push_back({ e0, e1, kind }); } }
+    explicit SpanGuard(int k) : on(opt.profile != 0), kind(k) { if (on) { e0 = take_event(); on = record_event(e0, g->stream); } }
+    ~SpanGuard() { if (on) { const size_t e1 = take_event(); if (record_event(e1, g->stream)) g->spans.push_back({ e0, e1, kind }); } }
 };
 constexpr size_t kLaunchSamples = 8192;
 inline void note_launch_us(float ms) { if (g->icp_launch_us.size() < kLaunchSamples) g->icp_launch_us.push_back(ms * 1e3f); }
@@ -1136,6 +1149,7 @@ int refine_wait(int slot)
         // the triangle buffer no longer has the box this batch was sized with: forget the host copy and run the batch again,
         // synchronously (that path derives every box on the device); outputs are overwritten in full
         g->aabb_host_valid = false; g->mesh_key = nullptr;
+        g->stat_repeated++;                                         // (pr_stats: the safety net is not free -- a caller that sees this count grow should call pr_invalidate)
         // (or a scene array no longer has the content its cached form was derived from: same cure)
         drain_all_slots();
         for (Slot &o : g->slots) o.packed.valid = false;
@@ -1340,12 +1354,19 @@ int refine_submit_async(Slot &sl, const pr_triangle *tris_dev, size_t n_tris, ui
     // it may start with this loop's first pass.  0.2-0.4 ms per start of a stream of batches (1-2 % of a 20-step run).
     bool pipeline_start = true;
     for (Slot &o : g->slots) if (&o != &sl && o.pending && !o.delivered) pipeline_start = false;
+    // a failed event creation or record drops the TIMING of this batch (never the batch): t_fail, checked when everything is enqueued
+    bool t_fail = false;
     auto t_event = [&]() -> size_t {
-        if (sl.t_used == sl.t_events.size()) { hipEvent_t e = nullptr; (void)hipEventCreate(&e); sl.t_events.push_back(e); }
+        if (sl.t_used == sl.t_events.size()) {
+            hipEvent_t e = nullptr;
+            if (hipEventCreate(&e) != hipSuccess || !e) { (void)hipGetLastError(); t_fail = true; return kNoEvent; }
+            sl.t_events.push_back(e);
+        }
         return sl.t_used++;
     };
-    auto t_begin = [&]() -> size_t { const size_t e = t_event(); (void)hipEventRecord(sl.t_events[e], st); return e; };
-    auto t_end = [&](size_t e0, int kind, uint32_t q0, uint32_t nq, bool edge) { const size_t e1 = t_event(); (void)hipEventRecord(sl.t_events[e1], st); sl.t_spans.push_back({ e0, e1, kind, q0, nq, edge, false, { 0, 0, 0 } }); };
+    auto t_record = [&](size_t e) { if (e == kNoEvent) { t_fail = true; return; } if (hipEventRecord(sl.t_events[e], st) != hipSuccess) { (void)hipGetLastError(); t_fail = true; } };
+    auto t_begin = [&]() -> size_t { const size_t e = t_event(); t_record(e); return e; };
+    auto t_end = [&](size_t e0, int kind, uint32_t q0, uint32_t nq, bool edge) { const size_t e1 = t_event(); t_record(e1); if (!t_fail) sl.t_spans.push_back({ e0, e1, kind, q0, nq, edge, false, { 0, 0, 0 } }); };
     pr_mat4 *d_poses = sl.poses_bbox.as<pr_mat4>();
     int4 *d_box = reinterpret_cast<int4 *>(d_poses + P);
     // Both phases are bound by the same units, so a batch that renders while the other slot is in the middle of its ICP loop
@@ -1416,10 +1437,11 @@ int refine_submit_async(Slot &sl, const pr_triangle *tris_dev, size_t n_tris, ui
                     // a kd-tree pass is four kernels: three more events between them give each kernel's own time (pr_profile_nn)
                     const bool marks = sc.kind == PR_SCENE_NN && sc.nn_split && bb.nn_prev && np <= 32768u;
                     size_t mi[3] = { 0, 0, 0 }; hipEvent_t me[3] = { nullptr, nullptr, nullptr };
-                    if (marks) for (int k = 0; k < 3; ++k) { mi[k] = t_event(); me[k] = sl.t_events[mi[k]]; }
-                    HIP_TRY(launch_pass(bb, sc, np, gs, marks ? me : nullptr));
+                    bool marks_ok = marks;
+                    if (marks) for (int k = 0; k < 3; ++k) { mi[k] = t_event(); if (mi[k] == kNoEvent) marks_ok = false; else me[k] = sl.t_events[mi[k]]; }
+                    HIP_TRY(launch_pass(bb, sc, np, gs, marks_ok ? me : nullptr));
                     t_end(e0, kSpanIcp, q0 + p0, np, it == 0 || it == (uint32_t)crit.max_iteration);
-                    if (marks) { Slot::TSpan &ts = sl.t_spans.back(); ts.marks = true; for (int k = 0; k < 3; ++k) ts.m[k] = mi[k]; }
+                    if (marks_ok && !t_fail) { Slot::TSpan &ts = sl.t_spans.back(); ts.marks = true; for (int k = 0; k < 3; ++k) ts.m[k] = mi[k]; }
                 } else HIP_TRY(launch_pass(bb, sc, np, gs));
                 if (!fused) HIP_TRY(prk::launch_icp_finalize_solve(bb.partial, meta + p0, nblk, steps, dstate + p0, crit, it, np, gs));
             }
@@ -1433,6 +1455,7 @@ int refine_submit_async(Slot &sl, const pr_triangle *tris_dev, size_t n_tris, ui
     HIP_TRY(prk::launch_pack_export(sl.dstate.as<prk::DevIcpState>(), dres, sl.counts.as<uint32_t>(), static_cast<uint32_t *>(h_out_dev),
                                     results_host ? reinterpret_cast<pr_result *>(static_cast<unsigned char *>(h_out_dev) + res_off) : nullptr, P, st));
     HIP_TRY(hipEventRecord(sl.done, st));
+    if (t_fail) { sl.timed = false; sl.t_spans.clear(); sl.t_used = 0; g->stat_timing_dropped++; }   // the batch runs; its timing is dropped, and counted
     return PR_OK;
 }
 
@@ -1853,6 +1876,31 @@ int pr_icp_nn(pr_vec3 *cloud_dev, uint32_t n_points, const pr_scene_nn *scene, p
     return pr_icp_batch(cloud_dev, off, 1, PR_SCENE_NN, scene, crit, result_out);
 }
 
+// Audit entry: what ONE correspondence pass contributes, point by point (29 floats each: the 21 upper-triangle products of J J^T row by
+// row, the 6 products J r, r^2 and the inlier flag -- thrust__pcd2Ab, icp.h:128-209), with the pending update applied to the cloud first
+// like the fused pass does.  A caller that adds the rows in point order reproduces the reference's single-thread sums (icp.cpp:139-148).
+int pr_debug_contrib29(pr_vec3 *cloud_dev, uint32_t n_points, int scene_kind, const void *scene, const float *update16, int want_packed, float *contrib_host)
+{
+    PR_ENTER();
+    if (n_points == 0) return PR_OK;
+    if (!cloud_dev || !contrib_host) { set_error("pr_debug_contrib29: null buffer"); return PR_ERR_INVALID; }
+    SceneSel sc;
+    std::memset(static_cast<void *>(&sc), 0, sizeof sc);
+    PR_TRY(make_scene(scene_kind, scene, want_packed != 0, sc));
+    DevBuf out;
+    PR_TRY(out.ensure(sizeof(float) * 29 * (size_t)n_points));
+    hipError_t e;
+    if (sc.kind == PR_SCENE_NN) e = prk::launch_contrib29_nn(cloud_dev, n_points, update16, sc.nn, out.as<float>(), g->stream);
+    else if (sc.packed) e = prk::launch_contrib29_proj_packed(cloud_dev, n_points, update16, sc.pk, out.as<float>(), g->stream);
+    else e = prk::launch_contrib29_proj_aos(cloud_dev, n_points, update16, sc.aos, out.as<float>(), g->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(contrib_host, out.p, sizeof(float) * 29 * (size_t)n_points, hipMemcpyDeviceToHost, g->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
+    g_writes.note(cloud_dev, sizeof(pr_vec3) * (size_t)n_points);
+    out.release();
+    if (e != hipSuccess) { (void)hipGetLastError(); set_error("pr_debug_contrib29: %s", hipGetErrorString(e)); return PR_ERR_HIP; }
+    return PR_OK;
+}
+
 int pr_refine_batch_roi(const pr_triangle *tris_dev, size_t n_tris, const pr_mat4 *poses_host, uint32_t n_poses, uint32_t width, uint32_t height,
                         const pr_mat4 *proj, const float K[9], int scene_kind, const void *scene, pr_criteria crit, pr_roi roi,
                         pr_result *results_host, uint32_t *cloud_sizes_host)
@@ -2115,6 +2163,14 @@ int pr_profile_reset(void)
     g->icp_launch_us.clear();
     for (double &v : g->nn_part_ms) v = 0;
     g->nn_part_n = 0;
+    return PR_OK;
+}
+int pr_stats(uint64_t *batches_repeated, uint64_t *timings_dropped)
+{
+    PR_TRY(bind_default());
+    std::lock_guard<std::mutex> lk(g->mu);
+    if (batches_repeated) *batches_repeated = g->stat_repeated;
+    if (timings_dropped) *timings_dropped = g->stat_timing_dropped;
     return PR_OK;
 }
 int pr_profile_launches(float *launch_us, uint32_t capacity, uint32_t *n)

@@ -1,0 +1,54 @@
+// pr_device.h -- device-side helpers shared by every kernel file: x86 float->int semantics, offset loads, DPP lane access
+// gfx950 (CDNA4, wave64); compiled with -ffp-contract=off: every per-element value is bit-identical to the CPU restatement.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <limits.h>
+#include <float.h>
+#include <stdlib.h>
+#include <atomic>
+
+#include "pr_internal.h"
+#include "pr_tuning.h"
+
+namespace prk {
+
+// ------------------------------------------------------------------------------------------------
+// conversions with the semantics the reference CPU build has on x86-64 (cvttss2si): out-of-range
+// and NaN inputs give INT_MIN.  v_cvt_i32_f32 saturates instead, so the range test is explicit.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int f2i_x86(float v)
+{
+    return (v > -2147483904.0f && v < 2147483648.0f) ? (int)v : INT_MIN;
+}
+// size_t(float) for loop starts that are later compared against a bound < 2^24: anything
+// outside (-1, 2^24) can never satisfy "(float)p <= bound", so it maps to "no iterations".
+__device__ __forceinline__ int loop_start(float v)
+{
+    return (v > -1.0f && v < 16777216.0f) ? (int)v : INT_MAX;
+}
+
+__device__ __forceinline__ float sel_max(float a, float b) { return (a > b) ? a : b; }
+__device__ __forceinline__ float sel_min(float a, float b) { return (a < b) ? a : b; }
+
+typedef float float2v __attribute__((ext_vector_type(2)));
+// base + 32-bit byte offset: lets the compiler address with a scalar base and one 32-bit VGPR (global_load ... v_off, s[base])
+// instead of building a 64-bit address per lane (v_lshl_add_u64 / v_mad_u64_u32 plus the copies that come with 64-bit values)
+template <class T> __device__ __forceinline__ T ld_off(const void *base, uint32_t byte_off)
+{ return *reinterpret_cast<const T *>(static_cast<const char *>(base) + byte_off); }
+template <class T> __device__ __forceinline__ void st_off(void *base, uint32_t byte_off, const T &v)
+{ *reinterpret_cast<T *>(static_cast<char *>(base) + byte_off) = v; }
+struct Corr { float dx, dy, dz, nx, ny, nz; };   // destination point and its normal
+
+// ------------------------------------------------------------------------------------------------
+// wave64 sum with a fixed balanced pairwise tree in lane order, result in lane 63:
+//   row_shr:1,2,4,8 inside each 16-lane row, row_bcast15 into rows 1 and 3, row_bcast31 into rows 2,3.
+// ------------------------------------------------------------------------------------------------
+template <int kCtrl, int kRowMask>
+__device__ __forceinline__ float dpp_get(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), kCtrl, kRowMask, 0xf, true));
+}
+
+constexpr uint32_t kBoxRowsPerBlock = 16;                        // rows of a pixel box per workgroup: 4 wavefronts x 4 rows (few, fatter workgroups: dispatch-bound otherwise)
+
+}  // namespace prk

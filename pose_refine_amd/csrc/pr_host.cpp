@@ -385,7 +385,8 @@ struct Gltf {
                 if (mode == 4) { for (size_t k = 0; k + 2 < iv.size(); k += 3) if (!tri((size_t)iv[k], (size_t)iv[k + 1], (size_t)iv[k + 2])) return false; }
                 else if (mode == 5) { for (size_t k = 0; k + 2 < iv.size(); ++k) if (!((k & 1) ? tri((size_t)iv[k + 1], (size_t)iv[k], (size_t)iv[k + 2]) : tri((size_t)iv[k], (size_t)iv[k + 1], (size_t)iv[k + 2]))) return false; }
                 else if (mode == 6) { for (size_t k = 1; k + 1 < iv.size(); ++k) if (!tri((size_t)iv[0], (size_t)iv[k], (size_t)iv[k + 1])) return false; }
-                else continue;                                      // points, lines: faces with fewer than three indices (renderer.cpp:78)
+                // (points, lines: faces with fewer than three indices give no triangle, renderer.cpp:78 -- but assimp keeps such a mesh's vertices,
+                // and the reference appends the vertices of EVERY mesh and walks them for the box, so they count here as well)
                 for (const pr_vec3 &v : verts) {                    // renderer.cpp:93-99, and get_bounding_box_for_node on the transformed copy
                     out->vertices.push_back(v);
                     const pr_vec3 tv = mat4_apply(m, v);
@@ -399,6 +400,32 @@ struct Gltf {
         return true;
     }
 };
+// percent-decoded relative path of a buffer / image uri; false for anything that could leave the model's directory
+bool uri_to_relative_path(const std::string &uri, std::string &out)
+{
+    out.clear();
+    for (size_t i = 0; i < uri.size(); ++i) {
+        if (uri[i] == '%') {
+            auto hex = [](char c) -> int { return (c >= '0' && c <= '9') ? c - '0' : (c >= 'a' && c <= 'f') ? c - 'a' + 10 : (c >= 'A' && c <= 'F') ? c - 'A' + 10 : -1; };
+            if (i + 2 >= uri.size()) return false;                // '%' needs two hex digits behind it
+            const int hi = hex(uri[i + 1]), lo = hex(uri[i + 2]);
+            if (hi < 0 || lo < 0 || (hi == 0 && lo == 0)) return false;
+            out.push_back((char)(hi * 16 + lo));
+            i += 2;
+        } else if (uri[i] == '?' || uri[i] == '#') return false;   // queries and fragments make no sense for a file
+        else out.push_back(uri[i]);
+    }
+    if (out.empty() || out[0] == '/' || out[0] == '\\') return false;
+    if (out.find(':') != std::string::npos) return false;          // scheme or drive prefix
+    size_t start = 0;
+    while (start <= out.size()) {                                   // no ".." segment, with either separator
+        size_t end = out.find_first_of("/\\", start);
+        if (end == std::string::npos) end = out.size();
+        if (out.compare(start, end - start, "..") == 0) return false;
+        start = end + 1;
+    }
+    return true;
+}
 bool read_file(const std::string &path, std::vector<unsigned char> &out)
 {
     std::ifstream in(path, std::ios::binary);
@@ -435,7 +462,13 @@ bool load_gltf(const char *path, Mesh &m, bool binary)
         const Json *uri = bufs->arr[i].get("uri");
         if (!uri || uri->kind != Json::kStr) { if (i == 0 && have_glb_bin) data = glb_bin; else { m.error = "glTF: buffer without a uri"; return false; } }
         else if (uri->str.compare(0, 5, "data:") == 0) { const size_t comma = uri->str.find(','); if (comma == std::string::npos) { m.error = "glTF: malformed data uri"; return false; } base64_decode(uri->str, comma + 1, data); }
-        else if (!read_file(g.dir + uri->str, data)) { m.error = "glTF: cannot open buffer " + g.dir + uri->str; return false; }
+        else {
+            // a relative file reference (glTF 2.0 2.8: RFC 3986 relative path, percent-encoded): decode %XX, and stay inside the model's
+            // directory -- no absolute paths, no drive or scheme prefixes, no ".." segments (a crafted file must not read arbitrary files)
+            std::string rel;
+            if (!uri_to_relative_path(uri->str, rel)) { m.error = "glTF: buffer uri is not a relative path inside the model's directory: " + uri->str; return false; }
+            if (!read_file(g.dir + rel, data)) { m.error = "glTF: cannot open buffer " + g.dir + rel; return false; }
+        }
         g.buffers.push_back(std::move(data));
     }
     m.has_box = true;

@@ -179,6 +179,10 @@ hipError_t launch_icp_pass_nn(const IcpBatch &b, const SceneNNDev &sc, uint32_t 
 // marks (or null): three events recorded after the search, the bound and the walk kernel (timed batches; n_poses <= 32768)
 hipError_t launch_nn_search(const IcpBatch &b, const SceneNNDev &sc, uint32_t n_poses, uint32_t max_points, uint32_t run, hipStream_t s, hipEvent_t *marks = nullptr);
 hipError_t launch_icp_pass_nn_winners(const IcpBatch &b, const SceneNNWinners &sc, uint32_t n_poses, hipStream_t s);
+// audit entry (icp_debug.hip): the 29 terms of every point of one cloud, out[n][29]; update12 (rows 0..2 of a 4x4) or null is applied first
+hipError_t launch_contrib29_proj_aos(pr_vec3 *cloud, uint32_t n, const float *update12, const SceneProjAoS &sc, float *out, hipStream_t s);
+hipError_t launch_contrib29_proj_packed(pr_vec3 *cloud, uint32_t n, const float *update12, const SceneProjPacked &sc, float *out, hipStream_t s);
+hipError_t launch_contrib29_nn(pr_vec3 *cloud, uint32_t n, const float *update12, const SceneNNDev &sc, float *out, hipStream_t s);
 // info[0] = 1 when every scene point owns a grid cell (the grid may be used), 0 otherwise
 // grid: gw*gh cells followed by the three pyramid levels (nn_grid_cells(gw, gh) cells in all)
 size_t nn_grid_cells(uint32_t gw, uint32_t gh);

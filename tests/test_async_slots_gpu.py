@@ -1,0 +1,332 @@
+"""GPU tests (-m gpu) of pr_refine_submit / pr_refine_wait: two asynchronous slots, timed batches, the arrival protocol of the fused solve tail.
+The HIP path is called through the C ABI (pose_refine_amd.api) and held to the CPU oracle on the same inputs: integers, inlier counts and
+per-pass sums bit-exact, transforms within 1e-4 (north_star).  @pytest.mark.device_solve = the 6x6 solve runs on the device (the headline
+configuration); without it the solve is on the host, as icp.cu:207 does it."""
+import ctypes as C
+import json
+import os
+import threading
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from pose_refine_amd import _lib, api, synth
+from gpu_common import *  # noqa: F401,F403 -- W, H, TOL_T, inliers, raw_h2d, make_scene, random_mesh ...
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("P,raster_mode", [(5, 0), (96, 0), (5, 1)])
+def test_async_slots_match_synchronous_path_bitwise(gpu, model, scenario, gscenes, P, raster_mode):
+    """pr_refine_submit / pr_refine_wait (host-computed pixel boxes, device-side start state, no mid-step read-back, two batches
+    in flight) against the synchronous path (profile=1 forces it): records and cloud sizes must be bit-identical, with fixed
+    and with early-exit criteria, for host and device result buffers, with an empty-cloud hypothesis in the batch."""
+    poses_a = synth.hypotheses(P, seed=11)
+    poses_b = synth.hypotheses(P, seed=12)
+    poses_b[1] = poses_b[1].copy()
+    poses_b[1].reshape(4, 4)[0, 3] += 1.0e6                      # a kilometre to the side: off-screen -> empty cloud -> identity result
+    api.set_option("solve", api.SOLVE_DEVICE)
+    api.set_option("raster_mode", raster_mode)                   # 1: not covered by the asynchronous path -> submit runs synchronously (replayed graphs)
+    api.set_option("sub_batch", 40)                              # P=96 runs as three sub-batches of 32 that reuse the same workspace
+    try:
+        for crit in ((0.0, 0.0, 20), (1e-5, 1e-5, 30)):
+            c = api.ICPConvergenceCriteria(*crit)
+            api.set_option("profile", 1)
+            ref_a = api.refine_batch(model, poses_a, W, H, scenario["proj"], scenario["K"], gscenes["proj"], c)
+            ref_b = api.refine_batch(model, poses_b, W, H, scenario["proj"], scenario["K"], gscenes["proj"], c)
+            api.set_option("profile", 0)
+            # the grid of an asynchronous batch is sized from the clouds of the batch before it: make that a batch of tiny
+            # clouds (3 m farther away) so that every workgroup of the next one has to walk several 2048-point blocks
+            far = poses_a.copy()
+            far.reshape(-1, 4, 4)[:, 2, 3] += 3000.0
+            _, far_sizes = api.refine_batch(model, far, W, H, scenario["proj"], scenario["K"], gscenes["proj"], c)
+            assert 0 < far_sizes.max() < 2048 < ref_a[1].max()
+            api.refine_submit(0, model, poses_a, W, H, scenario["proj"], scenario["K"], gscenes["proj"], c)
+            dev_b = api.DeviceVector(P * 18, np.float32)
+            api.refine_submit(1, model, poses_b, W, H, scenario["proj"], scenario["K"], gscenes["proj"], c, results_dev=dev_b.data())
+            got_a = api.refine_wait(0)
+            _, sizes_b = api.refine_wait(1)
+            got_b = np.frombuffer(dev_b.to_host().tobytes(), dtype=ref_b[0].dtype)
+            assert np.array_equal(got_a[1], ref_a[1]) and np.array_equal(sizes_b, ref_b[1])
+            assert got_a[0].tobytes() == ref_a[0].tobytes(), crit
+            assert got_b.tobytes() == ref_b[0].tobytes(), crit
+            assert ref_b[1][1] == 0 and np.array_equal(ref_b[0]["T"][1].reshape(4, 4), np.eye(4, dtype=np.float32))
+        with pytest.raises(api.PoseRefineError):
+            api.refine_wait(0)                                   # nothing pending
+    finally:
+        api.set_option("profile", 0)
+        api.set_option("raster_mode", 0)
+        api.set_option("sub_batch", 512)
+        api.set_option("solve", api.SOLVE_HOST)
+
+
+def test_submit_wait_contract_errors(gpu, model, scenario, gscenes):
+    """A slot holds one batch at a time; waiting on an idle slot, an out-of-range slot and frames beyond the raster's
+    coordinate packing (8192 per side, 2^24 pixels) are refused with PR_ERR_INVALID, and the slot stays usable."""
+    poses = synth.hypotheses(3)
+    c = api.ICPConvergenceCriteria(0.0, 0.0, 2)
+    api.set_option("solve", api.SOLVE_DEVICE)
+    try:
+        api.refine_submit(0, model, poses, W, H, scenario["proj"], scenario["K"], gscenes["proj"], c)
+        with pytest.raises(api.PoseRefineError):
+            api.refine_submit(0, model, poses, W, H, scenario["proj"], scenario["K"], gscenes["proj"], c)   # still pending
+        res, sizes = api.refine_wait(0)
+        assert (sizes > 0).all() and np.isfinite(res["T"]).all()
+        with pytest.raises(api.PoseRefineError):
+            api.refine_wait(0)
+        with pytest.raises(api.PoseRefineError):
+            api.refine_submit(2, model, poses, W, H, scenario["proj"], scenario["K"], gscenes["proj"], c)
+        with pytest.raises(api.PoseRefineError):
+            api.refine_batch(model, poses, 8200, 16, scenario["proj"], scenario["K"], gscenes["proj"], c)
+        again, _ = api.refine_batch(model, poses, W, H, scenario["proj"], scenario["K"], gscenes["proj"], c)
+        assert again.tobytes() == res.tobytes()
+    finally:
+        api.set_option("solve", api.SOLVE_HOST)
+
+
+# ---- kd-tree scenes on the asynchronous two-slot path (VERDICT r01 missing #4) -------------------------------------------------
+@pytest.mark.device_solve
+def test_kdtree_batches_on_both_slots_equal_the_synchronous_path(gpu, model, scenario, gscenes):
+    crit = api.ICPConvergenceCriteria(0.0, 0.0, 6)
+    batches = [synth.hypotheses(70, first=0), synth.hypotheses(96, first=70), synth.hypotheses(33, first=166)]
+    api.set_option("nn_count", 1)                                # an instrumented run is synchronous (refine_impl + icp_drive)
+    try:
+        want = [api.refine_batch(model, b, W, H, scenario["proj"], scenario["K"], gscenes["nn"], crit) for b in batches]
+    finally:
+        api.set_option("nn_count", 0)
+    want_proj = api.refine_batch(model, batches[1], W, H, scenario["proj"], scenario["K"], gscenes["proj"], crit)
+    for rep in range(3):
+        # slot 0 and slot 1 in flight together, kd-tree next to kd-tree and next to a projective batch
+        api.refine_submit(0, model, batches[0], W, H, scenario["proj"], scenario["K"], gscenes["nn"], crit)
+        api.refine_submit(1, model, batches[1], W, H, scenario["proj"], scenario["K"], gscenes["nn"], crit)
+        r0 = api.refine_wait(0)
+        api.refine_submit(0, model, batches[1], W, H, scenario["proj"], scenario["K"], gscenes["proj"], crit)
+        r1 = api.refine_wait(1)
+        api.refine_submit(1, model, batches[2], W, H, scenario["proj"], scenario["K"], gscenes["nn"], crit)
+        rp = api.refine_wait(0)
+        r2 = api.refine_wait(1)
+        for got, exp in ((r0, want[0]), (r1, want[1]), (r2, want[2]), (rp, want_proj)):
+            assert np.array_equal(got[1], exp[1])
+            assert got[0].tobytes() == exp[0].tobytes()
+    # and against the oracle (kd-tree association is slow on the CPU: the first four hypotheses)
+    ores, osizes, _ = O.refine_batch(scenario["tris"], batches[0][:4], W, H, scenario["proj"], scenario["K"], scenario["nn_scene"],
+                                     (0.0, 0.0, 6), O.SUM_CANONICAL, api.get_option("points_per_block"))
+    assert np.array_equal(osizes, want[0][1][:4]) and np.array_equal(ores["fitness"], want[0][0]["fitness"][:4])
+    assert np.allclose(ores["T"], want[0][0]["T"][:4], rtol=0, atol=TOL_T)
+
+
+@pytest.mark.device_solve
+def test_synchronous_call_while_slot_0_is_pending(gpu, model, scenario, gscenes):
+    """pr_refine_batch used to be submit(0) + wait(0) and failed with a batch pending on slot 0; it now takes the free slot,
+    and reports PR_ERR_INVALID only when both slots are taken."""
+    crit = api.ICPConvergenceCriteria(0.0, 0.0, 5)
+    a, b = synth.hypotheses(40, first=0), synth.hypotheses(24, first=40)
+    want_a = api.refine_batch(model, a, W, H, scenario["proj"], scenario["K"], gscenes["proj"], crit)
+    want_b = api.refine_batch(model, b, W, H, scenario["proj"], scenario["K"], gscenes["proj"], crit)
+    api.refine_submit(0, model, a, W, H, scenario["proj"], scenario["K"], gscenes["proj"], crit)
+    got_b = api.refine_batch(model, b, W, H, scenario["proj"], scenario["K"], gscenes["proj"], crit)       # runs on slot 1
+    api.refine_submit(1, model, b, W, H, scenario["proj"], scenario["K"], gscenes["proj"], crit)
+    with pytest.raises(api.PoseRefineError):
+        api.refine_batch(model, b, W, H, scenario["proj"], scenario["K"], gscenes["proj"], crit)
+    got_a = api.refine_wait(0)
+    got_b2 = api.refine_wait(1)
+    assert got_a[0].tobytes() == want_a[0].tobytes() and got_b[0].tobytes() == want_b[0].tobytes() and got_b2[0].tobytes() == want_b[0].tobytes()
+
+
+@pytest.mark.device_solve
+def test_free_with_a_batch_in_flight(gpu, model, scenario, gscenes):
+    """pr_free waits for everything the device is running: freeing the device-side results buffer of a batch that was only just
+    submitted returns after that batch has finished (the wait that follows finds it done), and the library stays usable."""
+    crit = api.ICPConvergenceCriteria(0.0, 0.0, 20)
+    poses = synth.hypotheses(64)
+    want = api.refine_batch(model, poses, W, H, scenario["proj"], scenario["K"], gscenes["proj"], crit)
+    dev = api.DeviceVector(64 * 18, np.float32)
+    api.refine_submit(0, model, poses, W, H, scenario["proj"], scenario["K"], gscenes["proj"], crit, results_dev=dev.data())
+    del dev                                                       # pr_free: drains the device first
+    api.refine_wait(0)
+    again = api.refine_batch(model, poses, W, H, scenario["proj"], scenario["K"], gscenes["proj"], crit)
+    assert again[0].tobytes() == want[0].tobytes()
+
+
+@pytest.mark.device_solve
+@pytest.mark.parametrize("kind,P", [("proj", 96), ("nn", 40)])
+def test_timed_asynchronous_batches(gpu, model, scenario, gscenes, kind, P):
+    """Option profile = 3: batches submitted on the slots carry HIP events around their launches and stay asynchronous.  Results equal the
+    untimed ones bit for bit; the accounts read after pr_refine_wait hold one entry per pass and sub-batch, the points of every cloud
+    per pass, and 36 / 48 algorithmic bytes per point on edge / inner passes -- as the synchronous timed path (profile 1) reports them."""
+    poses_a, poses_b = synth.hypotheses(P, seed=21), synth.hypotheses(P, seed=22)
+    crit = api.ICPConvergenceCriteria(0.0, 0.0, 6)
+    api.set_option("sub_batch", 64)                               # P = 96 runs as two sub-batches
+    try:
+        api.set_option("profile", 0)
+        ref_a = api.refine_batch(model, poses_a, W, H, scenario["proj"], scenario["K"], gscenes[kind], crit)
+        ref_b = api.refine_batch(model, poses_b, W, H, scenario["proj"], scenario["K"], gscenes[kind], crit)
+        api.set_option("profile", 1)
+        api.profile_reset()
+        api.refine_batch(model, poses_a, W, H, scenario["proj"], scenario["K"], gscenes[kind], crit)
+        sync = api.profile_read()
+        api.set_option("profile", 3)
+        api.profile_reset()
+        api.refine_submit(0, model, poses_a, W, H, scenario["proj"], scenario["K"], gscenes[kind], crit)
+        api.refine_submit(1, model, poses_b, W, H, scenario["proj"], scenario["K"], gscenes[kind], crit)     # timed as well: runs after slot 0's batch
+        got_a = api.refine_wait(0)
+        one = api.profile_read()
+        got_b = api.refine_wait(1)
+        both = api.profile_read()
+    finally:
+        api.set_option("profile", 0); api.set_option("sub_batch", 512)
+    assert got_a[0].tobytes() == ref_a[0].tobytes() and np.array_equal(got_a[1], ref_a[1])
+    assert got_b[0].tobytes() == ref_b[0].tobytes() and np.array_equal(got_b[1], ref_b[1])
+    n_sub = (P + 63) // 64
+    assert one["icp_launches"] == 7 * n_sub and sync["icp_launches"] == 7        # (the synchronous path does not split 96 hypotheses)
+    assert one["icp_points"] == 7 * int(ref_a[1].sum()) == sync["icp_points"] and one["icp_bytes"] == sync["icp_bytes"] == int(ref_a[1].sum()) * (2 * 36 + 5 * 48)
+    assert both["icp_launches"] == 14 * n_sub and both["icp_points"] == 7 * int(ref_a[1].sum() + ref_b[1].sum())
+    assert 0 < one["icp_kernel_ms"] < 50 and one["render_ms"] > 0 and one["cloud_ms"] > 0
+    # round 4: the timed launches one by one (pr_profile_launches) and, for a kd-tree scene, each of a pass' four kernels (pr_profile_nn)
+    lus = api.profile_launches()
+    assert len(lus) == both["icp_launches"] and np.all(lus > 0) and abs(float(lus.sum()) * 1e-3 - both["icp_kernel_ms"]) < 1e-3 * both["icp_kernel_ms"] + 1e-3
+    part_ms, n_pass = api.profile_nn()
+    if kind == "nn":
+        assert n_pass == 14 * n_sub and np.all(part_ms > 0) and abs(float(part_ms.sum()) - both["icp_kernel_ms"]) < 0.05 * both["icp_kernel_ms"]
+    else:
+        assert n_pass == 0 and not part_ms.any()
+    api.profile_reset()
+    assert len(api.profile_launches()) == 0 and api.profile_nn()[1] == 0
+    assert api.stats()[1] == 0                                    # no timing was dropped on the way
+
+
+def test_async_slots_random_job_stream(gpu):
+    """Random batch sizes / poses / criteria alternate over the two asynchronous slots (workspaces grow and shrink, the grid
+    hint of a batch comes from whatever ran before it, sub-batches of 256, hypotheses with empty clouds) and every batch
+    is compared bit for bit with the synchronous path."""
+    import os
+    from pose_refine_amd import synth
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    model = api.Model(os.path.join(root, "tests", "golden", "obj_06.ply"))
+    K = synth.K_TEST; W, H = 640, 480
+    proj = api.compute_proj(K, W, H)
+    sd = api.render_host(model, synth.scene_pose()[None], W, H, proj)[0]
+    scene = api.Scene_projective().init_Scene_projective_cuda(sd, K)
+    rng = np.random.default_rng(7)
+    jobs = []
+    for i in range(14):
+        P = int(rng.choice([1, 3, 31, 33, 64, 65, 200, 300, 513]))
+        poses = synth.hypotheses(P, seed=100 + i)
+        if rng.random() < 0.5:
+            poses.reshape(-1, 4, 4)[:, 2, 3] += float(rng.choice([0.0, 400.0, 1500.0, -300.0]))
+        if P > 2 and rng.random() < 0.3:
+            poses.reshape(-1, 4, 4)[1, 0, 3] += 1e6                # off-screen hypothesis -> empty cloud
+        crit = (api.ICPConvergenceCriteria(0.0, 0.0, int(rng.choice([0, 3, 20]))) if rng.random() < 0.7
+                else api.ICPConvergenceCriteria(1e-5, 1e-5, 30))
+        jobs.append((poses, crit))
+    api.set_option("solve", api.SOLVE_DEVICE)
+    api.set_option("sub_batch", 256)
+    try:
+        api.set_option("profile", 1)                               # forces the synchronous path
+        refs = [api.refine_batch(model, p, W, H, proj, K, scene, c) for p, c in jobs]
+        api.set_option("profile", 0)
+        got, inflight = [None] * len(jobs), [None, None]
+        for i, (p, c) in enumerate(jobs):
+            b = i & 1
+            if inflight[b] is not None:
+                got[inflight[b]] = api.refine_wait(b)
+            api.refine_submit(b, model, p, W, H, proj, K, scene, c)
+            inflight[b] = i
+        for b in (0, 1):
+            if inflight[b] is not None:
+                got[inflight[b]] = api.refine_wait(b)
+        for i, (g, r) in enumerate(zip(got, refs)):
+            assert np.array_equal(g[1], r[1]), i
+            assert g[0].tobytes() == r[0].tobytes(), (i, len(jobs[i][0]))
+    finally:
+        api.set_option("profile", 0)
+        api.set_option("sub_batch", 512)
+        api.set_option("solve", api.SOLVE_HOST)
+
+
+def test_async_slots_with_two_alternating_kdtree_scenes(gpu):
+    """Kd-tree batches on the two slots against TWO scenes: the traversal records and the pixel grid are shared by the slots and
+    hold one scene at a time, so a batch for the other scene rebuilds them while the previous batch may still be in flight
+    (the rebuild drains the slots first).  Mixed with projective batches; every result bit for bit equal to the synchronous path."""
+    import os
+    from pose_refine_amd import synth
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    model = api.Model(os.path.join(root, "tests", "golden", "obj_06.ply"))
+    K = synth.K_TEST; W, H = 640, 480
+    proj = api.compute_proj(K, W, H)
+    sd = api.render_host(model, synth.scene_pose()[None], W, H, proj)[0]
+    other = synth.scene_pose().copy()
+    other.reshape(4, 4)[0, 3] += 15.0; other.reshape(4, 4)[2, 3] += 25.0
+    sd2 = api.render_host(model, other[None], W, H, proj)[0]
+    scenes = [api.Scene_projective().init_Scene_projective_cuda(sd, K), api.Scene_nn().init_Scene_nn_cuda(sd, K),
+              api.Scene_nn().init_Scene_nn_cuda(sd2, K)]
+    rng = np.random.default_rng(11)
+    jobs = []
+    for i in range(18):
+        which = int(rng.integers(3))
+        P = int(rng.choice([1, 3, 31, 33, 64, 65])) if which else int(rng.choice([33, 200, 300]))
+        poses = synth.hypotheses(P, seed=300 + i)
+        if P > 2 and rng.random() < 0.3:
+            poses.reshape(-1, 4, 4)[1, 0, 3] += 1e6                # off-screen hypothesis -> empty cloud
+        jobs.append((poses, api.ICPConvergenceCriteria(0.0, 0.0, int(rng.choice([0, 3, 8]))), scenes[which]))
+    api.set_option("solve", api.SOLVE_DEVICE)
+    try:
+        api.set_option("profile", 1)                               # forces the synchronous path
+        refs = [api.refine_batch(model, p, W, H, proj, K, sc, c) for p, c, sc in jobs]
+        api.set_option("profile", 0)
+        got, inflight = [None] * len(jobs), [None, None]
+        for i, (p, c, sc) in enumerate(jobs):
+            b = i & 1
+            if inflight[b] is not None:
+                got[inflight[b]] = api.refine_wait(b)
+            api.refine_submit(b, model, p, W, H, proj, K, sc, c)
+            inflight[b] = i
+        for b in (0, 1):
+            if inflight[b] is not None:
+                got[inflight[b]] = api.refine_wait(b)
+        for i, (g, r) in enumerate(zip(got, refs)):
+            assert np.array_equal(g[1], r[1]), i
+            assert g[0].tobytes() == r[0].tobytes(), (i, len(jobs[i][0]))
+    finally:
+        api.set_option("profile", 0)
+        api.set_option("solve", api.SOLVE_HOST)
+
+
+def test_arrival_protocol_stress_tiny_clouds(gpu):
+    """The fused finalize + solve tail hands a hypothesis' partial sums from the workgroups that produce them to the one that draws
+    the last ticket of the arrival counter (system-scope stores -> s_waitcnt -> agent-scope atomic -> system-scope loads).  That
+    rests on how the hardware orders those accesses, so it is hammered here where it is most exposed: hundreds of hypotheses whose
+    clouds have ONE (sometimes two or three) 2048-point blocks (a far-away object), i.e. almost every workgroup is a last arrival and hundreds of
+    tails run in the same few microseconds, over four pose groups on four streams and both asynchronous slots, 30 times.  Every
+    repetition must reproduce the synchronous, un-fused result bit for bit."""
+    import os
+    from pose_refine_amd import synth
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    model = api.Model(os.path.join(root, "tests", "golden", "obj_06.ply"))
+    K = synth.K_TEST; W, H = 640, 480
+    proj = api.compute_proj(K, W, H)
+    far = synth.scene_pose().copy(); far[2, 3] = 1400.0
+    sd = api.render_host(model, far[None], W, H, proj)[0]              # the scene: the object at 1.4 m (~1.1 k pixels)
+    scene = api.Scene_projective().init_Scene_projective_cuda(sd, K)
+    P = 768
+    poses = synth.hypotheses(P, seed=11)
+    poses.reshape(-1, 4, 4)[:, 2, 3] += 1080.0                         # hypotheses at ~1.4 m: clouds of one 2048-point block
+    poses.reshape(-1, 4, 4)[::7, 2, 3] -= 500.0                        # every seventh at ~0.9 m: two or three blocks
+    crit = api.ICPConvergenceCriteria(0.0, 0.0, 12)
+    api.set_option("solve", api.SOLVE_DEVICE)
+    try:
+        api.set_option("fused_solve", 0); api.set_option("pose_groups", 1); api.set_option("profile", 1)
+        ref, ref_sizes = api.refine_batch(model, poses, W, H, proj, K, scene, crit)
+        api.set_option("profile", 0); api.set_option("fused_solve", 1); api.set_option("pose_groups", 4)
+        assert 0 < ref_sizes.max() <= 3 * 2048 and (ref_sizes <= 2048).mean() > 0.5
+        for rep in range(15):
+            api.refine_submit(0, model, poses, W, H, proj, K, scene, crit)
+            api.refine_submit(1, model, poses[::-1].copy(), W, H, proj, K, scene, crit)
+            a, sa = api.refine_wait(0)
+            b, sb = api.refine_wait(1)
+            assert np.array_equal(sa, ref_sizes) and a.tobytes() == ref.tobytes(), rep
+            assert np.array_equal(sb, ref_sizes[::-1]) and b.tobytes() == ref[::-1].tobytes(), rep
+    finally:
+        api.set_option("profile", 0); api.set_option("fused_solve", 1); api.set_option("pose_groups", 0)
+        api.set_option("solve", api.SOLVE_HOST)

@@ -1,0 +1,131 @@
+"""GPU tests (-m gpu) of caches keyed by caller-owned addresses (model box, packed scene, kd-tree records): write log, device-side checks, sampled fingerprint.
+The HIP path is called through the C ABI (pose_refine_amd.api) and held to the CPU oracle on the same inputs: integers, inlier counts and
+per-pass sums bit-exact, transforms within 1e-4 (north_star).  @pytest.mark.device_solve = the 6x6 solve runs on the device (the headline
+configuration); without it the solve is on the host, as icp.cu:207 does it."""
+import ctypes as C
+import json
+import os
+import threading
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from pose_refine_amd import _lib, api, synth
+from gpu_common import *  # noqa: F401,F403 -- W, H, TOL_T, inliers, raw_h2d, make_scene, random_mesh ...
+
+pytestmark = pytest.mark.gpu
+
+
+# ---- caches keyed by the caller's addresses -----------------------------------------------------------------------------
+@pytest.mark.device_solve
+def test_rewritten_triangle_buffer_is_never_rendered_with_a_stale_box(gpu, scenario, gscenes):
+    """the asynchronous path sizes a batch from a host copy of the model box keyed by (pointer, size).
+    The buffer is rewritten here behind the library's back (raw hipMemcpy, same address, same triangle count) with a mesh
+    twice the size: the batch must come out as if the box had been recomputed."""
+    tris = scenario["tris"][:20000].copy()
+    big = (tris * np.float32(1.6)).astype(np.float32)
+    poses = synth.hypotheses(40)
+    crit = api.ICPConvergenceCriteria(0.0, 0.0, 4)
+    m = api.Model(tris=tris)
+    r0, s0 = api.refine_batch(m, poses, W, H, scenario["proj"], scenario["K"], gscenes["proj"], crit)      # caches the small box
+    ref_big, ref_sizes = api.refine_batch(api.Model(tris=big), poses, W, H, scenario["proj"], scenario["K"], gscenes["proj"], crit)
+    raw_h2d(m.device_tris().data(), big)
+    r1, s1 = api.refine_batch(m, poses, W, H, scenario["proj"], scenario["K"], gscenes["proj"], crit)
+    assert np.array_equal(s1, ref_sizes) and r1.tobytes() == ref_big.tobytes()
+    assert not np.array_equal(s0, s1)
+    # and through the two asynchronous slots, with the stale box detected at wait time
+    raw_h2d(m.device_tris().data(), tris)
+    api.refine_submit(0, m, poses, W, H, scenario["proj"], scenario["K"], gscenes["proj"], crit)
+    api.refine_submit(1, m, poses[::-1].copy(), W, H, scenario["proj"], scenario["K"], gscenes["proj"], crit)
+    a, sa = api.refine_wait(0)
+    b, sb = api.refine_wait(1)
+    assert np.array_equal(sa, s0) and a.tobytes() == r0.tobytes()
+    assert np.array_equal(sb, s0[::-1]) and b.tobytes() == r0[::-1].tobytes()
+
+
+@pytest.mark.device_solve
+def test_scene_cache_follows_writes(gpu, model, scenario):
+    """The packed projective scene is cached by the address of the caller's arrays: writes through the library drop it,
+    writes the library cannot see need pr_invalidate (documented contract), scene_cache=0 never caches."""
+    K = scenario["K"]
+    d1, d0 = scenario["depth"][1], scenario["depth"][0]
+    poses = synth.hypotheses(8)
+    crit = api.ICPConvergenceCriteria(0.0, 0.0, 5)
+    sa = api.Scene_projective().init_Scene_projective_cuda(d1, K)
+    sb = api.Scene_projective().init_Scene_projective_cuda(d0, K)
+    ra, _ = api.refine_batch(model, poses, W, H, scenario["proj"], K, sa, crit)
+    rb, _ = api.refine_batch(model, poses, W, H, scenario["proj"], K, sb, crit)
+    assert ra.tobytes() != rb.tobytes()
+    lib = _lib.load()
+    # (1) overwrite scene A's arrays with scene B's content through the library: the cache must notice
+    n = sa.pcd_buffer.size() * 4
+    api.check(lib.pr_memcpy_d2d(sa.pcd_buffer.data(), sb.pcd_buffer.data(), n))
+    api.check(lib.pr_memcpy_d2d(sa.normal_buffer.data(), sb.normal_buffer.data(), n))
+    r1, _ = api.refine_batch(model, poses, W, H, scenario["proj"], K, sa, crit)
+    assert r1.tobytes() == rb.tobytes()
+    # (2) back to scene A behind the library's back + pr_invalidate
+    sa2 = api.Scene_projective().init_Scene_projective_cuda(d1, K)
+    raw_h2d(sa.pcd_buffer.data(), sa2.pcd_host)
+    raw_h2d(sa.normal_buffer.data(), sa2.normal_host)
+    api.invalidate(sa.pcd_buffer.data(), n)
+    api.invalidate(sa.normal_buffer.data())                      # 0 bytes = the whole allocation
+    r2, _ = api.refine_batch(model, poses, W, H, scenario["proj"], K, sa, crit)
+    assert r2.tobytes() == ra.tobytes()
+    # (3) caches off: raw writes are picked up without any announcement
+    api.set_option("scene_cache", 0)
+    try:
+        raw_h2d(sa.pcd_buffer.data(), sb.pcd_host)
+        raw_h2d(sa.normal_buffer.data(), sb.normal_host)
+        r3, _ = api.refine_batch(model, poses, W, H, scenario["proj"], K, sa, crit)
+        assert r3.tobytes() == rb.tobytes()
+    finally:
+        api.set_option("scene_cache", 1)
+
+
+@pytest.mark.device_solve
+def test_scene_rewritten_behind_the_librarys_back_is_noticed(gpu, model, scenario):
+    """the packed projective scene (like the kd-tree search records) is cached by the address of the caller's arrays.  A frame
+    that is replaced as a whole through a raw hipMemcpy (no pr_invalidate) changes the sampled fingerprint every asynchronous batch takes
+    of those arrays: the batch is repeated with fresh caches and returns what a new scene object returns.  (A kd-tree scene of another
+    frame has other point and node counts, which are part of its cache key.)"""
+    crit = api.ICPConvergenceCriteria(0.0, 0.0, 6)
+    poses = synth.hypotheses(48)
+    K = scenario["K"]
+    a = api.Scene_projective().init_Scene_projective_cuda(scenario["depth"][1], K)
+    b = api.Scene_projective().init_Scene_projective_cuda(scenario["depth"][0], K)       # another frame of the same size
+    want_b = api.refine_batch(model, poses, W, H, scenario["proj"], K, b, crit)
+    first = api.refine_batch(model, poses, W, H, scenario["proj"], K, a, crit)      # the caches of `a` are built here
+    assert first[0].tobytes() != want_b[0].tobytes()
+    raw_d2d(a.normal_buffer.data(), b.normal_buffer.data(), a.normal_buffer.size() * 4)
+    raw_d2d(a.pcd_buffer.data(), b.pcd_buffer.data(), a.pcd_buffer.size() * 4)
+    repeated0 = api.stats()[0]
+    got = api.refine_batch(model, poses, W, H, scenario["proj"], K, a, crit)
+    assert got[0].tobytes() == want_b[0].tobytes() and np.array_equal(got[1], want_b[1])
+    assert api.stats()[0] == repeated0 + 1                      # the repeated batch is counted (pr_stats), not silent
+    got = api.refine_batch(model, poses, W, H, scenario["proj"], K, a, crit)
+    assert got[0].tobytes() == want_b[0].tobytes() and api.stats()[0] == repeated0 + 1      # fresh caches: nothing to repeat
+
+
+@pytest.mark.device_solve
+def test_kdtree_scene_rewritten_behind_the_librarys_back_is_noticed_by_a_bare_icp_call(gpu, scenario):
+    """The same for the kd-tree search records and a synchronous call (pr_icp_nn checks a cache hit on the spot): points and nodes of a
+    scene are replaced by those of a shifted copy with the same counts, through raw copies."""
+    rng = np.random.default_rng(11)
+    pts = rng.uniform(-0.1, 0.1, size=(5000, 3)).astype(np.float32)
+    nrm = rng.normal(size=(5000, 3)).astype(np.float32)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    a = make_scene(pts.copy(), nrm.copy(), 10)
+    b = make_scene((pts + np.float32(0.003)).astype(np.float32), nrm.copy(), 10)
+    if len(a.nodes_host) != len(b.nodes_host):
+        pytest.skip("the shifted copy built a tree of another size")
+    cloud = rng.uniform(-0.1, 0.1, size=(3000, 3)).astype(np.float32)
+    crit = api.ICPConvergenceCriteria(0.0, 0.0, 5)
+    run = lambda sc: api.ICP_Point2Plane(api.DeviceVector.from_host(cloud.reshape(-1)), sc, crit)
+    want_b, first = run(b), run(a)                                # the search records of `b`, then of `a`, are built here
+    assert not np.array_equal(first.transformation_, want_b.transformation_)
+    for dst, src in ((a.pcd_buffer, b.pcd_buffer), (a.normal_buffer, b.normal_buffer)):
+        raw_d2d(dst.data(), src.data(), dst.size() * 4)
+    raw_d2d(a.nodes.data(), b.nodes.data(), len(a.nodes_host) * 52)
+    got = run(a)
+    assert np.array_equal(got.transformation_, want_b.transformation_) and got.fitness_ == want_b.fitness_

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Which kernels of libpose_refine_hip.so did a profiled run dispatch?  ("every kernel in pr_kernels.hip is
+"""Which kernels of libpose_refine_hip.so did a profiled run dispatch?  ("every kernel of the library is
 reached by a tracked -m gpu test".)
 
     rocprofv3 --kernel-trace -d gpurun_out/cov -o t -- python -m pytest tests -m gpu -q
