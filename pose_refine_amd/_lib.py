@@ -12,7 +12,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libpose_refine_hip.so")
+# (PR_LIB_PATH: same-box A/B runs of kernel variants, tools/ab_libs.sh -- the product is the in-tree library)
+LIB_PATH = os.environ.get("PR_LIB_PATH") or os.path.join(_HERE, "lib", "libpose_refine_hip.so")
 
 PR_OK = 0
 PR_ERR_NO_DEVICE, PR_ERR_HIP, PR_ERR_INVALID, PR_ERR_IO, PR_ERR_NOMEM, PR_ERR_COMM = -1, -2, -3, -4, -5, -6

@@ -14,14 +14,14 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
-OUT = os.path.join(HERE, "lib", "libpose_refine_hip.so")
+OUT = os.environ.get("PR_BUILD_OUT") or os.path.join(HERE, "lib", "libpose_refine_hip.so")      # PR_BUILD_OUT: a variant library for an A/B run
 # one translation unit per stage of the path (kernels + their launchers), the C ABI and the host-side code; headers = shared device code
 SOURCES = ["raster.hip", "d2c.hip", "icp_pass.hip", "icp_flow.hip", "icp_debug.hip", "nn_search.hip", "nn_build.hip", "kd_build.hip", "scene_prep.hip",
            "pr_api.cpp", "pr_host.cpp"]
 HEADERS = ["pr_internal.h", "pr_solver.inl", "pr_tuning.h", "pr_device.h", "pr_launch.h", "proj_query.h", "nn_query.h", "icp_accumulate.h",
            "icp_solve_device.h"]
 DEPS = SOURCES + HEADERS + [os.path.join(ROOT, "include", "pose_refine.h")]
-OBJ_DIR = os.path.join(HERE, "lib", "obj")
+OBJ_DIR = os.path.join(HERE, "lib", "obj") if not os.environ.get("PR_BUILD_OUT") else os.environ["PR_BUILD_OUT"] + ".obj"
 # -ffp-contract=off: no FMA contraction anywhere (bit-parity with the CPU restatement);
 # division and sqrt stay IEEE-correct (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt).
 # -fno-slp-vectorize: the SLP vectoriser packs the 29-term accumulation into v_pk_mul_f32 / v_pk_add_f32 plus ~230 v_mov to

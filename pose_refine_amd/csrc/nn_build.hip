@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void nn_records_kernel(const int4 *__restrict_
 //   the root box and rounded OUTWARDS (checked with the very dequantisation arithmetic the query uses).  A looser box can
 //   only make the search visit a subtree it could have skipped -- a subtree whose every point is farther than the current
 //   best -- so winners, distances and tie-breaks are those of the exact boxes.
-__global__ void nn_frame_kernel(const float4 *__restrict__ bmin, const float4 *__restrict__ bmax, uint32_t *__restrict__ info)
+__global__ void nn_frame_kernel(const float4 *__restrict__ bmin, const float4 *__restrict__ bmax, uint32_t *__restrict__ info, float wide_margin)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const float lo[3] = { bmin[0].x, bmin[0].y, bmin[0].z }, hi[3] = { bmax[0].x, bmax[0].y, bmax[0].z };
@@ -81,6 +81,23 @@ __global__ void nn_frame_kernel(const float4 *__restrict__ bmin, const float4 *_
         info[2 + a] = __float_as_uint(lo[a]);
         info[5 + a] = __float_as_uint(sc);
     }
+    // the wide records use ONE scale for the three axes (the longest edge of the root box): a box test then is integer differences in
+    // that unit and one sum of squares, no per-axis dequantisation (nn_tree_wide_kernel)
+    // The frame reaches `wide_margin` (the scene's acceptance radius) beyond the root box on every side: a query is clamped into the frame
+    // before its box tests, which would make every box look nearer than it is for a query outside -- hypotheses that start centimetres in
+    // front of the surface are outside the ROOT box along z -- and a query beyond the margin has no neighbour within the radius anyway.
+    if (!(wide_margin >= 0.0f && wide_margin < 1e30f)) wide_margin = 0.0f;
+    float edge = fmaxf(fmaxf(hi[0] - lo[0], hi[1] - lo[1]), hi[2] - lo[2]) + 2.0f * wide_margin;
+    float wsc = edge / 65535.0f * 1.000001f;
+    if (!(wsc > 1e-30f)) wsc = 1e-30f;
+    for (int a = 0; a < 3; ++a) info[16 + a] = __float_as_uint(lo[a] - wide_margin);      // ([12] is the scene fingerprint's word)
+    info[19] = __float_as_uint(wsc);
+    // The integer box test of the walk relies on a unit being at least one ulp of the largest coordinate (then a stored corner sits within
+    // half a unit of its real-number position and the query's interval, a unit wider on both sides, covers it): a scene far from the origin
+    // of its coordinate system with a tiny extent does not qualify and keeps the binary walk (info[20] = 0).
+    float cmax = 0.0f;
+    for (int a = 0; a < 3; ++a) cmax = fmaxf(cmax, fmaxf(fabsf(lo[a] - wide_margin), fabsf(hi[a] + wide_margin)));
+    info[20] = (cmax * 1.1920929e-7f <= wsc && cmax < 1e30f) ? 1u : 0u;
     info[1] = 1u;
 }
 __global__ __launch_bounds__(256) void nn_records32_kernel(const int4 *__restrict__ topo, const float4 *__restrict__ bmin,
@@ -138,7 +155,7 @@ __device__ __forceinline__ bool wide_quant_box(const float4 lo4, const float4 hi
     uint32_t q[6];
     bool ok = true;
     for (int a = 0; a < 3; ++a) {
-        const float qmin = __uint_as_float(info[2 + a]), qs = __uint_as_float(info[5 + a]);
+        const float qmin = __uint_as_float(info[16 + a]), qs = __uint_as_float(info[19]);     // the wide records' frame: one scale for all axes
         const float fl = floorf((lo[a] - qmin) / qs) - 1.0f;
         uint32_t ql = fl > 0.0f ? (fl < 65535.0f ? (uint32_t)fl : 65535u) : 0u;
         while (ql > 0 && !(nn_deq_fma(ql, qmin, qs) <= lo[a])) --ql;
@@ -166,7 +183,7 @@ __global__ __launch_bounds__(kWideBuildThreads) void nn_wide_build_kernel(const 
     __shared__ uint32_t part[kWideBuildThreads];
     __shared__ uint32_t s_bad;
     const uint32_t tid = threadIdx.x;
-    if (tid == 0) { wq[0] = 0u; s_bad = (info[1] == 1u) ? 0u : 1u; }
+    if (tid == 0) { wq[0] = 0u; s_bad = (info[1] == 1u && info[20] == 1u) ? 0u : 1u; }
     __syncthreads();
     uint32_t begin = 0, end = 1;
     for (int level = 0; level < 64 && begin < end; ++level) {
@@ -246,20 +263,41 @@ __global__ __launch_bounds__(kWideBuildThreads) void nn_wide_build_kernel(const 
         begin = end; end = end + total;
     }
     __syncthreads();
-    if (tid == 0) { info[8] = (s_bad || begin < end) ? 0u : 1u; info[9] = end; }
+    const bool ok = !(s_bad || begin < end);
+    // (D) the layout the task walk reads (kWidePaired): a wide node is two 64-byte halves, one per lane of a task; a half holds its four
+    // slots as two PAIRS -- per pair six words {lo.x, lo.y, lo.z, hi.x, hi.y, hi.z}, each word = first slot | second slot << 16, so that
+    // one packed 16-bit instruction works on both boxes -- followed by the four references.
+    if (ok)
+        for (uint32_t k = tid; k < end; k += kWideBuildThreads) {
+            uint4 sl[8];
+            for (int c = 0; c < 8; ++c) sl[c] = wide[(size_t)k * 8 + c];
+            for (int h = 0; h < 2; ++h) {
+                uint32_t w[16];
+                for (int pr = 0; pr < 2; ++pr) {
+                    const uint4 A = sl[4 * h + 2 * pr], B = sl[4 * h + 2 * pr + 1];
+                    // a slot: x = lo.x | lo.y << 16, y = lo.z | hi.x << 16, z = hi.y | hi.z << 16
+                    const uint32_t a6[6] = { A.x & 0xffffu, A.x >> 16, A.y & 0xffffu, A.y >> 16, A.z & 0xffffu, A.z >> 16 };
+                    const uint32_t b6[6] = { B.x & 0xffffu, B.x >> 16, B.y & 0xffffu, B.y >> 16, B.z & 0xffffu, B.z >> 16 };
+                    for (int f = 0; f < 6; ++f) w[6 * pr + f] = a6[f] | (b6[f] << 16);
+                }
+                for (int c = 0; c < 4; ++c) w[12 + c] = sl[4 * h + c].w;
+                for (int v = 0; v < 4; ++v) wide[(size_t)k * 8 + 4 * h + v] = make_uint4(w[4 * v], w[4 * v + 1], w[4 * v + 2], w[4 * v + 3]);
+            }
+        }
+    if (tid == 0) { info[8] = ok ? 1u : 0u; info[9] = end; }
 }
 
 hipError_t launch_build_nn_accel(const pr_kdnode *nodes, uint32_t n_nodes, const pr_vec3 *pcd, uint32_t n_points,
                                  int4 *topo, float4 *bmin, float4 *bmax, float4 *pts, float4 *rec, uint4 *rec32, uint2 *desc, uint32_t *info, hipStream_t s,
-                                 uint4 *wide, uint32_t *wide_scratch)
+                                 uint4 *wide, uint32_t *wide_scratch, float wide_margin)
 {
     const uint32_t m = (n_nodes > n_points) ? n_nodes : n_points;
     if (m == 0) return hipSuccess;
     hipLaunchKernelGGL(nn_accel_kernel, dim3((m + 255) / 256), dim3(256), 0, s, nodes, n_nodes, pcd, n_points, topo, bmin, bmax, pts);
-    hipError_t e = hipMemsetAsync(info, 0, 16 * sizeof(uint32_t), s);
+    hipError_t e = hipMemsetAsync(info, 0, 24 * sizeof(uint32_t), s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(nn_records_kernel, dim3((n_nodes + 255) / 256), dim3(256), 0, s, topo, bmin, bmax, n_nodes, rec, info);
-    hipLaunchKernelGGL(nn_frame_kernel, dim3(1), dim3(64), 0, s, bmin, bmax, info);
+    hipLaunchKernelGGL(nn_frame_kernel, dim3(1), dim3(64), 0, s, bmin, bmax, info, wide_margin);
     hipLaunchKernelGGL(nn_records32_kernel, dim3((n_nodes + 255) / 256), dim3(256), 0, s, topo, bmin, bmax, n_nodes, rec32, desc, info);
     if (wide && wide_scratch) {
         const uint32_t cap = (uint32_t)nn_wide_capacity(n_nodes);

@@ -322,26 +322,40 @@ __device__ __forceinline__ bool grid_window(const SceneNNDev &s, float sx, float
 __device__ __forceinline__ void grid_ring_min(const float4 *__restrict__ level, int lw, int lh, int x0, int y0, int nb, float sx, float sy, float sz,
                                               float &dmin, int &bx, int &by)
 {
-    dmin = FLT_MAX; bx = min(max(x0, 0), lw - 1); by = min(max(y0, 0), lh - 1);
-    // kRingRows rows (6 cells each) are in flight at a time: the descent is a chain of dependent round trips, three levels of them
+    // The descent is bound by its instruction count, not by its loads (SQ counters, profiles/r04): so the clamping is done once per column and
+    // row (12 clamps instead of 72), a cell's address is one 32-bit add on top of a scalar base, and the arg-min is kept as ONE index
+    // (same visiting order -- rows, then columns -- and the same strict '<' as before: the same minimum and the same winner).
+    // kRingRows rows (6 cells each) are in flight at a time.
     constexpr int kRingRows = PR_RING_ROWS;
-    for (int dy0 = 0; dy0 < nb; dy0 += kRingRows) {
+    uint32_t xo[6], yo[6];
+#pragma unroll
+    for (int d = 0; d < 6; ++d) {
+        xo[d] = (uint32_t)min(max(x0 + d, 0), lw - 1) * 16u;
+        yo[d] = (uint32_t)(min(max(y0 + min(d, nb - 1), 0), lh - 1) * lw) * 16u;
+    }
+    float best = FLT_MAX;
+    int kbest = 0;
+#pragma unroll
+    for (int dy0 = 0; dy0 < 6; dy0 += kRingRows) {
+        if (dy0 >= nb) break;
         float4 c[kRingRows][6];
-        int yy[kRingRows];
 #pragma unroll
-        for (int r = 0; r < kRingRows; ++r) {
-            yy[r] = min(max(y0 + min(dy0 + r, nb - 1), 0), lh - 1);
+        for (int r = 0; r < kRingRows; ++r)
 #pragma unroll
-            for (int dx = 0; dx < 6; ++dx) c[r][dx] = level[(size_t)yy[r] * lw + min(max(x0 + dx, 0), lw - 1)];
-        }
+            for (int dx = 0; dx < 6; ++dx) c[r][dx] = ld_off<float4>(level, yo[dy0 + r] + xo[dx]);
 #pragma unroll
         for (int r = 0; r < kRingRows; ++r)
 #pragma unroll
             for (int dx = 0; dx < 6; ++dx) {
                 const float d2 = (sx - c[r][dx].x) * (sx - c[r][dx].x) + (sy - c[r][dx].y) * (sy - c[r][dx].y) + (sz - c[r][dx].z) * (sz - c[r][dx].z);
-                if (d2 < dmin) { dmin = d2; bx = min(max(x0 + dx, 0), lw - 1); by = yy[r]; }
+                const bool lt = d2 < best;
+                best = lt ? d2 : best; kbest = lt ? (dy0 + r) * 6 + dx : kbest;
             }
     }
+    const int ky = (kbest * 43) >> 8;                            // kbest / 6 for 0..35
+    dmin = best;
+    bx = min(max(x0 + (kbest - ky * 6), 0), lw - 1);
+    by = min(max(y0 + min(ky, nb - 1), 0), lh - 1);
 }
 __device__ __forceinline__ void grid_pyramid_bound(const SceneNNDev &s, float sx, float sy, float sz, float &best)
 {

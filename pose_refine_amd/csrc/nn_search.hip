@@ -314,16 +314,45 @@ __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t &total)
     total = t0 + t1 + t2 + t3;
     return x - v;
 }
+// two unsigned 16-bit lanes per register: saturating difference and maximum (v_pk_sub_u16 clamp, v_pk_max_u16)
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_sub_sat_u16(uint32_t a, uint32_t b)
+{ return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b))); }
+__device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b)
+{ return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b))); }
+// Lower bounds of the squared distance from a query to the TWO boxes of a pair, in squared units of the wide records' frame.  The query
+// enters as an interval [qd, qu] of whole units that holds its coordinate (both halves of a word carry the same value); per axis the
+// distance is max(lo - qu, qd - hi, 0) -- saturating 16-bit differences, both boxes per instruction -- and the three are squared and
+// added in float (the sum of three squares of 16-bit numbers does not fit 32 bits).  Every rounding is covered by the margins of the
+// caller: qd + 1 < q < qu - 1, and the bound the result is compared with is inflated by 1e-6 and one squared unit.
+// (VALU instructions per box: 10 against the 31 of the per-axis float dequantisation it replaces; it also frees the registers that let
+// the walk run six wavefronts per SIMD.)
+__device__ __forceinline__ void wide_pair_lb(uint32_t lox, uint32_t loy, uint32_t loz, uint32_t hix, uint32_t hiy, uint32_t hiz,
+                                             uint32_t qdx, uint32_t qdy, uint32_t qdz, uint32_t qux, uint32_t quy, uint32_t quz, float &lb_a, float &lb_b)
+{
+    const uint32_t dx = pk_max_u16(pk_sub_sat_u16(lox, qux), pk_sub_sat_u16(qdx, hix));
+    const uint32_t dy = pk_max_u16(pk_sub_sat_u16(loy, quy), pk_sub_sat_u16(qdy, hiy));
+    const uint32_t dz = pk_max_u16(pk_sub_sat_u16(loz, quz), pk_sub_sat_u16(qdz, hiz));
+    const float ax = (float)(dx & 0xffffu), ay = (float)(dy & 0xffffu), az = (float)(dz & 0xffffu);
+    const float bx = (float)(dx >> 16), by = (float)(dy >> 16), bz = (float)(dz >> 16);
+    lb_a = __builtin_fmaf(az, az, __builtin_fmaf(ay, ay, ax * ax));
+    lb_b = __builtin_fmaf(bz, bz, __builtin_fmaf(by, by, bx * bx));
+}
 // Queue 2 -> the task walk.  Wavefronts are independent (no workgroup barrier): each takes 64 queries at a time.  kLanes lanes share a task:
 // 8 / kLanes boxes of a node, or 8 / kLanes points of a leaf per round, per lane; a step pops 64 / kLanes tasks of one kind.
+// Box bounds travel through the queues in SQUARED UNITS of the wide records' frame (wide_pair_lb); a query's bound is converted when a task
+// is popped (inflated by 1e-6, plus one unit), the runner-up bound when a step's skipped boxes are folded into `second` (deflated).
 template <int kLanes>
 __global__ __launch_bounds__(256, PR_WIDE_WAVES) void nn_tree_wide_kernel(IcpBatch b, SceneNNDev scene, uint32_t qbatch)
 {
+    static_assert(kLanes == 2, "the paired record layout (nn_wide_build_kernel, stage D) is made for two lanes per task");
     constexpr uint32_t kPer = 8u / kLanes, kTasks = 64u / kLanes;
     __shared__ uint2 s_nodeq[4][kTaskQCap], s_leafq[4][kTaskLCap];               // {reference, bound bits (low 6 bits cleared: rounded DOWN) | query slot}
     __shared__ float4 s_q[4][64];                                                // query point | bound (float bits, lowered with atomicMin)
     __shared__ uint32_t s_second[4][64], s_tied[4][64], s_ovf[4][64], s_root[4][64];
     __shared__ unsigned long long s_best[4][64];
+    __shared__ uint2 s_dump[64];                                                 // where a lane stores a task it does not keep (no exec-mask juggling per slot); never read,
+                                                                                 // shared by the four wavefronts: with it the kernel's LDS stays below 32 KiB (five workgroups per CU)
     const uint32_t pose = blockIdx.y;
     const PoseMeta &pm = b.meta[pose];
     if (pm.state == kSkip) return;
@@ -335,11 +364,18 @@ __global__ __launch_bounds__(256, PR_WIDE_WAVES) void nn_tree_wide_kernel(IcpBat
     uint32_t *win = b.nn_prev + pm.start;
     float *slk = b.nn_slack + pm.start;
     const uint2 *todo = b.nn_queue2 + pm.start;
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, c = lane % kLanes, grp = lane / kLanes;
+    // (the wavefront's index is uniform, but only readfirstlane tells the compiler: with it the queue fill levels, the batch loop and every
+    // branch on them live in scalar registers)
+    const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), c = lane % kLanes, grp = lane / kLanes;
     uint2 *nodeq = s_nodeq[wave], *leafq = s_leafq[wave];
     float4 *qs = s_q[wave];
     uint32_t *second = s_second[wave], *tied = s_tied[wave], *ovf = s_ovf[wave], *root = s_root[wave];
     unsigned long long *best = s_best[wave];
+    uint2 *dump = s_dump;
+    // the frame of the wide records: units per metre, the query's offset in units (minus the sixteenth of a unit that covers the rounding of
+    // this very conversion), and the factors between squared metres and squared units -- each rounded to the safe side
+    const float w_inv = 1.0f / scene.wscale;
+    const float w_to_units2 = w_inv * w_inv * 1.000001f, w_to_m2 = scene.wscale * scene.wscale * 0.999999f;
     uint32_t n_tree = 0, n_nodes = 0, n_leaves = 0, n_leaf_points = 0, n_redo_q = 0, n_steps = 0;
     for (uint32_t base = (blockIdx.x * 4u + wave) * qbatch; base < queued; base += gridDim.x * 4u * qbatch) {
         const bool have_q = lane < qbatch && base + lane < queued;
@@ -377,46 +413,63 @@ __global__ __launch_bounds__(256, PR_WIDE_WAVES) void nn_tree_wide_kernel(IcpBat
             const uint2 e = active ? (leaf_step ? leafq : nodeq)[avail - 1u - grp] : make_uint2(0u, 0u);
             if (leaf_step) nL -= k; else nN -= k;
             const uint32_t q = e.y & 63u, ref = e.x;
-            const float lb_in = __uint_as_float(e.y & ~63u);
+            const float lb_in = __uint_as_float(e.y & ~63u);         // squared units, rounded down
             const float4 qp = qs[q];
             const float sx = qp.x, sy = qp.y, sz = qp.z, bnd = qp.w;
             uint32_t *bound_q = reinterpret_cast<uint32_t *>(&qs[q]) + 3;
-            const bool alive = active && lb_in <= bnd;
-            float sec_l = (active && !alive) ? lb_in : FLT_MAX;      // what this lane rules out (lower bounds of other points' distances)
+            const float bnd_u = __builtin_fmaf(bnd, w_to_units2, 1.0f);   // the query's bound in squared units, rounded up generously
+            const bool alive = active && lb_in <= bnd_u;
+            float sec_u = (active && !alive) ? lb_in : FLT_MAX;      // what this lane rules out: boxes (squared units) ...
+            float sec_l = FLT_MAX;                                   // ... and points (squared metres)
             if (!leaf_step) {
-                // ---------------- node tasks: lane c of a group tests slots kPer*c .. kPer*c + kPer-1
-                uint4 r[kPer];
+                // ---------------- node tasks: lane c of a group tests the four slots of half c (two pairs, see nn_wide_build_kernel stage D)
+                uint4 r[4];
 #pragma unroll
-                for (uint32_t i = 0; i < kPer; ++i) r[i] = make_uint4(0u, 0u, 0u, kWideEmpty);
+                for (uint32_t i = 0; i < 3; ++i) r[i] = make_uint4(0u, 0u, 0u, 0u);
+                r[3] = make_uint4(kWideEmpty, kWideEmpty, kWideEmpty, kWideEmpty);
                 if (alive) {
-                    const uint4 *rec = scene.wide + (size_t)ref * 8u + kPer * c;
+                    const uint4 *rec = scene.wide + (size_t)ref * 8u + 4u * c;
 #pragma unroll
-                    for (uint32_t i = 0; i < kPer; ++i) r[i] = rec[i];
+                    for (uint32_t i = 0; i < 4; ++i) r[i] = rec[i];
                     if (c == 0u) ++n_nodes;
                 }
+                // The query in whole units of the frame: an interval [qd, qd + 3] that holds its coordinate with more than a unit to spare on
+                // either side (the difference to the frame's origin is formed first -- exact to half an ulp of a number below the frame's edge --
+                // then scaled; a unit is at least an ulp of the largest coordinate, nn_frame_kernel refuses the frame otherwise: that is also the
+                // slack a box's stored corners have against their real-number positions).  Negative and NaN values convert to 0.  Both halves of
+                // a word carry the same value.
+                const uint32_t ux = min((uint32_t)__builtin_fmaf(sx - scene.wmin[0], w_inv, -1.0625f), 65532u),
+                               uy = min((uint32_t)__builtin_fmaf(sy - scene.wmin[1], w_inv, -1.0625f), 65532u),
+                               uz = min((uint32_t)__builtin_fmaf(sz - scene.wmin[2], w_inv, -1.0625f), 65532u);
+                const uint32_t qdx = ux * 0x10001u, qdy = uy * 0x10001u, qdz = uz * 0x10001u;
+                float lb[kPer];
+                wide_pair_lb(r[0].x, r[0].y, r[0].z, r[0].w, r[1].x, r[1].y, qdx, qdy, qdz, qdx + 0x30003u, qdy + 0x30003u, qdz + 0x30003u, lb[0], lb[1]);
+                wide_pair_lb(r[1].z, r[1].w, r[2].x, r[2].y, r[2].z, r[2].w, qdx, qdy, qdz, qdx + 0x30003u, qdy + 0x30003u, qdz + 0x30003u, lb[2], lb[3]);
+                const uint32_t refs[kPer] = { r[3].x, r[3].y, r[3].z, r[3].w };
                 uint32_t cntI = 0, cntL = 0;
-                float lb[kPer]; bool keep[kPer], leaf[kPer];
+                bool keep[kPer], leaf[kPer];
 #pragma unroll
                 for (uint32_t i = 0; i < kPer; ++i) {
-                    const bool v = r[i].w != kWideEmpty;
-                    lb[i] = wide_box_lb(sx, sy, sz, r[i].x, r[i].y, r[i].z, scene);
-                    keep[i] = v && lb[i] <= bnd;
-                    leaf[i] = (r[i].w & kWideLeaf) != 0u;
-                    if (v && !keep[i]) sec_l = min_f32(sec_l, lb[i]);
+                    const bool v = refs[i] != kWideEmpty;
+                    keep[i] = v && lb[i] <= bnd_u;
+                    leaf[i] = (refs[i] & kWideLeaf) != 0u;
+                    sec_u = min_f32(sec_u, (v && !keep[i]) ? lb[i] : FLT_MAX);      // (a select, not a branch: the asm min cannot be if-converted)
                     cntI += (keep[i] && !leaf[i]) ? 1u : 0u; cntL += (keep[i] && leaf[i]) ? 1u : 0u;
                 }
                 uint32_t tot = 0;
                 const uint32_t ex = wave_excl_scan(cntI | (cntL << 16), tot);
                 uint32_t pI = nN + (ex & 0xffffu), pL = nL + (ex >> 16);
+                bool lost = false;
 #pragma unroll
-                for (uint32_t i = 0; i < kPer; ++i) {                  // straight-line: destination by selects, one predicated store per slot
+                for (uint32_t i = 0; i < kPer; ++i) {                  // straight-line: every slot stores -- into its queue, or into the lane's dump word
                     const uint32_t pos = leaf[i] ? pL : pI, cap = leaf[i] ? kTaskLCap : kTaskQCap;
-                    uint2 *dst = (leaf[i] ? leafq : nodeq) + pos;
-                    const bool fits = pos < cap;
-                    if (keep[i] && fits) *dst = make_uint2(r[i].w, (__float_as_uint(lb[i]) & ~63u) | q);
-                    if (keep[i] && !fits) ovf[q] = 1u;
+                    const bool fits = pos < cap, put = keep[i] && fits;
+                    uint2 *dst = put ? ((leaf[i] ? leafq : nodeq) + pos) : (dump + lane);
+                    *dst = make_uint2(refs[i], (__float_as_uint(lb[i]) & ~63u) | q);
+                    lost = lost || (keep[i] && !fits);
                     pL += (keep[i] && leaf[i]) ? 1u : 0u; pI += (keep[i] && !leaf[i]) ? 1u : 0u;
                 }
+                if (lost) ovf[q] = 1u;
                 nN += tot & 0xffffu; if (nN > kTaskQCap) nN = kTaskQCap;
                 nL += tot >> 16; if (nL > kTaskLCap) nL = kTaskLCap;
             } else {
@@ -430,9 +483,10 @@ __global__ __launch_bounds__(256, PR_WIDE_WAVES) void nn_tree_wide_kernel(IcpBat
                     for (uint32_t h = 0; h < kPer; ++h) pt[h] = scene.pts[first + (ka + h < cnt ? ka + h : 0u)];
 #pragma unroll
                     for (uint32_t h = 0; h < kPer; ++h) {
-                        if (ka + h >= cnt) continue;
                         const float d2 = (sx - pt[h].x) * (sx - pt[h].x) + (sy - pt[h].y) * (sy - pt[h].y) + (sz - pt[h].z) * (sz - pt[h].z);   // pcd_scene.h:88-91
-                        if (d2 <= bnd) {                               // rare: a point that may be the minimum
+                        const bool valid = ka + h < cnt, cand = valid && d2 <= bnd;
+                        sec_l = min_f32(sec_l, (valid && !cand) ? d2 : FLT_MAX);
+                        if (cand) {                                    // rare: a point that may be the minimum
                             const uint32_t idx = first + ka + h, db = __float_as_uint(d2);
                             const unsigned long long key = ((unsigned long long)db << 32) | idx;
                             const unsigned long long old = atomicMin(&best[q], key);
@@ -440,11 +494,12 @@ __global__ __launch_bounds__(256, PR_WIDE_WAVES) void nn_tree_wide_kernel(IcpBat
                             if (old_d == db && old_i != idx && old_i != kNoIdx) atomicMin(&tied[q], db);
                             if (key < old) { if (old_i != kNoIdx) sec_l = min_f32(sec_l, __uint_as_float(old_d)); if (d2 < bnd) atomicMin(bound_q, db); }
                             else sec_l = min_f32(sec_l, d2);
-                        } else sec_l = min_f32(sec_l, d2);
+                        }
                     }
                 }
             }
             nN = (uint32_t)__builtin_amdgcn_readfirstlane((int)nN); nL = (uint32_t)__builtin_amdgcn_readfirstlane((int)nL);     // wave-uniform by construction
+            sec_l = min_f32(sec_l, sec_u < FLT_MAX ? sec_u * w_to_m2 : FLT_MAX);   // boxes: squared units -> squared metres, rounded down
             float sec_g = sec_l;
             if (kLanes >= 2) sec_g = min_f32(sec_l, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sec_l), 0xB1, 0xf, 0xf, true)));          // quad_perm [1,0,3,2]
             if (kLanes == 4) sec_g = min_f32(sec_g, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sec_g), 0x4E, 0xf, 0xf, true)));   // quad_perm [2,3,0,1]

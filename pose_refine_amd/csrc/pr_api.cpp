@@ -227,7 +227,7 @@ struct Ctx {
     PinBuf h_sums, h_meta, h_counts, h_results, h_dstate, h_flow;
     PackedCache packed;              // synchronous paths (the asynchronous slots keep their own)
     struct { const void *pcd = nullptr, *normal = nullptr, *nodes = nullptr; uint32_t n_points = 0, n_nodes = 0; uint64_t gen = 0; bool valid = false;
-             uint32_t info[16] = { 0 };
+             uint32_t info[24] = { 0 };
              bool grid_valid = false, grid_usable = false; uint32_t gw = 0, gh = 0; float gk[4] = { 0, 0, 0, 0 }; } nn_cache;   // kd traversal records (topo ... nndesc) + pixel grid of the latest kd-tree scene
     DevBuf nn_cells, nn_grid, nn_counters;
     // profiling
@@ -472,7 +472,7 @@ int make_scene(int kind, const void *scene, bool want_packed, SceneSel &out, Pac
             PR_TRY(g->bmax.ensure((size_t)s->n_nodes * sizeof(float4)));
             PR_TRY(g->pts.ensure((size_t)s->n_points * sizeof(float4)));
             PR_TRY(g->nnrec.ensure((size_t)s->n_nodes * 4 * sizeof(float4)));
-            PR_TRY(g->nndepth.ensure(16 * sizeof(uint32_t)));
+            PR_TRY(g->nndepth.ensure(24 * sizeof(uint32_t)));      // [0] depth [1] rec32 valid [2..7] rec32 frame [8] wide valid [9] wide nodes [12] fingerprint [16..19] wide frame
             PR_TRY(g->nnrec32.ensure((size_t)s->n_nodes * 2 * sizeof(uint4)));
             PR_TRY(g->nndesc.ensure((size_t)s->n_nodes * sizeof(uint2)));
             // wide records: one 128-byte line per wide node
@@ -481,7 +481,7 @@ int make_scene(int kind, const void *scene, bool want_packed, SceneSel &out, Pac
             HIP_TRY(prk::launch_build_nn_accel(s->nodes, s->n_nodes, s->pcd, s->n_points, g->topo.as<int4>(), g->bmin.as<float4>(),
                                                g->bmax.as<float4>(), g->pts.as<float4>(), g->nnrec.as<float4>(), g->nnrec32.as<uint4>(),
                                                g->nndesc.as<uint2>(), g->nndepth.as<uint32_t>(), g->stream,
-                                               g->nnwide.as<uint4>(), g->nnwq.as<uint32_t>()));
+                                               g->nnwide.as<uint4>(), g->nnwq.as<uint32_t>(), s->max_dist_diff * 1.01f));
             HIP_TRY(prk::launch_scene_fingerprint(s->pcd, (size_t)s->n_points * sizeof(pr_vec3), s->nodes, (size_t)s->n_nodes * sizeof(pr_kdnode), s->normal,
                                                   (size_t)s->n_points * sizeof(pr_vec3), g->nndepth.as<uint32_t>() + 12, nullptr, false, g->stream));
             HIP_TRY(hipMemcpyAsync(nc.info, g->nndepth.p, sizeof nc.info, hipMemcpyDeviceToHost, g->stream));
@@ -503,7 +503,11 @@ int make_scene(int kind, const void *scene, bool want_packed, SceneSel &out, Pac
         if (stack && opt.nn_compact && info[1] == 1u) {
             out.nn.rec32 = g->nnrec32.as<uint4>();
             for (int a = 0; a < 3; ++a) { std::memcpy(&out.nn.qmin[a], &info[2 + a], 4); std::memcpy(&out.nn.qscale[a], &info[5 + a], 4); }
-            if (opt.nn_wide && info[8] == 1u && info[9] > 0u) { out.nn.wide = g->nnwide.as<uint4>(); out.nn.n_wide = info[9]; }
+            if (opt.nn_wide && info[8] == 1u && info[9] > 0u) {
+                out.nn.wide = g->nnwide.as<uint4>(); out.nn.n_wide = info[9];
+                for (int a = 0; a < 3; ++a) std::memcpy(&out.nn.wmin[a], &info[16 + a], 4);
+                std::memcpy(&out.nn.wscale, &info[19], 4);
+            }
         }
         // a bare ICP call has no camera of its own: the scene's hint, if it carries one (pose_refine.h)
         Camera hinted;

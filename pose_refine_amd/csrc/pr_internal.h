@@ -107,6 +107,7 @@ struct SceneNNDev {
     // cannot be expressed that way (the binary walk of nn_tree_kernel is used)
     const uint4 *wide;
     uint32_t n_wide;
+    float wmin[3], wscale;      // frame of the wide records: coordinate = wmin[a] + (float)q * wscale (one scale for the three axes)
     // instrumented runs (option "nn_count"): per ICP pass (IcpBatch::iter) eight 64-bit counters -- queries, settled by the pixel
     // window, handed to the tree, pyramid descents, tree nodes visited, leaves scanned, leaf points tested, window cells read; else null
     unsigned long long *counters;
@@ -221,7 +222,7 @@ hipError_t launch_pack_proj_scene(const pr_vec3 *pcd, const pr_vec3 *normal, flo
 inline size_t nn_wide_capacity(uint32_t n_nodes) { return (size_t)n_nodes / 2 + 2; }
 hipError_t launch_build_nn_accel(const pr_kdnode *nodes, uint32_t n_nodes, const pr_vec3 *pcd, uint32_t n_points,
                                  int4 *topo, float4 *bmin, float4 *bmax, float4 *pts, float4 *rec, uint4 *rec32, uint2 *desc, uint32_t *info, hipStream_t s,
-                                 uint4 *wide = nullptr, uint32_t *wide_scratch = nullptr);
+                                 uint4 *wide = nullptr, uint32_t *wide_scratch = nullptr, float wide_margin = 0.0f);   // wide_margin: how far beyond the root box the wide records' frame reaches (the acceptance radius)
 
 }  // namespace prk
 

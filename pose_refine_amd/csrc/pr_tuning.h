@@ -1,52 +1,61 @@
-// pr_tuning.h -- the compile-time knobs of the kernels, in one place.  Each is a NUMBER that was swept on hardware (DESIGN.md / profiles/NOTES.md hold the
-// sweeps); -DPR_X=... on the hipcc line (PR_EXTRA_FLAGS of pose_refine_amd/build.py) overrides one for an A/B build (tools/ab_flags.sh).
-// The on/off switches of rounds 1-3 whose A/B is decided are gone: their winning branch is the code.
+// pr_tuning.h -- the compile-time knobs of the kernels, in one place.  Each is a NUMBER that was swept on hardware (profiles/NOTES.md holds the
+// sweeps); -DPR_X=... on the hipcc line (PR_EXTRA_FLAGS of pose_refine_amd/build.py) overrides one for an A/B build, and tools/ab_libs.sh runs
+// variant libraries side by side on one box.  The on/off switches of rounds 1-3 whose A/B is decided are gone: the winning branch is the code.
 #pragma once
 
+// ---- correspondence pass (icp_pass.hip) --------------------------------------------------------------------------------------------
+#ifndef PR_PASS_WAVES
+#define PR_PASS_WAVES 1                                         // __launch_bounds__ minimum waves per SIMD of icp_pass_kernel: 4, 5, 6 waves ran within 2 % of each other; the compiler's own choice wins
+#endif
+#ifndef PR_GATHER_BATCH
+#define PR_GATHER_BATCH 4                                       // projective scene gathers issued back to back before the first is tested (all four points of a lane)
+#endif
+
+// ---- kd-tree search: ordered per-lane walks (nn_query.h) ---------------------------------------------------------------------------
 #ifndef PR_LEAF_BATCH
-#define PR_LEAF_BATCH 10
+#define PR_LEAF_BATCH 10                                        // points of a leaf fetched before the first compare (the reference's max_leaf)
 #endif
 #ifndef PR_NN_WIDE_BOUND
-#define PR_NN_WIDE_BOUND 4.0e-6f                                // (2 mm)^2: above it a node's whole record is fetched at once
+#define PR_NN_WIDE_BOUND 4.0e-6f                                // (2 mm)^2: above this bound a node's whole 32-byte record is fetched at once, below it the 8-byte descent word first
+#endif
+
+// ---- kd-tree search: pixel grid (nn_query.h, nn_search.hip) ------------------------------------------------------------------------
+#ifndef PR_GRID_MAXW
+#define PR_GRID_MAXW 2                                          // half-width of the largest pixel window scanned (5 x 5 cells); a larger window goes to the tree
+#endif
+#ifndef PR_RING_ROWS
+#define PR_RING_ROWS 2                                          // rows of a 6 x 6 ring of the descent in flight at a time (1, 2, 3, 6 measured: not latency-bound)
 #endif
 #ifndef PR_NN_COVER_PAD
 #define PR_NN_COVER_PAD 5.0e-4f                                 // metres a window search looks beyond its bound for the runner-up (about one pixel at 300 mm)
 #endif
-#ifndef PR_NN_NODESCENT
-#define PR_NN_NODESCENT 2.5e-7f                                // squared step up to which the previous winner's distance is bound enough (no descent through the representatives)
-#endif
-#ifndef PR_RING_ROWS
-#define PR_RING_ROWS 2
-#endif
 #ifndef PR_NN_SETTLE
-#define PR_NN_SETTLE 1                                           // grid_search: widest cover for points that have stopped moving
+#define PR_NN_SETTLE 1                                          // 1: a point that has stopped moving takes the widest cover the window holds (its margin then lasts for the rest of the loop)
 #endif
 #ifndef PR_NN_STILL
 #define PR_NN_STILL 2.5e-7f                                     // (0.5 mm)^2: below this step a point's previous winner is taken as a tight seed
 #endif
-#ifndef PR_GRID_MAXW
-#define PR_GRID_MAXW 2
-#endif
-#ifndef PR_PASS_WAVES
-#define PR_PASS_WAVES 1
-#endif
-#ifndef PR_GATHER_BATCH
-#define PR_GATHER_BATCH 4
-#endif
-#ifndef PR_WIDE_WAVES
-#define PR_WIDE_WAVES 5                                        // wavefronts per SIMD the task walk is compiled for
-#endif
-#ifndef PR_WIDE_LANES
-#define PR_WIDE_LANES 2                                        // lanes per task
-#endif
-#ifndef PR_WIDE_QCAP
-#define PR_WIDE_QCAP 384
-#endif
-#ifndef PR_WIDE_LCAP
-#define PR_WIDE_LCAP 288
-#endif
-#ifndef PR_TREE_GX
-#define PR_TREE_GX 8
+#ifndef PR_NN_NODESCENT
+#define PR_NN_NODESCENT 2.5e-7f                                 // squared step up to which the previous winner's distance is bound enough (no descent through the representatives)
 #endif
 
-#define PR_SEL_DOC 0   /* (PR_SEL / PR_TREE_LEVEL / PR_HD are local helper macros of their files, not knobs) */
+// ---- kd-tree search: task walk over wide nodes (nn_search.hip) ----------------------------------------------------------------------
+// Round 4 sweep, same box, 256 hypotheses, sum of the walk over the 21 passes: workgroups per hypothesis 5 / 8 / 12 / 16 / 32 -> 5.98 / 5.06 /
+// 4.58 / 4.91 / 5.46 ms (the bound kernel follows: 2.31 / 2.16 / 1.92 / 1.97 / 2.04); at 12, queue capacities and waves per SIMD (384, 288, 5) /
+// (256, 192, 6) / (320, 224, 6) / (224, 160, 7) / (192, 160, 6) / (160, 128, 8) -> 4.60 / 4.27 / 4.35 / 4.86 / 6.55 / 8.01 ms: more waves in flight
+// help every pass, but the first pass needs its queues (overflows are walked a second time).
+#ifndef PR_TREE_GX
+#define PR_TREE_GX 12                                           // workgroups per hypothesis of the bound kernel and the walk (more for launches with few hypotheses)
+#endif
+#ifndef PR_WIDE_WAVES
+#define PR_WIDE_WAVES 6                                         // wavefronts per SIMD the task walk is compiled for (<= 80 VGPRs; LDS: 24.5 KiB per workgroup)
+#endif
+#ifndef PR_WIDE_LANES
+#define PR_WIDE_LANES 2                                         // lanes per task: the paired record layout is made for 2
+#endif
+#ifndef PR_WIDE_QCAP
+#define PR_WIDE_QCAP 256                                        // entries of a wavefront's node-task queue
+#endif
+#ifndef PR_WIDE_LCAP
+#define PR_WIDE_LCAP 192                                        // entries of a wavefront's leaf-task queue
+#endif
