@@ -865,6 +865,21 @@ def host_solve_extra(args, api, model, poses, W, H, proj, K, scene, steps=30):
         t0 = time.perf_counter()
         for _ in range(steps):
             api.refine_batch(model, poses, W, H, proj, K, scene, crit)
+        dt_sync = (time.perf_counter() - t0) / steps
+        # the same batches pipelined through the two slots from this ONE thread, like the headline loop: with the solve on the host a
+        # submitted batch runs on its slot's helper thread (library-owned, private context), so batch k+1's render and host work run under
+        # batch k's passes -- the reference's "many host threads" (README.md:15) without the caller having to bring them
+        for k in range(4):
+            api.refine_submit(k & 1, model, poses, W, H, proj, K, scene, crit)
+            if k:
+                api.refine_wait((k - 1) & 1)
+        api.refine_wait(1)
+        t0 = time.perf_counter()
+        for k in range(steps):
+            api.refine_submit(k & 1, model, poses, W, H, proj, K, scene, crit)
+            if k:
+                api.refine_wait((k - 1) & 1)
+        api.refine_wait((steps - 1) & 1)
         dt = (time.perf_counter() - t0) / steps
         n_threads = 2
         barrier = threading.Barrier(n_threads + 1)
@@ -892,8 +907,10 @@ def host_solve_extra(args, api, model, poses, W, H, proj, K, scene, steps=30):
         [t.join() for t in ts]
     finally:
         api.set_option("solve", api.SOLVE_DEVICE)
-    out = {"value": len(poses) / dt, "unit": "poses/s", "ms_per_step": dt * 1e3, "steps": steps, "host_threads": 1,
-           "note": "PR_SOLVE_HOST, one synchronous call per step: 21 launches per pose group (two groups on two streams, software-pipelined: the host solves one group while the other group's pass runs); the workgroup that delivers a hypothesis' last partial sum stores its 29 totals straight into pinned host memory, the host solves (pivoted LDLT in double, as Eigen) and the next pass reads the update from the pinned array"}
+    out = {"value": len(poses) / dt, "unit": "poses/s", "ms_per_step": dt * 1e3, "steps": steps, "host_threads": "1 (+2 library: one helper thread per slot)",
+           "note": "PR_SOLVE_HOST, batches pipelined through pr_refine_submit / pr_refine_wait on the two slots from one caller thread; each slot's helper thread runs its batch: 21 launches per pose group (two groups on two streams, software-pipelined: the host solves one group while the other group's pass runs); the workgroup that delivers a hypothesis' last partial sum stores its 29 totals straight into pinned host memory, the host solves (pivoted LDLT in double, as Eigen) and the next pass reads the update from the pinned array",
+           "one_synchronous_call_per_step": {"value": len(poses) / dt_sync, "unit": "poses/s", "ms_per_step": dt_sync * 1e3, "steps": steps,
+                                             "note": "pr_refine_batch in a loop: nothing of batch k+1 can start before batch k has returned"}}
     if dt2:
         out["two_host_threads"] = {"value": len(poses) / dt2, "unit": "poses/s", "ms_per_step": dt2 * 1e3, "steps": steps * n_threads,
                                    "note": "the same synchronous calls from two host threads with private contexts (pr_thread_context), batches taken in turn"}

@@ -15,7 +15,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <memory>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -121,6 +124,7 @@ struct Options {
     int pose_groups = 0;             // split the batch over this many streams (1..4); 0 = by scene: 2 for projective scenes (1.31 vs 1.45 ms/step at
                                      // 256 poses), 3 for kd-tree scenes; launches of different groups overlap, so timed calls fall back to one group
     int solve_mode = PR_SOLVE_HOST;
+    int host_worker = 1;             // PR_SOLVE_HOST batches of pr_refine_submit run on the slot's helper thread (0: on the caller's thread, inside the call)
     int steps = 3;                   // 1024-point steps per workgroup -> 3072 points per workgroup (9 workgroups per 26 k-point cloud: measured 3-5 % faster than 2048 / 4096)
     int profile = 0;
     int sample_period = 32;          // profile 2: one timed (synchronous, single-group) call in this many
@@ -167,7 +171,28 @@ struct Resubmit {
     int scene_kind = 0; pr_scene_proj_crop sp{}; pr_scene_nn sn{}; pr_criteria crit{}; pr_roi roi{ 0, 0, 0, 0 };
     pr_result *results_dev = nullptr;
 };
+// A slot's helper thread (PR_SOLVE_HOST): the reference solves on the host (icp.cu:207), which makes a batch a chain of
+// launch -> wait -> solve -> launch that only a host thread can drive; the reference's answer is "many host threads, each refining its own
+// hypothesis" (README.md:15).  A caller that pipelines batches through pr_refine_submit / pr_refine_wait from ONE thread gets the same
+// overlap from the library: each slot owns a thread with a private context (its own streams, workspaces and caches, as pr_thread_context
+// gives a caller's thread) that runs the synchronous host-solve path for the batch while the caller goes on to submit the next one.
+struct SlotWorker {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    bool has_job = false, done = false, quit = false, alive = false;
+    int device = 0;
+    // the job: every input by value (the caller's arrays of poses may go away after pr_refine_submit returns)
+    Resubmit in;
+    std::vector<pr_mat4> poses;
+    pr_result *results_host = nullptr;
+    uint32_t *sizes_host = nullptr;
+    int rc = PR_OK;
+    std::string err;
+};
 struct Slot {
+    std::unique_ptr<SlotWorker> worker;
+    bool worker_job = false;         // the batch in flight runs on the helper thread
     DevBuf poses_bbox, depth, row_count, row_off, counts, cloud, meta, partial, dstate, dresults, arrive, aabb_keys, nn_prev;
     PackedCache packed;
     PinBuf h_in, h_out;
@@ -1049,8 +1074,24 @@ int slot_streams(Slot &sl)
     return PR_OK;
 }
 // wait for everything a slot has in flight (its stream and side streams)
+void slot_worker_wait(Slot &sl)      // the helper thread's batch, if one is running, has finished when this returns
+{
+    if (!sl.worker || !sl.worker_job) return;
+    std::unique_lock<std::mutex> lk(sl.worker->mu);
+    sl.worker->cv.wait(lk, [&] { return sl.worker->done || !sl.worker->alive; });
+}
+void slot_worker_stop(Slot &sl)
+{
+    if (!sl.worker) return;
+    { std::lock_guard<std::mutex> lk(sl.worker->mu); sl.worker->quit = true; }
+    sl.worker->cv.notify_all();
+    if (sl.worker->th.joinable()) sl.worker->th.join();
+    sl.worker.reset();
+    sl.worker_job = false;
+}
 void slot_drain(Slot &sl)
 {
+    slot_worker_wait(sl);
     for (int i = 0; i < 3; ++i) if (sl.side[i]) (void)hipStreamSynchronize(sl.side[i]);
     if (sl.stream) (void)hipStreamSynchronize(sl.stream);
 }
@@ -1061,6 +1102,7 @@ void drain_all_slots()
 void slot_release(Slot &sl)
 {
     slot_drain(sl);
+    slot_worker_stop(sl);
     for (DevBuf *b : { &sl.poses_bbox, &sl.depth, &sl.row_count, &sl.row_off, &sl.counts, &sl.cloud, &sl.meta, &sl.partial, &sl.dstate,
                        &sl.dresults, &sl.arrive, &sl.aabb_keys, &sl.nn_prev, &sl.packed.rec }) b->release();
     sl.packed = PackedCache();
@@ -1141,6 +1183,14 @@ int refine_wait(int slot)
     Slot &sl = g->slots[slot];
     if (!sl.pending) { set_error("pr_refine_wait: nothing was submitted on slot %d", slot); return PR_ERR_INVALID; }
     if (sl.delivered) { sl.pending = false; return PR_OK; }
+    if (sl.worker_job) {                                          // the batch ran on the slot's helper thread: collect its verdict
+        slot_worker_wait(sl);
+        sl.worker_job = false; sl.pending = false;
+        std::lock_guard<std::mutex> lk(sl.worker->mu);
+        if (!sl.worker->done) { set_error("pr_refine_wait: the slot's helper thread ended before its batch did"); return PR_ERR_HIP; }
+        if (sl.worker->rc != PR_OK) set_error("%s", sl.worker->err.c_str());
+        return sl.worker->rc;
+    }
     {
         // the slot stays occupied until its batch has really finished: if the wait itself fails, everything the slot has in flight is
         // drained before the error goes back (a later submit must never reuse the slot's buffers under a running batch)
@@ -1193,6 +1243,70 @@ int refine_wait(int slot)
     return PR_OK;
 }
 
+int refine_impl(const pr_triangle *tris_dev, size_t n_tris, const pr_mat4 *poses_host, uint32_t P, uint32_t W, uint32_t H,
+                const pr_mat4 *proj, const float K[9], int scene_kind, const void *scene, pr_criteria crit, pr_roi roi,
+                pr_result *results_host, pr_result *results_dev, uint32_t *sizes_host);
+// the helper thread of a slot: a private context on the slot's device, then one synchronous batch per job
+void slot_worker_main(SlotWorker *w)
+{
+    bool ready = bind_shared(w->device) == PR_OK && pr_thread_context(1) == PR_OK;
+    for (;;) {
+        std::unique_lock<std::mutex> lk(w->mu);
+        w->cv.wait(lk, [&] { return w->has_job || w->quit; });
+        if (w->quit) break;
+        lk.unlock();
+        int rc = PR_ERR_HIP;
+        if (!ready) set_error("the slot's helper thread could not create its context: %s", std::string(prh::g_err).c_str());
+        else {
+            std::lock_guard<std::mutex> ck(g->mu);
+            rc = require_ctx();
+            if (rc == PR_OK) {
+                const Resubmit &r = w->in;
+                const void *scene = (r.scene_kind == PR_SCENE_NN) ? static_cast<const void *>(&r.sn)
+                                    : (r.scene_kind == PR_SCENE_PROJ_CROP ? static_cast<const void *>(&r.sp) : static_cast<const void *>(&r.sp.view));
+                rc = refine_impl(r.tris, r.n_tris, w->poses.data(), (uint32_t)w->poses.size(), r.W, r.H, &r.proj, r.K, r.scene_kind, scene, r.crit, r.roi,
+                                 w->results_host, r.results_dev, w->sizes_host);
+            }
+        }
+        lk.lock();
+        w->rc = rc; w->err = (rc == PR_OK) ? std::string() : prh::g_err;
+        w->has_job = false; w->done = true;
+        lk.unlock();
+        w->cv.notify_all();
+    }
+    if (ready) (void)pr_thread_context(0);
+    { std::lock_guard<std::mutex> lk(w->mu); w->alive = false; }
+    w->cv.notify_all();
+}
+int slot_worker_post(Slot &sl, const pr_triangle *tris_dev, size_t n_tris, const pr_mat4 *poses_host, uint32_t P, uint32_t W, uint32_t H,
+                     const pr_mat4 *proj, const float K[9], int scene_kind, const void *scene, pr_criteria crit, pr_roi roi,
+                     pr_result *results_host, pr_result *results_dev, uint32_t *sizes_host)
+{
+    if (scene_kind != PR_SCENE_NN && scene_kind != PR_SCENE_PROJ && scene_kind != PR_SCENE_PROJ_CROP) { set_error("unknown scene kind %d", scene_kind); return PR_ERR_INVALID; }
+    if (!scene) { set_error("pr_refine_submit: null scene"); return PR_ERR_INVALID; }
+    if (!sl.worker) {
+        sl.worker.reset(new SlotWorker());
+        sl.worker->device = g->device; sl.worker->alive = true;
+        try { sl.worker->th = std::thread(slot_worker_main, sl.worker.get()); }
+        catch (...) { sl.worker.reset(); set_error("pr_refine_submit: cannot start the slot's helper thread"); return PR_ERR_NOMEM; }
+    }
+    SlotWorker &w = *sl.worker;
+    {
+        std::lock_guard<std::mutex> lk(w.mu);
+        Resubmit &r = w.in;
+        r.tris = tris_dev; r.n_tris = n_tris; r.W = W; r.H = H; r.proj = *proj; std::memcpy(r.K, K, sizeof r.K);
+        r.scene_kind = scene_kind; r.crit = crit; r.roi = roi; r.results_dev = results_dev;
+        if (scene_kind == PR_SCENE_NN) r.sn = *static_cast<const pr_scene_nn *>(scene);
+        else if (scene_kind == PR_SCENE_PROJ_CROP) r.sp = *static_cast<const pr_scene_proj_crop *>(scene);
+        else { r.sp.view = *static_cast<const pr_scene_proj *>(scene); r.sp.tl_x = r.sp.tl_y = 0; }
+        w.poses.assign(poses_host, poses_host + P);
+        w.results_host = results_host; w.sizes_host = sizes_host;
+        w.done = false; w.has_job = true;
+    }
+    w.cv.notify_all();
+    return PR_OK;
+}
+
 int refine_submit_async(Slot &sl, const pr_triangle *tris_dev, size_t n_tris, uint32_t P, uint32_t W, uint32_t H,
                         const pr_mat4 *proj, const float K[9], int scene_kind, const void *scene, pr_criteria crit, pr_roi roi,
                         pr_result *results_host, pr_result *results_dev);
@@ -1216,6 +1330,12 @@ int refine_submit(int slot, const pr_triangle *tris_dev, size_t n_tris, const pr
     (void)img;                                                   // (large frames: the asynchronous path sizes its sub-batches to its workspace bound)
     const bool async_ok = P > 0 && opt.solve_mode == PR_SOLVE_DEVICE && !opt.icp_flow && opt.raster_mode == 0 && (proj_scene || nn_scene)
                           && (opt.profile == 0 || opt.profile == 3 || (opt.profile == 2 && !sample_call));
+    if (!async_ok && P > 0 && opt.solve_mode == PR_SOLVE_HOST && opt.host_worker && opt.profile == 0 && !opt.icp_flow && !opt.nn_count) {
+        // host solve, nothing to time: the batch goes to the slot's helper thread (see SlotWorker) and this call returns
+        PR_TRY(slot_worker_post(sl, tris_dev, n_tris, poses_host, P, W, H, proj, K, scene_kind, scene, crit, roi, results_host, results_dev, sizes_host));
+        sl.pending = true; sl.delivered = false; sl.worker_job = true;
+        return PR_OK;
+    }
     if (!async_ok) {
         // the synchronous path (host solve, timed calls, oversized batches): let the other slot drain first so
         // that a timed launch has the chip to itself, then run to completion; pr_refine_wait has nothing left to do
@@ -2085,6 +2205,7 @@ int pr_set_option(const char *name, int value)
     if (!name) { set_error("pr_set_option: null name"); return PR_ERR_INVALID; }
     const std::string n(name);
     if (n == "solve") { if (value != PR_SOLVE_HOST && value != PR_SOLVE_DEVICE) { set_error("solve must be 0 or 1"); return PR_ERR_INVALID; } opt.solve_mode = value; }
+    else if (n == "host_worker") opt.host_worker = value ? 1 : 0;
     else if (n == "points_per_block") { if (value < 1024 || value % 1024) { set_error("points_per_block must be a multiple of 1024"); return PR_ERR_INVALID; } opt.steps = value / 1024; }
     else if (n == "profile") { if (value < 0 || value > 3) { set_error("profile must be 0, 1 (every launch, synchronous calls), 2 (every launch of one call in sample_period) or 3 (every launch, asynchronous batches stay asynchronous)"); return PR_ERR_INVALID; } opt.profile = value; }
     else if (n == "sample_period") opt.sample_period = std::max(1, value);
@@ -2117,6 +2238,7 @@ int pr_get_option(const char *name, int *value)
     if (!name || !value) { set_error("pr_get_option: null argument"); return PR_ERR_INVALID; }
     const std::string n(name);
     if (n == "solve") *value = opt.solve_mode;
+    else if (n == "host_worker") *value = opt.host_worker;
     else if (n == "points_per_block") *value = opt.steps * 1024;
     else if (n == "profile") *value = opt.profile;
     else if (n == "sample_period") *value = opt.sample_period;

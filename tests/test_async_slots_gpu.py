@@ -330,3 +330,45 @@ def test_arrival_protocol_stress_tiny_clouds(gpu):
     finally:
         api.set_option("profile", 0); api.set_option("fused_solve", 1); api.set_option("pose_groups", 0)
         api.set_option("solve", api.SOLVE_HOST)
+
+
+@pytest.mark.parametrize("kind,P", [("proj", 96), ("nn", 40)])
+def test_host_solve_batches_run_on_the_slots_helper_threads(gpu, model, scenario, gscenes, kind, P):
+    """with the solve on the host (icp.cu:207) a batch handed to pr_refine_submit runs on its slot's library-owned
+    helper thread, so one caller thread can keep two batches in flight.  Records equal the synchronous call's byte for byte -- with the
+    helper threads, without them (option host_worker = 0), for device result buffers -- and an error of the batch comes back from
+    pr_refine_wait with its message."""
+    poses_a, poses_b = synth.hypotheses(P, seed=31), synth.hypotheses(P, seed=32)
+    crit = api.ICPConvergenceCriteria(0.0, 0.0, 6)
+    args = (W, H, scenario["proj"], scenario["K"], gscenes[kind], crit)
+    api.set_option("solve", api.SOLVE_HOST)
+    try:
+        api.set_option("host_worker", 0)
+        ref_a = api.refine_batch(model, poses_a, *args)
+        ref_b = api.refine_batch(model, poses_b, *args)
+        api.set_option("host_worker", 1)
+        for _ in range(3):                                           # the helper threads persist from batch to batch
+            api.refine_submit(0, model, poses_a, *args)
+            api.refine_submit(1, model, poses_b, *args)              # both in flight: two helper threads, two private contexts
+            got_a = api.refine_wait(0)
+            got_b = api.refine_wait(1)
+            assert got_a[0].tobytes() == ref_a[0].tobytes() and np.array_equal(got_a[1], ref_a[1])
+            assert got_b[0].tobytes() == ref_b[0].tobytes() and np.array_equal(got_b[1], ref_b[1])
+        sync = api.refine_batch(model, poses_a, *args)               # submit + wait on a free slot
+        assert sync[0].tobytes() == ref_a[0].tobytes()
+        dev = api.DeviceVector(P * 18, np.float32)
+        api.refine_submit(1, model, poses_b, *args, results_dev=dev.data())
+        _, sizes = api.refine_wait(1)
+        assert dev.to_host().tobytes() == ref_b[0].tobytes() and np.array_equal(sizes, ref_b[1])
+        # a batch that fails on the helper thread: the error and its text arrive at pr_refine_wait, and the slot is free again
+        bad = api.Scene_projective()
+        bad.width, bad.height, bad.K = W, H, gscenes["proj"].K
+        bad.pcd_buffer = api.DeviceVector(0, np.float32); bad.normal_buffer = api.DeviceVector(0, np.float32)      # null arrays
+        api.refine_submit(0, model, poses_a, W, H, scenario["proj"], scenario["K"], bad, crit)
+        with pytest.raises(api.PoseRefineError) as e:
+            api.refine_wait(0)
+        assert "invalid pr_scene_proj" in str(e.value)
+        api.refine_submit(0, model, poses_a, *args)
+        assert api.refine_wait(0)[0].tobytes() == ref_a[0].tobytes()
+    finally:
+        api.set_option("host_worker", 1); api.set_option("solve", api.SOLVE_DEVICE if False else api.SOLVE_HOST)
