@@ -52,13 +52,15 @@ bash tools/nn_passes.sh "nn_wide=0" 2>/dev/null | grep -E "==|us:" >> $OUT/nn_pe
 timeout 600 python tools/config5.py 128 --check > $OUT/config5.txt 2>&1; tail -4 $OUT/config5.txt
 rocprofv3 --kernel-trace --stats -d $OUT/stats3 -o c5 -- python tools/config5.py 128 > /dev/null 2>&1
 summ $OUT/stats3/c5_results.db > $OUT/kernel_stats_config5.md
-# two ranks on the one GPU of this box (gloo gather on host copies; everything else is the N > 1 code path)
-PR_BENCH_SHARE_DEVICE=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 40 --warmup 5 2>/dev/null | tail -1 > $OUT/bench_2ranks_share_device.json
+# two ranks on the one GPU of this box, started by bench.py itself: one process per rank under torch.distributed.run, and one host thread per rank
+PR_BENCH_SHARE_DEVICE=1 timeout 600 python bench.py --gpus 2 --steps 40 --warmup 5 2>/dev/null | tail -1 > $OUT/bench_2ranks_share_device_processes.json
+PR_BENCH_SHARE_DEVICE=1 timeout 600 python bench.py --gpus 2 --steps 40 --warmup 5 --launcher threads 2>/dev/null | tail -1 > $OUT/bench_2ranks_share_device_threads.json
 # C++ host: shard driver
 g++ -std=c++14 -O2 -pthread -Iinclude tests/cpp/shard_test.cpp -o tests/cpp/shard_test -Lpose_refine_amd/lib -lpose_refine_hip -Wl,-rpath,$PWD/pose_refine_amd/lib && ./tests/cpp/shard_test tests/golden/ 4096 2>&1 | tail -1 > $OUT/shard_test_4096.json; cat $OUT/shard_test_4096.json
 python -c "from pose_refine_amd import api; print('visible devices:', api.device_count())" >> $OUT/shard_test_4096.json 2>/dev/null
 rm -rf $OUT/stats $OUT/stats1 $OUT/stats2 $OUT/stats3 $OUT/stats4 $OUT/pmc
 lscpu | grep -E 'Model name|^CPU\(s\)|Socket|Core' > $OUT/host_cpu.txt; cat /sys/fs/cgroup/cpu.max >> $OUT/host_cpu.txt 2>/dev/null
+bash tools/pmc_pass.sh 0 "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA" "SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INST_CYCLES_VMEM" -- - 2>&1 | grep -v "^$" > $OUT/sq_nn_pass0.txt
 for f in $OUT/bench_*.json; do echo "== $f"; python -c "
 import json
 d=json.loads(open('$f').read().strip().splitlines()[-1])
