@@ -6,7 +6,8 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import oracle_lib as O
 from pose_refine_amd import api
-import test_fuzz_gpu as F
+import test_render_gpu as FR
+import test_refine_batch_gpu as FB
 api.init(0)
 t0 = time.time()
 bad = []
@@ -17,8 +18,8 @@ while time.time() - t0 < budget:
     rng = np.random.default_rng(seed)
     W, H = int(rng.integers(16, 400)), int(rng.integers(16, 300))
     try:
-        F.test_render_random_scenes(True, seed, W, H)
-        F.test_fused_pipeline_random_scenes(True, seed + 1, W, H)
+        FR.test_render_random_scenes(True, seed, W, H)
+        FB.test_fused_pipeline_random_scenes(True, seed + 1, W, H)
     except AssertionError as e:
         bad.append((seed, W, H, str(e)[:200]))
         print("MISMATCH", seed, W, H, str(e)[:300], flush=True)

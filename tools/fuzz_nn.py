@@ -5,8 +5,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from pose_refine_amd import api
-import test_round3_gpu as R
-import test_parity_gpu as Pg
+import test_kdtree_search_gpu as R
+Pg = R
 api.init(0); api.set_option("solve", api.SOLVE_DEVICE)
 t0 = time.time(); budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 bad = []; n = 0; seed = int(sys.argv[2]) if len(sys.argv) > 2 else 5000
