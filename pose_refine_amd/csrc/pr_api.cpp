@@ -139,6 +139,10 @@ struct Options {
     int nn_run = 2;                  // 256-point chunks a workgroup of the search kernel takes (lane t of chunk k: point 256 k + t); 2: +1-2 % over 1 on configs[2]
     int nn_grid = 1;                 // fused path: pixel grid of the scene points (seeds + window search); 0 = tree only
     int nn_count = 0;                // instrumented runs: the search kernel counts its work per pass (pr_nn_counters)
+    int start_overlap = -1;          // asynchronous path, a batch submitted while the other slot is idle: the pass after which the next batch's render may start.
+                                     // -1 = the per-batch rule of a running pipeline.  Rounds 2-3 released the next render at pass 0 here; with the roofline
+                                     // sample out of the timed region that reads 239 / 240 / 251 k against 253 / 253 / 256 k poses/s for the rule in three
+                                     // alternating 20-step runs on one box: batches 1 and 2 then finish together and the third finds an empty chip
     int overlap_pass = -1;           // asynchronous path: the other slot's render may start once this slot has issued this pass of its loop (-1: chosen per batch, see refine_submit_async)
                                      // (-1: 70 % of the passes -- measured best of 6/10/14/17 at 256 and 512 poses per batch)
     int sub_batch = 512;             // asynchronous fused path: hypotheses per sub-batch (cache residency of the clouds)
@@ -1473,9 +1477,8 @@ int refine_submit_async(Slot &sl, const pr_triangle *tris_dev, size_t n_tris, ui
     // path (profile 1), without that path's host round trips and its idle render.
     const bool timed = (opt.profile == 3);
     sl.timed = timed; sl.t_used = 0; sl.t_spans.clear();
-    // A batch submitted while the other slot is idle starts a pipeline: there is no loop of the other slot for its own loop to share the chip
-    // with, so the NEXT batch's render need not be held back until this loop is half done (the rule below balances two running loops) --
-    // it may start with this loop's first pass.  0.2-0.4 ms per start of a stream of batches (1-2 % of a 20-step run).
+    // A batch submitted while the other slot is idle starts a pipeline.  Option start_overlap says when the NEXT batch's render may start
+    // in that case: -1 (default) = by the rule below, like any other batch; a pass number releases it earlier (see the option's note).
     bool pipeline_start = true;
     for (Slot &o : g->slots) if (&o != &sl && o.pending && !o.delivered) pipeline_start = false;
     // a failed event creation or record drops the TIMING of this batch (never the batch): t_fail, checked when everything is enqueued
@@ -1569,7 +1572,7 @@ int refine_submit_async(Slot &sl, const pr_triangle *tris_dev, size_t n_tris, ui
                 } else HIP_TRY(launch_pass(bb, sc, np, gs));
                 if (!fused) HIP_TRY(prk::launch_icp_finalize_solve(bb.partial, meta + p0, nblk, steps, dstate + p0, crit, it, np, gs));
             }
-            if (q0 + sub >= P && it == (timed ? (uint32_t)crit.max_iteration : std::min<uint32_t>((uint32_t)crit.max_iteration, pipeline_start ? 0u : (opt.overlap_pass >= 0 ? (uint32_t)opt.overlap_pass : auto_overlap)))) {
+            if (q0 + sub >= P && it == (timed ? (uint32_t)crit.max_iteration : std::min<uint32_t>((uint32_t)crit.max_iteration, (pipeline_start && opt.start_overlap >= 0) ? (uint32_t)opt.start_overlap : (opt.overlap_pass >= 0 ? (uint32_t)opt.overlap_pass : auto_overlap)))) {
                 HIP_TRY(hipEventRecord(sl.progress, st));
                 sl.progress_valid = true;
             }
@@ -2206,6 +2209,7 @@ int pr_set_option(const char *name, int value)
     const std::string n(name);
     if (n == "solve") { if (value != PR_SOLVE_HOST && value != PR_SOLVE_DEVICE) { set_error("solve must be 0 or 1"); return PR_ERR_INVALID; } opt.solve_mode = value; }
     else if (n == "host_worker") opt.host_worker = value ? 1 : 0;
+    else if (n == "start_overlap") opt.start_overlap = value;
     else if (n == "points_per_block") { if (value < 1024 || value % 1024) { set_error("points_per_block must be a multiple of 1024"); return PR_ERR_INVALID; } opt.steps = value / 1024; }
     else if (n == "profile") { if (value < 0 || value > 3) { set_error("profile must be 0, 1 (every launch, synchronous calls), 2 (every launch of one call in sample_period) or 3 (every launch, asynchronous batches stay asynchronous)"); return PR_ERR_INVALID; } opt.profile = value; }
     else if (n == "sample_period") opt.sample_period = std::max(1, value);
@@ -2239,6 +2243,7 @@ int pr_get_option(const char *name, int *value)
     const std::string n(name);
     if (n == "solve") *value = opt.solve_mode;
     else if (n == "host_worker") *value = opt.host_worker;
+    else if (n == "start_overlap") *value = opt.start_overlap;
     else if (n == "points_per_block") *value = opt.steps * 1024;
     else if (n == "profile") *value = opt.profile;
     else if (n == "sample_period") *value = opt.sample_period;
