@@ -194,7 +194,7 @@ def parse_args(argv=None):
     ap.add_argument("--scene", choices=["proj", "nn"], default="proj")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--solve", choices=["host", "device"], default=os.environ.get("PR_BENCH_SOLVE", "device"))
-    ap.add_argument("--pose-groups", type=int, default=0, help="streams the iteration loop is split over (0 = the library's choice: 2 for projective, 3 for kd-tree scenes)")
+    ap.add_argument("--pose-groups", type=int, default=0, help="streams the iteration loop is split over (0 = the library's choice: 2)")
     ap.add_argument("--fused-solve", type=int, default=1, help="1: finalize+solve in the tail of the pass kernel (library default)")
     ap.add_argument("--overlap-pass", type=int, default=-1, help="library option overlap_pass (-1: library default)")
     ap.add_argument("--sequential", action="store_true",
@@ -626,7 +626,7 @@ def run_rank(args, group, local_dev, share_device, launcher_note, comm_ready, co
         "config": {"workload": f"obj_06.ply, {P_max}-pose batch per GPU, 640x480 synthetic depth, "
                                f"{'projective' if args.scene == 'proj' else 'kd-tree NN (exact search with the reference tie-breaks: keep-the-winner test and pixel-window scan where the bound allows, order-free task walk over 128-byte wide nodes otherwise, ties repeated by the ordered walk)'} association, "
                                f"{args.iters} ICP iterations (21 passes), solve on {args.solve}"
-                               + (f", {args.pose_groups or (2 if args.scene == 'proj' else 3)} pose groups" if args.solve == "device" else ""),
+                               + (f", {args.pose_groups or 2} pose groups" if args.solve == "device" else ""),
                    "poses_per_gpu": P_max, "global_batch": global_poses, "points_per_pose_mean": float(np.mean(sizes)),
                    "parallelism": (f"pose-shard x{world}, no data-path collective, "
                                    + ("no gather (1 rank)" if not multi else

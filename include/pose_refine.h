@@ -281,7 +281,7 @@ int pr_gather_results(const pr_result *send_dev, uint32_t n_local, uint32_t n_to
  *   "points_per_block" [3072]  points per workgroup of the correspondence pass (multiple of 1024)
  *   "fused_solve"      [1]     the workgroup that delivers a hypothesis' last partial sum finalizes in the tail of the pass kernel instead of
  *                              a second launch: device solve = finalize + 6x6 solve there; host solve = the 29 totals stored into pinned host memory
- *   "pose_groups"      [0]     streams the batch is split over (1..4; 0 = 2 for projective scenes, 3 for kd-tree scenes): device solve = one group's solve tail under another's pass;
+ *   "pose_groups"      [0]     streams the batch is split over (1..4; 0 = 2): device solve = one group's solve tail under another's pass;
  *                              host solve = software pipeline (the host solves one group while another group's pass runs)
  *   "graph"            [1]     device solve, one pose group, synchronous path: replay the loop as a hipGraph
  *   "icp_flow"         [0]     device solve: one persistent dataflow launch for all iterations

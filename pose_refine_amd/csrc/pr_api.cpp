@@ -157,9 +157,11 @@ struct Options {
     int scene_cache = 1;             // keep the packed projective scene / kd traversal records of the latest scene between calls (pr_scene_invalidate)
 };
 Options opt;
-// streams a batch is split over: the option, or by scene -- 2 for projective scenes, 3 for kd-tree scenes (a kd-tree pass is a chain of four
-// launches with a latency-bound tail each: a third group fills what two leave idle, +1.5 % on configs[2]; a fourth loses 14 %)
-inline uint32_t pose_groups_for(int scene_kind) { return opt.pose_groups > 0 ? (uint32_t)opt.pose_groups : (scene_kind == PR_SCENE_NN ? 3u : 2u); }
+// streams a batch is split over: the option, or two.  (Round 3 ran kd-tree scenes as three groups: with 8 workgroups per hypothesis and five
+// waves per SIMD the search kernels left gaps a third group filled, +1.5 %.  With round 4's 12 workgroups and six waves two groups are
+// enough and the third only costs launches: 34.4 / 34.9 k against 32.2 / 31.9 k poses/s on configs[2], same box; one group 29.8 k, four 31.2 k.
+// Projective scenes with 16 hardware queues: three groups 174 k against 247 k.)
+inline uint32_t pose_groups_for(int scene_kind) { (void)scene_kind; return opt.pose_groups > 0 ? (uint32_t)opt.pose_groups : 2u; }
 
 // packed projective scene (one 16-byte record per pixel + the two back-projection tables) of the latest scene it was built for
 struct PackedCache {
@@ -1542,6 +1544,10 @@ int refine_submit_async(Slot &sl, const pr_triangle *tris_dev, size_t n_tris, ui
             const double left = std::max(5.0, 2800.0 * weight / (double)std::max(nq, 1u));   // passes of this sub-batch's loop still to run
             const double passes = (double)crit.max_iteration + 1.0;
             auto_overlap = left >= passes ? 0u : (uint32_t)(passes - left + 0.5);
+            // kd-tree scenes: the loop is seven times a render and its first passes are the heavy ones -- the other slot's render (and with it
+            // that slot's own first passes) should start at once: 37.3 / 37.5 k against 36.0 k poses/s for the rule above (pass 1 / 2 / 3 / 6: 37.2 /
+            // 37.2 / 37.1 / 37.0 k; 10: 35.7 k; 16: 34.0 k)
+            if (scene_kind == PR_SCENE_NN) auto_overlap = 0u;
         }
         prk::IcpBatch b{};
         b.cloud = sl.cloud.as<pr_vec3>(); b.nblk = nblk; b.grid_x = grid_x; b.steps = steps;

@@ -43,9 +43,10 @@
 // Round 4 sweep, same box, 256 hypotheses, sum of the walk over the 21 passes: workgroups per hypothesis 5 / 8 / 12 / 16 / 32 -> 5.98 / 5.06 /
 // 4.58 / 4.91 / 5.46 ms (the bound kernel follows: 2.31 / 2.16 / 1.92 / 1.97 / 2.04); at 12, queue capacities and waves per SIMD (384, 288, 5) /
 // (256, 192, 6) / (320, 224, 6) / (224, 160, 7) / (192, 160, 6) / (160, 128, 8) -> 4.60 / 4.27 / 4.35 / 4.86 / 6.55 / 8.01 ms: more waves in flight
-// help every pass, but the first pass needs its queues (overflows are walked a second time).
+// help every pass, but the first pass needs its queues (overflows are walked a second time).  PIPELINED (configs[2] through the two slots, two
+// pose groups, same box): 8 / 12 / 16 / 18 / 20 / 24 / 28 / 36 workgroups -> 32.6 / 34.6-35.0 / 33.5 / 35.6 / 35.6 / 35.3 / 36.0 / 35.8 k poses/s.
 #ifndef PR_TREE_GX
-#define PR_TREE_GX 12                                           // workgroups per hypothesis of the bound kernel and the walk (more for launches with few hypotheses)
+#define PR_TREE_GX 20                                           // workgroups per hypothesis of the bound kernel and the walk (more for launches with few hypotheses)
 #endif
 #ifndef PR_WIDE_WAVES
 #define PR_WIDE_WAVES 6                                         // wavefronts per SIMD the task walk is compiled for (<= 80 VGPRs; LDS: 24.5 KiB per workgroup)
