@@ -94,11 +94,17 @@ __global__ __launch_bounds__(256) void nn_search_kernel(IcpBatch b, SceneNNDev s
                 else { const float bnd = d2 * 1.000001f + 1e-30f; if (bnd < best) best = bnd; }              // = nn_seed_bound
             }
             if (!kept) {
-                uint32_t w = kNoPrev;
-                float bsq = 0.0f, osq = 0.0f;
-                const bool settled = scene.grid && best < accept && grid_search(scene, x, y, z, best, w, &n_cells, &bsq, &osq, still && PR_NN_SETTLE);
-                if (settled) { ++n_window; win[j] = w; slk[j] = sqrtf(osq) * 0.99999f; }
-                else { pending = true; if (prev != kNoPrev && step_sq <= PR_NN_NODESCENT) best = -best; }   // the sign carries "no descent needed" to the next kernel (best > 0 always)
+                // Everything else goes to the bound kernel -- the pixel-window scan too (round 4).  Done here, a window scan ran for the few
+                // lanes of a wavefront that needed it while the other lanes waited: with 1 % of the points in the window half of all
+                // wavefronts paid the 400 instructions of a scan, with 25-85 % (passes 2-8) every one did.  Queued, the scans run in dense lanes.
+                // The entry's bound carries two flags: its sign says "no descent needed" (a previous winner and a step below PR_NN_NODESCENT),
+                // its lowest mantissa bit says "settle" (the point has stopped moving: take the widest cover the window holds).  Setting
+                // or clearing that bit moves the bound by one ulp, far inside the 1e-6 by which a seed bound is inflated.
+                pending = true;
+                uint32_t bits = __float_as_uint(best) & ~1u;
+                if (still && PR_NN_SETTLE) bits |= 1u;
+                if (prev != kNoPrev && step_sq <= PR_NN_NODESCENT) bits |= 0x80000000u;
+                best = __uint_as_float(bits);
             }
         }
         // one slot range per workgroup and chunk: waves in order, lanes in order -- the queue keeps the points' order
@@ -155,9 +161,8 @@ __global__ __launch_bounds__(256) void nn_tree_kernel(IcpBatch b, SceneNNDev sce
     for (uint32_t i = blockIdx.x * kBlockThreads + threadIdx.x; i < queued; i += gridDim.x * kBlockThreads) {
         const uint2 e = queue[i];
         const uint32_t j = e.x;
-        float best = __uint_as_float(e.y);
-        const bool still = best < 0.0f;
-        best = still ? -best : best;
+        const bool still = (e.y & 0x80000000u) != 0u, settle = (e.y & 1u) != 0u;     // flags of the entry (nn_search_kernel)
+        float best = __uint_as_float((e.y & 0x7fffffffu) | 1u);
         const pr_vec3 q = ld_off<pr_vec3>(cl, j * 12u);          // as nn_search_kernel stored it
         const float x = q.x, y = q.y, z = q.z;
         // A point that has hardly moved still has (nearly) its true neighbour as temporal seed: d_old - step <= d_new <= d_old + step.
@@ -166,10 +171,10 @@ __global__ __launch_bounds__(256) void nn_tree_kernel(IcpBatch b, SceneNNDev sce
         uint32_t w = kNoPrev;
         bool settled = false;
         float other = 0.0f;
-        if (scene.grid && !still) {
+        if (scene.grid) {
             float bsq = 0.0f, osq = 0.0f;
-            grid_pyramid_bound(scene, x, y, z, best); ++n_pyramid;
-            settled = best < accept && grid_search(scene, x, y, z, best, w, &n_cells, &bsq, &osq);
+            if (!still) { grid_pyramid_bound(scene, x, y, z, best); ++n_pyramid; }
+            settled = best < accept && grid_search(scene, x, y, z, best, w, &n_cells, &bsq, &osq, settle);
             if (settled) other = sqrtf(osq) * 0.99999f;
         }
         if (settled) ++n_window;
@@ -237,9 +242,9 @@ __global__ __launch_bounds__(256) void nn_bound_kernel(IcpBatch b, SceneNNDev sc
         if (i < queued) {
             const uint2 e = queue[i];
             j = e.x;
-            bst = __uint_as_float(e.y);
-            const bool still = bst < 0.0f;                       // the sign carries "no descent needed" (nn_search_kernel)
-            bst = still ? -bst : bst;
+            const bool still = (e.y & 0x80000000u) != 0u;        // the sign carries "no descent needed", the lowest bit "settle" (nn_search_kernel)
+            const bool settle = (e.y & 1u) != 0u;
+            bst = __uint_as_float((e.y & 0x7fffffffu) | 1u);     // (the flag bit set: the bound rounded UP by at most an ulp)
             pending = true;
             if (!scene.grid && !still) {
                 // No pixel grid (a bare ICP call has no camera) and the query is new or has moved (its previous winner, centimetres away
@@ -267,12 +272,11 @@ __global__ __launch_bounds__(256) void nn_bound_kernel(IcpBatch b, SceneNNDev sc
                     cur = (c - __uint_as_float(d.x) < 0.0f) ? c1 : c1 + 1u;
                 }
             }
-            if (scene.grid && !still) {
+            if (scene.grid) {
                 const pr_vec3 q = ld_off<pr_vec3>(cl, j * 12u);
                 uint32_t w = kNoPrev; float bsq = 0.0f, osq = 0.0f;
-                grid_pyramid_bound(scene, q.x, q.y, q.z, bst);
-                ++n_pyramid;
-                if (bst < accept && grid_search(scene, q.x, q.y, q.z, bst, w, &n_cells, &bsq, &osq)) { pending = false; ++n_window; win[j] = w; slk[j] = sqrtf(osq) * 0.99999f; }
+                if (!still) { grid_pyramid_bound(scene, q.x, q.y, q.z, bst); ++n_pyramid; }
+                if (bst < accept && grid_search(scene, q.x, q.y, q.z, bst, w, &n_cells, &bsq, &osq, settle)) { pending = false; ++n_window; win[j] = w; slk[j] = sqrtf(osq) * 0.99999f; }
             }
         }
         const unsigned long long m = __ballot(pending);
