@@ -295,7 +295,7 @@ int pr_gather_results(const pr_result *send_dev, uint32_t n_local, uint32_t n_to
  *                              order; a query whose minimum is attained by more than one point is repeated by the ordered binary walk (0: binary walk only)
  *   "nn_seed"          [1]     compact records: start every search from the previous pass' / previous point's winner distance
  *   "nn_split"         [1]     compact records: the search runs in a kernel of its own (adjacent lanes = adjacent cloud points, a workgroup
- *                              takes "nn_run" [2] chunks of 256 points) and the pass gathers its winners in canonical order
+ *                              takes "nn_run" [8] chunks of 256 points) and the pass gathers its winners in canonical order
  *   "nn_count"         [0]     instrumented runs: the search kernel counts its work (pr_nn_counters)
  *   "nn_grid"          [1]     fused refinement with a kd-tree scene made from a depth image: scene points are also indexed by pixel
  *                              (first bounds, and an exact window scan once the bound is a few pixels wide)

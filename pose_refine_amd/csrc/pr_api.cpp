@@ -136,7 +136,8 @@ struct Options {
     int nn_wide = 1;                 // queued tree searches: order-free walk over 128-byte lines (eight subtree boxes per wide node, one line per leaf); ties go to the binary walk
     int nn_stack = 1;                // kd-tree query: per-lane LDS stack (1) or the reference's stackless walk (0)
     int nn_split = 1;                // kd-tree scenes on compact records: search kernel (runs of consecutive points, grid window) + winners pass
-    int nn_run = 2;                  // 256-point chunks a workgroup of the search kernel takes (lane t of chunk k: point 256 k + t); 2: +1-2 % over 1 on configs[2]
+    int nn_run = 8;                  // 256-point chunks a workgroup of the search kernel walks (1..8).  Since the window scans left that kernel (round 4) it is a light
+                                     // streaming pass and fewer, longer workgroups are a little better: 38.9 k (2) against 39.3 k (8) poses/s over five runs each
     int nn_grid = 1;                 // fused path: pixel grid of the scene points (seeds + window search); 0 = tree only
     int nn_count = 0;                // instrumented runs: the search kernel counts its work per pass (pr_nn_counters)
     int start_overlap = -1;          // asynchronous path, a batch submitted while the other slot is idle: the pass after which the next batch's render may start.
