@@ -17,8 +17,8 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.environ.get("PR_BUILD_OUT") or os.path.join(HERE, "lib", "libpose_refine_hip.so")      # PR_BUILD_OUT: a variant library for an A/B run
 # one translation unit per stage of the path (kernels + their launchers), the C ABI and the host-side code; headers = shared device code
 SOURCES = ["raster.hip", "d2c.hip", "icp_pass.hip", "icp_flow.hip", "icp_debug.hip", "nn_search.hip", "nn_build.hip", "kd_build.hip", "scene_prep.hip",
-           "pr_api.cpp", "pr_host.cpp"]
-HEADERS = ["pr_internal.h", "pr_solver.inl", "pr_tuning.h", "pr_device.h", "pr_launch.h", "proj_query.h", "nn_query.h", "icp_accumulate.h",
+           "pr_context.cpp", "pr_scene.cpp", "pr_icp.cpp", "pr_refine.cpp", "pr_comm.cpp", "pr_host.cpp"]
+HEADERS = ["pr_internal.h", "pr_runtime.h", "pr_solver.inl", "pr_tuning.h", "pr_device.h", "pr_launch.h", "proj_query.h", "nn_query.h", "icp_accumulate.h",
            "icp_solve_device.h"]
 DEPS = SOURCES + HEADERS + [os.path.join(ROOT, "include", "pose_refine.h")]
 OBJ_DIR = os.path.join(HERE, "lib", "obj") if not os.environ.get("PR_BUILD_OUT") else os.environ["PR_BUILD_OUT"] + ".obj"

@@ -22,7 +22,7 @@
 namespace prh {
 void solve_666(const float A[36], const float b[6], float T[16]) { prs::solve_666_impl(A, b, T); }
 void mat4_mul(const float A[16], const float B[16], float C[16]) { prs::mat4_mul_impl(A, B, C); }
-void set_error(const char *fmt, ...);   // pr_api.cpp
+void set_error(const char *fmt, ...);   // pr_context.cpp
 }  // namespace prh
 
 namespace {

@@ -1,0 +1,418 @@
+// pr_runtime.h -- the host-side runtime behind the C ABI, shared by its translation units: contexts and their registry, workspaces, the write
+// log of caller-owned memory, options, slots, profiling spans.  pr_context.cpp (contexts, memory, options, profiling entry points),
+// pr_scene.cpp (scene caches and device-side scene preparation), pr_icp.cpp (the batched ICP driver: device and host solve loops),
+// pr_refine.cpp (render, cloud, the fused batch path with its two asynchronous slots and helper threads), pr_comm.cpp (RCCL gather).
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>          // types and prototypes only: librccl is opened on first use (pr_comm_*), never linked
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
+#include <thread>
+#include <string>
+#include <vector>
+
+#include "pr_internal.h"
+
+#include "pr_internal.h"
+
+namespace prh {
+extern thread_local std::string g_err;
+void set_error(const char *fmt, ...);
+}  // namespace prh
+
+namespace prr {
+
+using prh::set_error;
+
+#define HIP_TRY(expr)                                                                           \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess) {                                                                 \
+            set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            (void)hipGetLastError();          /* the runtime's sticky copy of this error must not be found by the next launch's check */ \
+            return PR_ERR_HIP;                                                                  \
+        }                                                                                       \
+    } while (0)
+#define PR_TRY(expr) do { int rc_ = (expr); if (rc_ != PR_OK) return rc_; } while (0)
+
+struct DevBuf {                      // grow-only device workspace
+    void *p = nullptr; size_t cap = 0;
+    int ensure(size_t bytes)
+    {
+        if (bytes <= cap) return PR_OK;
+        if (p) { hipFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) { set_error("hipMalloc(%zu) failed: %s", want, hipGetErrorString(e)); p = nullptr; return PR_ERR_NOMEM; }
+        cap = want;
+        return PR_OK;
+    }
+    void release() { if (p) hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T *as() const { return static_cast<T *>(p); }
+};
+struct PinBuf {                      // grow-only pinned host staging
+    void *p = nullptr; size_t cap = 0;
+    int ensure(size_t bytes)
+    {
+        if (bytes <= cap) return PR_OK;
+        if (p) { hipHostFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        if (e != hipSuccess) { set_error("hipHostMalloc(%zu) failed: %s", want, hipGetErrorString(e)); p = nullptr; return PR_ERR_NOMEM; }
+        cap = want;
+        return PR_OK;
+    }
+    void release() { if (p) hipHostFree(p); p = nullptr; cap = 0; }
+    template <class T> T *as() const { return static_cast<T *>(p); }
+};
+
+// ---- which device ranges were written through this library, and when --------------------------------
+// Derived data (the packed projective scene, the kd traversal records, the host copy of a model box) is cached by the address
+// of the caller's buffers.  A cache entry remembers the write generation it was built at and is dropped as soon as a later
+// write through the library (pr_memcpy_*, pr_fill_i32, pr_free, the *_prepare_dev / *_build_dev functions, pr_render) or a
+// pr_invalidate() call overlaps one of its source ranges.  Writes the library cannot see (raw HIP calls, the caller's own
+// kernels) must be announced with pr_invalidate -- include/pose_refine.h states that contract.
+struct WriteLog {
+    std::mutex mu;
+    struct W { uintptr_t lo, hi; };
+    static constexpr uint64_t kRing = 128;
+    W ring[kRing];
+    uint64_t gen = 0;                                            // writes recorded so far; write k (1-based) sits in ring[k % kRing]
+    void note(const void *p, size_t bytes)
+    {
+        if (!p) return;
+        uintptr_t lo = reinterpret_cast<uintptr_t>(p), hi = lo + bytes;
+        if (bytes == 0) {                                        // unknown extent: the whole allocation that contains p
+            void *base = nullptr; size_t size = 0;
+            if (hipMemGetAddressRange(reinterpret_cast<hipDeviceptr_t *>(&base), &size, const_cast<void *>(p)) == hipSuccess && base) { lo = reinterpret_cast<uintptr_t>(base); hi = lo + size; }
+            else { (void)hipGetLastError(); lo = 0; hi = ~(uintptr_t)0; }
+        }
+        std::lock_guard<std::mutex> lk(mu);
+        ++gen;
+        ring[gen % kRing] = W{ lo, hi };
+    }
+    uint64_t now() { std::lock_guard<std::mutex> lk(mu); return gen; }
+    // may [p, p+bytes) have been written after generation `since`?
+    bool written_since(uint64_t since, const void *p, size_t bytes)
+    {
+        const uintptr_t lo = reinterpret_cast<uintptr_t>(p), hi = lo + bytes;
+        std::lock_guard<std::mutex> lk(mu);
+        if (gen - since >= kRing) return true;                   // older writes have left the ring: assume the worst
+        for (uint64_t k = since + 1; k <= gen; ++k) { const W &w = ring[k % kRing]; if (w.lo < hi && lo < w.hi) return true; }
+        return false;
+    }
+};
+extern WriteLog g_writes;
+
+// ---- process-wide options (pr_set_option): plain ints, shared by every context ---------------------
+constexpr int kSlots = 2;
+struct Options {
+    int pose_groups = 0;             // split the batch over this many streams (1..4); 0 = by scene: 2 for projective scenes (1.31 vs 1.45 ms/step at
+                                     // 256 poses), 3 for kd-tree scenes; launches of different groups overlap, so timed calls fall back to one group
+    int solve_mode = PR_SOLVE_HOST;
+    int host_worker = 1;             // PR_SOLVE_HOST batches of pr_refine_submit run on the slot's helper thread (0: on the caller's thread, inside the call)
+    int steps = 3;                   // 1024-point steps per workgroup -> 3072 points per workgroup (9 workgroups per 26 k-point cloud: measured 3-5 % faster than 2048 / 4096)
+    int profile = 0;
+    int sample_period = 32;          // profile 2: one timed (synchronous, single-group) call in this many
+    int nn_lds_nodes = 1024;
+    int nn_lds_records = 0;          // stack traversal: leading 64-byte node records staged in LDS; measured 0/64/128/256/512 -> 42.2/41.6/45.2/45.4/58.2 ms per step (occupancy lost to the extra LDS outweighs the saved L1 lookups)
+    int nn_seed = 1;                 // compact kd records: start every search from the previous pass' winner distance
+    int nn_compact = 1;              // stack traversal: 32-byte node records with 16-bit outward-rounded child boxes (half the L1 traffic)
+    int blocking_wait = 0;           // pr_refine_wait sleeps on the slot's event instead of spinning (set before the first asynchronous batch)
+    int nn_wide = 1;                 // queued tree searches: order-free walk over 128-byte lines (eight subtree boxes per wide node, one line per leaf); ties go to the binary walk
+    int nn_stack = 1;                // kd-tree query: per-lane LDS stack (1) or the reference's stackless walk (0)
+    int nn_split = 1;                // kd-tree scenes on compact records: search kernel (runs of consecutive points, grid window) + winners pass
+    int nn_run = 8;                  // 256-point chunks a workgroup of the search kernel walks (1..8).  Since the window scans left that kernel (round 4) it is a light
+                                     // streaming pass and fewer, longer workgroups are a little better: 38.9 k (2) against 39.3 k (8) poses/s over five runs each
+    int nn_grid = 1;                 // fused path: pixel grid of the scene points (seeds + window search); 0 = tree only
+    int nn_count = 0;                // instrumented runs: the search kernel counts its work per pass (pr_nn_counters)
+    int start_overlap = -1;          // asynchronous path, a batch submitted while the other slot is idle: the pass after which the next batch's render may start.
+                                     // -1 = the per-batch rule of a running pipeline.  Rounds 2-3 released the next render at pass 0 here; with the roofline
+                                     // sample out of the timed region that reads 239 / 240 / 251 k against 253 / 253 / 256 k poses/s for the rule in three
+                                     // alternating 20-step runs on one box: batches 1 and 2 then finish together and the third finds an empty chip
+    int overlap_pass = -1;           // asynchronous path: the other slot's render may start once this slot has issued this pass of its loop (-1: chosen per batch, see refine_submit_async)
+                                     // (-1: 70 % of the passes -- measured best of 6/10/14/17 at 256 and 512 poses per batch)
+    int sub_batch = 512;             // asynchronous fused path: hypotheses per sub-batch (cache residency of the clouds)
+    int fused_solve = 1;             // PR_SOLVE_DEVICE: the workgroup delivering a hypothesis' last partial sum also runs its finalize + solve (no second launch per iteration)
+    int icp_flow = 0;                // PR_SOLVE_DEVICE: 1 = one persistent dataflow launch for all iterations (bit-identical; measured equal at
+                                     // 256 poses and 35 % slower at 1024), 0 = one launch per pass + per solve
+    int use_graph = 1;               // PR_SOLVE_DEVICE, single pose group only (the runtime serialises the branches of a captured multi-stream
+                                     // graph, which forfeits the overlap): capture the whole iteration loop in a hipGraph and replay it
+    int eager_streams = 1;           // asynchronous path: create the streams of both slots in one run (see slot_streams)
+    int raster_mode = 0;             // fused path: 0 = global atomicMin inside the per-pose pixel box (reference scheme), 1 = LDS depth bands (int32),
+                                     // 2 = one workgroup per hypothesis with its whole box in LDS as 16-bit depth offsets (global path for boxes that do not fit)
+    int scene_cache = 1;             // keep the packed projective scene / kd traversal records of the latest scene between calls (pr_scene_invalidate)
+};
+extern Options opt;
+// streams a batch is split over: the option, or two.  (Round 3 ran kd-tree scenes as three groups: with 8 workgroups per hypothesis and five
+// waves per SIMD the search kernels left gaps a third group filled, +1.5 %.  With round 4's 12 workgroups and six waves two groups are
+// enough and the third only costs launches: 34.4 / 34.9 k against 32.2 / 31.9 k poses/s on configs[2], same box; one group 29.8 k, four 31.2 k.
+// Projective scenes with 16 hardware queues: three groups 174 k against 247 k.)
+inline uint32_t pose_groups_for(int scene_kind) { (void)scene_kind; return opt.pose_groups > 0 ? (uint32_t)opt.pose_groups : 2u; }
+
+// packed projective scene (one 16-byte record per pixel + the two back-projection tables) of the latest scene it was built for
+struct PackedCache {
+    DevBuf rec;                      // [n] float4, colf[w], rowf[h], exact flag (uint32), sampled fingerprint of the source arrays (uint32)
+    const void *pcd = nullptr, *normal = nullptr;
+    uint64_t w = 0, h = 0; float k[4] = { 0, 0, 0, 0 }; uint32_t tl[2] = { 0, 0 };
+    uint64_t gen = 0;
+    bool valid = false, exact = false;
+};
+// everything needed to run a submitted batch again (refine_wait does so when the model box the batch assumed turns out stale)
+struct Resubmit {
+    const pr_triangle *tris = nullptr; size_t n_tris = 0; uint32_t W = 0, H = 0; pr_mat4 proj{}; float K[9] = { 0 };
+    int scene_kind = 0; pr_scene_proj_crop sp{}; pr_scene_nn sn{}; pr_criteria crit{}; pr_roi roi{ 0, 0, 0, 0 };
+    pr_result *results_dev = nullptr;
+};
+// A slot's helper thread (PR_SOLVE_HOST): the reference solves on the host (icp.cu:207), which makes a batch a chain of
+// launch -> wait -> solve -> launch that only a host thread can drive; the reference's answer is "many host threads, each refining its own
+// hypothesis" (README.md:15).  A caller that pipelines batches through pr_refine_submit / pr_refine_wait from ONE thread gets the same
+// overlap from the library: each slot owns a thread with a private context (its own streams, workspaces and caches, as pr_thread_context
+// gives a caller's thread) that runs the synchronous host-solve path for the batch while the caller goes on to submit the next one.
+struct SlotWorker {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    bool has_job = false, done = false, quit = false, alive = false;
+    int device = 0;
+    // the job: every input by value (the caller's arrays of poses may go away after pr_refine_submit returns)
+    Resubmit in;
+    std::vector<pr_mat4> poses;
+    pr_result *results_host = nullptr;
+    uint32_t *sizes_host = nullptr;
+    int rc = PR_OK;
+    std::string err;
+};
+struct Slot {
+    std::unique_ptr<SlotWorker> worker;
+    bool worker_job = false;         // the batch in flight runs on the helper thread
+    DevBuf poses_bbox, depth, row_count, row_off, counts, cloud, meta, partial, dstate, dresults, arrive, aabb_keys, nn_prev;
+    PackedCache packed;
+    PinBuf h_in, h_out;
+    Resubmit again;
+    size_t flag_off = 0;             // offset in h_out of the word the device-side model-box check writes (1 = the assumed box was stale)
+    hipStream_t stream = nullptr, side[3] = { nullptr, nullptr, nullptr };
+    hipEvent_t fork = nullptr, join[3] = { nullptr, nullptr, nullptr }, done = nullptr, scene_ready = nullptr, progress = nullptr;
+    bool progress_valid = false;
+    bool pending = false, delivered = false;
+    uint32_t P = 0;
+    pr_result *user_results_host = nullptr;
+    uint32_t *user_sizes = nullptr;
+    // a TIMED asynchronous batch (option profile = 3): HIP events on the slot's stream around its render, its cloud emit and every
+    // correspondence pass (start / stop pairs in enqueue order), read by pr_refine_wait
+    bool timed = false;
+    std::vector<hipEvent_t> t_events;            // pool, reused from batch to batch
+    size_t t_used = 0;
+    struct TSpan { size_t e0, e1; int kind; uint32_t q0, nq; bool edge; bool marks; size_t m[3]; };   // edge: first or last pass (36 B / point instead of 48); marks: events between the kernels of a kd-tree pass
+    std::vector<TSpan> t_spans;
+};
+
+// ---- hipGraph cache for the device-solve iteration loop ------------------------------------------
+struct GraphKey {                    // every value a captured launch depends on, byte for byte (grows as needed)
+    std::vector<unsigned char> bytes;
+    template <class T> void add(const T &v) { const unsigned char *p = reinterpret_cast<const unsigned char *>(&v); bytes.insert(bytes.end(), p, p + sizeof(T)); }
+    bool operator==(const GraphKey &o) const { return bytes == o.bytes; }
+};
+struct CachedGraph {
+    GraphKey key; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
+    std::vector<hipEvent_t> events;      // pairs around every correspondence launch when captured with profiling on
+    uint64_t stamp = 0;
+};
+inline void destroy_graph(CachedGraph &c)
+{
+    if (c.exec) (void)hipGraphExecDestroy(c.exec);
+    if (c.graph) (void)hipGraphDestroy(c.graph);
+    for (hipEvent_t e : c.events) (void)hipEventDestroy(e);
+    c = CachedGraph();
+}
+
+struct Ctx {
+    std::mutex mu;                   // one call at a time per context; contexts of different devices / threads run side by side
+    bool ready = false;
+    bool is_private = false;         // pr_thread_context(1): owned by one host thread
+    int device = -1;
+    hipStream_t stream = nullptr;
+    hipStream_t side[3] = { nullptr, nullptr, nullptr };   // extra lanes of the device-solve loop (pose groups overlap one group's solve tail with another group's pass)
+    hipEvent_t ev_fork = nullptr, ev_join[3] = { nullptr, nullptr, nullptr };
+    int n_cus = 256;
+    // host copy of the model box the asynchronous path derives its pixel boxes from: keyed by (pointer, size) and VERIFIED on
+    // the device by every batch that uses it (refine_submit / refine_wait), so a rewritten triangle buffer cannot go unnoticed
+    float aabb_host[6] = { 0, 0, 0, 0, 0, 0 }; bool aabb_host_valid = false;
+    const void *mesh_key = nullptr; size_t mesh_n = 0;   // triangle buffer aabb_host belongs to
+    uint32_t cloud_hint = 0;          // largest cloud of the latest finished asynchronous batch: sizes the next batch's grid
+    // workspaces
+    DevBuf aabb, aabb_keys, bbox, poses, depth, row_count, row_off, counts, cloud, meta, partial, sums, topo, bmin, bmax, pts, nnrec, nnrec32, nndesc, nnwide, nnwq, nn_prev, nndepth, dstate, dresults, vbdesc, flowsync, arrive, conv16, conv8, kd_idx, kd_scratch, kd_child, kd_ctrl, kd_tmp, nn_full;
+    PinBuf h_sums, h_meta, h_counts, h_results, h_dstate, h_flow;
+    PackedCache packed;              // synchronous paths (the asynchronous slots keep their own)
+    struct { const void *pcd = nullptr, *normal = nullptr, *nodes = nullptr; uint32_t n_points = 0, n_nodes = 0; uint64_t gen = 0; bool valid = false;
+             uint32_t info[24] = { 0 };
+             bool grid_valid = false, grid_usable = false; uint32_t gw = 0, gh = 0; float gk[4] = { 0, 0, 0, 0 }; } nn_cache;   // kd traversal records (topo ... nndesc) + pixel grid of the latest kd-tree scene
+    DevBuf nn_cells, nn_grid, nn_counters;
+    // profiling
+    std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
+    struct Span { size_t e0, e1; int kind; };
+    std::vector<Span> spans;
+    double icp_ms = 0, render_ms = 0, cloud_ms = 0; uint64_t icp_launches = 0, icp_points = 0, icp_bytes = 0, sample_clock = 0;
+    std::vector<float> icp_launch_us;                            // the timed launches one by one (pr_profile_launches), bounded
+    uint64_t stat_repeated = 0, stat_timing_dropped = 0;         // pr_stats: batches run twice by the stale-cache safety net; timed spans lost to a failed event call
+    double nn_part_ms[4] = { 0, 0, 0, 0 }; uint64_t nn_part_n = 0;   // kd-tree pass by kernel: search, bound, task walk, winners pass (pr_profile_nn)
+    Slot slots[kSlots];
+    std::vector<CachedGraph> graphs;
+    uint64_t graph_clock = 0;
+    // RCCL communicator this context is a rank of (pr_comm_init_rank / pr_comm_init_all), or null
+    ncclComm_t comm = nullptr; int comm_rank = 0, comm_world = 1;
+    DevBuf gather_tmp;
+    // HIP events around the gathers issued while option "profile" is on (pr_gather_profile)
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> gather_ev; size_t gather_ev_used = 0; double gather_ms = 0; uint64_t gather_n = 0;
+};
+
+// ---- context registry --------------------------------------------------------------------------------
+// One shared context per device (created by pr_init / pr_set_device / first use) plus optional private contexts of single
+// host threads (pr_thread_context).  `g` is the context the calling thread is bound to; every entry point binds a thread
+// that never chose one to the process default (the device of the first pr_init, else device 0).
+extern std::mutex g_reg_mu;
+extern std::vector<Ctx *> g_shared;         // index = device ordinal
+extern int g_default_device;
+extern thread_local Ctx *g;
+struct PrivateCtx { Ctx *c = nullptr; ~PrivateCtx(); };   // destructor below, once the teardown helpers exist
+extern thread_local PrivateCtx tl_private;
+// every private context alive, so that pr_free can drain the device's contexts one by one (lock order: g_private_mu, then a context's mu;
+// nothing takes them the other way round: contexts register before and unregister after they are used)
+extern std::mutex g_private_mu;
+extern std::vector<Ctx *> g_private;
+inline void private_register(Ctx *c) { std::lock_guard<std::mutex> lk(g_private_mu); g_private.push_back(c); }
+inline void private_unregister(Ctx *c) { std::lock_guard<std::mutex> lk(g_private_mu); for (size_t i = 0; i < g_private.size(); ++i) if (g_private[i] == c) { g_private.erase(g_private.begin() + (long)i); break; } }
+
+inline void drop_graphs() { for (auto &c : g->graphs) destroy_graph(c); g->graphs.clear(); }
+void comm_teardown(Ctx *c);
+
+inline int device_count_checked(int *n_out)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        set_error("no usable HIP device (hipGetDeviceCount: %s, count %d) -- this library has no CPU fallback",
+                  hipGetErrorString(e), n);
+        return PR_ERR_NO_DEVICE;
+    }
+    *n_out = n;
+    return PR_OK;
+}
+
+// bind the calling thread to the shared context of `device` (-1: the process default), creating it if needed
+inline int bind_shared(int device)
+{
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    if (device < 0) device = g_default_device >= 0 ? g_default_device : 0;
+    int n = 0;
+    PR_TRY(device_count_checked(&n));
+    if (device >= n) { set_error("device %d out of range (%d visible)", device, n); return PR_ERR_NO_DEVICE; }
+    if ((int)g_shared.size() < n) g_shared.resize((size_t)n, nullptr);
+    if (!g_shared[(size_t)device]) { g_shared[(size_t)device] = new Ctx(); g_shared[(size_t)device]->device = device; }
+    if (g_default_device < 0) g_default_device = device;
+    g = g_shared[(size_t)device];
+    return PR_OK;
+}
+inline int bind_default() { return g ? PR_OK : bind_shared(-1); }
+
+// with g->mu held: make the context's device current for this thread and create its stream on first use
+inline int require_ctx()
+{
+    HIP_TRY(hipSetDevice(g->device));                            // the current device is per host thread
+    if (g->ready) return PR_OK;
+    HIP_TRY(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming));
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, g->device) == hipSuccess && prop.multiProcessorCount > 0) g->n_cus = prop.multiProcessorCount;
+    g->ready = true;
+    return PR_OK;
+}
+// every device entry point: bind, lock, make current
+#define PR_ENTER()                                   \
+    PR_TRY(bind_default());                          \
+    std::lock_guard<std::mutex> lk(g->mu);           \
+    PR_TRY(require_ctx())
+
+// ---- profiling spans (HIP events on the library stream) ------------------------------------------
+enum { kSpanIcp = 0, kSpanRender = 1, kSpanCloud = 2 };
+// (a failed event call must not vanish: HIP_TRY clears the sticky error, so the span is dropped HERE and counted -- pr_stats)
+constexpr size_t kNoEvent = (size_t)-1;
+inline size_t take_event()
+{
+    if (g->ev_used == g->ev_pool.size()) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess || !e) { (void)hipGetLastError(); g->stat_timing_dropped++; return kNoEvent; }
+        g->ev_pool.push_back(e);
+    }
+    return g->ev_used++;
+}
+inline bool record_event(size_t e, hipStream_t st)
+{
+    if (e == kNoEvent) return false;
+    if (hipEventRecord(g->ev_pool[e], st) != hipSuccess) { (void)hipGetLastError(); g->stat_timing_dropped++; return false; }
+    return true;
+}
+struct SpanGuard {
+    bool on; size_t e0 = 0; int kind;
+    explicit SpanGuard(int k) : on(opt.profile != 0), kind(k) { if (on) { e0 = take_event(); on = record_event(e0, g->stream); } }
+    ~SpanGuard() { if (on) { const size_t e1 = take_event(); if (record_event(e1, g->stream)) g->spans.push_back({ e0, e1, kind }); } }
+};
+constexpr size_t kLaunchSamples = 8192;
+inline void note_launch_us(float ms) { if (g->icp_launch_us.size() < kLaunchSamples) g->icp_launch_us.push_back(ms * 1e3f); }
+inline void drain_spans()                   // call after the stream has been synchronised
+{
+    for (const auto &s : g->spans) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, g->ev_pool[s.e0], g->ev_pool[s.e1]) != hipSuccess) continue;
+        if (s.kind == kSpanIcp) { g->icp_ms += ms; g->icp_launches++; note_launch_us(ms); }
+        else if (s.kind == kSpanRender) g->render_ms += ms;
+        else g->cloud_ms += ms;
+    }
+    g->spans.clear();
+    g->ev_used = 0;
+}
+
+inline void identity16(float *T) { for (int i = 0; i < 16; ++i) T[i] = (i % 5 == 0) ? 1.0f : 0.0f; }
+
+// ---- scene variants -----------------------------------------------------------------------------
+struct SceneSel {
+    int kind = PR_SCENE_PROJ;
+    bool packed = false;
+    prk::SceneProjAoS aos{};
+    prk::SceneProjPacked pk{};
+    prk::SceneNNDev nn{};
+    uint32_t nn_split = 0;           // kd-tree scene: search kernel + winners pass instead of the fused search pass
+    uint32_t nn_max_points = 0;      // largest cloud of the batch (grid of the search kernel)
+};
+constexpr uint32_t kCounterPasses = 64;
+// camera of the hypotheses (fused paths): lets a kd-tree scene be indexed by pixel as well
+struct Camera { uint32_t w = 0, h = 0; float fx = 0, fy = 0, cx = 0, cy = 0; };
+
+// ---- functions of the other translation units (pr_scene / pr_icp / pr_refine / pr_comm / pr_context) ---------------------------------
+int fingerprint_differs(const void *a, size_t ab, const void *b, size_t bb, const void *c, size_t cb, uint32_t *slot, hipStream_t st, bool &differs);
+int ensure_packed(PackedCache &pc, const pr_scene_proj &s, uint32_t tl_x, uint32_t tl_y, hipStream_t st, bool verify_now = false);
+int make_scene(int kind, const void *scene, bool want_packed, SceneSel &out, PackedCache *pc_in = nullptr, hipStream_t st = nullptr, const Camera *cam = nullptr,
+               bool verify_now = true);
+int kd_build_dev(pr_vec3 *pcd, pr_vec3 *nrm, uint32_t n, int max_leaf, pr_kdnode *nodes, size_t cap, uint32_t *n_nodes);
+hipError_t launch_pass(const prk::IcpBatch &b, const SceneSel &sc, uint32_t P, hipStream_t st = nullptr, hipEvent_t *nn_marks = nullptr);
+int ensure_stream(hipStream_t &st, hipEvent_t *ev = nullptr);
+int icp_drive(pr_vec3 *cloud_base, const uint32_t *start_h, const uint32_t *count_h, uint32_t P, const SceneSel &sc_in,
+              pr_criteria crit, pr_result *results_host, pr_result *results_dev);
+void drain_all_slots();
+void slot_release(Slot &sl);
+void slot_drain(Slot &sl);
+void comm_teardown(Ctx *c);
+void ctx_teardown(Ctx *c);
+int rccl_load();
+
+}  // namespace prr

@@ -1,0 +1,302 @@
+// pr_scene.cpp -- scene caches (packed projective record, kd-tree traversal records, pixel grid) and device-side scene preparation
+#include "pr_runtime.h"
+
+namespace prr {
+
+// Packed copy of a projective scene in `pc`: reused while the caller's arrays are unchanged as far as the library can tell
+// (option scene_cache, WriteLog above), rebuilt otherwise.  A rebuild also learns (one 4-byte read-back) whether the pcd array
+// is exactly what dep2pcd produces -- only then may the packed form stand in for it.
+// Synchronous callers (pr_icp_*, the synchronous fused path) check a cache hit on the spot: the sampled fingerprint of the source arrays
+// against the one stored with the cache (`slot[0]`), `slot[1]` receives the verdict.  ~15 us; the asynchronous path checks on its idle stream.
+int fingerprint_differs(const void *a, size_t ab, const void *b, size_t bb, const void *c, size_t cb, uint32_t *slot, hipStream_t st, bool &differs)
+{
+    HIP_TRY(hipMemsetAsync(slot + 1, 0, sizeof(uint32_t), st));
+    HIP_TRY(prk::launch_scene_fingerprint(a, ab, b, bb, c, cb, slot, slot + 1, true, st));
+    uint32_t flag = 0;
+    HIP_TRY(hipMemcpyAsync(&flag, slot + 1, sizeof flag, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    differs = flag != 0u;
+    return PR_OK;
+}
+int ensure_packed(PackedCache &pc, const pr_scene_proj &s, uint32_t tl_x, uint32_t tl_y, hipStream_t st, bool verify_now)
+{
+    const size_t n = (size_t)s.width * s.height;
+    const float k[4] = { s.K[0], s.K[4], s.K[2], s.K[5] };
+    const bool same = pc.valid && pc.pcd == s.pcd && pc.normal == s.normal && pc.w == s.width && pc.h == s.height &&
+                      std::memcmp(pc.k, k, sizeof k) == 0 && pc.tl[0] == tl_x && pc.tl[1] == tl_y;
+    if (same && opt.scene_cache && !g_writes.written_since(pc.gen, s.pcd, n * sizeof(pr_vec3)) &&
+        !g_writes.written_since(pc.gen, s.normal, n * sizeof(pr_vec3))) {
+        bool stale = false;
+        if (verify_now) {
+            const size_t tb = ((s.width + s.height) * sizeof(float) + 15) & ~(size_t)15;
+            uint32_t *ex = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(pc.rec.as<float4>() + n) + tb);
+            PR_TRY(fingerprint_differs(s.pcd, n * sizeof(pr_vec3), s.normal, n * sizeof(pr_vec3), nullptr, 0, ex + 1, st, stale));
+        }
+        if (!stale) { pc.gen = g_writes.now(); return PR_OK; }
+    }
+    pc.valid = false;
+    const uint64_t gen = g_writes.now();
+    const size_t tables = ((s.width + s.height) * sizeof(float) + 15) & ~(size_t)15;
+    PR_TRY(pc.rec.ensure(n * sizeof(float4) + tables + 16));
+    float *colf = reinterpret_cast<float *>(pc.rec.as<float4>() + n);
+    float *rowf = colf + s.width;
+    uint32_t *exact_dev = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(colf) + tables);
+    HIP_TRY(prk::launch_pack_proj_scene(s.pcd, s.normal, pc.rec.as<float4>(), n, colf, rowf, (uint32_t)s.width, (uint32_t)s.height,
+                                        k[0], k[1], k[2], k[3], tl_x, tl_y, exact_dev, st));
+    HIP_TRY(prk::launch_scene_fingerprint(s.pcd, n * sizeof(pr_vec3), s.normal, n * sizeof(pr_vec3), nullptr, 0, exact_dev + 1, nullptr, false, st));
+    uint32_t exact = 0;
+    HIP_TRY(hipMemcpyAsync(&exact, exact_dev, sizeof exact, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    pc.pcd = s.pcd; pc.normal = s.normal; pc.w = s.width; pc.h = s.height; std::memcpy(pc.k, k, sizeof k); pc.tl[0] = tl_x; pc.tl[1] = tl_y;
+    pc.gen = gen; pc.exact = exact != 0; pc.valid = true;
+    return PR_OK;
+}
+
+void drain_all_slots();
+int make_scene(int kind, const void *scene, bool want_packed, SceneSel &out, PackedCache *pc_in, hipStream_t st, const Camera *cam,
+               bool verify_now)
+{
+    PackedCache &pc = pc_in ? *pc_in : g->packed;
+    if (!st) st = g->stream;
+    out.kind = kind;
+    if (kind == PR_SCENE_PROJ || kind == PR_SCENE_PROJ_CROP) {
+        const pr_scene_proj *s = static_cast<const pr_scene_proj *>(scene);       // pr_scene_proj_crop starts with the plain view
+        if (!s || !s->pcd || !s->normal || s->width == 0 || s->height == 0) { set_error("invalid pr_scene_proj"); return PR_ERR_INVALID; }
+        if (s->width > 0x7fffffffull || s->height > 0x7fffffffull) { set_error("pr_scene_proj: frame too large"); return PR_ERR_INVALID; }
+        uint32_t tl_x = 0, tl_y = 0;
+        if (kind == PR_SCENE_PROJ_CROP) { const pr_scene_proj_crop *c = static_cast<const pr_scene_proj_crop *>(scene); tl_x = c->tl_x; tl_y = c->tl_y; }
+        out.kind = PR_SCENE_PROJ;
+        out.aos = prk::SceneProjAoS{ (uint32_t)s->width, (uint32_t)s->height, s->max_dist_diff, s->K[0], s->K[4], s->K[2], s->K[5],
+                                     (float)tl_x, (float)tl_y, s->pcd, s->normal };
+        out.packed = false;
+        if (want_packed) {
+            PR_TRY(ensure_packed(pc, *s, tl_x, tl_y, st, verify_now));
+            if (pc.exact) {                                         // else: the caller's pcd is not dep2pcd's -- use the arrays as they are
+                const size_t n = (size_t)s->width * s->height;
+                float *colf = reinterpret_cast<float *>(pc.rec.as<float4>() + n);
+                out.packed = true;
+                out.pk = prk::SceneProjPacked{ (uint32_t)s->width, (uint32_t)s->height, s->max_dist_diff, s->K[0], s->K[4], s->K[2], s->K[5],
+                                               (float)tl_x, (float)tl_y, pc.rec.as<float4>(), colf, colf + s->width };
+            }
+        }
+        return PR_OK;
+    }
+    if (kind == PR_SCENE_NN) {
+        const pr_scene_nn *s = static_cast<const pr_scene_nn *>(scene);
+        if (!s || !s->pcd || !s->normal || !s->nodes || s->n_nodes == 0 || s->n_points == 0) { set_error("invalid pr_scene_nn"); return PR_ERR_INVALID; }
+        auto &nc = g->nn_cache;
+        const bool same = nc.valid && nc.pcd == s->pcd && nc.normal == s->normal && nc.nodes == s->nodes && nc.n_points == s->n_points && nc.n_nodes == s->n_nodes;
+        bool hit = same && opt.scene_cache && !g_writes.written_since(nc.gen, s->pcd, (size_t)s->n_points * sizeof(pr_vec3)) &&
+                   !g_writes.written_since(nc.gen, s->nodes, (size_t)s->n_nodes * sizeof(pr_kdnode));
+        if (hit && verify_now) {
+            bool stale = false;
+            PR_TRY(fingerprint_differs(s->pcd, (size_t)s->n_points * sizeof(pr_vec3), s->nodes, (size_t)s->n_nodes * sizeof(pr_kdnode), s->normal,
+                                       (size_t)s->n_points * sizeof(pr_vec3), g->nndepth.as<uint32_t>() + 12, g->stream, stale));
+            hit = !stale;
+        }
+        if (hit) {
+            nc.gen = g_writes.now();                                // (the normals are read through the caller's pointer, never copied)
+        } else {
+            drain_all_slots();                                      // the records below are shared by both slots' batches
+            nc.valid = false; nc.grid_valid = false;
+            const uint64_t gen = g_writes.now();
+            PR_TRY(g->topo.ensure((size_t)s->n_nodes * sizeof(int4)));
+            PR_TRY(g->bmin.ensure((size_t)s->n_nodes * sizeof(float4)));
+            PR_TRY(g->bmax.ensure((size_t)s->n_nodes * sizeof(float4)));
+            PR_TRY(g->pts.ensure((size_t)s->n_points * sizeof(float4)));
+            PR_TRY(g->nnrec.ensure((size_t)s->n_nodes * 4 * sizeof(float4)));
+            PR_TRY(g->nndepth.ensure(24 * sizeof(uint32_t)));      // [0] depth [1] rec32 valid [2..7] rec32 frame [8] wide valid [9] wide nodes [12] fingerprint [16..19] wide frame
+            PR_TRY(g->nnrec32.ensure((size_t)s->n_nodes * 2 * sizeof(uint4)));
+            PR_TRY(g->nndesc.ensure((size_t)s->n_nodes * sizeof(uint2)));
+            // wide records: one 128-byte line per wide node
+            PR_TRY(g->nnwide.ensure(prk::nn_wide_capacity(s->n_nodes) * 128));
+            PR_TRY(g->nnwq.ensure(prk::nn_wide_capacity(s->n_nodes) * 2 * sizeof(uint32_t)));
+            HIP_TRY(prk::launch_build_nn_accel(s->nodes, s->n_nodes, s->pcd, s->n_points, g->topo.as<int4>(), g->bmin.as<float4>(),
+                                               g->bmax.as<float4>(), g->pts.as<float4>(), g->nnrec.as<float4>(), g->nnrec32.as<uint4>(),
+                                               g->nndesc.as<uint2>(), g->nndepth.as<uint32_t>(), g->stream,
+                                               g->nnwide.as<uint4>(), g->nnwq.as<uint32_t>(), s->max_dist_diff * 1.01f));
+            HIP_TRY(prk::launch_scene_fingerprint(s->pcd, (size_t)s->n_points * sizeof(pr_vec3), s->nodes, (size_t)s->n_nodes * sizeof(pr_kdnode), s->normal,
+                                                  (size_t)s->n_points * sizeof(pr_vec3), g->nndepth.as<uint32_t>() + 12, nullptr, false, g->stream));
+            HIP_TRY(hipMemcpyAsync(nc.info, g->nndepth.p, sizeof nc.info, hipMemcpyDeviceToHost, g->stream));
+            HIP_TRY(hipStreamSynchronize(g->stream));
+            nc.pcd = s->pcd; nc.normal = s->normal; nc.nodes = s->nodes; nc.n_points = s->n_points; nc.n_nodes = s->n_nodes; nc.gen = gen; nc.valid = true;
+        }
+        const uint32_t *info = nc.info;
+        const uint32_t depth = info[0];
+        if (depth >= 0x7fffffffu) { nc.valid = false; set_error("pr_scene_nn: the nodes do not form a consistent tree (child / parent links disagree or point outside the array)"); return PR_ERR_INVALID; }
+        uint32_t lds = (uint32_t)std::max(0, opt.nn_lds_nodes);
+        lds = std::min(lds, s->n_nodes);
+        lds = std::min<uint32_t>(lds, 8192);                      // <= 128 KiB of LDS
+        // pending far children on the stack never exceed the tree depth; deeper trees use the stackless walk
+        uint32_t stack = 0;
+        if (opt.nn_stack) stack = (depth <= 16) ? 16u : ((depth <= 24) ? 24u : 0u);
+        if (stack) lds = std::min<uint32_t>({ (uint32_t)std::max(0, opt.nn_lds_records), s->n_nodes, (65536u - stack * 2048u) / 64u });   // stacks + records <= 64 KiB
+        out.nn = prk::SceneNNDev{ s->max_dist_diff, g->topo.as<int4>(), g->bmin.as<float4>(), g->bmax.as<float4>(), g->pts.as<float4>(),
+                                  s->pcd, s->normal, s->n_nodes, lds, g->nnrec.as<float4>(), stack, nullptr, { 0, 0, 0 }, { 0, 0, 0 }, g->nndesc.as<uint2>() };
+        if (stack && opt.nn_compact && info[1] == 1u) {
+            out.nn.rec32 = g->nnrec32.as<uint4>();
+            for (int a = 0; a < 3; ++a) { std::memcpy(&out.nn.qmin[a], &info[2 + a], 4); std::memcpy(&out.nn.qscale[a], &info[5 + a], 4); }
+            if (opt.nn_wide && info[8] == 1u && info[9] > 0u) {
+                out.nn.wide = g->nnwide.as<uint4>(); out.nn.n_wide = info[9];
+                for (int a = 0; a < 3; ++a) std::memcpy(&out.nn.wmin[a], &info[16 + a], 4);
+                std::memcpy(&out.nn.wscale, &info[19], 4);
+            }
+        }
+        // a bare ICP call has no camera of its own: the scene's hint, if it carries one (pose_refine.h)
+        Camera hinted;
+        if (!cam && s->cam_magic == PR_SCENE_NN_CAM_MAGIC && s->cam_w && s->cam_h && s->cam_fx > 0.0f && s->cam_fy > 0.0f) { hinted = Camera{ s->cam_w, s->cam_h, s->cam_fx, s->cam_fy, s->cam_cx, s->cam_cy }; cam = &hinted; }
+        // pixel grid of the scene points under the hypotheses' camera (fused paths), or under the camera the scene says it was made with.  Usable
+        // when every scene point owns a cell -- a Scene_nn made from a depth image with these intrinsics -- else the tree alone.
+        if (cam && opt.nn_grid && out.nn.rec32 && (size_t)cam->w * cam->h <= ((size_t)1 << 24)) {
+            const float gk[4] = { cam->fx, cam->fy, cam->cx, cam->cy };
+            if (!(nc.grid_valid && nc.gw == cam->w && nc.gh == cam->h && std::memcmp(nc.gk, gk, sizeof gk) == 0)) {
+                drain_all_slots();
+                const size_t cells = (size_t)cam->w * cam->h;
+                PR_TRY(g->nn_cells.ensure(cells * sizeof(int32_t) + 16));
+                PR_TRY(g->nn_grid.ensure(prk::nn_grid_cells(cam->w, cam->h) * sizeof(float4)));
+                uint32_t *flag = reinterpret_cast<uint32_t *>(g->nn_cells.as<int32_t>() + cells);
+                HIP_TRY(prk::launch_build_nn_grid(s->pcd, s->n_points, cam->w, cam->h, gk[0], gk[1], gk[2], gk[3], g->nn_cells.as<int32_t>(),
+                                                  g->nn_grid.as<float4>(), flag, g->stream));
+                uint32_t usable = 0;
+                HIP_TRY(hipMemcpyAsync(&usable, flag, sizeof usable, hipMemcpyDeviceToHost, g->stream));
+                HIP_TRY(hipStreamSynchronize(g->stream));
+                nc.grid_valid = true; nc.grid_usable = usable != 0; nc.gw = cam->w; nc.gh = cam->h; std::memcpy(nc.gk, gk, sizeof gk);
+            }
+            if (nc.grid_usable) {
+                out.nn.grid = g->nn_grid.as<float4>(); out.nn.gw = cam->w; out.nn.gh = cam->h; out.nn.gfx = gk[0]; out.nn.gfy = gk[1]; out.nn.gcx = gk[2]; out.nn.gcy = gk[3];
+                const size_t w4 = (cam->w + 3) / 4, h4 = (cam->h + 3) / 4, w16 = (w4 + 3) / 4, h16 = (h4 + 3) / 4;
+                out.nn.pyr4 = out.nn.grid + (size_t)cam->w * cam->h; out.nn.pyr16 = out.nn.pyr4 + w4 * h4; out.nn.pyr64 = out.nn.pyr16 + w16 * h16;
+            }
+        }
+        return PR_OK;
+    }
+    set_error("unknown scene kind %d", kind);
+    return PR_ERR_INVALID;
+}
+
+// KDTree_cpu::build_tree on the device: level loop driven from the host (one 16-byte read-back per level)
+int kd_build_dev(pr_vec3 *pcd, pr_vec3 *nrm, uint32_t n, int max_leaf, pr_kdnode *nodes, size_t cap, uint32_t *n_nodes)
+{
+    if (n == 0 || cap == 0) { set_error("kd-tree build: no points"); return PR_ERR_INVALID; }
+    const uint32_t cap32 = (uint32_t)std::min<size_t>(cap, 0x7fffffff);
+    PR_TRY(g->kd_idx.ensure(sizeof(int) * n));
+    PR_TRY(g->kd_scratch.ensure(sizeof(int) * n));
+    PR_TRY(g->kd_child.ensure(sizeof(int) * cap32));
+    PR_TRY(g->kd_ctrl.ensure(sizeof(uint32_t) * 4));
+    PR_TRY(g->kd_tmp.ensure(sizeof(pr_vec3) * 2 * (size_t)n));
+    HIP_TRY(prk::launch_kd_init(nodes, cap32, g->kd_idx.as<int>(), n, g->kd_ctrl.as<uint32_t>(), g->stream));
+    uint32_t ctrl[4] = { 0, 1, 1, 1 };
+    for (int level = 0; level < 4096; ++level) {
+        HIP_TRY(prk::launch_kd_level(nodes, g->kd_ctrl.as<uint32_t>(), max_leaf, g->kd_child.as<int>(), cap32, 0, pcd, g->kd_idx.as<int>(),
+                                     g->kd_scratch.as<int>(), /*plan_only=*/true, g->stream));
+        HIP_TRY(hipMemcpyAsync(ctrl, g->kd_ctrl.p, sizeof ctrl, hipMemcpyDeviceToHost, g->stream));
+        HIP_TRY(hipStreamSynchronize(g->stream));
+        if (ctrl[3] > cap32) { set_error("kd-tree build: node capacity %u too small", cap32); return PR_ERR_NOMEM; }
+        if (ctrl[3] == ctrl[2]) break;                             // no node of this level split: done (pcd_scene.cpp:166-168)
+        HIP_TRY(prk::launch_kd_level(nodes, g->kd_ctrl.as<uint32_t>(), max_leaf, g->kd_child.as<int>(), cap32, ctrl[1] - ctrl[0], pcd,
+                                     g->kd_idx.as<int>(), g->kd_scratch.as<int>(), /*plan_only=*/false, g->stream));
+    }
+    pr_vec3 *tp = g->kd_tmp.as<pr_vec3>(), *tn = tp + n;
+    HIP_TRY(prk::launch_kd_permute(pcd, nrm, g->kd_idx.as<int>(), n, tp, tn, g->stream));
+    HIP_TRY(hipMemcpyAsync(pcd, tp, sizeof(pr_vec3) * n, hipMemcpyDeviceToDevice, g->stream));
+    HIP_TRY(hipMemcpyAsync(nrm, tn, sizeof(pr_vec3) * n, hipMemcpyDeviceToDevice, g->stream));
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    if (n_nodes) *n_nodes = ctrl[2];
+    return PR_OK;
+}
+
+template <typename T>
+int scene_nn_prepare_dev_t(const T *depth, const float K[9], uint32_t W, uint32_t H, int max_leaf, pr_vec3 *pcd, pr_vec3 *nrm,
+                           pr_kdnode *nodes, size_t cap, uint32_t *n_points, uint32_t *n_nodes)
+{
+    const size_t px = (size_t)W * H;
+    PR_TRY(g->nn_full.ensure(sizeof(pr_vec3) * 2 * px));
+    PR_TRY(g->row_count.ensure(sizeof(uint32_t) * H));
+    PR_TRY(g->row_off.ensure(sizeof(uint32_t) * H));
+    PR_TRY(g->counts.ensure(sizeof(uint32_t)));
+    pr_vec3 *full_pcd = g->nn_full.as<pr_vec3>(), *full_nrm = full_pcd + px;
+    // normals of every pixel (get_normal sees the uint16 image), then the valid pixels in row-major order
+    HIP_TRY(prk::launch_scene_proj_prepare<T>(depth, W, H, K[0], K[4], K[2], K[5], full_pcd, full_nrm, g->stream));
+    HIP_TRY(prk::launch_nn_gather<T>(depth, W, H, K[0], K[4], K[2], K[5], full_nrm, g->row_count.as<uint32_t>(), g->row_off.as<uint32_t>(),
+                                     g->counts.as<uint32_t>(), nullptr, nullptr, false, g->stream));
+    uint32_t n = 0;
+    HIP_TRY(hipMemcpyAsync(&n, g->counts.p, sizeof n, hipMemcpyDeviceToHost, g->stream));
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    if (n_points) *n_points = n;
+    if (n == 0) { if (n_nodes) *n_nodes = 0; return PR_OK; }
+    HIP_TRY(prk::launch_nn_gather<T>(depth, W, H, K[0], K[4], K[2], K[5], full_nrm, g->row_count.as<uint32_t>(), g->row_off.as<uint32_t>(),
+                                     g->counts.as<uint32_t>(), pcd, nrm, true, g->stream));
+    return kd_build_dev(pcd, nrm, n, max_leaf, nodes, cap, n_nodes);
+}
+
+}  // namespace prr
+
+using namespace prr;
+
+extern "C" {
+
+int pr_scene_proj_prepare_dev(const void *depth_dev, int depth_is_i32, const float K[9], size_t width, size_t height,
+                              pr_vec3 *pcd_dev_out, pr_vec3 *normal_dev_out)
+{
+    PR_ENTER();
+    if (!depth_dev || !K || !pcd_dev_out || !normal_dev_out || width == 0 || height == 0) { set_error("pr_scene_proj_prepare_dev: bad arguments"); return PR_ERR_INVALID; }
+    g_writes.note(pcd_dev_out, width * height * sizeof(pr_vec3)); g_writes.note(normal_dev_out, width * height * sizeof(pr_vec3));
+    if (depth_is_i32) HIP_TRY(prk::launch_scene_proj_prepare<int32_t>(static_cast<const int32_t *>(depth_dev), (uint32_t)width, (uint32_t)height, K[0], K[4], K[2], K[5], pcd_dev_out, normal_dev_out, g->stream));
+    else HIP_TRY(prk::launch_scene_proj_prepare<uint16_t>(static_cast<const uint16_t *>(depth_dev), (uint32_t)width, (uint32_t)height, K[0], K[4], K[2], K[5], pcd_dev_out, normal_dev_out, g->stream));
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    return PR_OK;
+}
+
+int pr_kdtree_build_dev(pr_vec3 *pcd_dev, pr_vec3 *normal_dev, size_t n_points, int max_leaf, pr_kdnode *nodes_dev_out, size_t cap_nodes, uint32_t *n_nodes)
+{
+    PR_ENTER();
+    if (!pcd_dev || !normal_dev || !nodes_dev_out) { set_error("pr_kdtree_build_dev: bad arguments"); return PR_ERR_INVALID; }
+    g_writes.note(pcd_dev, n_points * sizeof(pr_vec3)); g_writes.note(normal_dev, n_points * sizeof(pr_vec3)); g_writes.note(nodes_dev_out, cap_nodes * sizeof(pr_kdnode));
+    return kd_build_dev(pcd_dev, normal_dev, (uint32_t)n_points, max_leaf, nodes_dev_out, cap_nodes, n_nodes);
+}
+
+int pr_scene_nn_prepare_dev(const void *depth_dev, int depth_is_i32, const float K[9], int width, int height, int max_leaf,
+                            pr_vec3 *pcd_dev_out, pr_vec3 *normal_dev_out, pr_kdnode *nodes_dev_out, size_t cap_nodes,
+                            uint32_t *n_points, uint32_t *n_nodes)
+{
+    PR_ENTER();
+    if (!depth_dev || !K || !pcd_dev_out || !normal_dev_out || !nodes_dev_out || width <= 0 || height <= 0) { set_error("pr_scene_nn_prepare_dev: bad arguments"); return PR_ERR_INVALID; }
+    g_writes.note(pcd_dev_out, (size_t)width * height * sizeof(pr_vec3)); g_writes.note(normal_dev_out, (size_t)width * height * sizeof(pr_vec3)); g_writes.note(nodes_dev_out, cap_nodes * sizeof(pr_kdnode));
+    if (depth_is_i32) return scene_nn_prepare_dev_t<int32_t>(static_cast<const int32_t *>(depth_dev), K, (uint32_t)width, (uint32_t)height, max_leaf,
+                                                             pcd_dev_out, normal_dev_out, nodes_dev_out, cap_nodes, n_points, n_nodes);
+    return scene_nn_prepare_dev_t<uint16_t>(static_cast<const uint16_t *>(depth_dev), K, (uint32_t)width, (uint32_t)height, max_leaf,
+                                            pcd_dev_out, normal_dev_out, nodes_dev_out, cap_nodes, n_points, n_nodes);
+}
+
+int pr_raw2depth_mask(const int32_t *raw_dev, size_t count, uint16_t *depth_host_out, uint8_t *mask_host_out)
+{
+    PR_ENTER();
+    if (count == 0) return PR_OK;                                  // (an empty render stack has no array)
+    if (!raw_dev || (!depth_host_out && !mask_host_out)) { set_error("pr_raw2depth_mask: bad arguments"); return PR_ERR_INVALID; }
+    if (depth_host_out) PR_TRY(g->conv16.ensure(count * sizeof(uint16_t) + 16));
+    if (mask_host_out) PR_TRY(g->conv8.ensure(count + 16));
+    HIP_TRY(prk::launch_raw2depth_mask(raw_dev, count, depth_host_out ? g->conv16.as<uint16_t>() : nullptr, mask_host_out ? g->conv8.as<uint8_t>() : nullptr, g->stream));
+    // ONE copy per output for the whole stack (the reference issues one thrust::copy per pose, renderer.cu:370-373)
+    if (depth_host_out) HIP_TRY(hipMemcpyAsync(depth_host_out, g->conv16.p, count * sizeof(uint16_t), hipMemcpyDeviceToHost, g->stream));
+    if (mask_host_out) HIP_TRY(hipMemcpyAsync(mask_host_out, g->conv8.p, count, hipMemcpyDeviceToHost, g->stream));
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    return PR_OK;
+}
+
+// Scene_projective restricted to a window of the frame: copies the window's rows of the full-frame arrays
+int pr_scene_proj_crop_dev(const pr_vec3 *pcd_full_dev, const pr_vec3 *normal_full_dev, size_t width, size_t height, pr_roi window,
+                           pr_vec3 *pcd_out_dev, pr_vec3 *normal_out_dev)
+{
+    PR_ENTER();
+    if (!pcd_full_dev || !normal_full_dev || !pcd_out_dev || !normal_out_dev || window.width <= 0 || window.height <= 0 || window.x < 0 || window.y < 0 ||
+        (size_t)window.x + (size_t)window.width > width || (size_t)window.y + (size_t)window.height > height) { set_error("pr_scene_proj_crop_dev: bad arguments"); return PR_ERR_INVALID; }
+    const size_t cw = (size_t)window.width, ch = (size_t)window.height;
+    g_writes.note(pcd_out_dev, cw * ch * sizeof(pr_vec3)); g_writes.note(normal_out_dev, cw * ch * sizeof(pr_vec3));
+    const size_t off = (size_t)window.y * width + (size_t)window.x;
+    HIP_TRY(hipMemcpy2DAsync(pcd_out_dev, cw * sizeof(pr_vec3), pcd_full_dev + off, width * sizeof(pr_vec3), cw * sizeof(pr_vec3), ch, hipMemcpyDeviceToDevice, g->stream));
+    HIP_TRY(hipMemcpy2DAsync(normal_out_dev, cw * sizeof(pr_vec3), normal_full_dev + off, width * sizeof(pr_vec3), cw * sizeof(pr_vec3), ch, hipMemcpyDeviceToDevice, g->stream));
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    return PR_OK;
+}
+
+}  // extern "C"
