@@ -2,7 +2,8 @@
 """Stress of the asynchronous slots: random batch sizes / poses alternate over the two slots (growing and shrinking
 workspaces, changing grid hints, sub-batches, empty clouds) and every batch is compared bit for bit with the synchronous path.
 
-    [PR_STRESS_TIMED=1] python tools/stress_async.py [jobs] [kd-tree fraction]      (PR_STRESS_TIMED: every third batch is a timed one, profile 3)
+    [PR_STRESS_TIMED=1] [PR_STRESS_SOLVE=host] python tools/stress_async.py [jobs] [kd-tree fraction]
+    (PR_STRESS_TIMED: every third batch is a timed one, profile 3; PR_STRESS_SOLVE=host: the 6x6 solve on the host -- submitted batches run on the slots' helper threads)
 
 With a kd-tree fraction > 0 some jobs run against one of TWO kd-tree scenes: the search records and the pixel grid are shared by
 both slots and hold one scene at a time, so alternating scenes forces rebuilds while the other slot has a batch in flight."""
@@ -11,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
 from pose_refine_amd import api, synth
-api.init(0); api.set_option("solve", 1)
+api.init(0); api.set_option("solve", 0 if os.environ.get("PR_STRESS_SOLVE") == "host" else 1)   # host: the slots' helper threads run the batches
 model = api.Model(os.path.join(ROOT, "tests/golden/obj_06.ply"))
 K = synth.K_TEST; W, H = 640, 480; proj = api.compute_proj(K, W, H)
 sd = api.render_host(model, synth.scene_pose()[None], W, H, proj)[0]
