@@ -346,11 +346,12 @@ __device__ __forceinline__ void wide_pair_lb(uint32_t lox, uint32_t loy, uint32_
 // 8 / kLanes boxes of a node, or 8 / kLanes points of a leaf per round, per lane; a step pops 64 / kLanes tasks of one kind.
 // Box bounds travel through the queues in SQUARED UNITS of the wide records' frame (wide_pair_lb); a query's bound is converted when a task
 // is popped (inflated by 1e-6, plus one unit), the runner-up bound when a step's skipped boxes are folded into `second` (deflated).
-template <int kLanes>
+template <int kLanes, bool kCount>
 __global__ __launch_bounds__(256, PR_WIDE_WAVES) void nn_tree_wide_kernel(IcpBatch b, SceneNNDev scene, uint32_t qbatch)
 {
     static_assert(kLanes == 2, "the paired record layout (nn_wide_build_kernel, stage D) is made for two lanes per task");
     constexpr uint32_t kPer = 8u / kLanes, kTasks = 64u / kLanes;
+    constexpr uint32_t kLeafPer = PR_WIDE_LEAF_PER;               // points of a leaf per lane and round
     __shared__ uint2 s_nodeq[4][kTaskQCap], s_leafq[4][kTaskLCap];               // {reference, bound bits (low 6 bits cleared: rounded DOWN) | query slot}
     __shared__ float4 s_q[4][64];                                                // query point | bound (float bits, lowered with atomicMin)
     __shared__ uint32_t s_second[4][64], s_tied[4][64], s_ovf[4][64], s_root[4][64];
@@ -380,7 +381,7 @@ __global__ __launch_bounds__(256, PR_WIDE_WAVES) void nn_tree_wide_kernel(IcpBat
     // this very conversion), and the factors between squared metres and squared units -- each rounded to the safe side
     const float w_inv = 1.0f / scene.wscale;
     const float w_to_units2 = w_inv * w_inv * 1.000001f, w_to_m2 = scene.wscale * scene.wscale * 0.999999f;
-    uint32_t n_tree = 0, n_nodes = 0, n_leaves = 0, n_leaf_points = 0, n_redo_q = 0, n_steps = 0;
+    uint32_t n_tree = 0, n_nodes = 0, n_leaves = 0, n_leaf_points = 0;   // work counters of instrumented runs (kCount: option "nn_count"); the product instantiation carries none
     for (uint32_t base = (blockIdx.x * 4u + wave) * qbatch; base < queued; base += gridDim.x * 4u * qbatch) {
         const bool have_q = lane < qbatch && base + lane < queued;
         uint32_t nN = 0, nL = 0;                                    // fill levels of the two queues (wave-uniform)
@@ -391,7 +392,7 @@ __global__ __launch_bounds__(256, PR_WIDE_WAVES) void nn_tree_wide_kernel(IcpBat
             qs[lane] = make_float4(q.x, q.y, q.z, __uint_as_float(mine.y));
             best[lane] = ((unsigned long long)mine.y << 32) | kNoIdx;
             second[lane] = 0x7f7fffffu; tied[lane] = 0xffffffffu; ovf[lane] = 0u; root[lane] = lane;
-            if (have_q) ++n_tree;
+            if (kCount && have_q) ++n_tree;
         }
         // The walks of the 64 queries are started kTasks at a time, whenever the node queue runs low: all 64 root tasks at once would
         // spread three levels of every walk over the queues before the first leaf is reached (depth-first order keeps them short).
@@ -411,7 +412,6 @@ __global__ __launch_bounds__(256, PR_WIDE_WAVES) void nn_tree_wide_kernel(IcpBat
                 __builtin_amdgcn_wave_barrier();
             }
             const bool leaf_step = (nL >= kTasks) || (nN == 0u);
-            if (lane == 0u) ++n_steps;
             const uint32_t avail = leaf_step ? nL : nN, k = avail < kTasks ? avail : kTasks;
             const bool active = grp < k;
             const uint2 e = active ? (leaf_step ? leafq : nodeq)[avail - 1u - grp] : make_uint2(0u, 0u);
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(256, PR_WIDE_WAVES) void nn_tree_wide_kernel(IcpBat
                     const uint4 *rec = scene.wide + (size_t)ref * 8u + 4u * c;
 #pragma unroll
                     for (uint32_t i = 0; i < 4; ++i) r[i] = rec[i];
-                    if (c == 0u) ++n_nodes;
+                    if (kCount && c == 0u) ++n_nodes;
                 }
                 // The query in whole units of the frame: an interval [qd, qd + 3] that holds its coordinate with more than a unit to spare on
                 // either side (the difference to the frame's origin is formed first -- exact to half an ulp of a number below the frame's edge --
@@ -477,29 +477,39 @@ __global__ __launch_bounds__(256, PR_WIDE_WAVES) void nn_tree_wide_kernel(IcpBat
                 nN += tot & 0xffffu; if (nN > kTaskQCap) nN = kTaskQCap;
                 nL += tot >> 16; if (nL > kTaskLCap) nL = kTaskLCap;
             } else {
-                // ---------------- leaf tasks: kPer points per lane and round, all loaded before any is looked at
+                // ---------------- leaf tasks: kLeafPer points per lane and round, all loaded before any is looked at.  A lane first settles its own
+                // points in registers -- minimum, which one, and the runner-up -- and only the minimum goes to the query's record in LDS: ONE
+                // conditional block per round.  (Per point, as first built, "rare: a point that may be the minimum" was rare per lane but not per
+                // wavefront: with 256 point tests per step some lane took the branch -- an LDS atomic round trip and twenty instructions -- for
+                // nearly every point slot; and with four points per lane a leaf of nine or ten, one in three, cost every step a second round.)
                 const uint32_t first = ref & kWideFirstMask, cnt = alive ? ((ref >> 27) & 15u) : 0u;
-                if (alive && c == 0u) { ++n_leaves; n_leaf_points += cnt; }
-                for (uint32_t kb = 0; kb < cnt; kb += 8u) {
-                    const uint32_t ka = kb + kPer * c;
-                    float4 pt[kPer];
+                if (kCount && alive && c == 0u) { ++n_leaves; n_leaf_points += cnt; }
+                for (uint32_t kb = 0; kb < cnt; kb += kLanes * kLeafPer) {
+                    const uint32_t ka = kb + kLeafPer * c;
+                    float4 pt[kLeafPer];
 #pragma unroll
-                    for (uint32_t h = 0; h < kPer; ++h) pt[h] = scene.pts[first + (ka + h < cnt ? ka + h : 0u)];
+                    for (uint32_t h = 0; h < kLeafPer; ++h) pt[h] = scene.pts[first + (ka + h < cnt ? ka + h : 0u)];
+                    float m = FLT_MAX, s2 = FLT_MAX;                   // the lane's smallest distance and the smallest of its other points
+                    uint32_t hm = 0u;
 #pragma unroll
-                    for (uint32_t h = 0; h < kPer; ++h) {
-                        const float d2 = (sx - pt[h].x) * (sx - pt[h].x) + (sy - pt[h].y) * (sy - pt[h].y) + (sz - pt[h].z) * (sz - pt[h].z);   // pcd_scene.h:88-91
-                        const bool valid = ka + h < cnt, cand = valid && d2 <= bnd;
-                        sec_l = min_f32(sec_l, (valid && !cand) ? d2 : FLT_MAX);
-                        if (cand) {                                    // rare: a point that may be the minimum
-                            const uint32_t idx = first + ka + h, db = __float_as_uint(d2);
-                            const unsigned long long key = ((unsigned long long)db << 32) | idx;
-                            const unsigned long long old = atomicMin(&best[q], key);
-                            const uint32_t old_d = (uint32_t)(old >> 32), old_i = (uint32_t)old;
-                            if (old_d == db && old_i != idx && old_i != kNoIdx) atomicMin(&tied[q], db);
-                            if (key < old) { if (old_i != kNoIdx) sec_l = min_f32(sec_l, __uint_as_float(old_d)); if (d2 < bnd) atomicMin(bound_q, db); }
-                            else sec_l = min_f32(sec_l, d2);
-                        }
+                    for (uint32_t h = 0; h < kLeafPer; ++h) {
+                        const float e2 = (sx - pt[h].x) * (sx - pt[h].x) + (sy - pt[h].y) * (sy - pt[h].y) + (sz - pt[h].z) * (sz - pt[h].z);   // pcd_scene.h:88-91
+                        const float d2 = (ka + h < cnt) ? e2 : FLT_MAX;
+                        const bool lt = d2 < m;                         // strict: of equal points the first keeps the slot, the other shows up in s2
+                        s2 = min_f32(s2, lt ? m : d2);
+                        hm = lt ? h : hm;
+                        m = lt ? d2 : m;
                     }
+                    sec_l = min_f32(sec_l, s2);                        // none of them is this query's answer (an equal one: recorded as a tie below)
+                    if (m <= bnd) {                                    // the lane's minimum may be the query's (bnd is finite: m is a real point's distance)
+                        const uint32_t idx = first + ka + hm, db = __float_as_uint(m);
+                        const unsigned long long key = ((unsigned long long)db << 32) | idx;
+                        const unsigned long long old = atomicMin(&best[q], key);
+                        const uint32_t old_d = (uint32_t)(old >> 32), old_i = (uint32_t)old;
+                        if (s2 == m || (old_d == db && old_i != idx && old_i != kNoIdx)) atomicMin(&tied[q], db);
+                        if (key < old) { if (old_i != kNoIdx) sec_l = min_f32(sec_l, __uint_as_float(old_d)); if (m < bnd) atomicMin(bound_q, db); }
+                        else sec_l = min_f32(sec_l, m);
+                    } else sec_l = min_f32(sec_l, m);
                 }
             }
             nN = (uint32_t)__builtin_amdgcn_readfirstlane((int)nN); nL = (uint32_t)__builtin_amdgcn_readfirstlane((int)nL);     // wave-uniform by construction
@@ -538,7 +548,6 @@ __global__ __launch_bounds__(256, PR_WIDE_WAVES) void nn_tree_wide_kernel(IcpBat
             const bool found = idx != kNoIdx && m_bits < b0;
             if (ovf[lane] != 0u || (found && tied[lane] == m_bits)) {
                 // a tie or a dropped task: the ordered walk, from the minimum found (= nn_seed_bound: an existing point's distance)
-                ++n_redo_q;
                 const float bnd = found ? fminf(__uint_as_float(b0), __uint_as_float(m_bits) * 1.000001f + 1e-30f) : __uint_as_float(b0);
                 const float4 qp = qs[lane];
                 win[j] = query_nn_bounded(scene, qp.x, qp.y, qp.z, bnd);
@@ -548,9 +557,8 @@ __global__ __launch_bounds__(256, PR_WIDE_WAVES) void nn_tree_wide_kernel(IcpBat
         }
         __builtin_amdgcn_wave_barrier();
     }
-    if (scene.counters) {                                        // instrumented runs only (option "nn_count")
+    if (kCount && scene.counters) {
         uint32_t n_pyr = 0u;
-        (void)n_redo_q; (void)n_steps;
         const uint32_t v[8] = { 0u, 0u, n_tree, n_pyr, n_nodes, n_leaves, n_leaf_points, 0u };
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -628,7 +636,8 @@ hipError_t launch_nn_search(const IcpBatch &b, const SceneNNDev &sc, uint32_t n_
             // cloud: 26 k queries = 103 workgroups of 4 x 64): then 16 at a time in four times as many workgroups
             uint32_t qbatch = 64u, walk_gx = tree_gx;
             if ((size_t)np * max_points < (size_t)64 * 4 * 1024) { qbatch = 16u; walk_gx = (max_points + 4u * qbatch - 1u) / (4u * qbatch); if (walk_gx * np > 4096u) walk_gx = (4096u + np - 1u) / np; if (walk_gx < tree_gx) walk_gx = tree_gx; }
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(nn_tree_wide_kernel<PR_WIDE_LANES>), dim3(walk_gx, np), dim3(kBlockThreads), 0, s, bb, sc, qbatch);
+            if (sc.counters) hipLaunchKernelGGL(HIP_KERNEL_NAME(nn_tree_wide_kernel<PR_WIDE_LANES, true>), dim3(walk_gx, np), dim3(kBlockThreads), 0, s, bb, sc, qbatch);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(nn_tree_wide_kernel<PR_WIDE_LANES, false>), dim3(walk_gx, np), dim3(kBlockThreads), 0, s, bb, sc, qbatch);
         }
         else if (sc.stack_depth == 16) hipLaunchKernelGGL(HIP_KERNEL_NAME(nn_tree_kernel<16 + 0x100>), dim3(tree_gx, np), dim3(kBlockThreads), (size_t)16 * kBlockThreads * 8, s, bb, sc);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(nn_tree_kernel<24 + 0x100>), dim3(tree_gx, np), dim3(kBlockThreads), (size_t)24 * kBlockThreads * 8, s, bb, sc);

@@ -54,6 +54,9 @@
 #ifndef PR_WIDE_LANES
 #define PR_WIDE_LANES 2                                         // lanes per task: the paired record layout is made for 2
 #endif
+#ifndef PR_WIDE_LEAF_PER
+#define PR_WIDE_LEAF_PER 5                                      // points of a leaf a lane tests per round: 2 x 5 = the reference's max_leaf in ONE round (the records allow 15-point leaves: two)
+#endif
 #ifndef PR_WIDE_QCAP
 #define PR_WIDE_QCAP 256                                        // entries of a wavefront's node-task queue
 #endif
