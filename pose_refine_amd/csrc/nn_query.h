@@ -357,7 +357,7 @@ __device__ __forceinline__ void grid_ring_min(const float4 *__restrict__ level, 
     bx = min(max(x0 + (kbest - ky * 6), 0), lw - 1);
     by = min(max(y0 + min(ky, nb - 1), 0), lh - 1);
 }
-__device__ __forceinline__ bool grid_pyramid_bound(const SceneNNDev &s, float sx, float sy, float sz, float &best, int *land_x = nullptr, int *land_y = nullptr)
+__device__ __forceinline__ void grid_pyramid_bound(const SceneNNDev &s, float sx, float sy, float sz, float &best)
 {
     const int w4 = ((int)s.gw + 3) / 4, h4 = ((int)s.gh + 3) / 4, w16 = (w4 + 3) / 4, h16 = (h4 + 3) / 4, w64 = (w16 + 3) / 4, h64 = (h16 + 3) / 4;
     float dmin = FLT_MAX, dall;
@@ -390,21 +390,6 @@ __device__ __forceinline__ bool grid_pyramid_bound(const SceneNNDev &s, float sx
     grid_ring_min(s.grid, (int)s.gw, (int)s.gh, bx * 4 - 1, by * 4 - 1, 6, sx, sy, sz, d, bx, by);   dall = fminf(dall, d);
     const float b = dall * 1.000001f + 1e-30f;                       // empty cells hold huge coordinates: inf
     if (b < best) best = b;
-    if (land_x) { *land_x = bx; *land_y = by; }                      // the scene pixel the descent ended on (nn_bound_kernel: the next query of a run starts there)
-    return d < 1.0e20f;
-}
-// The same bound from a GUESS of where the neighbour's pixel is: the nearest scene point of the 6 x 6 cells [gx - 2, gx + 3] x [gy - 2, gy + 3].
-// nn_bound_kernel guesses from the query before it in the queue -- an image neighbour: the offset between a query's own pixel and its
-// neighbour's pixel varies slowly over the model's surface (the hypothesis is a rigid motion away from the scene), so the guess is within
-// a pixel or two and this ring finds what the descent through the three coarser levels would have found, for a third of its work.  Every
-// point met is an existing scene point: a wrong guess gives a looser bound, never a wrong one.  false: nothing but empty cells there.
-__device__ __forceinline__ bool grid_guess_bound(const SceneNNDev &s, float sx, float sy, float sz, int gx, int gy, float &best, int &land_x, int &land_y)
-{
-    float d;
-    grid_ring_min(s.grid, (int)s.gw, (int)s.gh, gx - 2, gy - 2, 6, sx, sy, sz, d, land_x, land_y);
-    const float b = d * 1.000001f + 1e-30f;
-    if (b < best) best = b;
-    return d < 1.0e20f;
 }
 __device__ __forceinline__ bool grid_search(const SceneNNDev &s, float sx, float sy, float sz, float bound, uint32_t &winner, uint32_t *cells = nullptr,
                                             float *best_sq = nullptr, float *other_sq = nullptr, bool settle = false)

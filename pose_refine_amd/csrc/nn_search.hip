@@ -354,6 +354,7 @@ __global__ __launch_bounds__(256, PR_WIDE_WAVES) void nn_tree_wide_kernel(IcpBat
     constexpr uint32_t kLeafPer = PR_WIDE_LEAF_PER;               // points of a leaf per lane and round
     __shared__ uint2 s_nodeq[4][kTaskQCap], s_leafq[4][kTaskLCap];               // {reference, bound bits (low 6 bits cleared: rounded DOWN) | query slot}
     __shared__ float4 s_q[4][64];                                                // query point | bound (float bits, lowered with atomicMin)
+    __shared__ uint2 s_qq[4][64];                                                // the query in whole units of the wide records' frame: ux | uy << 16, uz | uz << 16
     __shared__ uint32_t s_second[4][64], s_tied[4][64], s_ovf[4][64], s_root[4][64];
     __shared__ unsigned long long s_best[4][64];
     __shared__ uint2 s_dump[64];                                                 // where a lane stores a task it does not keep (no exec-mask juggling per slot); never read,
@@ -374,6 +375,7 @@ __global__ __launch_bounds__(256, PR_WIDE_WAVES) void nn_tree_wide_kernel(IcpBat
     const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), c = lane % kLanes, grp = lane / kLanes;
     uint2 *nodeq = s_nodeq[wave], *leafq = s_leafq[wave];
     float4 *qs = s_q[wave];
+    uint2 *qq = s_qq[wave];
     uint32_t *second = s_second[wave], *tied = s_tied[wave], *ovf = s_ovf[wave], *root = s_root[wave];
     unsigned long long *best = s_best[wave];
     uint2 *dump = s_dump;
@@ -390,6 +392,14 @@ __global__ __launch_bounds__(256, PR_WIDE_WAVES) void nn_tree_wide_kernel(IcpBat
         {
             const pr_vec3 q = have_q ? ld_off<pr_vec3>(cl, mine.x * 12u) : pr_vec3{ 0.0f, 0.0f, 0.0f };
             qs[lane] = make_float4(q.x, q.y, q.z, __uint_as_float(mine.y));
+            // The query in whole units of the frame, once per query: an interval [u, u + 3] that holds its coordinate with more than a unit to
+            // spare on either side (the difference to the frame's origin is formed first -- exact to half an ulp of a number below the frame's
+            // edge -- then scaled; a unit is at least an ulp of the largest coordinate, nn_frame_kernel refuses the frame otherwise: that is also
+            // the slack a box's stored corners have against their real-number positions).  Negative and NaN values convert to 0.
+            const uint32_t ux = min((uint32_t)__builtin_fmaf(q.x - scene.wmin[0], w_inv, -1.0625f), 65532u),
+                           uy = min((uint32_t)__builtin_fmaf(q.y - scene.wmin[1], w_inv, -1.0625f), 65532u),
+                           uz = min((uint32_t)__builtin_fmaf(q.z - scene.wmin[2], w_inv, -1.0625f), 65532u);
+            qq[lane] = make_uint2(ux | (uy << 16), uz * 0x10001u);
             best[lane] = ((unsigned long long)mine.y << 32) | kNoIdx;
             second[lane] = 0x7f7fffffu; tied[lane] = 0xffffffffu; ovf[lane] = 0u; root[lane] = lane;
             if (kCount && have_q) ++n_tree;
@@ -437,15 +447,9 @@ __global__ __launch_bounds__(256, PR_WIDE_WAVES) void nn_tree_wide_kernel(IcpBat
                     for (uint32_t i = 0; i < 4; ++i) r[i] = rec[i];
                     if (kCount && c == 0u) ++n_nodes;
                 }
-                // The query in whole units of the frame: an interval [qd, qd + 3] that holds its coordinate with more than a unit to spare on
-                // either side (the difference to the frame's origin is formed first -- exact to half an ulp of a number below the frame's edge --
-                // then scaled; a unit is at least an ulp of the largest coordinate, nn_frame_kernel refuses the frame otherwise: that is also the
-                // slack a box's stored corners have against their real-number positions).  Negative and NaN values convert to 0.  Both halves of
-                // a word carry the same value.
-                const uint32_t ux = min((uint32_t)__builtin_fmaf(sx - scene.wmin[0], w_inv, -1.0625f), 65532u),
-                               uy = min((uint32_t)__builtin_fmaf(sy - scene.wmin[1], w_inv, -1.0625f), 65532u),
-                               uz = min((uint32_t)__builtin_fmaf(sz - scene.wmin[2], w_inv, -1.0625f), 65532u);
-                const uint32_t qdx = ux * 0x10001u, qdy = uy * 0x10001u, qdz = uz * 0x10001u;
+                // the query's interval [qd, qd + 3] per axis, both halves of a word carrying the same value (two byte permutes of the stored pair)
+                const uint2 qw = qq[q];
+                const uint32_t qdx = __builtin_amdgcn_perm(qw.x, qw.x, 0x01000100u), qdy = __builtin_amdgcn_perm(qw.x, qw.x, 0x03020302u), qdz = qw.y;
                 float lb[kPer];
                 wide_pair_lb(r[0].x, r[0].y, r[0].z, r[0].w, r[1].x, r[1].y, qdx, qdy, qdz, qdx + 0x30003u, qdy + 0x30003u, qdz + 0x30003u, lb[0], lb[1]);
                 wide_pair_lb(r[1].z, r[1].w, r[2].x, r[2].y, r[2].z, r[2].w, qdx, qdy, qdz, qdx + 0x30003u, qdy + 0x30003u, qdz + 0x30003u, lb[2], lb[3]);
@@ -486,14 +490,22 @@ __global__ __launch_bounds__(256, PR_WIDE_WAVES) void nn_tree_wide_kernel(IcpBat
                 if (kCount && alive && c == 0u) { ++n_leaves; n_leaf_points += cnt; }
                 for (uint32_t kb = 0; kb < cnt; kb += kLanes * kLeafPer) {
                     const uint32_t ka = kb + kLeafPer * c;
+                    // kLeafPer consecutive records from ONE address (immediate offsets): a short leaf reads on into its neighbour's points, or into
+                    // the 16 records of padding behind the last leaf -- masked by `ka + h < cnt` below
+                    const float4 *lp = scene.pts + (first + ka);
                     float4 pt[kLeafPer];
 #pragma unroll
-                    for (uint32_t h = 0; h < kLeafPer; ++h) pt[h] = scene.pts[first + (ka + h < cnt ? ka + h : 0u)];
+                    for (uint32_t h = 0; h < kLeafPer; ++h) pt[h] = lp[h];
                     float m = FLT_MAX, s2 = FLT_MAX;                   // the lane's smallest distance and the smallest of its other points
                     uint32_t hm = 0u;
+                    const float2v sxy{ sx, sy };
 #pragma unroll
                     for (uint32_t h = 0; h < kLeafPer; ++h) {
-                        const float e2 = (sx - pt[h].x) * (sx - pt[h].x) + (sy - pt[h].y) * (sy - pt[h].y) + (sz - pt[h].z) * (sz - pt[h].z);   // pcd_scene.h:88-91
+                        // pcd_scene.h:88-91: (dx*dx + dy*dy) + dz*dz -- x and y side by side in packed instructions (each element rounded as in the scalar form)
+                        const float2v dxy = sxy - float2v{ pt[h].x, pt[h].y };
+                        const float2v qxy = dxy * dxy;
+                        const float dz = sz - pt[h].z;
+                        const float e2 = (qxy.x + qxy.y) + dz * dz;
                         const float d2 = (ka + h < cnt) ? e2 : FLT_MAX;
                         const bool lt = d2 < m;                         // strict: of equal points the first keeps the slot, the other shows up in s2
                         s2 = min_f32(s2, lt ? m : d2);

@@ -103,7 +103,7 @@ int make_scene(int kind, const void *scene, bool want_packed, SceneSel &out, Pac
             PR_TRY(g->topo.ensure((size_t)s->n_nodes * sizeof(int4)));
             PR_TRY(g->bmin.ensure((size_t)s->n_nodes * sizeof(float4)));
             PR_TRY(g->bmax.ensure((size_t)s->n_nodes * sizeof(float4)));
-            PR_TRY(g->pts.ensure((size_t)s->n_points * sizeof(float4)));
+            PR_TRY(g->pts.ensure(((size_t)s->n_points + 16u) * sizeof(float4)));   // + 16: a leaf task of the walk reads its ten slots whatever the leaf holds (nn_tree_wide_kernel)
             PR_TRY(g->nnrec.ensure((size_t)s->n_nodes * 4 * sizeof(float4)));
             PR_TRY(g->nndepth.ensure(24 * sizeof(uint32_t)));      // [0] depth [1] rec32 valid [2..7] rec32 frame [8] wide valid [9] wide nodes [12] fingerprint [16..19] wide frame
             PR_TRY(g->nnrec32.ensure((size_t)s->n_nodes * 2 * sizeof(uint4)));
