@@ -1,5 +1,6 @@
 """Steady-state probe of the fused projective path through the C ABI, without bench.py around it: 5 x 60 pipelined 256-hypothesis steps in one
-process (a process repeats to +-0.5 %; boxes of the pool differ by up to 7 %).   tools/steady_probe.py none|sleep|shutdown [option=value ...] [--torch]"""
+process (a process repeats to +-0.5 %; boxes of the pool differ by up to 7 %).   tools/steady_probe.py none|sleep|shutdown|shift [option=value ...] [--torch]
+shift: like shutdown, with a dummy device allocation of a different size kept across every re-initialisation (does WHERE the buffers land matter?)."""
 import os, sys, time
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -25,11 +26,14 @@ def run(n):
         api.refine_submit(k & 1, model, poses, W, H, proj, K, scene, crit, results_dev=res.data())
         if k: api.refine_wait((k - 1) & 1)
     api.refine_wait((n - 1) & 1)
-out = []
+out = []; hold = []
 for r in range(5):
     run(6)
     t0 = time.perf_counter(); run(60); dt = (time.perf_counter() - t0) / 60
     out.append(256 / dt / 1e3)
     if what == "shutdown": api.shutdown(); api.init(0); api.set_option("solve", 1)
+    elif what == "shift":
+        api.shutdown(); hold.append(api.DeviceVector((r + 1) * 9_437_184 + 4096 * r, np.float32)); api.init(0); api.set_option("solve", 1)
+        res = api.DeviceVector(256 * 18, np.float32)
     elif what == "sleep": time.sleep(0.5)
 print(what, " ".join(f"{v:.0f}" for v in out))
