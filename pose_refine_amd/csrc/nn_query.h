@@ -314,10 +314,10 @@ __device__ __forceinline__ bool grid_window(const SceneNNDev &s, float sx, float
     return true;
 }
 // Coarse-to-fine descent through the representative points: the nearest of ALL 64 x 64-block representatives, then the nearest
-// 16 x 16-block representative in and around that block (the block's 4 x 4 children plus one ring), then 4 x 4 blocks, then pixels.
+// 16 x 16-block representative in and around that block (the block's 4 x 4 children plus the row and column before them: PR_RING_W / PR_RING_OFF), then 4 x 4 blocks, then pixels.
 // Every point met is an existing scene point, so its distance is a valid bound (nn_seed_bound's argument); the descent itself
 // decides nothing.  On the test.cpp scene it lands on the true nearest neighbour for 70-85 % of the queries of a hypothesis that
-// starts centimetres off the surface and within a few points of it for the rest (188 distance evaluations at 640 x 480) -- which
+// starts centimetres off the surface and within a few points of it for the rest (9 + 3 x 25 distance evaluations) -- which
 // turns the tree search that follows from "find the neighbour" into "confirm it".
 __device__ __forceinline__ void grid_ring_min(const float4 *__restrict__ level, int lw, int lh, int x0, int y0, int nb, float sx, float sy, float sz,
                                               float &dmin, int &bx, int &by)
@@ -325,36 +325,37 @@ __device__ __forceinline__ void grid_ring_min(const float4 *__restrict__ level, 
     // The descent is bound by its instruction count, not by its loads (SQ counters, profiles/r04): so the clamping is done once per column and
     // row (12 clamps instead of 72), a cell's address is one 32-bit add on top of a scalar base, and the arg-min is kept as ONE index
     // (same visiting order -- rows, then columns -- and the same strict '<' as before: the same minimum and the same winner).
-    // kRingRows rows (6 cells each) are in flight at a time.
-    constexpr int kRingRows = PR_RING_ROWS;
-    uint32_t xo[6], yo[6];
+    // kRingRows rows (kW cells each) are in flight at a time.
+    constexpr int kRingRows = PR_RING_ROWS, kW = PR_RING_W;
+    uint32_t xo[kW], yo[kW];
 #pragma unroll
-    for (int d = 0; d < 6; ++d) {
+    for (int d = 0; d < kW; ++d) {
         xo[d] = (uint32_t)min(max(x0 + d, 0), lw - 1) * 16u;
         yo[d] = (uint32_t)(min(max(y0 + min(d, nb - 1), 0), lh - 1) * lw) * 16u;
     }
     float best = FLT_MAX;
     int kbest = 0;
 #pragma unroll
-    for (int dy0 = 0; dy0 < 6; dy0 += kRingRows) {
+    for (int dy0 = 0; dy0 < kW; dy0 += kRingRows) {
         if (dy0 >= nb) break;
-        float4 c[kRingRows][6];
+        float4 c[kRingRows][kW];
 #pragma unroll
         for (int r = 0; r < kRingRows; ++r)
 #pragma unroll
-            for (int dx = 0; dx < 6; ++dx) c[r][dx] = ld_off<float4>(level, yo[dy0 + r] + xo[dx]);
+            for (int dx = 0; dx < kW; ++dx) c[r][dx] = ld_off<float4>(level, yo[min(dy0 + r, kW - 1)] + xo[dx]);
 #pragma unroll
         for (int r = 0; r < kRingRows; ++r)
 #pragma unroll
-            for (int dx = 0; dx < 6; ++dx) {
+            for (int dx = 0; dx < kW; ++dx) {
+                if (dy0 + r >= kW) continue;
                 const float d2 = (sx - c[r][dx].x) * (sx - c[r][dx].x) + (sy - c[r][dx].y) * (sy - c[r][dx].y) + (sz - c[r][dx].z) * (sz - c[r][dx].z);
                 const bool lt = d2 < best;
-                best = lt ? d2 : best; kbest = lt ? (dy0 + r) * 6 + dx : kbest;
+                best = lt ? d2 : best; kbest = lt ? (dy0 + r) * kW + dx : kbest;
             }
     }
-    const int ky = (kbest * 43) >> 8;                            // kbest / 6 for 0..35
+    const int ky = kbest / kW;
     dmin = best;
-    bx = min(max(x0 + (kbest - ky * 6), 0), lw - 1);
+    bx = min(max(x0 + (kbest - ky * kW), 0), lw - 1);
     by = min(max(y0 + min(ky, nb - 1), 0), lh - 1);
 }
 __device__ __forceinline__ void grid_pyramid_bound(const SceneNNDev &s, float sx, float sy, float sz, float &best)
@@ -385,9 +386,9 @@ __device__ __forceinline__ void grid_pyramid_bound(const SceneNNDev &s, float sx
     }
     dall = dmin;
     float d;
-    grid_ring_min(s.pyr16, w16, h16, bx * 4 - 1, by * 4 - 1, 6, sx, sy, sz, d, bx, by);   dall = fminf(dall, d);
-    grid_ring_min(s.pyr4, w4, h4, bx * 4 - 1, by * 4 - 1, 6, sx, sy, sz, d, bx, by);       dall = fminf(dall, d);
-    grid_ring_min(s.grid, (int)s.gw, (int)s.gh, bx * 4 - 1, by * 4 - 1, 6, sx, sy, sz, d, bx, by);   dall = fminf(dall, d);
+    grid_ring_min(s.pyr16, w16, h16, bx * 4 - PR_RING_OFF, by * 4 - PR_RING_OFF, PR_RING_W, sx, sy, sz, d, bx, by);   dall = fminf(dall, d);
+    grid_ring_min(s.pyr4, w4, h4, bx * 4 - PR_RING_OFF, by * 4 - PR_RING_OFF, PR_RING_W, sx, sy, sz, d, bx, by);       dall = fminf(dall, d);
+    grid_ring_min(s.grid, (int)s.gw, (int)s.gh, bx * 4 - PR_RING_OFF, by * 4 - PR_RING_OFF, PR_RING_W, sx, sy, sz, d, bx, by);   dall = fminf(dall, d);
     const float b = dall * 1.000001f + 1e-30f;                       // empty cells hold huge coordinates: inf
     if (b < best) best = b;
 }

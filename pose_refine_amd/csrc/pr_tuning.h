@@ -26,6 +26,12 @@
 #ifndef PR_RING_ROWS
 #define PR_RING_ROWS 2                                          // rows of a 6 x 6 ring of the descent in flight at a time (1, 2, 3, 6 measured: not latency-bound)
 #endif
+#ifndef PR_RING_W
+#define PR_RING_W 5                                             // cells per side of a ring of the descent: a block's 4 x 4 children and the row / column BEFORE them (PR_RING_OFF = 1).
+#endif                                                          // Same box, configs[2] pipelined: 6 / off 1 (both neighbours, rounds 2-4) 41.8 k poses/s, 5 / 1 43.0 k (bound kernel 2.31 -> 1.92 ms per
+#ifndef PR_RING_OFF                                             // group-step, the walk as before); 6 / 2 41.9 k, 7 / 2 40.0 k; without the leading row -- 4 / 0, 5 / 0 -- or the last child -- 4 / 1 -- the
+#define PR_RING_OFF 1                                           // bound gets loose and the walk pays: 34.1 / 33.4 / 34.7 k
+#endif
 #ifndef PR_NN_COVER_PAD
 #define PR_NN_COVER_PAD 5.0e-4f                                 // metres a window search looks beyond its bound for the runner-up (about one pixel at 300 mm)
 #endif
