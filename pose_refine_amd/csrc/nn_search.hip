@@ -358,7 +358,7 @@ __global__ __launch_bounds__(256, PR_WIDE_WAVES) void nn_tree_wide_kernel(IcpBat
     __shared__ uint32_t s_second[4][64], s_tied[4][64], s_ovf[4][64], s_root[4][64];
     __shared__ unsigned long long s_best[4][64];
     __shared__ uint2 s_dump[64];                                                 // where a lane stores a task it does not keep (no exec-mask juggling per slot); never read,
-                                                                                 // shared by the four wavefronts: with it the kernel's LDS stays below 32 KiB (five workgroups per CU)
+                                                                                 // shared by the four wavefronts: with it the kernel's LDS is 26.5 KiB: six workgroups per CU
     const uint32_t pose = blockIdx.y;
     const PoseMeta &pm = b.meta[pose];
     if (pm.state == kSkip) return;

@@ -51,11 +51,12 @@
 // (256, 192, 6) / (320, 224, 6) / (224, 160, 7) / (192, 160, 6) / (160, 128, 8) -> 4.60 / 4.27 / 4.35 / 4.86 / 6.55 / 8.01 ms: more waves in flight
 // help every pass, but the first pass needs its queues (overflows are walked a second time).  PIPELINED (configs[2] through the two slots, two
 // pose groups, same box): 8 / 12 / 16 / 18 / 20 / 24 / 28 / 36 workgroups -> 32.6 / 34.6-35.0 / 33.5 / 35.6 / 35.6 / 35.3 / 36.0 / 35.8 k poses/s.
+// After the leaf-step change (same box, four runs each): capacities 256 / 192 (default) 43.2 k, 256 / 160 43.3 k, 240 / 176 41.9 k, 224 / 160 40.7 k poses/s.
 #ifndef PR_TREE_GX
 #define PR_TREE_GX 20                                           // workgroups per hypothesis of the bound kernel and the walk (more for launches with few hypotheses)
 #endif
 #ifndef PR_WIDE_WAVES
-#define PR_WIDE_WAVES 6                                         // wavefronts per SIMD the task walk is compiled for (<= 80 VGPRs; LDS: 24.5 KiB per workgroup)
+#define PR_WIDE_WAVES 6                                         // wavefronts per SIMD the task walk is compiled for (<= 80 VGPRs; LDS: 26.5 KiB per workgroup)
 #endif
 #ifndef PR_WIDE_LANES
 #define PR_WIDE_LANES 2                                         // lanes per task: the paired record layout is made for 2
