@@ -51,7 +51,8 @@
 // (256, 192, 6) / (320, 224, 6) / (224, 160, 7) / (192, 160, 6) / (160, 128, 8) -> 4.60 / 4.27 / 4.35 / 4.86 / 6.55 / 8.01 ms: more waves in flight
 // help every pass, but the first pass needs its queues (overflows are walked a second time).  PIPELINED (configs[2] through the two slots, two
 // pose groups, same box): 8 / 12 / 16 / 18 / 20 / 24 / 28 / 36 workgroups -> 32.6 / 34.6-35.0 / 33.5 / 35.6 / 35.6 / 35.3 / 36.0 / 35.8 k poses/s.
-// After the leaf-step change (same box, four runs each): capacities 256 / 192 (default) 43.2 k, 256 / 160 43.3 k, 240 / 176 41.9 k, 224 / 160 40.7 k poses/s.
+// After the leaf-step change (same box, four runs each): capacities 256 / 192 (rounds 3-4) 43.2 k, 256 / 160 43.3 k, 240 / 176 41.9 k, 224 / 160 40.7 k poses/s;
+// two more boxes, eight runs each: 256 / 192 43.0 k, **288 / 160 43.8 k** (the same LDS), 304 / 144 43.9 k, 320 / 128 43.5 k, 352 / 96 43.1 k, 320 / 160 43.6 k.
 #ifndef PR_TREE_GX
 #define PR_TREE_GX 20                                           // workgroups per hypothesis of the bound kernel and the walk (more for launches with few hypotheses)
 #endif
@@ -65,8 +66,8 @@
 #define PR_WIDE_LEAF_PER 5                                      // points of a leaf a lane tests per round: 2 x 5 = the reference's max_leaf in ONE round (the records allow 15-point leaves: two)
 #endif
 #ifndef PR_WIDE_QCAP
-#define PR_WIDE_QCAP 256                                        // entries of a wavefront's node-task queue
+#define PR_WIDE_QCAP 288                                        // entries of a wavefront's node-task queue
 #endif
 #ifndef PR_WIDE_LCAP
-#define PR_WIDE_LCAP 192                                        // entries of a wavefront's leaf-task queue
+#define PR_WIDE_LCAP 160                                        // entries of a wavefront's leaf-task queue
 #endif
