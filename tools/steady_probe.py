@@ -21,8 +21,12 @@ scene = api.Scene_projective().init_Scene_projective_cuda(sd, K)
 poses = synth.hypotheses(256)
 crit = api.ICPConvergenceCriteria(0.0, 0.0, 20)
 res = api.DeviceVector(256 * 18, np.float32)
+DELAY = float(os.environ.get("PR_PROBE_SUBMIT_DELAY_US", "0")) * 1e-6     # experiment: busy-wait before every submit (a slow host)
 def run(n):
     for k in range(n):
+        if DELAY:
+            t_ = time.perf_counter()
+            while time.perf_counter() - t_ < DELAY: pass
         api.refine_submit(k & 1, model, poses, W, H, proj, K, scene, crit, results_dev=res.data())
         if k: api.refine_wait((k - 1) & 1)
     api.refine_wait((n - 1) & 1)
