@@ -8,16 +8,18 @@ namespace prk {
 __global__ __launch_bounds__(256) void d2c_emit_box_kernel(const int32_t *__restrict__ depth, uint32_t width, uint32_t height,
                                                            const int4 *__restrict__ bbox, float fx, float fy, float cx, float cy,
                                                            const uint32_t *__restrict__ row_count, const uint32_t *__restrict__ row_off,
-                                                           pr_vec3 *__restrict__ cloud, size_t cloud_stride)
+                                                           pr_vec3 *__restrict__ cloud, size_t cloud_stride, const PoseMeta *__restrict__ meta)
 {
     const uint32_t lane = threadIdx.x & 63;
     const int4 bb = bbox[blockIdx.y];
+    // where this hypothesis' cloud starts: packed behind the one before it (fused asynchronous path: PoseMeta::start from d2c_pack_starts_kernel), or at a fixed stride
+    const size_t start = meta ? (size_t)meta[blockIdx.y].start : (size_t)blockIdx.y * cloud_stride;
     for (uint32_t r = 0; r < 4; ++r) {
         const uint32_t row = blockIdx.x * kBoxRowsPerBlock + (threadIdx.x >> 6) * 4 + r;
         if (row >= height) return;
         if (row_count[(size_t)blockIdx.y * height + row] == 0) continue;
         const int32_t *line = depth + ((size_t)blockIdx.y * height + row) * width;
-        pr_vec3 *out = cloud + (size_t)blockIdx.y * cloud_stride + row_off[(size_t)blockIdx.y * height + row];
+        pr_vec3 *out = cloud + start + row_off[(size_t)blockIdx.y * height + row];
         uint32_t done = 0;
         for (int x0 = bb.x; x0 <= bb.z; x0 += 512) {             // 8 independent loads in flight per lane
             int32_t dv[8];
@@ -118,7 +120,7 @@ __global__ __launch_bounds__(256) void d2c_scan_init_kernel(const uint32_t *__re
         counts[i] = c;
         arrive[i] = 0u;
         PoseMeta m;
-        m.start = i * cloud_stride; m.count = c; m.state = c > 0 ? kRun : kSkip; m.pad = 0;
+        m.start = i * cloud_stride; m.count = c; m.state = c > 0 ? kRun : kSkip; m.pad = 0;       // (start: overwritten by d2c_pack_starts_kernel when the clouds are packed)
 #pragma unroll
         for (int k = 0; k < 12; ++k) m.xform[k] = 0.0f;
         meta[i] = m;
@@ -128,6 +130,34 @@ __global__ __launch_bounds__(256) void d2c_scan_init_kernel(const uint32_t *__re
         if (threadIdx.x < 16) w = (threadIdx.x % 5 == 0) ? __float_as_uint(1.0f) : 0u;
         else if (threadIdx.x == 18) w = c > 0 ? 0u : 1u;
         reinterpret_cast<uint32_t *>(st + i)[threadIdx.x] = w;
+    }
+}
+
+// The clouds of a sub-batch PACKED one behind the other (each rounded up to kCloudAlign points = 128 bytes) instead of one per fixed stride of the
+// largest pixel box: exclusive scan of the sizes, one workgroup.  With a stride the 256 clouds of a batch are 264 KB islands 1.2 MB apart, and
+// how those islands fall on the memory system's interleave -- together with where the driver happened to put the two slots' buffers -- decided
+// between 246 and 262 k poses/s for the same process (profiles/r04/README.md, "the spread between processes"); packed, the loop streams one dense range.
+__global__ __launch_bounds__(256) void d2c_pack_starts_kernel(const uint32_t *__restrict__ counts, uint32_t n, PoseMeta *__restrict__ meta)
+{
+    __shared__ uint32_t buf[256];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n; base += 256) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = (i < n) ? ((counts[i] + (kCloudAlign - 1u)) & ~(kCloudAlign - 1u)) : 0u;
+        buf[threadIdx.x] = v;
+        __syncthreads();
+        for (uint32_t off = 1; off < 256; off <<= 1) {           // Hillis-Steele inclusive scan
+            const uint32_t t = (threadIdx.x >= off) ? buf[threadIdx.x - off] : 0;
+            __syncthreads();
+            buf[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < n) meta[i].start = carry + buf[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 255) carry += buf[255];
+        __syncthreads();
     }
 }
 
@@ -168,14 +198,14 @@ __global__ __launch_bounds__(256) void d2c_emit_kernel(const T *__restrict__ dep
 
 hipError_t launch_emit_box(const int32_t *depth, uint32_t n_poses, uint32_t width, uint32_t height, const int4 *bbox, float fx, float fy,
                            float cx, float cy, const uint32_t *row_count, const uint32_t *row_off, pr_vec3 *cloud, size_t cloud_stride,
-                           hipStream_t s)
+                           hipStream_t s, const PoseMeta *meta)
 {
     if (n_poses == 0) return hipSuccess;
     for (uint32_t i0 = 0; i0 < n_poses; i0 += 32768) {
         const uint32_t ni = (n_poses - i0 < 32768) ? (n_poses - i0) : 32768;
         hipLaunchKernelGGL(d2c_emit_box_kernel, dim3((height + kBoxRowsPerBlock - 1) / kBoxRowsPerBlock, ni), dim3(256), 0, s, depth + (size_t)i0 * width * height, width, height,
                            bbox + i0, fx, fy, cx, cy, row_count + (size_t)i0 * height, row_off + (size_t)i0 * height,
-                           cloud + (size_t)i0 * cloud_stride, cloud_stride);
+                           meta ? cloud : cloud + (size_t)i0 * cloud_stride, cloud_stride, meta ? meta + i0 : nullptr);
     }
     return hipGetLastError();
 }
@@ -224,6 +254,7 @@ hipError_t launch_d2c_scan_init(const uint32_t *row_count, uint32_t gh, uint32_t
 {
     if (n_img == 0) return hipSuccess;
     hipLaunchKernelGGL(d2c_scan_init_kernel, dim3(n_img), dim3(256), 0, s, row_count, gh, row_off, counts, meta, st, arrive, cloud_stride);
+    if (kCloudAlign) hipLaunchKernelGGL(d2c_pack_starts_kernel, dim3(1), dim3(256), 0, s, counts, n_img, meta);
     return hipGetLastError();
 }
 

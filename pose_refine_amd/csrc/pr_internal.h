@@ -7,6 +7,7 @@
 #include <stdint.h>
 
 #include "pose_refine.h"
+#include "pr_tuning.h"
 
 namespace prk {
 
@@ -15,6 +16,7 @@ constexpr uint32_t kBlockThreads   = 256;                       // 4 wavefronts
 constexpr uint32_t kPointsPerLane  = 4;                         // consecutive points per lane per step
 constexpr uint32_t kPointsPerStep  = kBlockThreads * kPointsPerLane;   // 1024
 constexpr uint32_t kAccStride      = 32;                        // 29 sums padded to 32 floats
+constexpr uint32_t kCloudAlign     = PR_CLOUD_PACK;                 // fused path: clouds of a sub-batch packed one behind the other, each rounded up to this many points (0: one per fixed stride)
 constexpr uint32_t kQCountStride   = 4;                         // queue counters per hypothesis (IcpBatch::nn_qcount)
 constexpr uint32_t kNNWordsPerPoint = 6;                        // per cloud point: winner | slack | queue 1 (2 words) | queue 2 (2 words)
 
@@ -171,7 +173,7 @@ hipError_t launch_pack_export(const DevIcpState *st, pr_result *out, const uint3
 hipError_t launch_stage_words(const void *src_host_mapped, void *dst, size_t bytes, hipStream_t s);
 hipError_t launch_emit_box(const int32_t *depth, uint32_t n_poses, uint32_t width, uint32_t height, const int4 *bbox, float fx, float fy,
                            float cx, float cy, const uint32_t *row_count, const uint32_t *row_off, pr_vec3 *cloud, size_t cloud_stride,
-                           hipStream_t s);
+                           hipStream_t s, const PoseMeta *meta = nullptr);     // meta: cloud i starts at meta[i].start (packed, launch_render_boxes wrote it) instead of i * cloud_stride
 
 hipError_t launch_icp_pass_proj_aos(const IcpBatch &b, const SceneProjAoS &sc, uint32_t n_poses, hipStream_t s);
 hipError_t launch_icp_pass_proj_packed(const IcpBatch &b, const SceneProjPacked &sc, uint32_t n_poses, hipStream_t s);

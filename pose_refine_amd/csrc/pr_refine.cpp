@@ -516,7 +516,8 @@ int refine_submit_async(Slot &sl, const pr_triangle *tris_dev, size_t n_tris, ui
         const int32_t *b = h_box + 4 * (size_t)i;
         max_area = std::max(max_area, (size_t)std::max(0, b[2] - b[0] + 1) * (size_t)std::max(0, b[3] - b[1] + 1));   // an off-screen pose has an empty box
     }
-    const size_t cstride = (max_area + 3) & ~(size_t)3;
+    // capacity per hypothesis (the clouds themselves are packed: PoseMeta::start; a multiple of the packing's alignment, so that no sum of rounded sizes exceeds P x cstride)
+    const size_t cstride = prk::kCloudAlign ? ((max_area + prk::kCloudAlign - 1) / prk::kCloudAlign) * prk::kCloudAlign : ((max_area + 3) & ~(size_t)3);
     const uint32_t steps = (uint32_t)std::max(1, opt.steps);
     const uint32_t ppb = steps * prk::kPointsPerStep;
     const uint32_t nblk = (uint32_t)((max_area + ppb - 1) / ppb);       // bound from the pixel boxes: capacity of the partial sums
@@ -603,7 +604,7 @@ int refine_submit_async(Slot &sl, const pr_triangle *tris_dev, size_t n_tris, ui
                                          /*compute_boxes=*/false, meta, dstate, arrive, (uint32_t)cstride));
         if (timed) { t_end(te, kSpanRender, q0, nq, false); te = t_begin(); }
         HIP_TRY(prk::launch_emit_box(sl.depth.as<int32_t>(), nq, W, H, d_box + q0, K[0], K[4], K[2], K[5], sl.row_count.as<uint32_t>(),
-                                     sl.row_off.as<uint32_t>(), sl.cloud.as<pr_vec3>(), cstride, st));
+                                     sl.row_off.as<uint32_t>(), sl.cloud.as<pr_vec3>(), cstride, st, prk::kCloudAlign ? meta : nullptr));
         if (timed) t_end(te, kSpanCloud, q0, nq, false);
         if (q0 == 0) HIP_TRY(hipStreamWaitEvent(st, sl.scene_ready, 0));
         if (timed && q0 == 0)                                     // the timed loop starts when the other slot's batch is complete

@@ -11,6 +11,11 @@
 #define PR_GATHER_BATCH 4                                       // projective scene gathers issued back to back before the first is tested (all four points of a lane)
 #endif
 
+// ---- render -> cloud (d2c.hip) ----------------------------------------------------------------------------------------------------
+#ifndef PR_CLOUD_PACK
+#define PR_CLOUD_PACK 32                                        // fused path: a hypothesis' cloud starts where the one before it ends, rounded up to this many points (32 = 128-byte lines; 0: fixed stride of the largest pixel box, rounds 1-4)
+#endif
+
 // ---- kd-tree search: ordered per-lane walks (nn_query.h) ---------------------------------------------------------------------------
 #ifndef PR_LEAF_BATCH
 #define PR_LEAF_BATCH 10                                        // points of a leaf fetched before the first compare (the reference's max_leaf)
