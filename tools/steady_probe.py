@@ -14,9 +14,11 @@ api.init(0); api.set_option("solve", 1)
 for kv in [a for a in sys.argv[2:] if "=" in a]:
     k_, v_ = kv.split("="); api.set_option(k_, int(v_))
 W, H, K = synth.WIDTH, synth.HEIGHT, synth.K_TEST
+HR = H + int(os.environ.get("PR_PROBE_EXTRA_ROWS", "0"))     # experiment: a taller render frame (same boxes, another image stride)
 model = api.Model(os.path.join(ROOT, "tests/golden/obj_06.ply"))
 proj = api.compute_proj(K, W, H)
 sd = api.render_host(model, synth.scene_pose()[None], W, H, proj)[0]
+if HR != H: proj = api.compute_proj(K, W, HR)
 scene = api.Scene_projective().init_Scene_projective_cuda(sd, K)
 poses = synth.hypotheses(256)
 crit = api.ICPConvergenceCriteria(0.0, 0.0, 20)
@@ -27,7 +29,7 @@ def run(n):
         if DELAY:
             t_ = time.perf_counter()
             while time.perf_counter() - t_ < DELAY: pass
-        api.refine_submit(k & 1, model, poses, W, H, proj, K, scene, crit, results_dev=res.data())
+        api.refine_submit(k & 1, model, poses, W, HR, proj, K, scene, crit, results_dev=res.data())
         if k: api.refine_wait((k - 1) & 1)
     api.refine_wait((n - 1) & 1)
 out = []; hold = []
