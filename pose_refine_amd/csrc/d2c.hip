@@ -8,7 +8,8 @@ namespace prk {
 __global__ __launch_bounds__(256) void d2c_emit_box_kernel(const int32_t *__restrict__ depth, uint32_t width, uint32_t height,
                                                            const int4 *__restrict__ bbox, float fx, float fy, float cx, float cy,
                                                            const uint32_t *__restrict__ row_count, const uint32_t *__restrict__ row_off,
-                                                           pr_vec3 *__restrict__ cloud, size_t cloud_stride, const PoseMeta *__restrict__ meta)
+                                                           pr_vec3 *__restrict__ cloud, size_t cloud_stride, const PoseMeta *__restrict__ meta,
+                                                           const uint32_t *__restrict__ box_off)
 {
     const uint32_t lane = threadIdx.x & 63;
     const int4 bb = bbox[blockIdx.y];
@@ -19,6 +20,11 @@ __global__ __launch_bounds__(256) void d2c_emit_box_kernel(const int32_t *__rest
         if (row >= height) return;
         if (row_count[(size_t)blockIdx.y * height + row] == 0) continue;
         const int32_t *line = depth + ((size_t)blockIdx.y * height + row) * width;
+        if (box_off) {                                           // packed boxes (fill_box_kernel): the box's own pitch, origin at its top-left pixel; rows outside it hold nothing
+            const int r0 = (int)height - 1 - bb.w;
+            if ((int)row < r0 || (int)row > (int)height - 1 - bb.y) continue;
+            line = depth + box_off[blockIdx.y] + ((ptrdiff_t)row - r0) * (ptrdiff_t)max(bb.z - bb.x + 1, 0) - (ptrdiff_t)bb.x;
+        }
         pr_vec3 *out = cloud + start + row_off[(size_t)blockIdx.y * height + row];
         uint32_t done = 0;
         for (int x0 = bb.x; x0 <= bb.z; x0 += 512) {             // 8 independent loads in flight per lane
@@ -198,14 +204,14 @@ __global__ __launch_bounds__(256) void d2c_emit_kernel(const T *__restrict__ dep
 
 hipError_t launch_emit_box(const int32_t *depth, uint32_t n_poses, uint32_t width, uint32_t height, const int4 *bbox, float fx, float fy,
                            float cx, float cy, const uint32_t *row_count, const uint32_t *row_off, pr_vec3 *cloud, size_t cloud_stride,
-                           hipStream_t s, const PoseMeta *meta)
+                           hipStream_t s, const PoseMeta *meta, const uint32_t *box_off)
 {
     if (n_poses == 0) return hipSuccess;
     for (uint32_t i0 = 0; i0 < n_poses; i0 += 32768) {
         const uint32_t ni = (n_poses - i0 < 32768) ? (n_poses - i0) : 32768;
-        hipLaunchKernelGGL(d2c_emit_box_kernel, dim3((height + kBoxRowsPerBlock - 1) / kBoxRowsPerBlock, ni), dim3(256), 0, s, depth + (size_t)i0 * width * height, width, height,
+        hipLaunchKernelGGL(d2c_emit_box_kernel, dim3((height + kBoxRowsPerBlock - 1) / kBoxRowsPerBlock, ni), dim3(256), 0, s, box_off ? depth : depth + (size_t)i0 * width * height, width, height,
                            bbox + i0, fx, fy, cx, cy, row_count + (size_t)i0 * height, row_off + (size_t)i0 * height,
-                           meta ? cloud : cloud + (size_t)i0 * cloud_stride, cloud_stride, meta ? meta + i0 : nullptr);
+                           meta ? cloud : cloud + (size_t)i0 * cloud_stride, cloud_stride, meta ? meta + i0 : nullptr, box_off ? box_off + i0 : nullptr);
     }
     return hipGetLastError();
 }

@@ -17,6 +17,7 @@ constexpr uint32_t kPointsPerLane  = 4;                         // consecutive p
 constexpr uint32_t kPointsPerStep  = kBlockThreads * kPointsPerLane;   // 1024
 constexpr uint32_t kAccStride      = 32;                        // 29 sums padded to 32 floats
 constexpr uint32_t kCloudAlign     = PR_CLOUD_PACK;                 // fused path: clouds of a sub-batch packed one behind the other, each rounded up to this many points (0: one per fixed stride)
+constexpr uint32_t kBoxPack        = PR_BOX_PACK;                   // fused asynchronous path: depth boxes of a sub-batch packed (each rounded up to this many ints; 0: full frames)
 constexpr uint32_t kQCountStride   = 4;                         // queue counters per hypothesis (IcpBatch::nn_qcount)
 constexpr uint32_t kNNWordsPerPoint = 6;                        // per cloud point: winner | slack | queue 1 (2 words) | queue 2 (2 words)
 
@@ -167,13 +168,14 @@ hipError_t launch_render_bands(const pr_triangle *tris, uint32_t n_tris, const p
 hipError_t launch_render_boxes(const pr_triangle *tris, uint32_t n_tris, const pr_mat4 *poses_dev, uint32_t n_poses, const float *aabb,
                                int4 *bbox, int32_t *depth, uint32_t *row_count, uint32_t *row_off, uint32_t *counts,
                                uint32_t width, uint32_t height, const pr_mat4 &proj, pr_roi roi, hipStream_t s, bool compute_boxes = true,
-                               PoseMeta *meta = nullptr, DevIcpState *st = nullptr, uint32_t *arrive = nullptr, uint32_t cloud_stride = 0);
+                               PoseMeta *meta = nullptr, DevIcpState *st = nullptr, uint32_t *arrive = nullptr, uint32_t cloud_stride = 0,
+                               const uint32_t *box_off = nullptr);   // box_off: the boxes packed into `depth` at these offsets (ints), each with its own pitch (fill_box_kernel)
 hipError_t launch_pack_export(const DevIcpState *st, pr_result *out, const uint32_t *counts, uint32_t *host_counts, pr_result *host_results,
                               uint32_t n, hipStream_t s);
 hipError_t launch_stage_words(const void *src_host_mapped, void *dst, size_t bytes, hipStream_t s);
 hipError_t launch_emit_box(const int32_t *depth, uint32_t n_poses, uint32_t width, uint32_t height, const int4 *bbox, float fx, float fy,
                            float cx, float cy, const uint32_t *row_count, const uint32_t *row_off, pr_vec3 *cloud, size_t cloud_stride,
-                           hipStream_t s, const PoseMeta *meta = nullptr);     // meta: cloud i starts at meta[i].start (packed, launch_render_boxes wrote it) instead of i * cloud_stride
+                           hipStream_t s, const PoseMeta *meta = nullptr, const uint32_t *box_off = nullptr);     // meta: cloud i starts at meta[i].start (packed, launch_render_boxes wrote it) instead of i * cloud_stride
 
 hipError_t launch_icp_pass_proj_aos(const IcpBatch &b, const SceneProjAoS &sc, uint32_t n_poses, hipStream_t s);
 hipError_t launch_icp_pass_proj_packed(const IcpBatch &b, const SceneProjPacked &sc, uint32_t n_poses, hipStream_t s);

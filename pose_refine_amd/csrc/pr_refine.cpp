@@ -437,7 +437,7 @@ int refine_submit(int slot, const pr_triangle *tris_dev, size_t n_tris, const pr
     }
     g->sample_clock++;
     // the host copies of this batch's inputs (the poses are staged from here; the rest is what a re-run needs)
-    const size_t in_bytes = (sizeof(pr_mat4) + sizeof(int4)) * (size_t)P;
+    const size_t in_bytes = (sizeof(pr_mat4) + sizeof(int4) + sizeof(uint32_t)) * (size_t)P;      // [poses][pixel boxes][box offsets]
     PR_TRY(sl.h_in.ensure(in_bytes + 16));
     std::memcpy(sl.h_in.p, poses_host, sizeof(pr_mat4) * P);
     Resubmit &r = sl.again;
@@ -505,8 +505,8 @@ int refine_submit_async(Slot &sl, const pr_triangle *tris_dev, size_t n_tris, ui
     }
     HIP_TRY(hipEventRecord(sl.scene_ready, scene_stream));
 
-    // staging: [poses][boxes]; the cloud stride and the grid come from the largest box
-    const size_t in_bytes = (sizeof(pr_mat4) + sizeof(int4)) * (size_t)P;
+    // staging: [poses][boxes][box offsets]; the cloud stride and the grid come from the largest box
+    const size_t in_bytes = (sizeof(pr_mat4) + sizeof(int4) + sizeof(uint32_t)) * (size_t)P;
     PR_TRY(sl.poses_bbox.ensure(in_bytes + 16));
     pr_mat4 *h_poses = sl.h_in.as<pr_mat4>();
     int32_t *h_box = reinterpret_cast<int32_t *>(h_poses + P);
@@ -534,7 +534,19 @@ int refine_submit_async(Slot &sl, const pr_triangle *tris_dev, size_t n_tris, ui
     sub_cap = (uint32_t)std::max<size_t>(1, std::min<size_t>({ (size_t)sub_cap, ((size_t)4 << 30) / (img * sizeof(int32_t)), ((size_t)1 << 30) / cstride }));     // (2^30 cloud points per sub-batch: 12 GiB of clouds, 24 GiB of kd-tree search state at most)
     const uint32_t n_sub = (P + sub_cap - 1) / sub_cap;
     const uint32_t sub = (P + n_sub - 1) / n_sub;
-    PR_TRY(sl.depth.ensure(sizeof(int32_t) * img * sub));
+    PR_TRY(sl.depth.ensure(sizeof(int32_t) * (img + prk::kBoxPack) * sub));
+    // the pixel boxes of a sub-batch packed into the depth workspace: box i at h_off[i] ints, its own width as pitch (fill_box_kernel)
+    uint32_t *h_off = reinterpret_cast<uint32_t *>(h_box + 4 * (size_t)P);
+    if (prk::kBoxPack) {
+        size_t acc = 0;
+        for (uint32_t i = 0; i < P; ++i) {
+            if (i % sub == 0) acc = 0;
+            const int32_t *b = h_box + 4 * (size_t)i;
+            const size_t area = (size_t)std::max(0, b[2] - b[0] + 1) * (size_t)std::max(0, b[3] - b[1] + 1);
+            h_off[i] = (uint32_t)acc;
+            acc += (area + prk::kBoxPack - 1) / prk::kBoxPack * prk::kBoxPack;
+        }
+    }
     PR_TRY(sl.row_count.ensure(sizeof(uint32_t) * (size_t)H * sub));
     PR_TRY(sl.row_off.ensure(sizeof(uint32_t) * (size_t)H * sub));
     PR_TRY(sl.counts.ensure(sizeof(uint32_t) * P));
@@ -584,6 +596,7 @@ int refine_submit_async(Slot &sl, const pr_triangle *tris_dev, size_t n_tris, ui
     auto t_end = [&](size_t e0, int kind, uint32_t q0, uint32_t nq, bool edge) { const size_t e1 = t_event(); t_record(e1); if (!t_fail) sl.t_spans.push_back({ e0, e1, kind, q0, nq, edge, false, { 0, 0, 0 } }); };
     pr_mat4 *d_poses = sl.poses_bbox.as<pr_mat4>();
     int4 *d_box = reinterpret_cast<int4 *>(d_poses + P);
+    const uint32_t *d_off = prk::kBoxPack ? reinterpret_cast<const uint32_t *>(d_box + P) : nullptr;
     // Both phases are bound by the same units, so a batch that renders while the other slot is in the middle of its ICP loop
     // slows that loop by more than it gains; its render is therefore held back until the other slot has issued pass
     // `overlap_pass` of its (last sub-batch's) loop -- late enough to disturb little, early enough that the GPU never idles.
@@ -601,10 +614,10 @@ int refine_submit_async(Slot &sl, const pr_triangle *tris_dev, size_t n_tris, ui
         size_t te = timed ? t_begin() : 0;
         HIP_TRY(prk::launch_render_boxes(tris_dev, (uint32_t)n_tris, d_poses + q0, nq, nullptr, d_box + q0, sl.depth.as<int32_t>(),
                                          sl.row_count.as<uint32_t>(), sl.row_off.as<uint32_t>(), sl.counts.as<uint32_t>() + q0, W, H, *proj, none, st,
-                                         /*compute_boxes=*/false, meta, dstate, arrive, (uint32_t)cstride));
+                                         /*compute_boxes=*/false, meta, dstate, arrive, (uint32_t)cstride, d_off ? d_off + q0 : nullptr));
         if (timed) { t_end(te, kSpanRender, q0, nq, false); te = t_begin(); }
         HIP_TRY(prk::launch_emit_box(sl.depth.as<int32_t>(), nq, W, H, d_box + q0, K[0], K[4], K[2], K[5], sl.row_count.as<uint32_t>(),
-                                     sl.row_off.as<uint32_t>(), sl.cloud.as<pr_vec3>(), cstride, st, prk::kCloudAlign ? meta : nullptr));
+                                     sl.row_off.as<uint32_t>(), sl.cloud.as<pr_vec3>(), cstride, st, prk::kCloudAlign ? meta : nullptr, d_off ? d_off + q0 : nullptr));
         if (timed) t_end(te, kSpanCloud, q0, nq, false);
         if (q0 == 0) HIP_TRY(hipStreamWaitEvent(st, sl.scene_ready, 0));
         if (timed && q0 == 0)                                     // the timed loop starts when the other slot's batch is complete

@@ -16,6 +16,10 @@
 #define PR_CLOUD_PACK 32                                        // fused path: a hypothesis' cloud starts where the one before it ends, rounded up to this many points (32 = 128-byte lines; 0: fixed stride of the largest pixel box, rounds 1-4)
 #endif
 
+#ifndef PR_BOX_PACK
+#define PR_BOX_PACK 32                                          // fused asynchronous path: a hypothesis' pixel box is its own little image in the depth workspace, packed behind the one before it, rounded up to this many pixels (0: full frames, rounds 1-4)
+#endif
+
 // ---- kd-tree search: ordered per-lane walks (nn_query.h) ---------------------------------------------------------------------------
 #ifndef PR_LEAF_BATCH
 #define PR_LEAF_BATCH 10                                        // points of a leaf fetched before the first compare (the reference's max_leaf)

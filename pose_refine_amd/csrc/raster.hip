@@ -179,7 +179,8 @@ __device__ __forceinline__ void wave_raster(const TriSetup &t, int n, float (*w)
 __global__ __launch_bounds__(256) void raster_kernel(const pr_triangle *__restrict__ tris, uint32_t n_tris,
                                                      const pr_mat4 *__restrict__ poses, int32_t *__restrict__ depth,
                                                      uint32_t width, uint32_t height, pr_mat4 proj, pr_roi roi,
-                                                     uint32_t rw, uint32_t rh, const int4 *__restrict__ boxes, uint32_t n_poses, uint32_t pose_run)
+                                                     uint32_t rw, uint32_t rh, const int4 *__restrict__ boxes, uint32_t n_poses, uint32_t pose_run,
+                                                     const uint32_t *__restrict__ box_off)
 {
     __shared__ float sh[4][kSetupWords][64];
     __shared__ uint32_t shq[4][128];
@@ -207,9 +208,15 @@ __global__ __launch_bounds__(256) void raster_kernel(const pr_triangle *__restri
         const float *M = poses[by].m;                            // wave-uniform -> scalar loads
         int32_t *img = depth + (size_t)by * rw * rh;
         float cmin0 = rmin0, cmin1 = rmin1, cmax0 = rmax0, cmax1 = rmax1;
+        uint32_t pitch = rw;                                     // image row pitch; packed boxes (box_off): the box's own width, origin at its top-left pixel
         if (boxes) {                                             // fused path: the hypothesis' pixel box (already intersected with the caller's ROI,
             const int4 bb = boxes[by];                           // if any); a conservative box clips nothing, an ROI clips like renderer.cu:106-113
             cmin0 = (float)bb.x; cmin1 = (float)bb.y; cmax0 = (float)bb.z; cmax1 = (float)bb.w;
+            if (box_off) {
+                pitch = (uint32_t)max(bb.z - bb.x + 1, 0);
+                // pixel (x, image row r) of the box lives at off + (r - r0) * pitch + (x - bb.x), r0 = height - 1 - bb.w: fold the origin into the base
+                img = depth + box_off[by] - ((ptrdiff_t)((int)height - 1 - bb.w) * (ptrdiff_t)pitch + (ptrdiff_t)bb.x);
+            }
         }
         TriSetup t;
         int n = 0;
@@ -220,7 +227,7 @@ __global__ __launch_bounds__(256) void raster_kernel(const pr_triangle *__restri
         wave_raster(t, n, sh[wave], shq[wave], [&](int x, int y, int d) {
             const uint32_t xw = (uint32_t)(x - roi.x);
             const uint32_t yw = (uint32_t)((int)height - 1 - y - roi.y);
-            atomicMin(&img[xw + (size_t)yw * rw], d);
+            atomicMin(&img[xw + (size_t)yw * pitch], d);
         });
     }
 }
@@ -315,7 +322,17 @@ __global__ __launch_bounds__(256) void pose_bbox_kernel(const float *__restrict_
 
 // INT_MAX-fill and per-row valid counts restricted to each hypothesis' pixel box (image rows are
 // the flipped raster rows).  One wavefront per image row; rows outside the box only write count 0.
-__global__ __launch_bounds__(256) void fill_box_kernel(int32_t *__restrict__ depth, const int4 *__restrict__ bbox, uint32_t width, uint32_t height)
+// box_off (fused asynchronous path): the boxes of a sub-batch PACKED one behind the other, each as its own little image (pitch = its width) at
+// box_off[hypothesis] ints -- like the clouds (d2c_pack_starts_kernel), and for the same reason: 290 KB boxes 1.2 MB apart make the render depend
+// on the frame's size (a frame 17 or 32 rows taller: -3 %).  nullptr: full frames [hypothesis][height][width].
+__device__ __forceinline__ int32_t *box_line(int32_t *depth, const uint32_t *box_off, const int4 bb, uint32_t pose, uint32_t row, uint32_t width, uint32_t height)
+{
+    if (!box_off) return depth + ((size_t)pose * height + row) * width;
+    const ptrdiff_t pitch = max(bb.z - bb.x + 1, 0);
+    return depth + box_off[pose] + ((ptrdiff_t)row - (ptrdiff_t)((int)height - 1 - bb.w)) * pitch - (ptrdiff_t)bb.x;      // line[x] for bb.x <= x <= bb.z
+}
+__global__ __launch_bounds__(256) void fill_box_kernel(int32_t *__restrict__ depth, const int4 *__restrict__ bbox, uint32_t width, uint32_t height,
+                                                       const uint32_t *__restrict__ box_off)
 {
     const uint32_t lane = threadIdx.x & 63;
     const int4 bb = bbox[blockIdx.y];
@@ -324,12 +341,12 @@ __global__ __launch_bounds__(256) void fill_box_kernel(int32_t *__restrict__ dep
         if (row >= height) return;
         const int ry = (int)height - 1 - (int)row;                  // raster row of this image row
         if (ry < bb.y || ry > bb.w) continue;
-        int32_t *line = depth + ((size_t)blockIdx.y * height + row) * width;
+        int32_t *line = box_line(depth, box_off, bb, blockIdx.y, row, width, height);
         for (int x = bb.x + (int)lane; x <= bb.z; x += 64) line[x] = INT_MAX;
     }
 }
 __global__ __launch_bounds__(256) void count_box_kernel(const int32_t *__restrict__ depth, const int4 *__restrict__ bbox, uint32_t width,
-                                                        uint32_t height, uint32_t *__restrict__ row_count)
+                                                        uint32_t height, uint32_t *__restrict__ row_count, const uint32_t *__restrict__ box_off)
 {
     // latency-bound, not bandwidth-bound: every lane keeps 4 rows x 4 column chunks = 16 loads in flight before the first ballot
     const uint32_t lane = threadIdx.x & 63;
@@ -343,7 +360,7 @@ __global__ __launch_bounds__(256) void count_box_kernel(const int32_t *__restric
             const uint32_t row = row0 + r;
             const int ry = (int)height - 1 - (int)row;
             const bool live = row < height && ry >= bb.y && ry <= bb.w;
-            const int32_t *line = depth + ((size_t)blockIdx.y * height + (live ? row : 0)) * width;
+            const int32_t *line = live ? box_line(const_cast<int32_t *>(depth), box_off, bb, blockIdx.y, row, width, height) : depth;
 #pragma unroll
             for (int j = 0; j < 4; ++j) { const int x = x0 + 64 * j + (int)lane; v[r][j] = (live && x <= bb.z) ? line[x] : 0; }
         }
@@ -479,7 +496,7 @@ hipError_t launch_raster(const pr_triangle *tris, uint32_t n_tris, const pr_mat4
         const uint32_t np = (n_poses - p0 < 32768) ? (n_poses - p0) : 32768;
         const uint32_t run = raster_pose_run(n_tris, np);
         hipLaunchKernelGGL(raster_kernel, dim3((n_tris + 255) / 256, (np + run - 1) / run), dim3(256), 0, s, tris, n_tris, poses_dev + p0,
-                           depth + (size_t)p0 * rw * rh, width, height, proj, roi, rw, rh, (const int4 *)nullptr, np, run);
+                           depth + (size_t)p0 * rw * rh, width, height, proj, roi, rw, rh, (const int4 *)nullptr, np, run, (const uint32_t *)nullptr);
     }
     return hipGetLastError();
 }
@@ -525,7 +542,7 @@ hipError_t launch_render_bands(const pr_triangle *tris, uint32_t n_tris, const p
 hipError_t launch_render_boxes(const pr_triangle *tris, uint32_t n_tris, const pr_mat4 *poses_dev, uint32_t n_poses, const float *aabb,
                                int4 *bbox, int32_t *depth, uint32_t *row_count, uint32_t *row_off, uint32_t *counts,
                                uint32_t width, uint32_t height, const pr_mat4 &proj, pr_roi roi, hipStream_t s, bool compute_boxes,
-                               PoseMeta *meta, DevIcpState *st, uint32_t *arrive, uint32_t cloud_stride)
+                               PoseMeta *meta, DevIcpState *st, uint32_t *arrive, uint32_t cloud_stride, const uint32_t *box_off)
 {
     if (n_poses == 0) return hipSuccess;
     if (compute_boxes)
@@ -533,14 +550,15 @@ hipError_t launch_render_boxes(const pr_triangle *tris, uint32_t n_tris, const p
     const pr_roi none{ 0, 0, 0, 0 };
     for (uint32_t p0 = 0; p0 < n_poses; p0 += 32768) {
         const uint32_t np = (n_poses - p0 < 32768) ? (n_poses - p0) : 32768;
-        const size_t off = (size_t)p0 * width * height;
-        hipLaunchKernelGGL(fill_box_kernel, dim3((height + kBoxRowsPerBlock - 1) / kBoxRowsPerBlock, np), dim3(256), 0, s, depth + off, bbox + p0, width, height);
+        const size_t off = box_off ? 0 : (size_t)p0 * width * height;
+        const uint32_t *bo = box_off ? box_off + p0 : nullptr;
+        hipLaunchKernelGGL(fill_box_kernel, dim3((height + kBoxRowsPerBlock - 1) / kBoxRowsPerBlock, np), dim3(256), 0, s, depth + off, bbox + p0, width, height, bo);
         if (n_tris > 0)                                          // an empty mesh renders nothing: every cloud is empty
         { const uint32_t run = raster_pose_run(n_tris, np);
         hipLaunchKernelGGL(raster_kernel, dim3((n_tris + 255) / 256, (np + run - 1) / run), dim3(256), 0, s, tris, n_tris, poses_dev + p0, depth + off,
-                           width, height, proj, none, width, height, (const int4 *)(bbox + p0), np, run); }
+                           width, height, proj, none, width, height, (const int4 *)(bbox + p0), np, run, bo); }
         hipLaunchKernelGGL(count_box_kernel, dim3((height + kBoxRowsPerBlock - 1) / kBoxRowsPerBlock, np), dim3(256), 0, s, depth + off, bbox + p0, width, height,
-                           row_count + (size_t)p0 * height);
+                           row_count + (size_t)p0 * height, bo);
     }
     if (meta) { hipError_t e = launch_d2c_scan_init(row_count, height, row_off, counts, n_poses, meta, st, arrive, cloud_stride, s); if (e != hipSuccess) return e; }
     else { hipError_t e = launch_d2c_scan(row_count, height, row_off, counts, n_poses, s); if (e != hipSuccess) return e; }
