@@ -255,6 +255,12 @@ hipError_t launch_d2c_scan(const uint32_t *row_count, uint32_t gh, uint32_t *row
     hipLaunchKernelGGL(d2c_scan_kernel, dim3(n_img), dim3(256), 0, s, row_count, gh, row_off, counts);
     return hipGetLastError();
 }
+hipError_t launch_d2c_pack_starts(const uint32_t *counts, uint32_t n, PoseMeta *meta, hipStream_t s)
+{
+    if (n == 0 || !kCloudAlign) return hipSuccess;
+    hipLaunchKernelGGL(d2c_pack_starts_kernel, dim3(1), dim3(256), 0, s, counts, n, meta);
+    return hipGetLastError();
+}
 hipError_t launch_d2c_scan_init(const uint32_t *row_count, uint32_t gh, uint32_t *row_off, uint32_t *counts, uint32_t n_img,
                                 PoseMeta *meta, DevIcpState *st, uint32_t *arrive, uint32_t cloud_stride, hipStream_t s)
 {

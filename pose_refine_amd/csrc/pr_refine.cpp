@@ -117,14 +117,25 @@ int refine_impl(const pr_triangle *tris_dev, size_t n_tris, const pr_mat4 *poses
         HIP_TRY(hipStreamSynchronize(g->stream));
         uint32_t max_n = 0;
         for (uint32_t i = 0; i < np; ++i) max_n = std::max(max_n, h_counts[i]);
-        const size_t cstride = ((size_t)max_n + 3) & ~(size_t)3;           // keeps every cloud 16-byte aligned
-        PR_TRY(g->cloud.ensure(sizeof(pr_vec3) * std::max<size_t>(4, cstride) * np));
+        // the clouds packed one behind the other, as in the asynchronous path (d2c_pack_starts_kernel; the host adds the same rounded sizes)
+        size_t total = 0;
+        for (uint32_t i = 0; i < np; ++i) {
+            start[i] = (uint32_t)total; count[i] = h_counts[i];
+            total += prk::kCloudAlign ? ((size_t)h_counts[i] + prk::kCloudAlign - 1) / prk::kCloudAlign * prk::kCloudAlign : (((size_t)max_n + 3) & ~(size_t)3);
+        }
+        if (total > 0xffffffffull) { set_error("pr_refine_batch: more than 2^32 cloud points in one chunk"); return PR_ERR_INVALID; }
+        const size_t cstride = ((size_t)max_n + 3) & ~(size_t)3;           // (fixed-stride layout, kCloudAlign == 0: keeps every cloud 16-byte aligned)
+        PR_TRY(g->cloud.ensure(sizeof(pr_vec3) * std::max<size_t>(4, total)));
         if (max_n > 0) {
             SpanGuard sp(kSpanCloud);
+            if (prk::kCloudAlign) {
+                PR_TRY(g->meta.ensure(sizeof(prk::PoseMeta) * np));
+                HIP_TRY(prk::launch_d2c_pack_starts(g->counts.as<uint32_t>(), np, g->meta.as<prk::PoseMeta>(), g->stream));
+            }
             HIP_TRY(prk::launch_emit_box(g->depth.as<int32_t>(), np, W, H, g->bbox.as<int4>(), K[0], K[4], K[2], K[5],
-                                         g->row_count.as<uint32_t>(), g->row_off.as<uint32_t>(), g->cloud.as<pr_vec3>(), cstride, g->stream));
+                                         g->row_count.as<uint32_t>(), g->row_off.as<uint32_t>(), g->cloud.as<pr_vec3>(), cstride, g->stream,
+                                         prk::kCloudAlign ? g->meta.as<prk::PoseMeta>() : nullptr));
         }
-        for (uint32_t i = 0; i < np; ++i) { start[i] = (uint32_t)(i * cstride); count[i] = h_counts[i]; }
         if (sizes_host) std::memcpy(sizes_host + p0, count.data(), sizeof(uint32_t) * np);
         PR_TRY(icp_drive(g->cloud.as<pr_vec3>(), start.data(), count.data(), np, sc, crit,
                          results_host ? results_host + p0 : nullptr, results_dev ? results_dev + p0 : nullptr));
