@@ -651,7 +651,11 @@ int refine_submit_async(Slot &sl, const pr_triangle *tris_dev, size_t n_tris, ui
         uint32_t auto_overlap = 0;
         {
             const double weight = ((double)std::max<size_t>(n_tris, 1) / 31468.0) * (27400.0 / (double)std::max(g->cloud_hint, 1000u));
-            const double left = std::max(5.0, 2800.0 * weight / (double)std::max(nq, 1u));   // passes of this sub-batch's loop still to run
+            double left = std::max(5.0, 2800.0 * weight / (double)std::max(nq, 1u));   // passes of this sub-batch's loop still to run
+            // Since the clouds are packed (end of round 4) a render disturbs the loop beside it less, as long as the clouds of BOTH slots stay in
+            // the 256 MiB Infinity Cache: then the render is released with 13 passes to go (256 hypotheses: passes 5-9 give 272 k poses/s, the rule
+            // above -- pass 10 -- 268 k; 384: pass 8 277 k against 272 k at 14; 512, whose two slots' clouds do not fit: 275 k at pass 16, 263 k at 10).
+            if (2.0 * (double)nq * (double)std::max(g->cloud_hint, 1000u) * sizeof(pr_vec3) <= 240.0e6) left = std::max(left, 13.0);
             const double passes = (double)crit.max_iteration + 1.0;
             auto_overlap = left >= passes ? 0u : (uint32_t)(passes - left + 0.5);
             // kd-tree scenes: the loop is seven times a render and its first passes are the heavy ones -- the other slot's render (and with it

@@ -20,9 +20,10 @@ proj = api.compute_proj(K, W, H)
 sd = api.render_host(model, synth.scene_pose()[None], W, H, proj)[0]
 if HR != H: proj = api.compute_proj(K, W, HR)
 scene = api.Scene_projective().init_Scene_projective_cuda(sd, K)
-poses = synth.hypotheses(256)
+NP = int(os.environ.get("PR_PROBE_POSES", "256"))
+poses = synth.hypotheses(NP)
 crit = api.ICPConvergenceCriteria(0.0, 0.0, 20)
-res = api.DeviceVector(256 * 18, np.float32)
+res = api.DeviceVector(NP * 18, np.float32)
 DELAY = float(os.environ.get("PR_PROBE_SUBMIT_DELAY_US", "0")) * 1e-6     # experiment: busy-wait before every submit (a slow host)
 def run(n):
     for k in range(n):
@@ -36,10 +37,10 @@ out = []; hold = []
 for r in range(5):
     run(6)
     t0 = time.perf_counter(); run(60); dt = (time.perf_counter() - t0) / 60
-    out.append(256 / dt / 1e3)
+    out.append(NP / dt / 1e3)
     if what == "shutdown": api.shutdown(); api.init(0); api.set_option("solve", 1)
     elif what == "shift":
         api.shutdown(); hold.append(api.DeviceVector((r + 1) * 9_437_184 + 4096 * r, np.float32)); api.init(0); api.set_option("solve", 1)
-        res = api.DeviceVector(256 * 18, np.float32)
+        res = api.DeviceVector(NP * 18, np.float32)
     elif what == "sleep": time.sleep(0.5)
 print(what, " ".join(f"{v:.0f}" for v in out))
