@@ -92,15 +92,16 @@ int refine_impl(const pr_triangle *tris_dev, size_t n_tris, const pr_mat4 *poses
     HIP_TRY(prk::launch_model_aabb(tris_dev, (uint32_t)n_tris, g->aabb_keys.as<uint32_t>(), g->aabb.as<float>(), nullptr, nullptr, g->stream));
     for (uint32_t p0 = 0; p0 < P; p0 += chunk) {
         const uint32_t np = std::min(chunk, P - p0);
-        PR_TRY(g->depth.ensure(sizeof(int32_t) * img * np));
+        PR_TRY(g->depth.ensure(sizeof(int32_t) * (img + prk::kBoxPack) * np));
         PR_TRY(g->row_count.ensure(sizeof(uint32_t) * (size_t)H * np));
         PR_TRY(g->row_off.ensure(sizeof(uint32_t) * (size_t)H * np));
         PR_TRY(g->counts.ensure(sizeof(uint32_t) * np));
         PR_TRY(g->h_counts.ensure(sizeof(uint32_t) * np));
         uint32_t *h_counts = g->h_counts.as<uint32_t>();
         // per-pose pixel boxes; raster + row counts + row scan
-        PR_TRY(g->bbox.ensure(sizeof(int4) * np));
+        PR_TRY(g->bbox.ensure(sizeof(int4) * np + sizeof(uint32_t) * np));   // boxes, then the offsets of the packed boxes (box_pack_offsets_kernel)
         PR_TRY(g->poses.ensure(sizeof(pr_mat4) * np));
+        uint32_t *box_off = (prk::kBoxPack && opt.raster_mode != 1) ? reinterpret_cast<uint32_t *>(g->bbox.as<int4>() + np) : nullptr;
         {
             SpanGuard sp(kSpanRender);
             HIP_TRY(hipMemcpyAsync(g->poses.p, poses_host + p0, sizeof(pr_mat4) * np, hipMemcpyHostToDevice, g->stream));
@@ -111,7 +112,7 @@ int refine_impl(const pr_triangle *tris_dev, size_t n_tris, const pr_mat4 *poses
             else
                 HIP_TRY(prk::launch_render_boxes(tris_dev, (uint32_t)n_tris, g->poses.as<pr_mat4>(), np, g->aabb.as<float>(), g->bbox.as<int4>(),
                                                  g->depth.as<int32_t>(), g->row_count.as<uint32_t>(), g->row_off.as<uint32_t>(),
-                                                 g->counts.as<uint32_t>(), W, H, *proj, roi, g->stream));
+                                                 g->counts.as<uint32_t>(), W, H, *proj, roi, g->stream, /*compute_boxes=*/true, nullptr, nullptr, nullptr, 0, box_off));
         }
         HIP_TRY(hipMemcpyAsync(h_counts, g->counts.p, sizeof(uint32_t) * np, hipMemcpyDeviceToHost, g->stream));
         HIP_TRY(hipStreamSynchronize(g->stream));
@@ -134,7 +135,7 @@ int refine_impl(const pr_triangle *tris_dev, size_t n_tris, const pr_mat4 *poses
             }
             HIP_TRY(prk::launch_emit_box(g->depth.as<int32_t>(), np, W, H, g->bbox.as<int4>(), K[0], K[4], K[2], K[5],
                                          g->row_count.as<uint32_t>(), g->row_off.as<uint32_t>(), g->cloud.as<pr_vec3>(), cstride, g->stream,
-                                         prk::kCloudAlign ? g->meta.as<prk::PoseMeta>() : nullptr));
+                                         prk::kCloudAlign ? g->meta.as<prk::PoseMeta>() : nullptr, box_off));
         }
         if (sizes_host) std::memcpy(sizes_host + p0, count.data(), sizeof(uint32_t) * np);
         PR_TRY(icp_drive(g->cloud.as<pr_vec3>(), start.data(), count.data(), np, sc, crit,

@@ -538,6 +538,32 @@ hipError_t launch_render_bands(const pr_triangle *tris, uint32_t n_tris, const p
     return hipGetLastError();
 }
 
+// offsets of the packed boxes from boxes computed on the device (synchronous path; the asynchronous path's host computes both): exclusive scan of
+// the areas rounded up to kBoxPack pixels, one workgroup
+__global__ __launch_bounds__(256) void box_pack_offsets_kernel(const int4 *__restrict__ bbox, uint32_t n, uint32_t *__restrict__ off)
+{
+    __shared__ uint32_t buf[256];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n; base += 256) {
+        const uint32_t i = base + threadIdx.x;
+        uint32_t v = 0;
+        if (i < n) { const int4 b = bbox[i]; const uint32_t area = (uint32_t)max(b.z - b.x + 1, 0) * (uint32_t)max(b.w - b.y + 1, 0); v = (area + (kBoxPack - 1u)) / (kBoxPack ? kBoxPack : 1u) * kBoxPack; }
+        buf[threadIdx.x] = v;
+        __syncthreads();
+        for (uint32_t o = 1; o < 256; o <<= 1) {
+            const uint32_t t = (threadIdx.x >= o) ? buf[threadIdx.x - o] : 0;
+            __syncthreads();
+            buf[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < n) off[i] = carry + buf[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 255) carry += buf[255];
+        __syncthreads();
+    }
+}
 // fused-path render, reference scheme (global int32 atomicMin) but only inside each hypothesis' box
 hipError_t launch_render_boxes(const pr_triangle *tris, uint32_t n_tris, const pr_mat4 *poses_dev, uint32_t n_poses, const float *aabb,
                                int4 *bbox, int32_t *depth, uint32_t *row_count, uint32_t *row_off, uint32_t *counts,
@@ -545,8 +571,10 @@ hipError_t launch_render_boxes(const pr_triangle *tris, uint32_t n_tris, const p
                                PoseMeta *meta, DevIcpState *st, uint32_t *arrive, uint32_t cloud_stride, const uint32_t *box_off)
 {
     if (n_poses == 0) return hipSuccess;
-    if (compute_boxes)
+    if (compute_boxes) {
         hipLaunchKernelGGL(pose_bbox_kernel, dim3((n_poses + 255) / 256), dim3(256), 0, s, aabb, poses_dev, n_poses, proj, width, height, roi, bbox);
+        if (box_off && kBoxPack) hipLaunchKernelGGL(box_pack_offsets_kernel, dim3(1), dim3(256), 0, s, (const int4 *)bbox, n_poses, const_cast<uint32_t *>(box_off));   // (the caller's scratch: filled here)
+    }
     const pr_roi none{ 0, 0, 0, 0 };
     for (uint32_t p0 = 0; p0 < n_poses; p0 += 32768) {
         const uint32_t np = (n_poses - p0 < 32768) ? (n_poses - p0) : 32768;
