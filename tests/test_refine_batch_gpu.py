@@ -275,3 +275,41 @@ def test_more_hypotheses_than_a_launch_has_rows_and_empty_models(gpu):
         assert np.array_equal(api.render_host(m, poses[:5], W, H, proj), O.render(tris[:n], poses[:5], W, H, proj) if n else np.zeros((5, H, W), np.int32))
         res, sizes = api.refine_batch(m, poses[:5], W, H, proj, K, scene, crit)
         assert [int(s) for s in sizes] == [int((r > 0).sum()) for r in O.render(tris[:n], poses[:5], W, H, proj)] if n else not sizes.any()
+
+
+@pytest.mark.device_solve
+@pytest.mark.parametrize("W,H", [(96, 64), (97, 61)])
+def test_packed_clouds_and_boxes_at_their_capacity_bound(gpu, W, H):
+    """The fused paths pack the clouds and the pixel boxes of a batch one behind the other; the capacity they reserve is the largest
+    box per hypothesis.  A wall that fills the frame makes every box the whole frame and every cloud W x H points -- the sum of the
+    packed sizes then EQUALS the reservation -- next to a hypothesis that renders nothing and one that fills part of the frame:
+    sizes, inlier counts and transforms of the synchronous call and of the asynchronous slots against the oracle."""
+    K = np.array([1.2 * W, 0, W / 2, 0, 1.2 * W, H / 2, 0, 0, 1], np.float32)
+    proj = O.compute_proj(K, W, H)
+    s = 4000.0                                                        # a wall far larger than the view, 300 mm in front of the camera
+    wall = np.array([[[-s, -s, 0], [s, -s, 0], [s, s, 0]], [[-s, -s, 0], [s, s, 0], [-s, s, 0]]], np.float32)
+    small = wall * np.float32(0.01)                                   # ... and a 80 mm patch of it, 20 mm nearer
+    small[:, :, 2] -= 20.0
+    tris = np.concatenate([wall, small]).astype(np.float32)
+    base = np.eye(4, dtype=np.float32); base[2, 3] = 300.0
+    scene_depth = O.render(tris, base[None], W, H, proj)[0]
+    poses = []
+    for k in range(11):
+        p = base.copy(); p[0, 3] += 0.7 * k; p[2, 3] += 1.5 * k
+        poses.append(p)
+    gone = base.copy(); gone[2, 3] = -500.0                           # behind the camera: renders nothing
+    poses = np.stack(poses[:5] + [gone] + poses[5:])
+    crit = (0.0, 0.0, 4)
+    osc = O.ProjScene(scene_depth, K)
+    ores, osizes, _ = O.refine_batch(tris, poses, W, H, proj, K, osc, crit, O.SUM_CANONICAL, api.get_option("points_per_block"))
+    assert osizes.max() == W * H and osizes[5] == 0
+    model = api.Model(tris=tris)
+    gs = api.Scene_projective().init_Scene_projective_cuda(scene_depth, K, W, H)
+    res, sizes = api.refine_batch(model, poses, W, H, proj, K, gs, api.ICPConvergenceCriteria(*crit))
+    assert np.array_equal(sizes, osizes) and np.array_equal(res["fitness"], ores["fitness"])
+    assert np.allclose(res["T"], ores["T"], rtol=0, atol=1e-4)
+    for b in (0, 1, 0):
+        api.refine_submit(b, model, poses, W, H, proj, K, gs, api.ICPConvergenceCriteria(*crit))
+        ares, asizes = api.refine_wait(b)
+        assert np.array_equal(asizes, osizes) and np.array_equal(ares["fitness"], ores["fitness"])
+        assert np.array_equal(ares["T"], res["T"])
