@@ -41,6 +41,12 @@ def test_device_nn_scene_preparation_bit_exact(gpu, scenario, dtype):
     assert np.array_equal(dev.pcd_buffer.to_host()[:3 * n], host.pcd_host.reshape(-1))
     assert np.array_equal(dev.normal_buffer.to_host()[:3 * n], host.normal_host.reshape(-1))
     assert dev.nodes.to_host()[:m].tobytes() == host.nodes_host.tobytes()
+    # ... and, directly, == the ORACLE's preparation (pcd_scene.cpp:10-184 restated in oracle/pose_oracle.c): points, normals, nodes
+    ref = O.NNScene(d, scenario["K"])
+    assert (n, m) == (len(ref.pcd), len(ref.nodes))
+    assert np.array_equal(dev.pcd_buffer.to_host()[:3 * n], ref.pcd.reshape(-1))
+    assert np.array_equal(dev.normal_buffer.to_host()[:3 * n], ref.normal.reshape(-1))
+    assert dev.nodes.to_host()[:m].tobytes() == ref.nodes.tobytes()
     # and ICP against the device-built scene gives the same answer
     r0 = api.ICP_Point2Plane(api.DeviceVector.from_host(scenario["cloud"].reshape(-1)), host, api.ICPConvergenceCriteria(0.0, 0.0, 5))
     r1 = api.ICP_Point2Plane(api.DeviceVector.from_host(scenario["cloud"].reshape(-1)), dev, api.ICPConvergenceCriteria(0.0, 0.0, 5))
@@ -63,6 +69,12 @@ def test_device_kdtree_build_random_points_with_ties(gpu, max_leaf, n):
     assert dcnt.value == cnt.value
     assert dnodes.to_host()[:cnt.value].tobytes() == hnodes[:cnt.value].tobytes()
     assert np.array_equal(dp.to_host(), hp.reshape(-1)) and np.array_equal(dn.to_host(), hn.reshape(-1))
+    # the device build against the ORACLE's build_tree (pcd_scene.cpp:45-184), not only against the library's own host build
+    op, on = pts.copy(), nrm.copy()
+    onodes = np.zeros(2 * n + 1, O.KDNODE)
+    ocnt = O.lib().po_kd_build(op.reshape(-1), on.reshape(-1), n, max_leaf, onodes.ctypes.data, len(onodes))
+    assert dcnt.value == ocnt and dnodes.to_host()[:ocnt].tobytes() == onodes[:ocnt].tobytes()
+    assert np.array_equal(dp.to_host(), op.reshape(-1)) and np.array_equal(dn.to_host(), on.reshape(-1))
 
 
 # ---- cropped projective scene: pcd2dep / dep2pcd with tl_x, tl_y (common.h:47-73) ------------------------------------------
