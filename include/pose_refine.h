@@ -284,7 +284,6 @@ int pr_gather_results(const pr_result *send_dev, uint32_t n_local, uint32_t n_to
  *   "pose_groups"      [0]     streams the batch is split over (1..4; 0 = 2): device solve = one group's solve tail under another's pass;
  *                              host solve = software pipeline (the host solves one group while another group's pass runs)
  *   "graph"            [1]     device solve, one pose group, synchronous path: replay the loop as a hipGraph
- *   "icp_flow"         [0]     device solve: one persistent dataflow launch for all iterations
  *   "sub_batch"        [512]   asynchronous path: hypotheses per sub-batch (cache residency of the clouds)
  *   "overlap_pass"     [-1]    asynchronous path: the other slot's render may start after this pass of a slot's loop (-1 = chosen per batch)
  *   "raster_mode"      [0]     fused render: 0 = global atomicMin inside the pose's pixel box, 1 = LDS depth bands (synchronous path)

@@ -16,7 +16,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.environ.get("PR_BUILD_OUT") or os.path.join(HERE, "lib", "libpose_refine_hip.so")      # PR_BUILD_OUT: a variant library for an A/B run
 # one translation unit per stage of the path (kernels + their launchers), the C ABI and the host-side code; headers = shared device code
-SOURCES = ["raster.hip", "d2c.hip", "icp_pass.hip", "icp_flow.hip", "icp_debug.hip", "nn_search.hip", "nn_build.hip", "kd_build.hip", "scene_prep.hip",
+SOURCES = ["raster.hip", "d2c.hip", "icp_pass.hip", "icp_debug.hip", "nn_search.hip", "nn_build.hip", "kd_build.hip", "scene_prep.hip",
            "pr_context.cpp", "pr_scene.cpp", "pr_icp.cpp", "pr_refine.cpp", "pr_comm.cpp", "pr_host.cpp"]
 HEADERS = ["pr_internal.h", "pr_runtime.h", "pr_solver.inl", "pr_tuning.h", "pr_device.h", "pr_launch.h", "proj_query.h", "nn_query.h", "icp_accumulate.h",
            "icp_solve_device.h"]

@@ -395,10 +395,11 @@ __global__ __launch_bounds__(256, PR_WIDE_WAVES) void nn_tree_wide_kernel(IcpBat
             // The query in whole units of the frame, once per query: an interval [u, u + 3] that holds its coordinate with more than a unit to
             // spare on either side (the difference to the frame's origin is formed first -- exact to half an ulp of a number below the frame's
             // edge -- then scaled; a unit is at least an ulp of the largest coordinate, nn_frame_kernel refuses the frame otherwise: that is also
-            // the slack a box's stored corners have against their real-number positions).  Negative and NaN values convert to 0.
-            const uint32_t ux = min((uint32_t)__builtin_fmaf(q.x - scene.wmin[0], w_inv, -1.0625f), 65532u),
-                           uy = min((uint32_t)__builtin_fmaf(q.y - scene.wmin[1], w_inv, -1.0625f), 65532u),
-                           uz = min((uint32_t)__builtin_fmaf(q.z - scene.wmin[2], w_inv, -1.0625f), 65532u);
+            // the slack a box's stored corners have against their real-number positions).  Negative and NaN values become 0.
+            // (clamped in float BEFORE the conversion -- a float -> unsigned cast of a negative, NaN or > 2^32 value is undefined in C++; v_max_f32 with 0 returns 0 for NaN)
+            const uint32_t ux = (uint32_t)__builtin_fminf(__builtin_fmaxf(__builtin_fmaf(q.x - scene.wmin[0], w_inv, -1.0625f), 0.0f), 65532.0f),
+                           uy = (uint32_t)__builtin_fminf(__builtin_fmaxf(__builtin_fmaf(q.y - scene.wmin[1], w_inv, -1.0625f), 0.0f), 65532.0f),
+                           uz = (uint32_t)__builtin_fminf(__builtin_fmaxf(__builtin_fmaf(q.z - scene.wmin[2], w_inv, -1.0625f), 0.0f), 65532.0f);
             qq[lane] = make_uint2(ux | (uy << 16), uz * 0x10001u);
             best[lane] = ((unsigned long long)mine.y << 32) | kNoIdx;
             second[lane] = 0x7f7fffffu; tied[lane] = 0xffffffffu; ovf[lane] = 0u; root[lane] = lane;

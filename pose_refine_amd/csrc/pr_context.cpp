@@ -30,8 +30,8 @@ void ctx_teardown(Ctx *c)        // c->mu held (or c unreachable); the calling t
     hipStreamSynchronize(c->stream);
     for (Slot &sl : c->slots) slot_release(sl);
     for (DevBuf *b : { &c->aabb, &c->aabb_keys, &c->bbox, &c->poses, &c->depth, &c->row_count, &c->row_off, &c->counts, &c->cloud, &c->meta, &c->partial,
-                       &c->sums, &c->packed.rec, &c->topo, &c->bmin, &c->bmax, &c->pts, &c->nnrec, &c->nnrec32, &c->nndesc, &c->nnwide, &c->nnwq, &c->nn_prev, &c->nndepth, &c->dstate, &c->dresults, &c->vbdesc, &c->flowsync, &c->arrive, &c->conv16, &c->conv8, &c->kd_idx, &c->kd_scratch, &c->kd_child, &c->kd_ctrl, &c->kd_tmp, &c->nn_full, &c->gather_tmp, &c->nn_cells, &c->nn_grid, &c->nn_counters }) b->release();
-    for (PinBuf *b : { &c->h_sums, &c->h_meta, &c->h_counts, &c->h_results, &c->h_dstate, &c->h_flow }) b->release();
+                       &c->sums, &c->packed.rec, &c->topo, &c->bmin, &c->bmax, &c->pts, &c->nnrec, &c->nnrec32, &c->nndesc, &c->nnwide, &c->nnwq, &c->nn_prev, &c->nndepth, &c->dstate, &c->dresults, &c->arrive, &c->conv16, &c->conv8, &c->kd_idx, &c->kd_scratch, &c->kd_child, &c->kd_ctrl, &c->kd_tmp, &c->nn_full, &c->gather_tmp, &c->nn_cells, &c->nn_grid, &c->nn_counters }) b->release();
+    for (PinBuf *b : { &c->h_sums, &c->h_meta, &c->h_counts, &c->h_results, &c->h_dstate }) b->release();
     c->packed = PackedCache(); c->nn_cache.valid = false;
     for (auto &gr : c->graphs) destroy_graph(gr);
     c->graphs.clear();
@@ -55,6 +55,7 @@ PrivateCtx::~PrivateCtx()               // a thread that ends with a private con
     if (!c) return;
     private_unregister(c);
     { std::lock_guard<std::mutex> lk(c->mu); comm_teardown(c); ctx_teardown(c); }
+    private_wait_unpinned(c);
     delete c; c = nullptr;
 }
 
@@ -129,6 +130,7 @@ int pr_thread_context(int enable)
     const int dev = tl_private.c->device;
     private_unregister(tl_private.c);
     { std::lock_guard<std::mutex> lk(tl_private.c->mu); comm_teardown(tl_private.c); ctx_teardown(tl_private.c); }
+    private_wait_unpinned(tl_private.c);
     delete tl_private.c; tl_private.c = nullptr; g = nullptr;
     return bind_shared(dev);
 }
@@ -175,14 +177,22 @@ int pr_free(void *dev_ptr)
     {
         std::vector<Ctx *> others;
         { std::lock_guard<std::mutex> lk(g_reg_mu); for (Ctx *c : g_shared) if (c && c != self && c->device == self->device) others.push_back(c); }
-        std::lock_guard<std::mutex> plk(g_private_mu);
-        for (Ctx *c : g_private) if (c != self && c->device == self->device) others.push_back(c);
-        for (Ctx *c : others) {
-            std::lock_guard<std::mutex> lk(c->mu);
-            if (!c->ready) continue;
-            if (c->stream) (void)hipStreamSynchronize(c->stream);
-            for (hipStream_t sd : c->side) if (sd) (void)hipStreamSynchronize(sd);
-            for (Slot &sl : c->slots) slot_drain(sl);
+        const size_t n_shared = others.size();
+        {   // private contexts: pinned under the list's mutex, drained without it (pr_runtime.h "context registry")
+            std::lock_guard<std::mutex> plk(g_private_mu);
+            for (Ctx *c : g_private) if (c != self && c->device == self->device) { c->pins.fetch_add(1, std::memory_order_acq_rel); others.push_back(c); }
+        }
+        for (size_t i = 0; i < others.size(); ++i) {
+            Ctx *c = others[i];
+            {
+                std::lock_guard<std::mutex> lk(c->mu);
+                if (c->ready) {
+                    if (c->stream) (void)hipStreamSynchronize(c->stream);
+                    for (hipStream_t sd : c->side) if (sd) (void)hipStreamSynchronize(sd);
+                    for (Slot &sl : c->slots) slot_drain(sl);
+                }
+            }
+            if (i >= n_shared) c->pins.fetch_sub(1, std::memory_order_acq_rel);
         }
     }
     HIP_TRY(hipFree(dev_ptr));
@@ -243,7 +253,6 @@ int pr_set_option(const char *name, int value)
     else if (n == "nn_grid") opt.nn_grid = value ? 1 : 0;
     else if (n == "nn_count") opt.nn_count = value ? 1 : 0;
     else if (n == "graph") opt.use_graph = value ? 1 : 0;
-    else if (n == "icp_flow") opt.icp_flow = value ? 1 : 0;
     else if (n == "fused_solve") opt.fused_solve = value ? 1 : 0;
     else if (n == "sub_batch") opt.sub_batch = std::min(32768, std::max(32, value));    // (the hypothesis index is the y dimension of the launches)
     else if (n == "overlap_pass") opt.overlap_pass = std::max(-1, value);
@@ -280,7 +289,6 @@ int pr_get_option(const char *name, int *value)
     else if (n == "raster_mode") *value = opt.raster_mode;
     else if (n == "eager_streams") *value = opt.eager_streams;
     else if (n == "graph") *value = opt.use_graph;
-    else if (n == "icp_flow") *value = opt.icp_flow;
     else if (n == "fused_solve") *value = opt.fused_solve;
     else if (n == "sub_batch") *value = opt.sub_batch;
     else if (n == "overlap_pass") *value = opt.overlap_pass;

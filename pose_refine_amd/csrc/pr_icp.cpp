@@ -56,7 +56,7 @@ int icp_drive(pr_vec3 *cloud_base, const uint32_t *start_h, const uint32_t *coun
     prk::IcpBatch b{};
     b.cloud = cloud_base; b.meta = g->meta.as<prk::PoseMeta>(); b.partial = g->partial.as<float>();
     b.nblk = nblk; b.steps = steps;
-    sc.nn_split = (sc.kind == PR_SCENE_NN && sc.nn.rec32 && opt.nn_split && !opt.icp_flow) ? 1u : 0u;
+    sc.nn_split = (sc.kind == PR_SCENE_NN && sc.nn.rec32 && opt.nn_split) ? 1u : 0u;
     sc.nn_max_points = max_n;
     if (sc.nn_split && opt.nn_count) {                            // instrumented run: kCounterPasses x 8 counters, accumulated until read
         const bool fresh = g->nn_counters.p == nullptr;
@@ -97,54 +97,6 @@ int icp_drive(pr_vec3 *cloud_base, const uint32_t *start_h, const uint32_t *coun
         const bool may_exit_early = (crit.relative_fitness > 0.0f && crit.relative_rmse > 0.0f);
         const bool fused = opt.fused_solve != 0;
         if (fused) PR_TRY(g->arrive.ensure(sizeof(uint32_t) * P));
-
-        if (opt.icp_flow) {
-            // ---- dataflow path: one persistent launch runs every iteration of every hypothesis ------------------
-            std::vector<uint2> desc;
-            desc.reserve((size_t)P * std::max(1u, nblk));
-            for (uint32_t i = 0; i < P; ++i) {
-                const uint32_t nb = (count_h[i] + ppb - 1) / ppb;
-                for (uint32_t gi = 0; gi < nb; ++gi) desc.push_back(make_uint2(i, gi));
-            }
-            const uint32_t n_vbs = (uint32_t)desc.size();
-            const size_t sync_words = (size_t)2 * P + 1;
-            PR_TRY(g->vbdesc.ensure(sizeof(uint2) * std::max<size_t>(1, n_vbs)));
-            PR_TRY(g->flowsync.ensure(sizeof(uint32_t) * sync_words));
-            PR_TRY(g->h_flow.ensure(sizeof(uint2) * std::max<size_t>(1, n_vbs) + sizeof(uint32_t) * (sync_words + 1)));
-            uint32_t *h_sync = g->h_flow.as<uint32_t>();
-            uint2 *h_desc = reinterpret_cast<uint2 *>(h_sync + ((sync_words + 2) & ~(size_t)1));
-            for (uint32_t i = 0; i < P; ++i) { h_sync[i] = 0; h_sync[P + i] = (h_meta[i].state == prk::kSkip) ? 0xffffffffu : 0u; }
-            h_sync[2 * P] = 0;
-            if (n_vbs) std::memcpy(h_desc, desc.data(), sizeof(uint2) * n_vbs);
-            HIP_TRY(hipMemcpyAsync(g->dstate.p, init, sizeof(prk::DevIcpState) * P, hipMemcpyHostToDevice, g->stream));
-            HIP_TRY(hipMemcpyAsync(g->meta.p, h_meta, sizeof(prk::PoseMeta) * P, hipMemcpyHostToDevice, g->stream));
-            HIP_TRY(hipMemcpyAsync(g->flowsync.p, h_sync, sizeof(uint32_t) * sync_words, hipMemcpyHostToDevice, g->stream));
-            if (n_vbs) {
-                HIP_TRY(hipMemcpyAsync(g->vbdesc.p, h_desc, sizeof(uint2) * n_vbs, hipMemcpyHostToDevice, g->stream));
-                prk::FlowArgs fa{};
-                fa.cloud = cloud_base; fa.meta = g->meta.as<prk::PoseMeta>(); fa.partial = g->partial.as<float>();
-                fa.st = g->dstate.as<prk::DevIcpState>(); fa.vb_desc = g->vbdesc.as<uint2>();
-                fa.arrive = g->flowsync.as<uint32_t>(); fa.ready = fa.arrive + P; fa.abort_flag = fa.arrive + 2 * P;
-                fa.n_vbs = n_vbs; fa.nblk = nblk; fa.steps = steps; fa.crit = crit;
-                uint32_t grid = 0;
-                SpanGuard sp(kSpanIcp);
-                if (sc.kind == PR_SCENE_NN) HIP_TRY(prk::launch_icp_flow_nn(fa, sc.nn, (uint32_t)g->n_cus, g->stream, &grid));
-                else if (sc.packed) HIP_TRY(prk::launch_icp_flow_proj_packed(fa, sc.pk, (uint32_t)g->n_cus, g->stream, &grid));
-                else HIP_TRY(prk::launch_icp_flow_proj_aos(fa, sc.aos, (uint32_t)g->n_cus, g->stream, &grid));
-                if (opt.profile) {                                  // one launch = all passes: 36 B/point on pass 0, 48 B/point afterwards
-                    g->icp_points += sum_n * (uint64_t)(crit.max_iteration + 1);
-                    g->icp_bytes += sum_n * (36ull + 48ull * (uint64_t)crit.max_iteration);
-                }
-            }
-            HIP_TRY(prk::launch_pack_results(g->dstate.as<prk::DevIcpState>(), dres, P, g->stream));
-            if (results_host) HIP_TRY(hipMemcpyAsync(res, dres, sizeof(pr_result) * P, hipMemcpyDeviceToHost, g->stream));
-            HIP_TRY(hipMemcpyAsync(h_sync + 2 * P, g->flowsync.as<uint32_t>() + 2 * P, sizeof(uint32_t), hipMemcpyDeviceToHost, g->stream));
-            HIP_TRY(hipStreamSynchronize(g->stream));
-            drain_spans();
-            if (h_sync[2 * P] != 0) { set_error("dataflow ICP kernel timed out waiting on a hypothesis (workgroups not co-resident?)"); return PR_ERR_HIP; }
-            if (results_host) std::memcpy(results_host, res, sizeof(pr_result) * P);
-            return PR_OK;
-        }
 
         // profile==2: every sample_period-th call is a timed call -- it runs synchronously, as one pose group, with the other slot
         // drained, and times every correspondence launch of its loop

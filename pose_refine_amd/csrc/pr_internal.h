@@ -131,20 +131,6 @@ struct DevIcpState {
     int32_t passes;
 };
 
-// arguments of the persistent dataflow ICP kernel (icp_flow_kernel)
-struct FlowArgs {
-    pr_vec3       *cloud;
-    PoseMeta      *meta;        // [P]   read/written through system-scope accesses inside the kernel
-    float         *partial;     // [P][nblk][kAccStride]
-    DevIcpState   *st;          // [P]
-    const uint2   *vb_desc;     // [n_vbs] {pose, g}: the virtual workgroups of the canonical tree, pose-major
-    uint32_t      *arrive;      // [P] zeroed before launch: partial sums delivered so far (monotonic over iterations)
-    uint32_t      *ready;       // [P] zeroed (0xffffffff for empty clouds): iterations whose update is published
-    uint32_t      *abort_flag;  // [1] zeroed; set when a bounded spin times out
-    uint32_t       n_vbs, nblk, steps;
-    pr_criteria    crit;
-};
-
 // ---- launchers (all asynchronous on `s`) ----------------------------------------------------------
 hipError_t launch_fill_i32(int32_t *dst, size_t n, int32_t v, hipStream_t s);
 hipError_t launch_raster(const pr_triangle *tris, uint32_t n_tris, const pr_mat4 *poses_dev, uint32_t n_poses,
@@ -195,9 +181,6 @@ hipError_t launch_contrib29_nn(pr_vec3 *cloud, uint32_t n, const float *update12
 size_t nn_grid_cells(uint32_t gw, uint32_t gh);
 hipError_t launch_build_nn_grid(const pr_vec3 *pcd, uint32_t n_points, uint32_t gw, uint32_t gh, float fx, float fy, float cx, float cy,
                                 int32_t *cell_idx, float4 *grid, uint32_t *info, hipStream_t s);
-hipError_t launch_icp_flow_proj_aos(const FlowArgs &a, const SceneProjAoS &sc, uint32_t n_cus, hipStream_t s, uint32_t *grid_out);
-hipError_t launch_icp_flow_proj_packed(const FlowArgs &a, const SceneProjPacked &sc, uint32_t n_cus, hipStream_t s, uint32_t *grid_out);
-hipError_t launch_icp_flow_nn(const FlowArgs &a, const SceneNNDev &sc, uint32_t n_cus, hipStream_t s, uint32_t *grid_out);
 hipError_t launch_icp_finalize(const float *partial, const PoseMeta *meta, uint32_t nblk,
                                uint32_t steps, float *sums, uint32_t n_poses, hipStream_t s);
 // PR_SOLVE_DEVICE: finalize + convergence test + 6x6 solve + state update in one kernel

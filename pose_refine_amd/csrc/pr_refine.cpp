@@ -431,9 +431,9 @@ int refine_submit(int slot, const pr_triangle *tris_dev, size_t n_tris, const pr
     const bool proj_scene = (scene_kind == PR_SCENE_PROJ || scene_kind == PR_SCENE_PROJ_CROP);
     const bool nn_scene = (scene_kind == PR_SCENE_NN) && !opt.nn_count;     // (an instrumented kd-tree run stays synchronous)
     (void)img;                                                   // (large frames: the asynchronous path sizes its sub-batches to its workspace bound)
-    const bool async_ok = P > 0 && opt.solve_mode == PR_SOLVE_DEVICE && !opt.icp_flow && opt.raster_mode == 0 && (proj_scene || nn_scene)
+    const bool async_ok = P > 0 && opt.solve_mode == PR_SOLVE_DEVICE && opt.raster_mode == 0 && (proj_scene || nn_scene)
                           && (opt.profile == 0 || opt.profile == 3 || (opt.profile == 2 && !sample_call));
-    if (!async_ok && P > 0 && opt.solve_mode == PR_SOLVE_HOST && opt.host_worker && opt.profile == 0 && !opt.icp_flow && !opt.nn_count) {
+    if (!async_ok && P > 0 && opt.solve_mode == PR_SOLVE_HOST && opt.host_worker && opt.profile == 0 && !opt.nn_count) {
         // host solve, nothing to time: the batch goes to the slot's helper thread (see SlotWorker) and this call returns
         PR_TRY(slot_worker_post(sl, tris_dev, n_tris, poses_host, P, W, H, proj, K, scene_kind, scene, crit, roi, results_host, results_dev, sizes_host));
         sl.pending = true; sl.delivered = false; sl.worker_job = true;

@@ -8,6 +8,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cfloat>
 #include <cmath>
 #include <cstdarg>
@@ -117,8 +118,8 @@ extern WriteLog g_writes;
 // ---- process-wide options (pr_set_option): plain ints, shared by every context ---------------------
 constexpr int kSlots = 2;
 struct Options {
-    int pose_groups = 0;             // split the batch over this many streams (1..4); 0 = by scene: 2 for projective scenes (1.31 vs 1.45 ms/step at
-                                     // 256 poses), 3 for kd-tree scenes; launches of different groups overlap, so timed calls fall back to one group
+    int pose_groups = 0;             // split the batch over this many streams (1..4); 0 = two, for either scene kind (pose_groups_for below has the measurements);
+                                     // launches of different groups overlap, so timed calls fall back to one group
     int solve_mode = PR_SOLVE_HOST;
     int host_worker = 1;             // PR_SOLVE_HOST batches of pr_refine_submit run on the slot's helper thread (0: on the caller's thread, inside the call)
     int steps = 3;                   // 1024-point steps per workgroup -> 3072 points per workgroup (9 workgroups per 26 k-point cloud: measured 3-5 % faster than 2048 / 4096)
@@ -140,17 +141,15 @@ struct Options {
                                      // -1 = the per-batch rule of a running pipeline.  Rounds 2-3 released the next render at pass 0 here; with the roofline
                                      // sample out of the timed region that reads 239 / 240 / 251 k against 253 / 253 / 256 k poses/s for the rule in three
                                      // alternating 20-step runs on one box: batches 1 and 2 then finish together and the third finds an empty chip
-    int overlap_pass = -1;           // asynchronous path: the other slot's render may start once this slot has issued this pass of its loop (-1: chosen per batch, see refine_submit_async)
-                                     // (-1: 70 % of the passes -- measured best of 6/10/14/17 at 256 and 512 poses per batch)
+    int overlap_pass = -1;           // asynchronous path: the other slot's render may start once this slot has issued this pass of its loop; -1 = chosen per batch
+                                     // (refine_submit_async: with 13 passes to go while both slots' clouds fit the Infinity Cache, later by the render's weight when
+                                     // they do not; kd-tree scenes: pass 0)
     int sub_batch = 512;             // asynchronous fused path: hypotheses per sub-batch (cache residency of the clouds)
     int fused_solve = 1;             // PR_SOLVE_DEVICE: the workgroup delivering a hypothesis' last partial sum also runs its finalize + solve (no second launch per iteration)
-    int icp_flow = 0;                // PR_SOLVE_DEVICE: 1 = one persistent dataflow launch for all iterations (bit-identical; measured equal at
-                                     // 256 poses and 35 % slower at 1024), 0 = one launch per pass + per solve
     int use_graph = 1;               // PR_SOLVE_DEVICE, single pose group only (the runtime serialises the branches of a captured multi-stream
                                      // graph, which forfeits the overlap): capture the whole iteration loop in a hipGraph and replay it
     int eager_streams = 1;           // asynchronous path: create the streams of both slots in one run (see slot_streams)
-    int raster_mode = 0;             // fused path: 0 = global atomicMin inside the per-pose pixel box (reference scheme), 1 = LDS depth bands (int32),
-                                     // 2 = one workgroup per hypothesis with its whole box in LDS as 16-bit depth offsets (global path for boxes that do not fit)
+    int raster_mode = 0;             // fused path: 0 = global atomicMin inside the per-pose pixel box (reference scheme), 1 = LDS depth bands (int32); pr_set_option refuses anything else
     int scene_cache = 1;             // keep the packed projective scene / kd traversal records of the latest scene between calls (pr_scene_invalidate)
 };
 extern Options opt;
@@ -238,6 +237,7 @@ inline void destroy_graph(CachedGraph &c)
 
 struct Ctx {
     std::mutex mu;                   // one call at a time per context; contexts of different devices / threads run side by side
+    std::atomic<int> pins{ 0 };      // pr_free holds a private context alive through this while it drains it WITHOUT g_private_mu (private_unregister_and_wait)
     bool ready = false;
     bool is_private = false;         // pr_thread_context(1): owned by one host thread
     int device = -1;
@@ -251,11 +251,12 @@ struct Ctx {
     const void *mesh_key = nullptr; size_t mesh_n = 0;   // triangle buffer aabb_host belongs to
     uint32_t cloud_hint = 0;          // largest cloud of the latest finished asynchronous batch: sizes the next batch's grid
     // workspaces
-    DevBuf aabb, aabb_keys, bbox, poses, depth, row_count, row_off, counts, cloud, meta, partial, sums, topo, bmin, bmax, pts, nnrec, nnrec32, nndesc, nnwide, nnwq, nn_prev, nndepth, dstate, dresults, vbdesc, flowsync, arrive, conv16, conv8, kd_idx, kd_scratch, kd_child, kd_ctrl, kd_tmp, nn_full;
-    PinBuf h_sums, h_meta, h_counts, h_results, h_dstate, h_flow;
+    DevBuf aabb, aabb_keys, bbox, poses, depth, row_count, row_off, counts, cloud, meta, partial, sums, topo, bmin, bmax, pts, nnrec, nnrec32, nndesc, nnwide, nnwq, nn_prev, nndepth, dstate, dresults, arrive, conv16, conv8, kd_idx, kd_scratch, kd_child, kd_ctrl, kd_tmp, nn_full;
+    PinBuf h_sums, h_meta, h_counts, h_results, h_dstate;
     PackedCache packed;              // synchronous paths (the asynchronous slots keep their own)
     struct { const void *pcd = nullptr, *normal = nullptr, *nodes = nullptr; uint32_t n_points = 0, n_nodes = 0; uint64_t gen = 0; bool valid = false;
              uint32_t info[24] = { 0 };
+             float frame_margin = 0.0f;                             // the acceptance radius (x 1.01) the wide records' frame was built for: a larger radius rebuilds
              bool grid_valid = false, grid_usable = false; uint32_t gw = 0, gh = 0; float gk[4] = { 0, 0, 0, 0 }; } nn_cache;   // kd traversal records (topo ... nndesc) + pixel grid of the latest kd-tree scene
     DevBuf nn_cells, nn_grid, nn_counters;
     // profiling
@@ -286,12 +287,16 @@ extern int g_default_device;
 extern thread_local Ctx *g;
 struct PrivateCtx { Ctx *c = nullptr; ~PrivateCtx(); };   // destructor below, once the teardown helpers exist
 extern thread_local PrivateCtx tl_private;
-// every private context alive, so that pr_free can drain the device's contexts one by one (lock order: g_private_mu, then a context's mu;
-// nothing takes them the other way round: contexts register before and unregister after they are used)
+// every private context alive, so that pr_free can drain the device's contexts one by one.  g_private_mu guards the LIST only and is never
+// held while a context's mu is taken or waited for (a slot's helper thread registers / unregisters its private context while its
+// caller holds the caller's context mutex and waits for it; pr_free on a third thread used to hold g_private_mu while it locked every context
+// of the device -- a three-way wait).  pr_free pins the contexts it found (under g_private_mu), drops g_private_mu, then locks them one by
+// one; a context that is being released is unregistered first (no new pins), torn down, and deleted once its pins are gone.
 extern std::mutex g_private_mu;
 extern std::vector<Ctx *> g_private;
 inline void private_register(Ctx *c) { std::lock_guard<std::mutex> lk(g_private_mu); g_private.push_back(c); }
 inline void private_unregister(Ctx *c) { std::lock_guard<std::mutex> lk(g_private_mu); for (size_t i = 0; i < g_private.size(); ++i) if (g_private[i] == c) { g_private.erase(g_private.begin() + (long)i); break; } }
+inline void private_wait_unpinned(Ctx *c) { while (c->pins.load(std::memory_order_acquire) != 0) std::this_thread::yield(); }   // call with NO lock held, after private_unregister
 
 inline void drop_graphs() { for (auto &c : g->graphs) destroy_graph(c); g->graphs.clear(); }
 void comm_teardown(Ctx *c);

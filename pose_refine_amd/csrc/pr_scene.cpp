@@ -85,7 +85,8 @@ int make_scene(int kind, const void *scene, bool want_packed, SceneSel &out, Pac
         const pr_scene_nn *s = static_cast<const pr_scene_nn *>(scene);
         if (!s || !s->pcd || !s->normal || !s->nodes || s->n_nodes == 0 || s->n_points == 0) { set_error("invalid pr_scene_nn"); return PR_ERR_INVALID; }
         auto &nc = g->nn_cache;
-        const bool same = nc.valid && nc.pcd == s->pcd && nc.normal == s->normal && nc.nodes == s->nodes && nc.n_points == s->n_points && nc.n_nodes == s->n_nodes;
+        const bool same = nc.valid && nc.pcd == s->pcd && nc.normal == s->normal && nc.nodes == s->nodes && nc.n_points == s->n_points && nc.n_nodes == s->n_nodes &&
+                          s->max_dist_diff * 1.01f <= nc.frame_margin;     // (a smaller radius keeps its pruning inside the larger frame; a larger one would lose it outside the old)
         bool hit = same && opt.scene_cache && !g_writes.written_since(nc.gen, s->pcd, (size_t)s->n_points * sizeof(pr_vec3)) &&
                    !g_writes.written_since(nc.gen, s->nodes, (size_t)s->n_nodes * sizeof(pr_kdnode));
         if (hit && verify_now) {
@@ -120,6 +121,7 @@ int make_scene(int kind, const void *scene, bool want_packed, SceneSel &out, Pac
             HIP_TRY(hipMemcpyAsync(nc.info, g->nndepth.p, sizeof nc.info, hipMemcpyDeviceToHost, g->stream));
             HIP_TRY(hipStreamSynchronize(g->stream));
             nc.pcd = s->pcd; nc.normal = s->normal; nc.nodes = s->nodes; nc.n_points = s->n_points; nc.n_nodes = s->n_nodes; nc.gen = gen; nc.valid = true;
+            nc.frame_margin = s->max_dist_diff * 1.01f;
         }
         const uint32_t *info = nc.info;
         const uint32_t depth = info[0];

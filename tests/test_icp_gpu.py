@@ -115,26 +115,6 @@ def test_icp_degenerate_clouds(gpu, scenario, gscenes):
         assert np.allclose(res[i]["T"], o["T"], rtol=0, atol=TOL_T), i
 
 
-@pytest.mark.parametrize("kind,P", [("proj", 70), ("nn", 5)])
-def test_dataflow_and_multilaunch_icp_agree_bitwise(gpu, model, scenario, gscenes, kind, P):
-    """The persistent dataflow kernel (all iterations in one launch, option icp_flow=1) and the launch-per-pass loop run the same
-    canonical tree and the same solver: results must be bit-identical, with fixed and with early-exit criteria."""
-    poses = synth.hypotheses(P)
-    api.set_option("solve", api.SOLVE_DEVICE)
-    try:
-        for crit in ((0.0, 0.0, 20), (1e-5, 1e-5, 30)):
-            out = []
-            for flow in (1, 0):
-                api.set_option("icp_flow", flow)
-                out.append(api.refine_batch(model, poses, W, H, scenario["proj"], scenario["K"], gscenes[kind],
-                                            api.ICPConvergenceCriteria(*crit)))
-            assert np.array_equal(out[0][1], out[1][1])
-            assert out[0][0].tobytes() == out[1][0].tobytes(), crit
-    finally:
-        api.set_option("icp_flow", 0)
-        api.set_option("solve", api.SOLVE_HOST)
-
-
 @pytest.mark.device_solve
 @pytest.mark.parametrize("kind", ["proj", "nn"])
 def test_cloud_with_non_finite_and_absurd_points_matches_the_oracle(gpu, scenario, gscenes, kind):

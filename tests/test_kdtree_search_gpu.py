@@ -139,12 +139,11 @@ def test_graph_cache_keeps_kdtree_batches_of_equal_shape_apart(gpu, scenario, gs
 
 
 @pytest.mark.device_solve
-def test_deep_tree_runs_the_24_entry_stacks_and_every_dataflow_form(gpu, scenario, gscenes):
+def test_deep_tree_runs_the_24_entry_stacks_in_every_search_form(gpu, scenario, gscenes):
     """A scene of 140 000 points with one point per leaf is 18-19 levels deep: the per-lane stacks take their 24-entry form
-    (`icp_pass_kernel<SceneNNDev, true, 24 | 280>`, `nn_tree_kernel<280>`, `icp_flow_kernel<SceneNNDev, true, 24>`), which no scene of
-    a 640x480 frame reaches.  All searches -- task walk, binary walk after the search kernel, fused compact and exact stack walks, the
-    stackless walk, each as launch-per-pass loop and as the persistent dataflow kernel -- give bit-identical results; so does the
-    dataflow kernel on a projective scene whose arrays are used as they are (`icp_flow_kernel<SceneProjAoS>`)."""
+    (`icp_pass_kernel<SceneNNDev, true, 24 | 280>`, `nn_tree_kernel<280>`), which no scene of a 640x480 frame reaches.  All searches --
+    task walk, binary walk after the search kernel, fused compact and exact stack walks, the stackless walk -- give bit-identical
+    results; so does a projective scene whose arrays are used as they are (`icp_pass_kernel<SceneProjAoS>`) against the packed one."""
     rng = np.random.default_rng(77)
     n = 140000
     pts = rng.uniform(-0.2, 0.2, size=(n, 3)).astype(np.float32)
@@ -161,30 +160,29 @@ def test_deep_tree_runs_the_24_entry_stacks_and_every_dataflow_form(gpu, scenari
     assert 16 < depth <= 24
     cloud = rng.uniform(-0.2, 0.2, size=(3000, 3)).astype(np.float32)
     crit = api.ICPConvergenceCriteria(0.0, 0.0, 3)
-    names = ("nn_stack", "nn_compact", "nn_wide", "nn_split", "icp_flow")
+    names = ("nn_stack", "nn_compact", "nn_wide", "nn_split")
     out = {}
     try:
-        for combo in ((1, 1, 1, 1, 0), (1, 1, 0, 1, 0), (1, 1, 0, 0, 0), (1, 0, 0, 0, 0), (0, 0, 0, 0, 0), (1, 1, 0, 0, 1), (1, 0, 0, 0, 1), (0, 0, 0, 0, 1)):
+        for combo in ((1, 1, 1, 1), (1, 1, 0, 1), (1, 1, 0, 0), (1, 0, 0, 0), (0, 0, 0, 0)):
             for k, v in zip(names, combo):
                 api.set_option(k, v)
             dev = api.DeviceVector.from_host(cloud.reshape(-1))
             r = api.ICP_Point2Plane(dev, scene, crit)
             out[combo] = (r.transformation_.tobytes(), r.fitness_, r.inlier_rmse_, dev.to_host().tobytes())
-        ref = out[(0, 0, 0, 0, 0)]
+        ref = out[(0, 0, 0, 0)]
         assert ref[1] > 0.5
         for combo, o in out.items():
             assert o == ref, combo
-        # projective scene without the packed records, dataflow against launch-per-pass
-        api.set_option("scene_cache", 0)
+        # projective scene: the caller's arrays as they are (no packed records) against the packed scene
         got = []
-        for flow in (0, 1):
-            api.set_option("icp_flow", flow)
+        for cache in (0, 1):
+            api.set_option("scene_cache", cache)
             dev = api.DeviceVector.from_host(scenario["cloud"].reshape(-1))
             r = api.ICP_Point2Plane(dev, gscenes["proj"], api.ICPConvergenceCriteria(0.0, 0.0, 6))
             got.append((r.transformation_.tobytes(), r.fitness_, r.inlier_rmse_, dev.to_host().tobytes()))
         assert got[0] == got[1] and got[0][1] > 0.5
     finally:
-        for k, v in zip(names, (1, 1, 1, 1, 0)):
+        for k, v in zip(names, (1, 1, 1, 1)):
             api.set_option(k, v)
         api.set_option("scene_cache", 1)
 
