@@ -305,9 +305,9 @@ constexpr int kGridMaxW = PR_GRID_MAXW;                                     // w
 // half-widths of the pixel window that holds every scene point closer than sqrt(bound); false when it exceeds kGridMaxW
 __device__ __forceinline__ bool grid_window(const SceneNNDev &s, float sx, float sy, float sz, float bound, int &wx, int &wy)
 {
-    const float r = sqrtf(bound) * 1.0001f;
+    const float r = margin_sqrt(bound) * 1.0001f;
     if (!(sz - r > 0.25f * sz)) return false;                    // also NaN and points at or behind the camera
-    const float k = r / (sz * (sz - r));
+    const float k = r * margin_rcp(sz * (sz - r)) * 1.000001f;
     const float du = s.gfx * k * (sz + fabsf(sx)), dv = s.gfy * k * (sz + fabsf(sy));
     if (!(du <= (float)kGridMaxW - 1e-3f && dv <= (float)kGridMaxW - 1e-3f)) return false;
     wx = (int)ceilf(du + 1e-3f); wy = (int)ceilf(dv + 1e-3f);
@@ -358,6 +358,56 @@ __device__ __forceinline__ void grid_ring_min(const float4 *__restrict__ level, 
     bx = min(max(x0 + (kbest - ky * kW), 0), lw - 1);
     by = min(max(y0 + min(ky, nb - 1), 0), lh - 1);
 }
+// Round 5: the rings of the descent as SELECTION KEYS.  The descent decides nothing -- it only has to land on a near scene point, whose distance
+// (inflated) is the bound -- so its arithmetic is free to be approximate: a cell's key is its squared distance with the products contracted into
+// FMAs (x and y side by side in packed instructions), the low six mantissa bits replaced by the cell's number in the ring; the ring's minimum
+// is one unsigned minimum per cell (v_min3_u32: two cells per instruction).  6.5 VALU instructions per cell instead of 12 (three subtractions,
+// three multiplications, two additions, a compare and two selects), and the ring is clamped as a whole (its origin moved inside the level),
+// not cell by cell.  The key of the landing cell understates that cell's exact distance (the search's own expression, pcd_scene.h:88-91) by at
+// most the truncation (2^-17 relative) plus the rounding differences of three contracted products (< 3e-7): the bound taken from it is
+// inflated by 2e-5 instead of nn_seed_bound's 1e-6 -- a tenth of a micron at 15 mm, far inside the 5-micron units of the wide records.
+constexpr uint32_t kRingKeyMask = ~63u;
+__device__ __forceinline__ uint32_t ring_key(const float4 c, const float2v sxy, float sz, uint32_t idx)
+{
+    const float2v dxy = float2v{ c.x, c.y } - sxy;
+    const float2v qxy = dxy * dxy;
+    const float dz = c.z - sz;
+    const float d2 = __builtin_fmaf(dz, dz, qxy.x) + qxy.y;          // empty cells hold huge coordinates: +inf (0x7f800000), above every real key
+    return (__float_as_uint(d2) & kRingKeyMask) | idx;
+}
+// the kW x kW ring whose first cell is (x0, y0), moved inside the level; returns the smallest key (index bits cleared) and that cell
+template <int kW>
+__device__ __forceinline__ uint32_t grid_ring_key(const float4 *__restrict__ level, int lw, int lh, int x0, int y0, const float2v sxy, float sz, int &bx, int &by)
+{
+    static_assert(kW * kW <= 64, "a ring's cell number has six bits in the key");
+    constexpr int kRingRows = PR_RING_ROWS;
+    const int xc = min(max(x0, 0), lw - kW), yc = min(max(y0, 0), lh - kW);          // (the caller guarantees lw, lh >= kW)
+    const uint32_t pitch = (uint32_t)lw * 16u;
+    uint32_t row = (uint32_t)(yc * lw + xc) * 16u, best = 0xffffffffu;
+#pragma unroll
+    for (int dy0 = 0; dy0 < kW; dy0 += kRingRows) {
+        float4 c[kRingRows][kW];
+#pragma unroll
+        for (int r = 0; r < kRingRows; ++r)
+#pragma unroll
+            for (int dx = 0; dx < kW; ++dx)
+                if (dy0 + r < kW) c[r][dx] = ld_off<float4>(level, row + (uint32_t)r * pitch + (uint32_t)dx * 16u);
+#pragma unroll
+        for (int r = 0; r < kRingRows; ++r)
+#pragma unroll
+            for (int dx = 0; dx < kW; ++dx)
+                if (dy0 + r < kW) best = min(best, ring_key(c[r][dx], sxy, sz, (uint32_t)((dy0 + r) * kW + dx)));
+        row += (uint32_t)kRingRows * pitch;
+#if PR_RING_STAGED
+        // the next rows' loads stay behind this group's keys: with nothing between them the compiler issues all kW x kW loads of a ring at once
+        // (their addresses no longer depend on anything) and the kernel needs 101 VGPRs instead of 72 -- four wavefronts per SIMD instead of seven
+        asm volatile("" : "+v"(best) : : "memory");
+#endif
+    }
+    const int k = (int)(best & 63u), ky = k / kW;
+    bx = xc + (k - ky * kW); by = yc + ky;
+    return best & kRingKeyMask;
+}
 __device__ __forceinline__ void grid_pyramid_bound(const SceneNNDev &s, float sx, float sy, float sz, float &best)
 {
     const int w4 = ((int)s.gw + 3) / 4, h4 = ((int)s.gh + 3) / 4, w16 = (w4 + 3) / 4, h16 = (h4 + 3) / 4, w64 = (w16 + 3) / 4, h64 = (h16 + 3) / 4;
@@ -385,6 +435,17 @@ __device__ __forceinline__ void grid_pyramid_bound(const SceneNNDev &s, float sx
         if (d2 < dmin) { dmin = d2; bx = i % w64; by = i / w64; }
     }
     dall = dmin;
+    if (w16 >= PR_RING_W && h16 >= PR_RING_W) {                      // (wave-uniform: every level holds a whole ring -- any frame of 320 x 320 pixels or more)
+        const float2v sxy{ sx, sy };
+        uint32_t k = grid_ring_key<PR_RING_W>(s.pyr16, w16, h16, bx * 4 - PR_RING_OFF, by * 4 - PR_RING_OFF, sxy, sz, bx, by);
+        k = min(k, grid_ring_key<PR_RING_W>(s.pyr4, w4, h4, bx * 4 - PR_RING_OFF, by * 4 - PR_RING_OFF, sxy, sz, bx, by));
+        k = min(k, grid_ring_key<PR_RING_W>(s.grid, (int)s.gw, (int)s.gh, bx * 4 - PR_RING_OFF, by * 4 - PR_RING_OFF, sxy, sz, bx, by));
+        const float bk = __uint_as_float(k) * 1.00002f + 1e-30f;     // the landing cell's exact distance is below this (see above); +inf / NaN keys give no bound
+        const float b0 = dall * 1.000001f + 1e-30f;
+        if (b0 < best) best = b0;
+        if (bk < best) best = bk;
+        return;
+    }
     float d;
     grid_ring_min(s.pyr16, w16, h16, bx * 4 - PR_RING_OFF, by * 4 - PR_RING_OFF, PR_RING_W, sx, sy, sz, d, bx, by);   dall = fminf(dall, d);
     grid_ring_min(s.pyr4, w4, h4, bx * 4 - PR_RING_OFF, by * 4 - PR_RING_OFF, PR_RING_W, sx, sy, sz, d, bx, by);       dall = fminf(dall, d);
@@ -392,10 +453,24 @@ __device__ __forceinline__ void grid_pyramid_bound(const SceneNNDev &s, float sx
     const float b = dall * 1.000001f + 1e-30f;                       // empty cells hold huge coordinates: inf
     if (b < best) best = b;
 }
+// `full` (round 5, "window first"): the caller has no tight bound yet -- only a previous winner a few millimetres away.  The LARGEST window is
+// scanned without one: the radius it covers (`rc`, the formula of `settle`) takes the bound's place, and whatever minimum the scan finds below
+// rc^2 is the global one (every closer point projects into the window) -- exact under the same uniqueness rule, without the 84-cell descent
+// through the representative points that would otherwise have to tighten the bound first.  When nothing lies within rc the call fails and the
+// query takes the usual way (descent, tree); `*full_min` then carries the nearest point the window did hold (a valid bound), if any.
 __device__ __forceinline__ bool grid_search(const SceneNNDev &s, float sx, float sy, float sz, float bound, uint32_t &winner, uint32_t *cells = nullptr,
-                                            float *best_sq = nullptr, float *other_sq = nullptr, bool settle = false)
+                                            float *best_sq = nullptr, float *other_sq = nullptr, bool settle = false, bool full = false)
 {
     int wx, wy;
+    if (full) {
+        const float W = (float)kGridMaxW - 4e-3f;
+        const float rx = W * sz * sz * margin_rcp(s.gfx * (sz + fabsf(sx)) + W * sz), ry = W * sz * sz * margin_rcp(s.gfy * (sz + fabsf(sy)) + W * sz);
+        const float rc = fminf(rx, ry) * 0.999f;                   // (grid_window below VERIFIES that the window of rc fits: rc itself may be approximate)
+        if (!(rc > 0.0f) || !grid_window(s, sx, sy, sz, rc * rc, wx, wy)) return false;
+        const float c2 = rc * rc * 0.9999f;
+        if (c2 < bound) bound = c2;                                // only points strictly inside the covered radius can win
+        settle = true;                                             // (the margin: everything the window holds)
+    }
     // The window has to hold every point closer than sqrt(bound) for the search to be exact.  When a slightly larger window still
     // fits it is taken instead: the extra ring costs a few cells and tells how far the RUNNER-UP is (other_sq), which is what lets
     // the following passes keep this winner without searching (nn_search_kernel).  `settle`: the point has (nearly) stopped moving,
@@ -405,12 +480,12 @@ __device__ __forceinline__ bool grid_search(const SceneNNDev &s, float sx, float
     // millimetres) never got a margin at all and went through the window in every pass.
     float cover = bound;
     if (other_sq) {
-        const float rb = sqrtf(bound);
+        const float rb = margin_sqrt(bound) * 1.000001f;
         float rc = rb + PR_NN_COVER_PAD;
         if (settle) {
             const float W = (float)kGridMaxW - 4e-3f;
-            const float rx = W * sz * sz / (s.gfx * (sz + fabsf(sx)) + W * sz), ry = W * sz * sz / (s.gfy * (sz + fabsf(sy)) + W * sz);
-            rc = fminf(rx, ry) * 0.999f;
+            const float rx = W * sz * sz * margin_rcp(s.gfx * (sz + fabsf(sx)) + W * sz), ry = W * sz * sz * margin_rcp(s.gfy * (sz + fabsf(sy)) + W * sz);
+            rc = fminf(rx, ry) * 0.999f;                           // (approximate is fine: grid_window verifies the window of whatever radius is taken)
         }
         if (rc > rb && grid_window(s, sx, sy, sz, rc * rc, wx, wy)) cover = rc * rc;
         else if (settle) { rc = rb + PR_NN_COVER_PAD; if (grid_window(s, sx, sy, sz, rc * rc, wx, wy)) cover = rc * rc; }
@@ -439,27 +514,33 @@ __device__ __forceinline__ bool grid_search(const SceneNNDev &s, float sx, float
             else if (d2 == best && best_i >= 0) ++ties;
             else if (d2 < second) second = d2;
         }
-        if (best_i < 0 || ties != 0) return false;
+        if (best_i < 0 || ties != 0) { if (full && best_sq && best_i >= 0) *best_sq = best; return false; }     // (a tie: still an existing point's distance)
         winner = (uint32_t)best_i;
         if (best_sq) *best_sq = best;
         if (other_sq) *other_sq = second;
         return true;
     }
-    for (int y = y0; y <= y1; ++y) {
-        const float4 *row = s.grid + (size_t)y * s.gw;
-        float4 c[2 * kGridMaxW + 1];
+    constexpr int kWinRows = PR_WIN_ROWS;                           // rows of the window in flight at a time (one round trip per group)
+    for (int y = y0; y <= y1; y += kWinRows) {
+        float4 c[kWinRows][2 * kGridMaxW + 1];
 #pragma unroll
-        for (int i = 0; i < 2 * kGridMaxW + 1; ++i) c[i] = row[min(x0 + i, x1)];          // one round trip per row
+        for (int r = 0; r < kWinRows; ++r) {
+            const float4 *row = s.grid + (size_t)min(y + r, y1) * s.gw;
 #pragma unroll
-        for (int i = 0; i < 2 * kGridMaxW + 1; ++i) {
-            if (x0 + i > x1) continue;                           // (clamped repeats must not count as ties)
-            const float d2 = (sx - c[i].x) * (sx - c[i].x) + (sy - c[i].y) * (sy - c[i].y) + (sz - c[i].z) * (sz - c[i].z);
-            if (d2 < best) { if (best_i >= 0) second = best; best = d2; best_i = __float_as_int(c[i].w); ties = 0; }
-            else if (d2 == best && best_i >= 0) ++ties;
-            else if (d2 < second) second = d2;
+            for (int i = 0; i < 2 * kGridMaxW + 1; ++i) c[r][i] = row[min(x0 + i, x1)];
         }
+#pragma unroll
+        for (int r = 0; r < kWinRows; ++r)
+#pragma unroll
+            for (int i = 0; i < 2 * kGridMaxW + 1; ++i) {
+                if (y + r > y1 || x0 + i > x1) continue;             // (clamped repeats must not count as ties)
+                const float d2 = (sx - c[r][i].x) * (sx - c[r][i].x) + (sy - c[r][i].y) * (sy - c[r][i].y) + (sz - c[r][i].z) * (sz - c[r][i].z);
+                if (d2 < best) { if (best_i >= 0) second = best; best = d2; best_i = __float_as_int(c[r][i].w); ties = 0; }
+                else if (d2 == best && best_i >= 0) ++ties;
+                else if (d2 < second) second = d2;
+            }
     }
-    if (best_i < 0 || ties != 0) return false;
+    if (best_i < 0 || ties != 0) { if (full && best_sq && best_i >= 0) *best_sq = best; return false; }
     winner = (uint32_t)best_i;
     if (best_sq) *best_sq = best;
     if (other_sq) *other_sq = second;

@@ -89,8 +89,8 @@ __global__ __launch_bounds__(256) void nn_search_kernel(IcpBatch b, SceneNNDev s
                 // visiting order.
                 const pr_vec3 pw = ld_off<pr_vec3>(scene.pcd, prev * 12u);
                 const float d2 = (x - pw.x) * (x - pw.x) + (y - pw.y) * (y - pw.y) + (z - pw.z) * (z - pw.z);
-                const float slack = slk[j] - sqrtf(step_sq) * 1.000001f;
-                if (d2 < accept && sqrtf(d2) * 1.00001f < slack) { kept = true; slk[j] = slack; ++n_kept; }
+                const float slack = slk[j] - margin_sqrt(step_sq) * 1.000002f;
+                if (d2 < accept && margin_sqrt(d2) * 1.00001f < slack) { kept = true; slk[j] = slack; ++n_kept; }
                 else { const float bnd = d2 * 1.000001f + 1e-30f; if (bnd < best) best = bnd; }              // = nn_seed_bound
             }
             if (!kept) {
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void nn_tree_kernel(IcpBatch b, SceneNNDev sce
 constexpr uint32_t kTaskQCap = PR_WIDE_QCAP, kTaskLCap = PR_WIDE_LCAP;   // entries of the node / leaf task queue of a wavefront (a leaf queue is drained from 16 entries on)
 constexpr uint32_t kNoIdx = 0xffffffffu;
 // Queue 1 (nn_search_kernel's leftovers) -> bound + pixel window, one query per lane -> winners, or queue 2 (point, bound).
-__global__ __launch_bounds__(256) void nn_bound_kernel(IcpBatch b, SceneNNDev scene)
+__global__ __launch_bounds__(256, PR_BOUND_WAVES) void nn_bound_kernel(IcpBatch b, SceneNNDev scene)
 {
     __shared__ uint32_t wave_n[4], wg_base;
     const uint32_t pose = blockIdx.y;
@@ -275,8 +275,20 @@ __global__ __launch_bounds__(256) void nn_bound_kernel(IcpBatch b, SceneNNDev sc
             if (scene.grid) {
                 const pr_vec3 q = ld_off<pr_vec3>(cl, j * 12u);
                 uint32_t w = kNoPrev; float bsq = 0.0f, osq = 0.0f;
-                if (!still) { grid_pyramid_bound(scene, q.x, q.y, q.z, bst); ++n_pyramid; }
-                if (bst < accept && grid_search(scene, q.x, q.y, q.z, bst, w, &n_cells, &bsq, &osq, settle)) { pending = false; ++n_window; win[j] = w; slk[j] = sqrtf(osq) * 0.99999f; }
+                bool done = false, tried = false;
+                if (!still && bst <= PR_NN_WINFIRST) {
+                    // WINDOW FIRST (round 5): the previous winner is a few millimetres away, so the neighbour is probably within the largest window's
+                    // reach -- scan it without a tight bound (grid_search `full`) and spare the descent.  A failure (nothing within the covered
+                    // radius, or a tie) means the window cannot settle this query after a descent either: it goes on to the tree.
+                    tried = true;
+                    done = grid_search(scene, q.x, q.y, q.z, bst, w, &n_cells, &bsq, &osq, settle, true);
+                    if (!done && bsq > 0.0f) { const float bb = bsq * 1.000001f + 1e-30f; if (bb < bst) bst = bb; }
+                }
+                if (!done) {
+                    if (!still) { grid_pyramid_bound(scene, q.x, q.y, q.z, bst); ++n_pyramid; }
+                    if (!tried) done = bst < accept && grid_search(scene, q.x, q.y, q.z, bst, w, &n_cells, &bsq, &osq, settle);
+                }
+                if (done) { pending = false; ++n_window; win[j] = w; slk[j] = margin_sqrt(osq) * 0.99999f; }
             }
         }
         const unsigned long long m = __ballot(pending);
@@ -352,13 +364,11 @@ __global__ __launch_bounds__(256, PR_WIDE_WAVES) void nn_tree_wide_kernel(IcpBat
     static_assert(kLanes == 2, "the paired record layout (nn_wide_build_kernel, stage D) is made for two lanes per task");
     constexpr uint32_t kPer = 8u / kLanes, kTasks = 64u / kLanes;
     constexpr uint32_t kLeafPer = PR_WIDE_LEAF_PER;               // points of a leaf per lane and round
-    __shared__ uint2 s_nodeq[4][kTaskQCap], s_leafq[4][kTaskLCap];               // {reference, bound bits (low 6 bits cleared: rounded DOWN) | query slot}
+    __shared__ uint2 s_taskq[4][kTaskQCap + kTaskLCap];                          // per wavefront: node-task queue, leaf-task queue behind it; {reference, bound bits (low 6 bits cleared: rounded DOWN) | query slot}
     __shared__ float4 s_q[4][64];                                                // query point | bound (float bits, lowered with atomicMin)
     __shared__ uint2 s_qq[4][64];                                                // the query in whole units of the wide records' frame: ux | uy << 16, uz | uz << 16
     __shared__ uint32_t s_second[4][64], s_tied[4][64], s_ovf[4][64], s_root[4][64];
     __shared__ unsigned long long s_best[4][64];
-    __shared__ uint2 s_dump[64];                                                 // where a lane stores a task it does not keep (no exec-mask juggling per slot); never read,
-                                                                                 // shared by the four wavefronts: with it the kernel's LDS is 26.5 KiB: six workgroups per CU
     const uint32_t pose = blockIdx.y;
     const PoseMeta &pm = b.meta[pose];
     if (pm.state == kSkip) return;
@@ -373,12 +383,11 @@ __global__ __launch_bounds__(256, PR_WIDE_WAVES) void nn_tree_wide_kernel(IcpBat
     // (the wavefront's index is uniform, but only readfirstlane tells the compiler: with it the queue fill levels, the batch loop and every
     // branch on them live in scalar registers)
     const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), c = lane % kLanes, grp = lane / kLanes;
-    uint2 *nodeq = s_nodeq[wave], *leafq = s_leafq[wave];
+    uint2 *nodeq = s_taskq[wave], *leafq = nodeq + kTaskQCap;
     float4 *qs = s_q[wave];
     uint2 *qq = s_qq[wave];
     uint32_t *second = s_second[wave], *tied = s_tied[wave], *ovf = s_ovf[wave], *root = s_root[wave];
     unsigned long long *best = s_best[wave];
-    uint2 *dump = s_dump;
     // the frame of the wide records: units per metre, the query's offset in units (minus the sixteenth of a unit that covers the rounding of
     // this very conversion), and the factors between squared metres and squared units -- each rounded to the safe side
     const float w_inv = 1.0f / scene.wscale;
@@ -438,15 +447,14 @@ __global__ __launch_bounds__(256, PR_WIDE_WAVES) void nn_tree_wide_kernel(IcpBat
             float sec_l = FLT_MAX;                                   // ... and points (squared metres)
             if (!leaf_step) {
                 // ---------------- node tasks: lane c of a group tests the four slots of half c (two pairs, see nn_wide_build_kernel stage D)
+                // The record is loaded by every lane (a lane without a live task reads wide node 0 and masks the outcome with `alive`): no
+                // zero-initialised copy of the record, no branch around the loads.
                 uint4 r[4];
-#pragma unroll
-                for (uint32_t i = 0; i < 3; ++i) r[i] = make_uint4(0u, 0u, 0u, 0u);
-                r[3] = make_uint4(kWideEmpty, kWideEmpty, kWideEmpty, kWideEmpty);
-                if (alive) {
-                    const uint4 *rec = scene.wide + (size_t)ref * 8u + 4u * c;
+                {
+                    const uint4 *rec = scene.wide + (size_t)(alive ? ref : 0u) * 8u + 4u * c;
 #pragma unroll
                     for (uint32_t i = 0; i < 4; ++i) r[i] = rec[i];
-                    if (kCount && c == 0u) ++n_nodes;
+                    if (kCount && alive && c == 0u) ++n_nodes;
                 }
                 // the query's interval [qd, qd + 3] per axis, both halves of a word carrying the same value (two byte permutes of the stored pair)
                 const uint2 qw = qq[q];
@@ -455,32 +463,46 @@ __global__ __launch_bounds__(256, PR_WIDE_WAVES) void nn_tree_wide_kernel(IcpBat
                 wide_pair_lb(r[0].x, r[0].y, r[0].z, r[0].w, r[1].x, r[1].y, qdx, qdy, qdz, qdx + 0x30003u, qdy + 0x30003u, qdz + 0x30003u, lb[0], lb[1]);
                 wide_pair_lb(r[1].z, r[1].w, r[2].x, r[2].y, r[2].z, r[2].w, qdx, qdy, qdz, qdx + 0x30003u, qdy + 0x30003u, qdz + 0x30003u, lb[2], lb[3]);
                 const uint32_t refs[kPer] = { r[3].x, r[3].y, r[3].z, r[3].w };
-                uint32_t cntI = 0, cntL = 0;
+                // Round 5: counts packed in one word (internal | leaf << 16), ONE prefix scan, and -- the common case, decided per step on the
+                // totals -- a straight run of stores without a capacity test per slot: the wavefront's two queues are ONE array (node tasks
+                // first, leaf tasks behind them), so a child's place is a single index whatever its kind.  (Tried first: numbering the
+                // children slot by slot with ballots + v_mbcnt -- 151 VALU per step instead of 180, but 150 SALU instead of 54; the scalar
+                // unit is shared by the four SIMDs of a CU and the walk already issues 0.45 scalar instructions per vector one.)
+                uint32_t cnt = 0u;
                 bool keep[kPer], leaf[kPer];
 #pragma unroll
                 for (uint32_t i = 0; i < kPer; ++i) {
-                    const bool v = refs[i] != kWideEmpty;
+                    const bool v = alive && refs[i] != kWideEmpty;
                     keep[i] = v && lb[i] <= bnd_u;
-                    leaf[i] = (refs[i] & kWideLeaf) != 0u;
+                    leaf[i] = (int32_t)refs[i] < 0;                    // kWideLeaf = the sign bit (an empty slot reads as a leaf: never kept)
                     sec_u = min_f32(sec_u, (v && !keep[i]) ? lb[i] : FLT_MAX);      // (a select, not a branch: the asm min cannot be if-converted)
-                    cntI += (keep[i] && !leaf[i]) ? 1u : 0u; cntL += (keep[i] && leaf[i]) ? 1u : 0u;
+                    cnt += keep[i] ? (leaf[i] ? 0x10000u : 1u) : 0u;
                 }
                 uint32_t tot = 0;
-                const uint32_t ex = wave_excl_scan(cntI | (cntL << 16), tot);
-                uint32_t pI = nN + (ex & 0xffffu), pL = nL + (ex >> 16);
-                bool lost = false;
+                const uint32_t ex = wave_excl_scan(cnt, tot);
+                const uint32_t totI = tot & 0xffffu, totL = tot >> 16;
+                if (nN + totI <= kTaskQCap && nL + totL <= kTaskLCap) {
+                    uint32_t pI = nN + (ex & 0xffffu), pL = kTaskQCap + nL + (ex >> 16);
 #pragma unroll
-                for (uint32_t i = 0; i < kPer; ++i) {                  // straight-line: every slot stores -- into its queue, or into the lane's dump word
-                    const uint32_t pos = leaf[i] ? pL : pI, cap = leaf[i] ? kTaskLCap : kTaskQCap;
-                    const bool fits = pos < cap, put = keep[i] && fits;
-                    uint2 *dst = put ? ((leaf[i] ? leafq : nodeq) + pos) : (dump + lane);
-                    *dst = make_uint2(refs[i], (__float_as_uint(lb[i]) & ~63u) | q);
-                    lost = lost || (keep[i] && !fits);
-                    pL += (keep[i] && leaf[i]) ? 1u : 0u; pI += (keep[i] && !leaf[i]) ? 1u : 0u;
+                    for (uint32_t i = 0; i < kPer; ++i) {
+                        if (keep[i]) nodeq[leaf[i] ? pL : pI] = make_uint2(refs[i], (__float_as_uint(lb[i]) & ~63u) | q);
+                        pI += (keep[i] && !leaf[i]) ? 1u : 0u; pL += (keep[i] && leaf[i]) ? 1u : 0u;
+                    }
+                    nN += totI; nL += totL;
+                } else {
+                    // a queue would overflow in this step: every slot checks its place; a child that does not fit marks its query (walked again)
+                    uint32_t pI = nN + (ex & 0xffffu), pL = nL + (ex >> 16);
+                    bool lost = false;
+#pragma unroll 1
+                    for (uint32_t i = 0; i < kPer; ++i) {
+                        const uint32_t pos = leaf[i] ? pL : pI, cap = leaf[i] ? kTaskLCap : kTaskQCap;
+                        if (keep[i]) { if (pos < cap) (leaf[i] ? leafq : nodeq)[pos] = make_uint2(refs[i], (__float_as_uint(lb[i]) & ~63u) | q); else lost = true; }
+                        pL += (keep[i] && leaf[i]) ? 1u : 0u; pI += (keep[i] && !leaf[i]) ? 1u : 0u;
+                    }
+                    if (lost) ovf[q] = 1u;
+                    nN += totI; if (nN > kTaskQCap) nN = kTaskQCap;
+                    nL += totL; if (nL > kTaskLCap) nL = kTaskLCap;
                 }
-                if (lost) ovf[q] = 1u;
-                nN += tot & 0xffffu; if (nN > kTaskQCap) nN = kTaskQCap;
-                nL += tot >> 16; if (nL > kTaskLCap) nL = kTaskLCap;
             } else {
                 // ---------------- leaf tasks: kLeafPer points per lane and round, all loaded before any is looked at.  A lane first settles its own
                 // points in registers -- minimum, which one, and the runner-up -- and only the minimum goes to the query's record in LDS: ONE

@@ -30,6 +30,12 @@ __device__ __forceinline__ int loop_start(float v)
 __device__ __forceinline__ float sel_max(float a, float b) { return (a > b) ? a : b; }
 __device__ __forceinline__ float sel_min(float a, float b) { return (a < b) ? a : b; }
 
+// One-instruction square root / reciprocal (v_sqrt_f32 / v_rcp_f32: 1 ulp) for SAFETY MARGINS only -- step lengths, window radii, slack: every
+// use multiplies the result by a factor at least 1e-6 away from 1 on the safe side.  Never for a value the oracle is compared with bit by bit
+// (sqrtf and '/' expand to the correctly rounded sequences there: ten instructions and more each).
+__device__ __forceinline__ float margin_sqrt(float v) { return __builtin_amdgcn_sqrtf(v); }
+__device__ __forceinline__ float margin_rcp(float v) { return __builtin_amdgcn_rcpf(v); }
+
 typedef float float2v __attribute__((ext_vector_type(2)));
 // base + 32-bit byte offset: lets the compiler address with a scalar base and one 32-bit VGPR (global_load ... v_off, s[base])
 // instead of building a 64-bit address per lane (v_lshl_add_u64 / v_mad_u64_u32 plus the copies that come with 64-bit values)

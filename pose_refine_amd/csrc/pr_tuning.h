@@ -35,11 +35,23 @@
 #ifndef PR_RING_ROWS
 #define PR_RING_ROWS 2                                          // rows of a 6 x 6 ring of the descent in flight at a time (1, 2, 3, 6 measured: not latency-bound)
 #endif
+#ifndef PR_RING_STAGED
+#define PR_RING_STAGED 1                                        // 1: a ring's rows are loaded PR_RING_ROWS at a time (72 VGPRs: seven wavefronts per SIMD); 0: all at once (101 VGPRs: four)
+#endif
+#ifndef PR_BOUND_WAVES
+#define PR_BOUND_WAVES 1                                        // __launch_bounds__ minimum waves per SIMD of nn_bound_kernel (1: the compiler's own choice)
+#endif
 #ifndef PR_RING_W
 #define PR_RING_W 5                                             // cells per side of a ring of the descent: a block's 4 x 4 children and the row / column BEFORE them (PR_RING_OFF = 1).
 #endif                                                          // Same box, configs[2] pipelined: 6 / off 1 (both neighbours, rounds 2-4) 41.8 k poses/s, 5 / 1 43.0 k (bound kernel 2.31 -> 1.92 ms per
 #ifndef PR_RING_OFF                                             // group-step, the walk as before); 6 / 2 41.9 k, 7 / 2 40.0 k; without the leading row -- 4 / 0, 5 / 0 -- or the last child -- 4 / 1 -- the
 #define PR_RING_OFF 1                                           // bound gets loose and the walk pays: 34.1 / 33.4 / 34.7 k
+#endif
+#ifndef PR_WIN_ROWS
+#define PR_WIN_ROWS 1                                           // rows of a pixel window loaded before the first is looked at (beyond the 3 x 3 case, which is one round trip anyway)
+#endif
+#ifndef PR_NN_WINFIRST
+#define PR_NN_WINFIRST 4.0e-4f                                  // (20 mm)^2 [same box: off 47.4 k, (2 mm)^2 47.4 k, (3 mm)^2 47.8 k, (5 mm)^2 48.2 k, (10 mm)^2 48.8 k, (20 mm)^2 49.3 k, always 48.9 k poses/s]: a query whose previous winner is within this (but which moved too far to go without a new bound) scans the largest window BEFORE any descent
 #endif
 #ifndef PR_NN_COVER_PAD
 #define PR_NN_COVER_PAD 5.0e-4f                                 // metres a window search looks beyond its bound for the runner-up (about one pixel at 300 mm)
