@@ -133,6 +133,8 @@ class TorchGroup:
         import torch.distributed as dist
         self.dist, self.world, self.rank = dist, world, rank
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:                                               # PR_BENCH_FORCE_COMM=1 without a launcher around it: a rendezvous of one
+            os.environ.setdefault("MASTER_PORT", str(free_port()))
         if share_device:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -476,10 +478,14 @@ def run_rank(args, group, local_dev, share_device, launcher_note, comm_ready, co
 
         def sample(self):
             """One step with HIP events around every correspondence launch, its loop alone on the chip (option profile = 3)."""
+            sync = group.barrier if (threads_mode and multi) else (lambda: None)   # library options are process-wide: rank THREADS switch them at the same point
+            sync()
             api.set_option("profile", sample_profile)
+            sync()
             self.step()
             self.fence(gather=False)
             api.set_option("profile", 0)
+            sync()
 
         def run(self, warmup, burn_in=0, sample_in="warmup", sequential=False, marks_out=None):
             """`warmup` untimed steps, then exactly `steps` timed ones between two fences (barrier + device drained on both sides).
@@ -509,6 +515,7 @@ def run_rank(args, group, local_dev, share_device, launcher_note, comm_ready, co
             self.fence()                                             # also warms the job's exchange up
             self.k = 0
             self.gathers = 0
+            c0 = time.process_time()
             t0 = time.perf_counter()
             for i in range(self.steps):
                 if prof is None and sample_in in ("timed", "warmup") and not sequential and i == self.steps - 1:
@@ -518,6 +525,7 @@ def run_rank(args, group, local_dev, share_device, launcher_note, comm_ready, co
                     marks_out.append(time.perf_counter() - t0)
             self.fence()
             elapsed = time.perf_counter() - t0
+            self.cpu_timed_s = time.process_time() - c0                # CPU seconds of every thread of this process over the TIMED region only
             self.gathers_timed = self.gathers                        # exchanges inside the timed region (the sample step below is outside it)
             api.set_option("profile", 0)
             if sequential:
@@ -543,6 +551,18 @@ def run_rank(args, group, local_dev, share_device, launcher_note, comm_ready, co
         both = group.all_gather((elapsed, mine))
         return max(e for e, _ in both), [m for _, m in both]
 
+    def cpu_over_ranks(cpu_s, wall_s, steps):
+        """every rank's host CPU time over its timed region: ms per step and CPU-seconds per wall-second.  One process per rank: the
+        process' own clock (all its threads: the caller, the library's helper threads, the HIP runtime's).  Host threads as ranks share
+        one process clock: the total is reported once and divided by the ranks."""
+        if not multi:
+            return [1e3 * cpu_s / steps], [cpu_s / wall_s if wall_s > 0 else None]
+        if threads_mode:
+            both = group.all_gather((cpu_s / world, wall_s))
+        else:
+            both = group.all_gather((cpu_s, wall_s))
+        return [1e3 * c / steps for c, _ in both], [(c / w if w > 0 else None) for c, w in both]
+
     if args.scaling == "strong":
         global_poses = args.global_poses or 4096
     else:
@@ -559,10 +579,13 @@ def run_rank(args, group, local_dev, share_device, launcher_note, comm_ready, co
     # (sampled in the last warm-up step, 5 ms after the first launch, the same launches read 41.9 instead of 39.2 us: clocks still coming up).
     # --sample-in timed puts it back into the timed region (its last step, as in rounds 1-3), --sample-in warmup into the last warm-up step.
     elapsed, prof, launches_us = job.run(args.warmup, burn_in=args.burn_in, sample_in=args.sample_in, sequential=args.sequential, marks_out=marks)
+    step_ms = np.diff(np.asarray([0.0] + marks)) * 1e3               # host clock after every step's (submit + wait for the step before it); the closing fence comes on top
     if os.environ.get("PR_BENCH_MARKS") and rank == 0:             # where a run's time went: cumulative ms after every step's submit + previous wait, and the closing fence
         print("[bench] marks ms:", " ".join(f"{1e3 * m:.2f}" for m in marks), "| fence", f"{1e3 * (elapsed - marks[-1]):.2f}", file=sys.stderr, flush=True)
-    host_cpu_s = time.process_time() - cpu0                          # CPU time of ALL threads of this process (warm-up + timed region)
+    wall_s_rank0 = elapsed                                           # this rank's own clock (before the max over ranks)
+    host_cpu_s = job.cpu_timed_s                                     # CPU time of ALL threads of this process over the timed region (round 5: warm-up excluded)
     wall_s = elapsed
+    rank_cpu_ms, rank_cpu_per_wall = cpu_over_ranks(host_cpu_s, wall_s, args.steps)
     sizes = job.last_sizes
     gathers_timed = job.gathers_timed
     gather_ms, gather_n = (api.gather_profile() if (multi and gather_mode == "cabi") else (0.0, 0))
@@ -611,6 +634,11 @@ def run_rank(args, group, local_dev, share_device, launcher_note, comm_ready, co
     else:
         frac_dram, dram_note = PMC_DRAM_FRAC.get(args.scene), PMC_DRAM_SOURCE
     lus = np.sort(np.asarray(launches_us, np.float64)) if launches_us is not None and len(launches_us) else None
+    valu_rate = (PMC_VALU_WAVE_INSTR_PER_POINT[args.scene] * pts_per_launch / avg_launch_s) if (PMC_VALU_WAVE_INSTR_PER_POINT[args.scene] and avg_launch_s > 0) else None
+    n_mean = float(np.mean(sizes))
+    # SURVEY 8d, per hypothesis: render 36 T + 4 W H (clear) + 4 W H (read by the extraction) = 3.59 MB; cloud 12 N; loop: projective
+    # N (21 x 36 + 20 x 12) = 996 N, kd-tree (HBM-compulsory) N (21 x 12 + 20 x 12) = 492 N
+    e2e_bytes_per_pose = (36.0 * len(model.tris) + 8.0 * W * H) + 12.0 * n_mean + (996.0 if args.scene == "proj" else 492.0) * n_mean
     n_samples = 1
     out = {
         "metric": "refined poses/sec (640x480, 20 ICP iters)",
@@ -644,18 +672,28 @@ def run_rank(args, group, local_dev, share_device, launcher_note, comm_ready, co
         # `bound`: what the counters say limits this kernel.  `frac` is the contract's figure -- SURVEY 8d's ALGORITHMIC bytes over the launch
         # time, against the HBM peak; it exceeds what HBM really carries (the packed 16-byte scene record, Infinity-Cache-resident clouds), so
         # it is a throughput score, not a statement that the kernel sits on the HBM roof: the projective pass is VALU-bound (`valu_frac`).
+        # Round 5: `frac` = achieved / peak of the BINDING resource -- VALU issue for this kernel, so `achieved`, `peak`, `unit`
+        # are wave-instructions per second -- and can never exceed 1.  SURVEY 8d's contract score (ALGORITHMIC bytes over the launch time against
+        # the HBM peak) stays next to it as `frac_algorithmic` / `hbm_algorithmic`: a throughput score that exceeds what HBM really carries (the
+        # packed 16-byte scene record, Infinity-Cache-resident clouds) and passes 1 at 512+ hypotheses per batch.  `frac_end_to_end` = SURVEY 8d's
+        # algorithmic bytes of the WHOLE step (render 3.59 MB + cloud 12 N + loop 996 N per hypothesis) x poses/s over the HBM peak.
         "roofline": {"bound": ("valu" if args.scene == "proj" else "l1/lds + valu (cache-resident search: HBM carries only clouds and winners)"),
                      "bound_contract_enum": "hbm",
                      "kernel": ("icp_pass_kernel (correspondence + 29-term reduce" if args.scene == "proj" else
                                                  "one correspondence pass = nn_search_kernel + nn_bound_kernel + nn_tree_wide_kernel + icp_pass_kernel<SceneNNWinners> (search, bound + window, task walk of the queued queries, 29-term reduce over the winners")
                                                 + (" + finalize/solve tail)" if args.fused_solve and args.solve == "device" else ")"),
-                     "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK,
-                     # (`frac` can exceed 1: SURVEY 8d's algorithmic bytes charge the reference's 24-byte scene gather and a cloud
-                     # that streams from HBM; the packed 16-byte scene record and the cache-resident clouds move fewer real bytes)
-                     # readings of the same launches: SURVEY 8d's ALGORITHMIC bytes (what `frac` is), the fabric bytes the PMC counters
-                     # saw for this kernel (Infinity-Cache hits included), and the DRAM figure of a batch that does not fit that cache
+                     "achieved": (valu_rate / 1e9) if valu_rate else achieved / 1e9, "peak": (VALU_PEAK / 1e9) if valu_rate else HBM_PEAK / 1e9,
+                     "unit": "G wave-instructions/s (VALU issue)" if valu_rate else "GB/s",
+                     "frac": (valu_rate / VALU_PEAK) if valu_rate else min(1.0, achieved / HBM_PEAK),
+                     "frac_of": "VALU issue slots (the binding resource by the SQ counters)" if valu_rate else "HBM peak, SURVEY 8d algorithmic bytes",
+                     # readings of the same launches: SURVEY 8d's ALGORITHMIC bytes (the contract's score; it may exceed 1: it charges the
+                     # reference's 24-byte scene gather and a cloud that streams from HBM), the fabric bytes the PMC counters saw for this
+                     # kernel (Infinity-Cache hits included), and the DRAM figure of a batch that does not fit that cache
                      "frac_algorithmic": achieved / HBM_PEAK,
+                     "hbm_algorithmic": {"achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
+                                         "bytes": "SURVEY 8d: 36 B/point on the first and last pass, 48 B/point between"},
+                     "frac_end_to_end": e2e_bytes_per_pose * (total_poses / elapsed) / HBM_PEAK,
+                     "end_to_end_algorithmic_bytes_per_pose": e2e_bytes_per_pose,
                      "frac_fabric_counter": (traffic / avg_launch_s / HBM_PEAK) if (traffic and avg_launch_s > 0) else None,
                      "frac_dram_counter": frac_dram, "frac_dram_counter_source": dram_note, "dram_live": dram,
                      "valu_frac": (PMC_VALU_WAVE_INSTR_PER_POINT[args.scene] * pts_per_launch / avg_launch_s / VALU_PEAK)
@@ -682,7 +720,14 @@ def run_rank(args, group, local_dev, share_device, launcher_note, comm_ready, co
         "gather_event_us": (1e3 * gather_ms / gather_n) if gather_n else None,      # HIP events around the exchange on the library stream, sampled steps (rank 0)
         "gather_events": int(gather_n),
         "per_rank_ms_per_step": per_rank_ms,
-        "host_cpu_per_wall": host_cpu_s / wall_s if wall_s > 0 else None,   # rank 0's process: CPU seconds (all threads, warm-up included) per second of the timed region
+        "host_cpu_per_wall": host_cpu_s / wall_s if wall_s > 0 else None,   # rank 0's process: CPU seconds (all threads) per second, both over the timed region only
+        "host_cpu_ms_per_step": 1e3 * host_cpu_s / args.steps,
+        "per_rank_host_cpu_ms_per_step": rank_cpu_ms, "per_rank_host_cpu_per_wall": rank_cpu_per_wall,
+        "host_cpu_note": ("one process, host threads as ranks: the process' CPU time divided by the ranks" if threads_mode else "per rank: the process' CPU time (all its threads) over its timed region"),
+        # the timed steps one by one (host clock between consecutive submits of the pipelined loop; the first two fill the pipeline), and the closing fence
+        "step_ms_spread": ({"min": float(step_ms.min()), "median": float(np.median(step_ms)), "max": float(step_ms.max()), "n": int(len(step_ms)),
+                            "steady_median": float(np.median(step_ms[2:])) if len(step_ms) > 4 else None,
+                            "closing_fence_ms": float(1e3 * wall_s_rank0 - 1e3 * marks[-1])} if len(step_ms) else None),
         "blocking_wait": bool(api.get_option("blocking_wait")),
         "phase_ms_per_timed_step": {"render": prof["render_ms"] / max(1, launches // (args.iters + 1)),
                                     "cloud": prof["cloud_ms"] / max(1, launches // (args.iters + 1))},
@@ -692,8 +737,15 @@ def run_rank(args, group, local_dev, share_device, launcher_note, comm_ready, co
     solo = world == 1 and not multi
     if solo and args.scene == "proj" and args.solve == "device" and not args.sequential and not args.no_kdtree_extra:
         out["solve_on_host"] = host_solve_extra(args, api, model, job.poses, W, H, proj, K, scene)
+    if "solve_on_host" in out:
+        # `north_star` words the solve as "SVD solve on host": that configuration's figure next to the headline's, in `config` (the full record: `solve_on_host`)
+        out["config"]["north_star_solve_on_host"] = {"value": out["solve_on_host"]["value"], "unit": "poses/s", "ms_per_step": out["solve_on_host"]["ms_per_step"],
+                                                     "one_synchronous_call_per_step": out["solve_on_host"]["one_synchronous_call_per_step"]["value"],
+                                                     "note": "same batches, PR_SOLVE_HOST, pipelined through the two slots from one caller thread; the headline `value` keeps the 6x6 solve on the device"}
     if solo and args.scene == "proj" and not args.no_kdtree_extra and not args.sequential:
         out["config2_kdtree"] = kdtree_extra(args, api, model, job.poses, scene_depth, W, H, proj, K)
+    if solo and not args.no_kdtree_extra and not args.sequential:
+        out["default_criteria"] = default_criteria_extra(args, api, model, job.poses, scene_depth, W, H, proj, K)
     if solo and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, args.scene, model.tris, scene_depth, K, W, H)
         if "config2_kdtree" in out:
@@ -830,6 +882,7 @@ def kdtree_extra(args, api, model, poses, scene_depth, W, H, proj, K, steps=20):
                 "per_kernel_ms_per_step": {n: float(v) for n, v in zip(names, part_ms)}, "passes": int(n_pass), "one_group_step_ms": step_ms,
                 "first_passes_us": [float(v) for v in pass_us[:4]],
                 "bound": "valu issue (pass 0: 0.79 of the chip's VALU issue slots, 626 M wave-instructions for 5.4 M tree searches; a wavefront has a VALU instruction in flight 25 % of its resident cycles, six share a SIMD; HBM ~ 0)",
+                "frac": NN_WALK_VALU_ISSUE_FRAC, "frac_of": "VALU issue slots of the chip in pass 0 (the binding resource by the SQ counters; committed pass, see valu_active_frac_source)",
                 "valu_issue_frac": NN_WALK_VALU_ISSUE_FRAC,
                 "valu_active_frac": NN_WALK_VALU_ACTIVE_FRAC,
                 "valu_active_frac_source": "committed: profiles/r04/sq_nn_pass0.txt (nn_tree_wide_kernel, pass 0 of a 256-hypothesis batch)",
@@ -851,6 +904,32 @@ def kdtree_extra(args, api, model, poses, scene_depth, W, H, proj, K, steps=20):
             "hbm_frac_of_peak": (hbm / dt / HBM_PEAK) if hbm else None,
             "note": "the kd-tree kernels are cache- and latency-bound by design (SURVEY 8d): their working set (0.85 MB tree + 4.9 MB grid) "
                     "lives in L2, so HBM carries only the clouds and winners; `logical` counts every byte the search asks the caches for"}
+
+
+def default_criteria_extra(args, api, model, poses, scene_depth, W, H, proj, K, steps=20):
+    """"also report default criteria (1e-5, 1e-5, 30)" -- the reference's ICPConvergenceCriteria defaults (icp.h:42-45): a hypothesis
+    leaves the loop when fitness and rmse both change by less than 1e-5 (icp.cu:191-194), so hypotheses of a batch drop out at different
+    passes (the early-exit path; parity: tests/test_golden_full_gpu.py holds every hypothesis of both scene kinds to the oracle).  Same
+    batches, same two-slot loop as the headline, both scene kinds."""
+    crit = api.ICPConvergenceCriteria(1e-5, 1e-5, 30)
+    out = {"criteria": [1e-5, 1e-5, 30], "note": "reference defaults (icp.h:42-45): per-hypothesis early exit, at most 31 passes; pipelined through the two slots like the headline"}
+    for kind in ("proj", "nn"):
+        scene = (api.Scene_projective().init_Scene_projective_cuda(scene_depth, K) if kind == "proj" else api.Scene_nn().init_Scene_nn_cuda(scene_depth, K))
+        n = steps if kind == "proj" else max(6, steps // 2)
+        for k in range(3):
+            api.refine_submit(k & 1, model, poses, W, H, proj, K, scene, crit)
+            if k:
+                api.refine_wait((k - 1) & 1)
+        api.refine_wait(0)
+        t0 = time.perf_counter()
+        for k in range(n):
+            api.refine_submit(k & 1, model, poses, W, H, proj, K, scene, crit)
+            if k:
+                api.refine_wait((k - 1) & 1)
+        api.refine_wait((n - 1) & 1)
+        dt = (time.perf_counter() - t0) / n
+        out["projective" if kind == "proj" else "kdtree"] = {"value": len(poses) / dt, "unit": "poses/s", "ms_per_step": 1e3 * dt, "steps": n}
+    return out
 
 
 def host_solve_extra(args, api, model, poses, W, H, proj, K, scene, steps=30):

@@ -81,15 +81,19 @@ def test_thread_group_is_a_barrier_and_an_all_gather():
         assert got[r] == ([("first", i) for i in range(world)], [i * i for i in range(world)])
 
 
-def _run_bench(extra, env_extra):
-    env = dict(os.environ, PR_BENCH_SHARE_DEVICE="1", **env_extra)
+def _run_bench(extra, env_extra, gpus=2, share=True):
+    env = dict(os.environ, **env_extra)
+    if share:
+        env["PR_BENCH_SHARE_DEVICE"] = "1"
+    else:
+        env.pop("PR_BENCH_SHARE_DEVICE", None)
     env.pop("WORLD_SIZE", None)
     # the child is measured, not profiled: when this suite itself runs under rocprofv3 (tools/gpu_round.sh does, for the kernel coverage), the
     # tool's environment must not reach bench.py -- rocprofv3 7.2 aborts in stream_stack.cpp when HIP is driven from Python threads
     for k in list(env):
         if k.startswith(("ROCPROF", "ROCP_", "ROCTX", "HSA_TOOLS", "ROCPROFILER")) or (k == "LD_PRELOAD" and "rocprof" in env[k]):
             env.pop(k)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--no-config3"] + extra,
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "6", "--warmup", "2", "--no-config3"] + extra,
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
@@ -114,3 +118,30 @@ def test_bench_uneven_shards_gather_per_step():
     d = _run_bench(["--launcher", "threads", "--global-poses", "301", "--gather", "job"], {})
     assert d["gather_when"] == "step" and d["gathers_in_timed_region"] == 6 and "do not divide" in d["gather_when_note"]
     assert d["config"]["poses_per_gpu"] == 151
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("launcher", ["processes", "threads"])
+def test_bench_starts_eight_ranks_by_itself(launcher):
+    """the 8-rank job of the driver's SCALE run, on the one GPU of this box (test mode: every rank on device 0, the gather
+    on host copies): eight shards of the seeded stream, eight per-rank clocks, and every rank's host CPU time over its timed region."""
+    d = _run_bench(["--launcher", launcher, "--poses", "64"], {}, gpus=8)
+    assert d["n_gpus"] == 8 and len(d["per_rank_ms_per_step"]) == 8
+    assert d["launcher"]["kind"] == launcher and d["launcher"]["share_device_test_mode"] is True
+    assert d["config"]["global_batch"] == 512 and d["config"]["poses_per_gpu"] == 64 and d["value"] > 1000
+    assert d["blocking_wait"] is True                              # more than one rank on the host: pr_refine_wait sleeps
+    assert len(d["per_rank_host_cpu_ms_per_step"]) == 8 and all(c > 0 for c in d["per_rank_host_cpu_ms_per_step"])
+    assert d["gather_when"] == "job" and d["gathers_in_timed_region"] == 1
+
+
+@pytest.mark.gpu
+def test_bench_force_comm_runs_the_rccl_gather_with_a_world_of_one():
+    """PR_BENCH_FORCE_COMM=1: the whole N > 1 machinery with ONE rank -- torch's process group on the RCCL backend and the library's own
+    dlopened RCCL communicator (pr_comm_init_rank, pr_gather_results) in one process, on every round's GPU box."""
+    d = _run_bench([], {"PR_BENCH_FORCE_COMM": "1"}, gpus=1, share=False)
+    assert d["n_gpus"] == 1 and d["launcher"]["kind"] == "processes"
+    assert d["gather"].startswith("pr_gather_results") and d["gather_when"] == "job" and d["gathers_in_timed_region"] == 1
+    assert d["gather_bytes_per_rank"] == 72 * 256 * 6 and d["value"] > 1000
+    for key in ("step_ms_spread", "host_cpu_ms_per_step", "roofline"):
+        assert key in d
+    assert d["roofline"]["frac"] <= 1.0 and d["roofline"]["frac_end_to_end"] > 0
