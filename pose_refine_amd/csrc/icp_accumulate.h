@@ -189,6 +189,23 @@ __device__ __forceinline__ void vb_accumulate(float (&acc_out)[29], float *cl, u
         }
     };
 
+#if PR_PASS_PREFETCH
+    // the NEXT step's cloud points are requested before this step's gathers are looked at: one dependent round trip per step instead of two
+    {
+        float p[12];
+        uint32_t j0, cnt;
+        load_step(0, p, j0, cnt);
+        for (uint32_t s = 0; s < b.steps && cnt != 0; ++s) {
+            float pn[12];
+            uint32_t j0n = 0, cntn = 0;
+            if (s + 1 < b.steps) load_step(s + 1, pn, j0n, cntn);
+            process_step(p, j0, cnt);
+#pragma unroll
+            for (int i = 0; i < 12; ++i) p[i] = pn[i];
+            j0 = j0n; cnt = cntn;
+        }
+    }
+#else
     for (uint32_t s = 0; s < b.steps; ++s) {
         float p[12];
         uint32_t j0, cnt;
@@ -196,6 +213,7 @@ __device__ __forceinline__ void vb_accumulate(float (&acc_out)[29], float *cl, u
         if (cnt == 0) break;
         process_step(p, j0, cnt);
     }
+#endif
     acc_export(acc, acc_out);
 }
 

@@ -55,6 +55,33 @@ __device__ __forceinline__ float dpp_get(float v)
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), kCtrl, kRowMask, 0xf, true));
 }
 
+// sampled fingerprint of up to three caller-owned arrays (scene_fingerprint_kernel, batch_check_kernel): this lane's share of the hash of a
+// 256-lane workgroup -- 16 of the 4096 samples per array; the workgroup's fingerprint is the SUM of its lanes' values (order-free)
+__device__ __forceinline__ uint32_t fingerprint_lane(const uint32_t *__restrict__ a, unsigned long long na, const uint32_t *__restrict__ b, unsigned long long nb,
+                                                     const uint32_t *__restrict__ c, unsigned long long nc)
+{
+    uint32_t h = 0;
+    const uint32_t *arr[3] = { a, b, c };
+    const unsigned long long len[3] = { na, nb, nc };
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (!arr[k] || len[k] == 0) continue;
+        // sample s of 4096 sits in stripe s of the array, at a hashed offset inside it (32-bit arithmetic: __umulhi maps a hash onto a range)
+        const uint32_t n = len[k] > 0xffffffffull ? 0xffffffffu : (uint32_t)len[k];
+        const uint32_t stripe = n / 4096u;                            // 0 for short arrays: every word is visited, wrapping around
+        uint32_t w[16];
+#pragma unroll
+        for (uint32_t i = 0; i < 16u; ++i) {
+            const uint32_t s = threadIdx.x * 16u + i;
+            const uint32_t pos = stripe ? s * stripe + __umulhi(s * 2654435761u + 0x9e3779b9u, stripe) : (n >= 4096u ? s : s % n);
+            w[i] = arr[k][pos] ^ pos;
+        }
+#pragma unroll
+        for (uint32_t i = 0; i < 16u; ++i) h += w[i] * 2654435761u + (uint32_t)k;      // a sum: the order of the lanes does not matter
+    }
+    return h;
+}
+
 constexpr uint32_t kBoxRowsPerBlock = 16;                        // rows of a pixel box per workgroup: 4 wavefronts x 4 rows (few, fatter workgroups: dispatch-bound otherwise)
 
 }  // namespace prk

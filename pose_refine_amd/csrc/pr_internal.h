@@ -151,11 +151,22 @@ hipError_t launch_model_aabb(const pr_triangle *tris, uint32_t n_tris, uint32_t 
 hipError_t launch_render_bands(const pr_triangle *tris, uint32_t n_tris, const pr_mat4 *poses_dev, uint32_t n_poses, const float *aabb,
                                int4 *bbox, int32_t *depth, uint32_t *row_count, uint32_t *row_off, uint32_t *counts,
                                uint32_t width, uint32_t height, const pr_mat4 &proj, pr_roi roi, uint32_t n_cus, hipStream_t s);
+// The two per-batch safety nets of the asynchronous path, carried by the raster launch itself (round 5): the workgroups of the launch's FIRST
+// hypothesis fold their triangles' vertices into keys[0..5] (running minima; keys[6] = arrival ticket; armed once by the caller with six
+// words of ones and a zero, re-armed by the last workgroup), the last one compares with the box the host assumed; workgroup (0, 0) takes
+// the sampled fingerprint of the caller's scene arrays (fp_expected null: none).  Both only ever RAISE *flag.  keys null: no check.
+struct AabbExpected { float v[6]; };
+struct BatchCheck {
+    uint32_t *keys; AabbExpected expect;
+    const uint32_t *fa, *fb, *fc; unsigned long long na, nb, nc; const uint32_t *fp_expected;
+    uint32_t *flag;
+};
 hipError_t launch_render_boxes(const pr_triangle *tris, uint32_t n_tris, const pr_mat4 *poses_dev, uint32_t n_poses, const float *aabb,
                                int4 *bbox, int32_t *depth, uint32_t *row_count, uint32_t *row_off, uint32_t *counts,
                                uint32_t width, uint32_t height, const pr_mat4 &proj, pr_roi roi, hipStream_t s, bool compute_boxes = true,
                                PoseMeta *meta = nullptr, DevIcpState *st = nullptr, uint32_t *arrive = nullptr, uint32_t cloud_stride = 0,
-                               const uint32_t *box_off = nullptr);   // box_off: the boxes packed into `depth` at these offsets (ints), each with its own pitch (fill_box_kernel)
+                               const uint32_t *box_off = nullptr,    // box_off: the boxes packed into `depth` at these offsets (ints), each with its own pitch (fill_box_kernel)
+                               const BatchCheck *check = nullptr);
 hipError_t launch_pack_export(const DevIcpState *st, pr_result *out, const uint32_t *counts, uint32_t *host_counts, pr_result *host_results,
                               uint32_t n, hipStream_t s);
 hipError_t launch_stage_words(const void *src_host_mapped, void *dst, size_t bytes, hipStream_t s);

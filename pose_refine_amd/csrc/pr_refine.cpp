@@ -494,28 +494,41 @@ int refine_submit_async(Slot &sl, const pr_triangle *tris_dev, size_t n_tris, ui
     void *h_in_dev = nullptr, *h_out_dev = nullptr;              // the pinned staging buffers as the device sees them
     HIP_TRY(hipHostGetDevicePointer(&h_in_dev, sl.h_in.p, 0));
     HIP_TRY(hipHostGetDevicePointer(&h_out_dev, sl.h_out.p, 0));
-    // ... and checked against the buffer's present content by every batch (refine_wait acts on the flag)
-    PR_TRY(sl.aabb_keys.ensure(6 * sizeof(uint32_t)));
+    HIP_TRY(hipEventRecord(sl.scene_ready, scene_stream));      // (complete as it is recorded unless a cache missed and the scene is being rebuilt on this stream)
+    // ... and checked against the buffer's present content by every batch (refine_wait acts on the flag), together with the scene caches: a
+    // sampled fingerprint of the caller's arrays against the one taken when the cache was built.  Round 5: both checks ride on the raster launch
+    // (BatchCheck, pr_internal.h) -- as launches of their own on the scene stream (a memset, two box kernels, the fingerprint kernel) they cost
+    // 1.3-1.5 % of the headline whatever their number (skipped: 277.6 against 273.6 k poses/s on one box; fused into one launch: 274.1 k).
+    const bool keys_new = sl.aabb_keys.p == nullptr;
+    PR_TRY(sl.aabb_keys.ensure(8 * sizeof(uint32_t)));
+    if (keys_new) {                                               // armed once; the last workgroup of every check re-arms the words itself
+        HIP_TRY(hipMemsetAsync(sl.aabb_keys.p, 0xff, 6 * sizeof(uint32_t), sl.stream));
+        HIP_TRY(hipMemsetAsync(sl.aabb_keys.as<uint32_t>() + 6, 0, 2 * sizeof(uint32_t), sl.stream));
+    }
     *reinterpret_cast<volatile uint32_t *>(sl.h_out.as<unsigned char>() + sl.flag_off) = 0u;
-    HIP_TRY(prk::launch_model_aabb(tris_dev, (uint32_t)n_tris, sl.aabb_keys.as<uint32_t>(), nullptr, g->aabb_host,
-                                   reinterpret_cast<uint32_t *>(static_cast<unsigned char *>(h_out_dev) + sl.flag_off), scene_stream));
-    if (opt.scene_cache) {
-        // ... and so are the scene caches: a sampled fingerprint of the caller's arrays against the one taken when the cache was built
-        // (after the box check on the same stream: that one writes the flag either way, this one only ever raises it)
-        uint32_t *flag = reinterpret_cast<uint32_t *>(static_cast<unsigned char *>(h_out_dev) + sl.flag_off);
-        if (scene_kind == PR_SCENE_NN) {
-            const pr_scene_nn *sn = static_cast<const pr_scene_nn *>(scene);
-            HIP_TRY(prk::launch_scene_fingerprint(sn->pcd, (size_t)sn->n_points * sizeof(pr_vec3), sn->nodes, (size_t)sn->n_nodes * sizeof(pr_kdnode), sn->normal,
-                                                  (size_t)sn->n_points * sizeof(pr_vec3), g->nndepth.as<uint32_t>() + 12, flag, true, scene_stream));
-        } else if (sl.packed.valid) {
-            const pr_scene_proj *sp = static_cast<const pr_scene_proj *>(scene);
-            const size_t n = (size_t)sp->width * sp->height;
-            const size_t tables = ((sp->width + sp->height) * sizeof(float) + 15) & ~(size_t)15;
-            uint32_t *exact_dev = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(sl.packed.rec.as<float4>() + n) + tables);
-            HIP_TRY(prk::launch_scene_fingerprint(sp->pcd, n * sizeof(pr_vec3), sp->normal, n * sizeof(pr_vec3), nullptr, 0, exact_dev + 1, flag, true, scene_stream));
+    prk::BatchCheck chk{};
+    {
+        chk.keys = sl.aabb_keys.as<uint32_t>();
+        for (int a = 0; a < 6; ++a) chk.expect.v[a] = g->aabb_host[a];
+        chk.flag = reinterpret_cast<uint32_t *>(static_cast<unsigned char *>(h_out_dev) + sl.flag_off);
+        if (opt.scene_cache) {
+            if (scene_kind == PR_SCENE_NN) {
+                const pr_scene_nn *sn = static_cast<const pr_scene_nn *>(scene);
+                chk.fa = reinterpret_cast<const uint32_t *>(sn->pcd); chk.na = (size_t)sn->n_points * sizeof(pr_vec3) / 4;
+                chk.fb = reinterpret_cast<const uint32_t *>(sn->nodes); chk.nb = (size_t)sn->n_nodes * sizeof(pr_kdnode) / 4;
+                chk.fc = reinterpret_cast<const uint32_t *>(sn->normal); chk.nc = (size_t)sn->n_points * sizeof(pr_vec3) / 4;
+                chk.fp_expected = g->nndepth.as<uint32_t>() + 12;
+            } else if (sl.packed.valid) {
+                const pr_scene_proj *sp = static_cast<const pr_scene_proj *>(scene);
+                const size_t n = (size_t)sp->width * sp->height;
+                const size_t tables = ((sp->width + sp->height) * sizeof(float) + 15) & ~(size_t)15;
+                const uint32_t *exact_dev = reinterpret_cast<const uint32_t *>(reinterpret_cast<const unsigned char *>(sl.packed.rec.as<float4>() + n) + tables);
+                chk.fa = reinterpret_cast<const uint32_t *>(sp->pcd); chk.na = n * sizeof(pr_vec3) / 4;
+                chk.fb = reinterpret_cast<const uint32_t *>(sp->normal); chk.nb = n * sizeof(pr_vec3) / 4;
+                chk.fp_expected = exact_dev + 1;
+            }
         }
     }
-    HIP_TRY(hipEventRecord(sl.scene_ready, scene_stream));
 
     // staging: [poses][boxes][box offsets]; the cloud stride and the grid come from the largest box
     const size_t in_bytes = (sizeof(pr_mat4) + sizeof(int4) + sizeof(uint32_t)) * (size_t)P;
@@ -624,14 +637,16 @@ int refine_submit_async(Slot &sl, const pr_triangle *tris_dev, size_t n_tris, ui
         prk::DevIcpState *dstate = sl.dstate.as<prk::DevIcpState>() + q0;
         uint32_t *arrive = sl.arrive.as<uint32_t>() + q0;
         size_t te = timed ? t_begin() : 0;
+        // (the first render carries the batch's checks: the fingerprint's expected value belongs to the scene build, so the scene comes first --
+        // an event that is complete when recorded unless a cache missed)
+        if (q0 == 0) HIP_TRY(hipStreamWaitEvent(st, sl.scene_ready, 0));
         HIP_TRY(prk::launch_render_boxes(tris_dev, (uint32_t)n_tris, d_poses + q0, nq, nullptr, d_box + q0, sl.depth.as<int32_t>(),
                                          sl.row_count.as<uint32_t>(), sl.row_off.as<uint32_t>(), sl.counts.as<uint32_t>() + q0, W, H, *proj, none, st,
-                                         /*compute_boxes=*/false, meta, dstate, arrive, (uint32_t)cstride, d_off ? d_off + q0 : nullptr));
+                                         /*compute_boxes=*/false, meta, dstate, arrive, (uint32_t)cstride, d_off ? d_off + q0 : nullptr, q0 == 0 ? &chk : nullptr));
         if (timed) { t_end(te, kSpanRender, q0, nq, false); te = t_begin(); }
         HIP_TRY(prk::launch_emit_box(sl.depth.as<int32_t>(), nq, W, H, d_box + q0, K[0], K[4], K[2], K[5], sl.row_count.as<uint32_t>(),
                                      sl.row_off.as<uint32_t>(), sl.cloud.as<pr_vec3>(), cstride, st, prk::kCloudAlign ? meta : nullptr, d_off ? d_off + q0 : nullptr));
         if (timed) t_end(te, kSpanCloud, q0, nq, false);
-        if (q0 == 0) HIP_TRY(hipStreamWaitEvent(st, sl.scene_ready, 0));
         if (timed && q0 == 0)                                     // the timed loop starts when the other slot's batch is complete
             for (Slot &o : g->slots) if (&o != &sl && o.pending && !o.delivered && o.done) HIP_TRY(hipStreamWaitEvent(st, o.done, 0));
 

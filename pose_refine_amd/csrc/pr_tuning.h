@@ -7,8 +7,16 @@
 #ifndef PR_PASS_WAVES
 #define PR_PASS_WAVES 1                                         // __launch_bounds__ minimum waves per SIMD of icp_pass_kernel: 4, 5, 6 waves ran within 2 % of each other; the compiler's own choice wins
 #endif
+#ifndef PR_PASS_PREFETCH
+#define PR_PASS_PREFETCH 0                                      // 1: the next 1024-point step's cloud points are loaded before this step's gathers are consumed (12 more VGPRs)
+#endif
 #ifndef PR_GATHER_BATCH
 #define PR_GATHER_BATCH 4                                       // projective scene gathers issued back to back before the first is tested (all four points of a lane)
+#endif
+
+// ---- raster (raster.hip) ----------------------------------------------------------------------------------------------------------
+#ifndef PR_RASTER_CHUNKS
+#define PR_RASTER_CHUNKS 1                                      // fused path: the raster of a (sub-)batch as this many launches over consecutive hypotheses
 #endif
 
 // ---- render -> cloud (d2c.hip) ----------------------------------------------------------------------------------------------------

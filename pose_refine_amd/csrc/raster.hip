@@ -173,6 +173,54 @@ __device__ __forceinline__ void wave_raster(const TriSetup &t, int n, float (*w)
 }
 
 // one lane = one (triangle, hypothesis); depth resolved with int32 atomicMin in global memory (the reference scheme).
+__device__ __forceinline__ uint32_t f32_key(float v) { const uint32_t b = __float_as_uint(v); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
+__device__ __forceinline__ float key_f32(uint32_t k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+// The per-batch safety nets, carried by the raster (BatchCheck, pr_internal.h): called by the workgroups of the launch's first hypothesis with
+// their 256 triangles in registers.  `red` / `part`: LDS scratch (6 x 4 floats, 4 + 1 words).
+__device__ __forceinline__ void raster_batch_check(const float (&tv)[9], bool have, const BatchCheck &chk, float (*red)[6], uint32_t *part)
+{
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (blockIdx.x == 0 && chk.fp_expected) {
+        uint32_t h = fingerprint_lane(chk.fa, chk.na, chk.fb, chk.nb, chk.fc, chk.nc);
+        for (int off = 32; off > 0; off >>= 1) h += __shfl_xor(h, off);
+        if (lane == 0) part[wave] = h;
+        __syncthreads();
+        if (threadIdx.x == 0 && *chk.fp_expected != part[0] + part[1] + part[2] + part[3]) *chk.flag = 1u;
+        __syncthreads();
+    }
+    float lo[3], hi[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        lo[a] = have ? fminf(fminf(tv[a], tv[3 + a]), tv[6 + a]) : FLT_MAX;
+        hi[a] = have ? fmaxf(fmaxf(tv[a], tv[3 + a]), tv[6 + a]) : -FLT_MAX;
+        for (int off = 32; off > 0; off >>= 1) { lo[a] = fminf(lo[a], __shfl_xor(lo[a], off)); hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], off)); }
+    }
+    if (lane == 0) for (int a = 0; a < 3; ++a) { red[wave][a] = lo[a]; red[wave][3 + a] = hi[a]; }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        float r = red[0][threadIdx.x];
+        for (int w = 1; w < 4; ++w) r = (threadIdx.x < 3) ? fminf(r, red[w][threadIdx.x]) : fmaxf(r, red[w][threadIdx.x]);
+        atomicMin(&chk.keys[threadIdx.x], (threadIdx.x < 3) ? f32_key(r) : ~f32_key(r));
+        __threadfence();                                             // this workgroup's minima are in place before its ticket is drawn
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) part[4] = (atomicAdd(&chk.keys[6], 1u) == gridDim.x - 1u) ? 1u : 0u;
+    __syncthreads();
+    if (part[4] != 0u && threadIdx.x == 0) {                         // the last workgroup to arrive: compare, and re-arm the words for the next batch
+        __threadfence();
+        bool differs = false;
+        for (int a = 0; a < 6; ++a) {
+            const uint32_t k = atomicExch(&chk.keys[a], 0xffffffffu);
+            float val = (a < 3) ? key_f32(k) : key_f32(~k);
+            if (k == 0xffffffffu) val = (a < 3) ? FLT_MAX : -FLT_MAX;
+            if (!(val == chk.expect.v[a])) differs = true;
+        }
+        atomicExch(&chk.keys[6], 0u);
+        if (differs) *chk.flag = 1u;
+    }
+    __syncthreads();
+}
+
 // A workgroup keeps its 256 triangles in registers and walks `pose_run` consecutive hypotheses with them: a mesh that does not fit
 // the L2 (the 1 M-triangle mesh of BASELINE configs[4]: 36 MB) is then streamed from the Infinity Cache / HBM once per pose_run
 // hypotheses instead of once per hypothesis -- at 128 hypotheses that stream (4.6 GB, 3.2 TB/s) was what bounded the kernel.
@@ -180,7 +228,7 @@ __global__ __launch_bounds__(256) void raster_kernel(const pr_triangle *__restri
                                                      const pr_mat4 *__restrict__ poses, int32_t *__restrict__ depth,
                                                      uint32_t width, uint32_t height, pr_mat4 proj, pr_roi roi,
                                                      uint32_t rw, uint32_t rh, const int4 *__restrict__ boxes, uint32_t n_poses, uint32_t pose_run,
-                                                     const uint32_t *__restrict__ box_off)
+                                                     const uint32_t *__restrict__ box_off, BatchCheck chk)
 {
     __shared__ float sh[4][kSetupWords][64];
     __shared__ uint32_t shq[4][128];
@@ -195,6 +243,8 @@ __global__ __launch_bounds__(256) void raster_kernel(const pr_triangle *__restri
 #pragma unroll
         for (int k = 0; k < 9; ++k) tv[k] = 0.0f;
     }
+    if (chk.keys && blockIdx.y == 0)                             // (wave-uniform) the asynchronous path's per-batch checks ride on the first hypothesis' workgroups
+        raster_batch_check(tv, ti < n_tris, chk, reinterpret_cast<float (*)[6]>(&sh[0][0][0]), &shq[0][0]);
     float rmin0 = 0.0f, rmin1 = 0.0f, rmax0 = (float)(width - 1), rmax1 = (float)(height - 1);
     if (roi.width > 0 && roi.height > 0) {                       // renderer.cu:106-113 (image is flipped in y)
         rmin0 = (float)roi.x;
@@ -242,8 +292,6 @@ __global__ __launch_bounds__(256) void raster_kernel(const pr_triangle *__restri
 // axis-aligned box of the mesh: {minx,miny,minz,maxx,maxy,maxz}.  Any number of workgroups: each reduces a slice and merges it
 // into six 32-bit keys with atomicMin -- a float maps to a key that orders like the float (sign bit flipped for positives, all
 // bits for negatives); minima store the key, maxima its complement, so all six start from 0xffffffff (one memset).
-__device__ __forceinline__ uint32_t f32_key(float v) { const uint32_t b = __float_as_uint(v); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
-__device__ __forceinline__ float key_f32(uint32_t k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
 __global__ __launch_bounds__(256) void model_aabb_kernel(const pr_triangle *__restrict__ tris, uint32_t n_tris, uint32_t *__restrict__ keys)
 {
     __shared__ float red[4][6];
@@ -267,7 +315,6 @@ __global__ __launch_bounds__(256) void model_aabb_kernel(const pr_triangle *__re
 }
 // keys -> floats (aabb_out, optional) and/or a check against the box the host assumed (flag_out, optional: 1 = differs).
 // An empty mesh leaves the keys untouched: +FLT_MAX / -FLT_MAX like the single-pass form.
-struct AabbExpected { float v[6]; };
 __global__ void model_aabb_finish_kernel(const uint32_t *__restrict__ keys, float *__restrict__ aabb_out, AabbExpected expect, uint32_t *__restrict__ flag_out)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -496,7 +543,7 @@ hipError_t launch_raster(const pr_triangle *tris, uint32_t n_tris, const pr_mat4
         const uint32_t np = (n_poses - p0 < 32768) ? (n_poses - p0) : 32768;
         const uint32_t run = raster_pose_run(n_tris, np);
         hipLaunchKernelGGL(raster_kernel, dim3((n_tris + 255) / 256, (np + run - 1) / run), dim3(256), 0, s, tris, n_tris, poses_dev + p0,
-                           depth + (size_t)p0 * rw * rh, width, height, proj, roi, rw, rh, (const int4 *)nullptr, np, run, (const uint32_t *)nullptr);
+                           depth + (size_t)p0 * rw * rh, width, height, proj, roi, rw, rh, (const int4 *)nullptr, np, run, (const uint32_t *)nullptr, BatchCheck{});
     }
     return hipGetLastError();
 }
@@ -568,7 +615,7 @@ __global__ __launch_bounds__(256) void box_pack_offsets_kernel(const int4 *__res
 hipError_t launch_render_boxes(const pr_triangle *tris, uint32_t n_tris, const pr_mat4 *poses_dev, uint32_t n_poses, const float *aabb,
                                int4 *bbox, int32_t *depth, uint32_t *row_count, uint32_t *row_off, uint32_t *counts,
                                uint32_t width, uint32_t height, const pr_mat4 &proj, pr_roi roi, hipStream_t s, bool compute_boxes,
-                               PoseMeta *meta, DevIcpState *st, uint32_t *arrive, uint32_t cloud_stride, const uint32_t *box_off)
+                               PoseMeta *meta, DevIcpState *st, uint32_t *arrive, uint32_t cloud_stride, const uint32_t *box_off, const BatchCheck *check)
 {
     if (n_poses == 0) return hipSuccess;
     if (compute_boxes) {
@@ -583,8 +630,15 @@ hipError_t launch_render_boxes(const pr_triangle *tris, uint32_t n_tris, const p
         hipLaunchKernelGGL(fill_box_kernel, dim3((height + kBoxRowsPerBlock - 1) / kBoxRowsPerBlock, np), dim3(256), 0, s, depth + off, bbox + p0, width, height, bo);
         if (n_tris > 0)                                          // an empty mesh renders nothing: every cloud is empty
         { const uint32_t run = raster_pose_run(n_tris, np);
-        hipLaunchKernelGGL(raster_kernel, dim3((n_tris + 255) / 256, (np + run - 1) / run), dim3(256), 0, s, tris, n_tris, poses_dev + p0, depth + off,
-                           width, height, proj, none, width, height, (const int4 *)(bbox + p0), np, run, bo); }
+          // PR_RASTER_CHUNKS > 1 (experiment of round 5): the hypotheses of a launch in that many launches one behind the other
+          const uint32_t chunks = (uint32_t)PR_RASTER_CHUNKS < np ? (uint32_t)PR_RASTER_CHUNKS : 1u;
+          for (uint32_t c = 0; c < chunks; ++c) {
+              const uint32_t c0 = (uint32_t)(((uint64_t)np * c) / chunks), c1 = (uint32_t)(((uint64_t)np * (c + 1)) / chunks), nc = c1 - c0;
+              if (nc == 0) continue;
+              hipLaunchKernelGGL(raster_kernel, dim3((n_tris + 255) / 256, (nc + run - 1) / run), dim3(256), 0, s, tris, n_tris, poses_dev + p0 + c0,
+                                 depth + off + (bo ? 0 : (size_t)c0 * width * height), width, height, proj, none, width, height, (const int4 *)(bbox + p0 + c0), nc, run,
+                                 bo ? bo + c0 : nullptr, (check && p0 == 0 && c == 0) ? *check : BatchCheck{});
+          } }
         hipLaunchKernelGGL(count_box_kernel, dim3((height + kBoxRowsPerBlock - 1) / kBoxRowsPerBlock, np), dim3(256), 0, s, depth + off, bbox + p0, width, height,
                            row_count + (size_t)p0 * height, bo);
     }

@@ -146,25 +146,7 @@ __global__ __launch_bounds__(256) void scene_fingerprint_kernel(const uint32_t *
                                                                 uint32_t *__restrict__ expected, uint32_t *__restrict__ flag, int check)
 {
     __shared__ uint32_t part[4];
-    uint32_t h = 0;
-    const uint32_t *arr[3] = { a, b, c };
-    const unsigned long long len[3] = { na, nb, nc };
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        if (!arr[k] || len[k] == 0) continue;
-        // sample s of 4096 sits in stripe s of the array, at a hashed offset inside it (32-bit arithmetic: __umulhi maps a hash onto a range)
-        const uint32_t n = len[k] > 0xffffffffull ? 0xffffffffu : (uint32_t)len[k];
-        const uint32_t stripe = n / 4096u;                            // 0 for short arrays: every word is visited, wrapping around
-        uint32_t w[16];
-#pragma unroll
-        for (uint32_t i = 0; i < 16u; ++i) {
-            const uint32_t s = threadIdx.x * 16u + i;
-            const uint32_t pos = stripe ? s * stripe + __umulhi(s * 2654435761u + 0x9e3779b9u, stripe) : (n >= 4096u ? s : s % n);
-            w[i] = arr[k][pos] ^ pos;
-        }
-#pragma unroll
-        for (uint32_t i = 0; i < 16u; ++i) h += w[i] * 2654435761u + (uint32_t)k;      // a sum: the order of the lanes does not matter
-    }
+    uint32_t h = fingerprint_lane(a, na, b, nb, c, nc);
     for (int off = 32; off > 0; off >>= 1) h += __shfl_xor(h, off);
     if ((threadIdx.x & 63u) == 0u) part[threadIdx.x >> 6] = h;
     __syncthreads();
