@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "pr_internal.h"
+#include "pr_tuning.h"
 
 #include "pr_internal.h"
 
@@ -116,7 +117,7 @@ struct WriteLog {
 extern WriteLog g_writes;
 
 // ---- process-wide options (pr_set_option): plain ints, shared by every context ---------------------
-constexpr int kSlots = 2;
+constexpr int kSlots = PR_SLOTS;            // asynchronous slots per context (pr_tuning.h)
 struct Options {
     int pose_groups = 0;             // split the batch over this many streams (1..4); 0 = two, for either scene kind (pose_groups_for below has the measurements);
                                      // launches of different groups overlap, so timed calls fall back to one group

@@ -3,6 +3,11 @@
 // variant libraries side by side on one box.  The on/off switches of rounds 1-3 whose A/B is decided are gone: the winning branch is the code.
 #pragma once
 
+// ---- asynchronous path (pr_refine.cpp) ------------------------------------------------------------------------------------------------
+#ifndef PR_SLOTS
+#define PR_SLOTS 2                                              // asynchronous slots per context (pr_refine_submit's slot argument: 0 .. PR_SLOTS - 1)
+#endif
+
 // ---- correspondence pass (icp_pass.hip) --------------------------------------------------------------------------------------------
 #ifndef PR_PASS_WAVES
 #define PR_PASS_WAVES 1                                         // __launch_bounds__ minimum waves per SIMD of icp_pass_kernel: 4, 5, 6 waves ran within 2 % of each other; the compiler's own choice wins

@@ -46,6 +46,7 @@ done
 PR_OPTS="sub_batch=1024,pose_groups=1" rocprofv3 --kernel-trace --stats -d $OUT/stats4 -o big -- python tools/pmc_workload.py 1024 > /dev/null 2>&1
 summ $OUT/stats4/big_results.db > $OUT/kernel_stats_p1024_onebatch.md
 python tools/nn_counters.py > $OUT/nn_work_counters.md 2>/dev/null
+bash tools/pmc_allpasses.sh "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_LDS" "TA_BUSY_avr GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES" -- - 2>/dev/null | grep -v "^$" > $OUT/sq_nn_allpasses.txt
 bash tools/nn_passes_env.sh "PR_OPTS_EXTRA=default" 2>/dev/null | grep -E "==|us:" > $OUT/nn_per_pass_us.txt
 bash tools/nn_passes.sh "nn_wide=0" 2>/dev/null | grep -E "==|us:" >> $OUT/nn_per_pass_us.txt
 # BASELINE configs[4]: 1M triangles, 1280x720, 128 hypotheses (the per-GPU share of 1024 over 8)
@@ -55,6 +56,11 @@ summ $OUT/stats3/c5_results.db > $OUT/kernel_stats_config5.md
 # two ranks on the one GPU of this box, started by bench.py itself: one process per rank under torch.distributed.run, and one host thread per rank
 PR_BENCH_SHARE_DEVICE=1 timeout 600 python bench.py --gpus 2 --steps 40 --warmup 5 2>/dev/null | tail -1 > $OUT/bench_2ranks_share_device_processes.json
 PR_BENCH_SHARE_DEVICE=1 timeout 600 python bench.py --gpus 2 --steps 40 --warmup 5 --launcher threads 2>/dev/null | tail -1 > $OUT/bench_2ranks_share_device_threads.json
+# EIGHT ranks on the one GPU: the driver's SCALE job on this box's 16-CPU cgroup, both launchers; per-rank host CPU over the timed region is in the line
+PR_BENCH_SHARE_DEVICE=1 timeout 900 python bench.py --gpus 8 --steps 20 --warmup 5 2>/dev/null | tail -1 > $OUT/bench_8ranks_share_device_processes.json
+PR_BENCH_SHARE_DEVICE=1 timeout 900 python bench.py --gpus 8 --steps 20 --warmup 5 --launcher threads 2>/dev/null | tail -1 > $OUT/bench_8ranks_share_device_threads.json
+# the whole N > 1 machinery with a world of one: torch's RCCL process group and the library's own dlopened RCCL in one process
+PR_BENCH_FORCE_COMM=1 timeout 300 python bench.py --steps 20 --warmup 5 2>/dev/null | tail -1 > $OUT/bench_force_comm_world1.json
 # C++ host: shard driver
 g++ -std=c++14 -O2 -pthread -Iinclude tests/cpp/shard_test.cpp -o tests/cpp/shard_test -Lpose_refine_amd/lib -lpose_refine_hip -Wl,-rpath,$PWD/pose_refine_amd/lib && ./tests/cpp/shard_test tests/golden/ 4096 2>&1 | tail -1 > $OUT/shard_test_4096.json; cat $OUT/shard_test_4096.json
 python -c "from pose_refine_amd import api; print('visible devices:', api.device_count())" >> $OUT/shard_test_4096.json 2>/dev/null
@@ -65,4 +71,4 @@ for f in $OUT/bench_*.json; do echo "== $f"; python -c "
 import json
 d=json.loads(open('$f').read().strip().splitlines()[-1])
 r=d['roofline']
-print('%.0f poses/s  %.3f ms/step  frac %.3f  launch %.1f us' % (d['value'], d['ms_per_step'], r['frac'], r['avg_launch_us']), d.get('cpu_baseline',{}).get('value',''), d.get('config2_kdtree',{}).get('value',''))"; done
+print('%.0f poses/s  %.3f ms/step  frac %.3f (algorithmic %.3f, end to end %.3f)  launch %.1f us' % (d['value'], d['ms_per_step'], r['frac'], r['frac_algorithmic'], r['frac_end_to_end'], r['avg_launch_us']), d.get('cpu_baseline',{}).get('value',''), d.get('config2_kdtree',{}).get('value',''), d.get('default_criteria',{}).get('projective',{}).get('value',''), d.get('default_criteria',{}).get('kdtree',{}).get('value',''))"; done
