@@ -52,19 +52,19 @@ BYTES_PER_POINT_PASS0, BYTES_PER_POINT_PASSK = 36.0, 48.0
 # max2zero_kernel, which moves a known number of bytes) and VALU wave-instructions per point (SQ_INSTS_VALU).  FETCH_SIZE counts what the
 # L2s fetch from the fabric, Infinity-Cache hits included (guide, HBM section): the counter figure is FABRIC traffic, an upper bound of DRAM
 # traffic -- with <= 512 hypotheses per sub-batch the clouds are Infinity-Cache resident by design.
-PMC_TRAFFIC_BYTES_PER_POINT = {"proj": 25.2, "nn": 69.0}       # P = 1024 as ONE sub-batch (clouds spill the Infinity Cache): 23.9 B/point -- the same: it is the cloud read + write-back
+PMC_TRAFFIC_BYTES_PER_POINT = {"proj": 25.1, "nn": 70.9}       # P = 1024 as ONE sub-batch (clouds spill the Infinity Cache): 23.9 B/point -- the same: it is the cloud read + write-back
 PMC_VALU_WAVE_INSTR_PER_POINT = {"proj": 2.085, "nn": None}
 # what DRAM carries when the clouds do NOT fit the Infinity Cache (1024 hypotheses as one sub-batch): committed fallback of the run's own passes
-PMC_DRAM_FRAC = {"proj": 0.46, "nn": None}
-PMC_DRAM_SOURCE = "committed: profiles/r03/pmc_proj_p1024_onebatch_*.md + kernel_stats_p1024_onebatch.md (537 MB per 147.1 us launch = 3.65 TB/s)"
-# committed SQ counter passes of the kd-tree task walk, pass 0 (profiles/r04/sq_nn_pass0.txt): SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES = the share of a
+PMC_DRAM_FRAC = {"proj": 0.52, "nn": None}
+PMC_DRAM_SOURCE = "committed: profiles/r05/pmc_proj_p1024_onebatch_*.md + kernel_stats_p1024_onebatch.md (23.8 B/point x 22.47 M points = 536 MB per 128.9 us launch = 4.16 TB/s)"
+# committed SQ counter passes of the kd-tree task walk, pass 0 (profiles/r05/sq_nn_pass0.txt): SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES = the share of a
 # wavefront's resident cycles with one of its VALU instructions in flight (six wavefronts share a SIMD), and 4 x SQ_ACTIVE_INST_VALU over
 # (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs) = the share of the chip's VALU issue slots the kernel fills
-NN_WALK_VALU_ACTIVE_FRAC = 0.25
+NN_WALK_VALU_ACTIVE_FRAC = 0.21
 NN_WALK_VALU_ISSUE_FRAC = 0.79
-NN_WALK_HBM_BYTES_PER_POINT = 4.9                                  # profiles/r03/pmc_nn_*.md: the walk reads queue entries + cloud points, writes winners
-PMC_TRAFFIC_SOURCE = {"proj": "profiles/r03/pmc_proj_FETCH_SIZE.md + pmc_proj_WRITE_SIZE.md + sq_proj_SQ_INSTS_VALU*.md (icp_pass_kernel<SceneProjPacked>)",
-                      "nn": "profiles/r03/pmc_nn_FETCH_SIZE.md + pmc_nn_WRITE_SIZE.md (search 39.7 + bound 6.3 + task walk 4.9 + winners pass 18.1 B/point)"}
+NN_WALK_HBM_BYTES_PER_POINT = 4.6                                  # profiles/r05/pmc_nn_*.md: the walk reads queue entries + cloud points, writes winners
+PMC_TRAFFIC_SOURCE = {"proj": "profiles/r05/pmc_proj_FETCH_SIZE.md + pmc_proj_WRITE_SIZE.md + sq_proj_SQ_INSTS_VALU*.md (icp_pass_kernel<SceneProjPacked>)",
+                      "nn": "profiles/r05/pmc_nn_FETCH_SIZE.md + pmc_nn_WRITE_SIZE.md (search 37.1 + bound 11.2 + task walk 4.6 + winners pass 17.9 B/point)"}
 
 
 def effective_cpus():
@@ -881,11 +881,11 @@ def kdtree_extra(args, api, model, poses, scene_depth, W, H, proj, K, steps=20):
                 "avg_launch_us": 1e3 * part_ms[k] / n_pass, "share_of_step": part_ms[k] / step_ms if step_ms > 0 else None,
                 "per_kernel_ms_per_step": {n: float(v) for n, v in zip(names, part_ms)}, "passes": int(n_pass), "one_group_step_ms": step_ms,
                 "first_passes_us": [float(v) for v in pass_us[:4]],
-                "bound": "valu issue (pass 0: 0.79 of the chip's VALU issue slots, 626 M wave-instructions for 5.4 M tree searches; a wavefront has a VALU instruction in flight 25 % of its resident cycles, six share a SIMD; HBM ~ 0)",
+                "bound": "valu issue (pass 0: 0.79 of the chip's VALU issue slots, 568 M wave-instructions for 5.4 M tree searches; a wavefront has a VALU instruction in flight 21 % of its resident cycles, six share a SIMD; HBM ~ 0)",
                 "frac": NN_WALK_VALU_ISSUE_FRAC, "frac_of": "VALU issue slots of the chip in pass 0 (the binding resource by the SQ counters; committed pass, see valu_active_frac_source)",
                 "valu_issue_frac": NN_WALK_VALU_ISSUE_FRAC,
                 "valu_active_frac": NN_WALK_VALU_ACTIVE_FRAC,
-                "valu_active_frac_source": "committed: profiles/r04/sq_nn_pass0.txt (nn_tree_wide_kernel, pass 0 of a 256-hypothesis batch)",
+                "valu_active_frac_source": "committed: profiles/r05/sq_nn_pass0.txt (nn_tree_wide_kernel, pass 0 of a 256-hypothesis batch: SQ_ACTIVE_INST_VALU 5.68e8, SQ_WAVE_CYCLES 2.69e9, GRBM_GUI_ACTIVE 2.24e7 over 8 XCDs)",
                 # HBM side of the task walk alone: committed counter bytes per cloud point x this batch's points over this run's launch time
                 "hbm_GBps": (NN_WALK_HBM_BYTES_PER_POINT * pts / walk_s / 1e9) if walk_s > 0 else None,
                 "hbm_frac": (NN_WALK_HBM_BYTES_PER_POINT * pts / walk_s / HBM_PEAK) if walk_s > 0 else None,

@@ -289,6 +289,8 @@ int pr_gather_results(const pr_result *send_dev, uint32_t n_local, uint32_t n_to
  *   "raster_mode"      [0]     fused render: 0 = global atomicMin inside the pose's pixel box, 1 = LDS depth bands (synchronous path)
  *   "nn_stack"         [1]     kd-tree query: per-lane LDS stack (1) or the reference's stackless walk (0)
  *   "nn_compact"       [1]     stack query on 32-byte node records with 16-bit outward-rounded boxes (0: exact 64-byte records)
+ *   "host_worker"      [1]     host solve: a batch given to pr_refine_submit runs on a library-owned helper thread of its slot (private context: its own
+ *                              workspaces and scene caches -- about as much device memory again per slot in use); 0: inside the call, on the caller's thread
  *   "blocking_wait"    [0]     pr_refine_wait sleeps on the slot's event (hipEventBlockingSync) instead of spinning; takes effect for slots created afterwards
  *   "nn_wide"          [1]     queued tree searches walk 128-byte lines (wide nodes of eight subtree boxes, one line per leaf) in nearest-first
  *                              order; a query whose minimum is attained by more than one point is repeated by the ordered binary walk (0: binary walk only)

@@ -41,15 +41,6 @@ __global__ __launch_bounds__(256, PR_PASS_WAVES) void icp_pass_kernel(IcpBatch b
         lds_topo = reinterpret_cast<const int4 *>(recs);
     }
     if constexpr (kNN && kStack == -1) scene.winner += pm.start;  // winners are indexed like the cloud
-    if constexpr (!kNN && kStack == 1) {
-        // Packed projective scene, round 5: the two tables colf[x], rowf[y] (W + H floats, contiguous) are staged in LDS, so that of a point's
-        // three gathers -- the 16-byte record and one word of each table -- only the record goes through the texture addresser.
-        float *tab = reinterpret_cast<float *>(lds_raw);
-        const uint32_t nt = scene.width + scene.height;
-        for (uint32_t i = threadIdx.x; i < nt; i += kBlockThreads) tab[i] = scene.colf[i];
-        __syncthreads();
-        scene.colf = tab; scene.rowf = tab + scene.width;
-    }
 
     float *cl = reinterpret_cast<float *>(b.cloud + pm.start);
     // a pending update that nn_search_kernel has already applied to the cloud must not be applied again
@@ -215,13 +206,10 @@ static hipError_t launch_pass(const IcpBatch &b, const Scene &sc, uint32_t n_pos
 }
 hipError_t launch_icp_pass_proj_aos(const IcpBatch &b, const SceneProjAoS &sc, uint32_t n_poses, hipStream_t s)
 { return launch_pass<SceneProjAoS, false>(b, sc, n_poses, 0, s); }
+// (Round 5 measured the two tables colf / rowf of the packed scene staged in LDS per workgroup -- two of a point's three gathers off the texture
+// addresser: 0.84 against 0.82 ms per 21 launches, 272 / 263 k against 277 / 276 k poses/s on one box.  Not kept.)
 hipError_t launch_icp_pass_proj_packed(const IcpBatch &b, const SceneProjPacked &sc, uint32_t n_poses, hipStream_t s)
-{
-    // tables in LDS while they are small (640 x 480: 4.4 KiB per workgroup) and laid out one behind the other, as pr_scene.cpp builds them
-    const size_t table_bytes = ((size_t)sc.width + sc.height) * sizeof(float);
-    if (PR_PASS_LDS_TABLES && table_bytes <= 16384 && sc.rowf == sc.colf + sc.width) return launch_pass<SceneProjPacked, false, 1>(b, sc, n_poses, table_bytes, s);
-    return launch_pass<SceneProjPacked, false>(b, sc, n_poses, 0, s);
-}
+{ return launch_pass<SceneProjPacked, false>(b, sc, n_poses, 0, s); }
 hipError_t launch_icp_pass_nn(const IcpBatch &b, const SceneNNDev &sc, uint32_t n_poses, hipStream_t s)
 {
     if (sc.stack_depth == 16 && sc.rec32) return launch_pass<SceneNNDev, true, 16 + 0x100>(b, sc, n_poses, (size_t)16 * kBlockThreads * 8, s);

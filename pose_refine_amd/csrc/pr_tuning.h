@@ -12,9 +12,6 @@
 #ifndef PR_PASS_WAVES
 #define PR_PASS_WAVES 1                                         // __launch_bounds__ minimum waves per SIMD of icp_pass_kernel: 4, 5, 6 waves ran within 2 % of each other; the compiler's own choice wins
 #endif
-#ifndef PR_PASS_LDS_TABLES
-#define PR_PASS_LDS_TABLES 0                                    // 1: packed projective scene, colf / rowf staged in LDS per workgroup (two of a point's three gathers leave the texture addresser).  Same box: pass 0.84 against 0.82 ms per 21 launches, 272 / 263 k against 277 / 276 k poses/s -- not kept
-#endif
 #ifndef PR_PASS_PREFETCH
 #define PR_PASS_PREFETCH 0                                      // 1: the next 1024-point step's cloud points are loaded before this step's gathers are consumed (12 more VGPRs: 106, four waves per SIMD).  Same box: 262 k against 274 k poses/s -- not kept
 #endif
