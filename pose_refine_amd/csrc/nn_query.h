@@ -462,6 +462,7 @@ __device__ __forceinline__ bool grid_search(const SceneNNDev &s, float sx, float
                                             float *best_sq = nullptr, float *other_sq = nullptr, bool settle = false, bool full = false)
 {
     int wx, wy;
+    float cover_full = 0.0f;
     if (full) {
         const float W = (float)kGridMaxW - 4e-3f;
         const float rx = W * sz * sz * margin_rcp(s.gfx * (sz + fabsf(sx)) + W * sz), ry = W * sz * sz * margin_rcp(s.gfy * (sz + fabsf(sy)) + W * sz);
@@ -469,7 +470,7 @@ __device__ __forceinline__ bool grid_search(const SceneNNDev &s, float sx, float
         if (!(rc > 0.0f) || !grid_window(s, sx, sy, sz, rc * rc, wx, wy)) return false;
         const float c2 = rc * rc * 0.9999f;
         if (c2 < bound) bound = c2;                                // only points strictly inside the covered radius can win
-        settle = true;                                             // (the margin: everything the window holds)
+        cover_full = rc * rc;                                      // (the margin: everything the window holds; wx, wy are its window)
     }
     // The window has to hold every point closer than sqrt(bound) for the search to be exact.  When a slightly larger window still
     // fits it is taken instead: the extra ring costs a few cells and tells how far the RUNNER-UP is (other_sq), which is what lets
@@ -479,7 +480,8 @@ __device__ __forceinline__ bool grid_search(const SceneNNDev &s, float sx, float
     // fixed pad a point whose neighbour is more than half a millimetre away (a quarter of them: the depth image is in whole
     // millimetres) never got a margin at all and went through the window in every pass.
     float cover = bound;
-    if (other_sq) {
+    if (full) cover = cover_full;
+    else if (other_sq) {
         const float rb = margin_sqrt(bound) * 1.000001f;
         float rc = rb + PR_NN_COVER_PAD;
         if (settle) {
@@ -490,7 +492,7 @@ __device__ __forceinline__ bool grid_search(const SceneNNDev &s, float sx, float
         if (rc > rb && grid_window(s, sx, sy, sz, rc * rc, wx, wy)) cover = rc * rc;
         else if (settle) { rc = rb + PR_NN_COVER_PAD; if (grid_window(s, sx, sy, sz, rc * rc, wx, wy)) cover = rc * rc; }
     }
-    if (cover == bound && !grid_window(s, sx, sy, sz, bound, wx, wy)) return false;
+    if (!full && cover == bound && !grid_window(s, sx, sy, sz, bound, wx, wy)) return false;
     float u, v;
     grid_project(s, sx, sy, sz, u, v);
     if (!(u > -1e6f && u < 1e6f && v > -1e6f && v < 1e6f)) return false;

@@ -216,9 +216,15 @@ __global__ __launch_bounds__(256) void nn_tree_kernel(IcpBatch b, SceneNNDev sce
 constexpr uint32_t kTaskQCap = PR_WIDE_QCAP, kTaskLCap = PR_WIDE_LCAP;   // entries of the node / leaf task queue of a wavefront (a leaf queue is drained from 16 entries on)
 constexpr uint32_t kNoIdx = 0xffffffffu;
 // Queue 1 (nn_search_kernel's leftovers) -> bound + pixel window, one query per lane -> winners, or queue 2 (point, bound).
+// Round 5: the kernel works in two phases per workgroup.  (A) every queued query: the window scans that need no descent -- `still` queries with their
+// seed bound, "window first" for queries whose previous winner is near; what the window settles is done, a `still` query it does not settle goes to
+// queue 2.  Everything that needs the DESCENT is deferred into a list in LDS and (B) descended 256 at a time in dense lanes.  Before, a wavefront paid
+// for window scan AND descent whenever one of its lanes needed the descent -- in passes 2-4, where 13-46 % of the lanes do, that was every wavefront.
+constexpr uint32_t kDeferCap = 512;                              // (at most 255 left over + 256 new entries)
 __global__ __launch_bounds__(256, PR_BOUND_WAVES) void nn_bound_kernel(IcpBatch b, SceneNNDev scene)
 {
-    __shared__ uint32_t wave_n[4], wg_base;
+    __shared__ uint32_t wave_n[4], wave_d[4], wg_base, s_ndefer;
+    __shared__ uint2 s_defer[kDeferCap];                         // {point | tried << 30 | settle << 31, bound bits}
     const uint32_t pose = blockIdx.y;
     const PoseMeta &pm = b.meta[pose];
     if (pm.state == kSkip) return;
@@ -235,15 +241,51 @@ __global__ __launch_bounds__(256, PR_BOUND_WAVES) void nn_bound_kernel(IcpBatch 
     const float accept = scene.max_dist_diff * scene.max_dist_diff;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint32_t n_window = 0, n_pyramid = 0, n_cells = 0;
+    if (threadIdx.x == 0) s_ndefer = 0u;
+    __syncthreads();
+    // the lanes with `pending` append (point, bound) to queue 2, in lane order (called by every lane of the workgroup)
+    auto push_q2 = [&](bool pending, uint32_t j, float bst) {
+        const unsigned long long m = __ballot(pending);
+        if (lane == 0) wave_n[wave] = (uint32_t)__popcll(m);
+        __syncthreads();
+        if (threadIdx.x == 0) { const uint32_t t = wave_n[0] + wave_n[1] + wave_n[2] + wave_n[3]; wg_base = t ? atomicAdd(q2_count, t) : 0u; }
+        __syncthreads();
+        if (pending) {
+            uint32_t slot = wg_base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            for (uint32_t w2 = 0; w2 < wave; ++w2) slot += wave_n[w2];
+            queue2[slot] = make_uint2(j, __float_as_uint(bst));
+        }
+        __syncthreads();
+    };
+    // (B) deferred entries [first, first + n), n <= 256, one per lane: descent through the representative points, the window if it has not been
+    // tried with this query, then the winner or queue 2
+    auto descend = [&](uint32_t first, uint32_t n) {
+        bool pending = false;
+        uint32_t j = 0; float bst = 0.0f;
+        if (threadIdx.x < n) {
+            const uint2 e = s_defer[first + threadIdx.x];
+            j = e.x & 0x3fffffffu;
+            const bool tried = (e.x & 0x40000000u) != 0u, settle = (e.x & 0x80000000u) != 0u;
+            bst = __uint_as_float(e.y);
+            const pr_vec3 q = ld_off<pr_vec3>(cl, j * 12u);
+            grid_pyramid_bound(scene, q.x, q.y, q.z, bst); ++n_pyramid;
+            uint32_t w = kNoPrev; float bsq = 0.0f, osq = 0.0f;
+            // (a query whose largest window held nothing within its reach, or a tie, cannot be settled by the window after a descent either)
+            const bool done = !tried && bst < accept && grid_search(scene, q.x, q.y, q.z, bst, w, &n_cells, &bsq, &osq, settle);
+            if (done) { ++n_window; win[j] = w; slk[j] = margin_sqrt(osq) * 0.99999f; }
+            else pending = true;
+        }
+        push_q2(pending, j, bst);
+    };
     for (uint32_t i0 = blockIdx.x * kBlockThreads; i0 < queued; i0 += gridDim.x * kBlockThreads) {
         const uint32_t i = i0 + threadIdx.x;
-        bool pending = false;
+        bool pending = false, defer = false, tried = false, settle = false;
         uint32_t j = 0; float bst = 0.0f;
         if (i < queued) {
             const uint2 e = queue[i];
             j = e.x;
             const bool still = (e.y & 0x80000000u) != 0u;        // the sign carries "no descent needed", the lowest bit "settle" (nn_search_kernel)
-            const bool settle = (e.y & 1u) != 0u;
+            settle = (e.y & 1u) != 0u;
             bst = __uint_as_float((e.y & 0x7fffffffu) | 1u);     // (the flag bit set: the bound rounded UP by at most an ulp)
             pending = true;
             if (!scene.grid && !still) {
@@ -275,33 +317,46 @@ __global__ __launch_bounds__(256, PR_BOUND_WAVES) void nn_bound_kernel(IcpBatch 
             if (scene.grid) {
                 const pr_vec3 q = ld_off<pr_vec3>(cl, j * 12u);
                 uint32_t w = kNoPrev; float bsq = 0.0f, osq = 0.0f;
-                bool done = false, tried = false;
-                if (!still && bst <= PR_NN_WINFIRST) {
-                    // WINDOW FIRST (round 5): the previous winner is a few millimetres away, so the neighbour is probably within the largest window's
-                    // reach -- scan it without a tight bound (grid_search `full`) and spare the descent.  A failure (nothing within the covered
-                    // radius, or a tie) means the window cannot settle this query after a descent either: it goes on to the tree.
+                bool done = false;
+                if (still) done = bst < accept && grid_search(scene, q.x, q.y, q.z, bst, w, &n_cells, &bsq, &osq, settle);
+                else if (bst <= PR_NN_WINFIRST) {
+                    // WINDOW FIRST (round 5): the previous winner is near, so the neighbour is probably within the largest window's reach -- scan it
+                    // without a tight bound (grid_search `full`) and spare the descent.  A failure (nothing within the covered radius, or a tie)
+                    // means the window cannot settle this query after a descent either: it is descended (a bound for the tree) and goes to queue 2.
                     tried = true;
                     done = grid_search(scene, q.x, q.y, q.z, bst, w, &n_cells, &bsq, &osq, settle, true);
                     if (!done && bsq > 0.0f) { const float bb = bsq * 1.000001f + 1e-30f; if (bb < bst) bst = bb; }
                 }
-                if (!done) {
-                    if (!still) { grid_pyramid_bound(scene, q.x, q.y, q.z, bst); ++n_pyramid; }
-                    if (!tried) done = bst < accept && grid_search(scene, q.x, q.y, q.z, bst, w, &n_cells, &bsq, &osq, settle);
-                }
                 if (done) { pending = false; ++n_window; win[j] = w; slk[j] = margin_sqrt(osq) * 0.99999f; }
+                else if (!still) { pending = false; defer = true; }
             }
         }
-        const unsigned long long m = __ballot(pending);
-        if (lane == 0) wave_n[wave] = (uint32_t)__popcll(m);
-        __syncthreads();
-        if (threadIdx.x == 0) { const uint32_t t = wave_n[0] + wave_n[1] + wave_n[2] + wave_n[3]; wg_base = t ? atomicAdd(q2_count, t) : 0u; }
-        __syncthreads();
-        if (pending) {
-            uint32_t slot = wg_base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-            for (uint32_t w2 = 0; w2 < wave; ++w2) slot += wave_n[w2];
-            queue2[slot] = make_uint2(j, __float_as_uint(bst));
+        // the deferred queries of this chunk join the list (lane order); thread 0 alone advances the count, between two barriers
+        {
+            const unsigned long long md = __ballot(defer);
+            if (lane == 0) wave_d[wave] = (uint32_t)__popcll(md);
+            __syncthreads();
+            const uint32_t base = s_ndefer;
+            if (defer) {
+                uint32_t slot = base + (uint32_t)__popcll(md & ((1ull << lane) - 1ull));
+                for (uint32_t w2 = 0; w2 < wave; ++w2) slot += wave_d[w2];
+                s_defer[slot] = make_uint2(j | (tried ? 0x40000000u : 0u) | (settle ? 0x80000000u : 0u), __float_as_uint(bst));
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) s_ndefer = base + wave_d[0] + wave_d[1] + wave_d[2] + wave_d[3];
         }
-        __syncthreads();
+        push_q2(pending, j, bst);                                // (its barriers also publish the list and its count)
+        const uint32_t nd = s_ndefer;
+        if (nd >= kBlockThreads) {                               // workgroup-uniform
+            descend(nd - kBlockThreads, kBlockThreads);
+            if (threadIdx.x == 0) s_ndefer = nd - kBlockThreads;
+            __syncthreads();
+        }
+    }
+    for (uint32_t nd = s_ndefer; nd > 0u; ) {                    // what is left: fewer than 256 (workgroup-uniform: nobody writes s_ndefer any more)
+        const uint32_t n = nd < kBlockThreads ? nd : kBlockThreads;
+        descend(nd - n, n);
+        nd -= n;
     }
     if (scene.counters) {                                        // instrumented runs only (option "nn_count")
         const uint32_t v[8] = { 0u, n_window, 0u, n_pyramid, 0u, 0u, 0u, n_cells };
