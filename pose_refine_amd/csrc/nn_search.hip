@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256, PR_BOUND_WAVES) void nn_bound_kernel(IcpBatch 
                 uint32_t w = kNoPrev; float bsq = 0.0f, osq = 0.0f;
                 bool done = false;
                 if (still) done = bst < accept && grid_search(scene, q.x, q.y, q.z, bst, w, &n_cells, &bsq, &osq, settle);
-                else if (bst <= PR_NN_WINFIRST) {
+                else if (bst <= (b.iter <= 1u ? PR_NN_WINFIRST_EARLY : PR_NN_WINFIRST)) {
                     // WINDOW FIRST (round 5): the previous winner is near, so the neighbour is probably within the largest window's reach -- scan it
                     // without a tight bound (grid_search `full`) and spare the descent.  A failure (nothing within the covered radius, or a tie)
                     // means the window cannot settle this query after a descent either: it is descended (a bound for the tree) and goes to queue 2.

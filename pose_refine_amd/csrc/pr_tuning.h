@@ -66,6 +66,9 @@
 #ifndef PR_NN_WINFIRST
 #define PR_NN_WINFIRST 4.0e-4f                                  // (20 mm)^2 [same box: off 47.4 k, (2 mm)^2 47.4 k, (3 mm)^2 47.8 k, (5 mm)^2 48.2 k, (10 mm)^2 48.8 k, (20 mm)^2 49.3 k, always 48.9 k poses/s]: a query whose previous winner is within this (but which moved too far to go without a new bound) scans the largest window BEFORE any descent
 #endif
+#ifndef PR_NN_WINFIRST_EARLY
+#define PR_NN_WINFIRST_EARLY 4.0e-6f                            // the same threshold in pass 1, where the cloud has just made its largest step and 87 % of the attempts would fail: (2 mm)^2
+#endif
 #ifndef PR_NN_COVER_PAD
 #define PR_NN_COVER_PAD 5.0e-4f                                 // metres a window search looks beyond its bound for the runner-up (about one pixel at 300 mm)
 #endif
