@@ -408,11 +408,38 @@ __device__ __forceinline__ uint32_t grid_ring_key(const float4 *__restrict__ lev
     bx = xc + (k - ky * kW); by = yc + ky;
     return best & kRingKeyMask;
 }
-__device__ __forceinline__ void grid_pyramid_bound(const SceneNNDev &s, float sx, float sy, float sz, float &best)
+__device__ __forceinline__ void grid_pyramid_bound(const SceneNNDev &s, float sx, float sy, float sz, float &best, bool late = false)
 {
     const int w4 = ((int)s.gw + 3) / 4, h4 = ((int)s.gh + 3) / 4, w16 = (w4 + 3) / 4, h16 = (h4 + 3) / 4, w64 = (w16 + 3) / 4, h64 = (h16 + 3) / 4;
     float dmin = FLT_MAX, dall;
     int bx = 0, by = 0;
+    // Round 5: the descent starts AT THE QUERY'S OWN PROJECTION -- a 5 x 5 ring of 16 x 16-pixel blocks centred on it (`late`, from pass 1 on, where
+    // the cloud is within millimetres of the surface: PR_DESCENT_LATE) -- instead of choosing one of the 3 x 3 blocks of 64 x 64 pixels around it
+    // first: nine cells fewer, and a BETTER landing (the chosen 64-block's children did not always hold the neighbour of a query near the block's
+    // edge): same box, bound 1.58 -> 1.54 ms and walk 2.94 -> 2.79 ms per group-step, configs[2] 50.9 -> 53.0 k poses/s.  A ring that holds no scene
+    // point at all (the query projects far off the object) falls through to the blocks of 64 x 64 pixels below.
+    if (w16 >= PR_RING16_W && h16 >= PR_RING16_W && w16 >= PR_RING_W && h16 >= PR_RING_W) {
+        float u, v;
+        grid_project(s, sx, sy, sz, u, v);
+        if (u > -1e6f && u < 1e6f && v > -1e6f && v < 1e6f) {
+            const float2v sxy{ sx, sy };
+            uint32_t k = 0xffffffffu;
+            const int pu = (int)floorf(u), pv = (int)floorf(v);
+            if (late && PR_DESCENT_LATE == 2) {                  // straight to the 4 x 4-pixel blocks around the projection
+                k = grid_ring_key<PR_RING_W>(s.pyr4, w4, h4, (pu >> 2) - PR_RING_W / 2, (pv >> 2) - PR_RING_W / 2, sxy, sz, bx, by);
+            } else {
+                if (late && PR_DESCENT_LATE == 1) k = grid_ring_key<3>(s.pyr16, w16, h16, (pu >> 4) - 1, (pv >> 4) - 1, sxy, sz, bx, by);
+                else k = grid_ring_key<PR_RING16_W>(s.pyr16, w16, h16, (pu >> 4) - PR_RING16_W / 2, (pv >> 4) - PR_RING16_W / 2, sxy, sz, bx, by);
+                if (k < 0x7f800000u) k = min(k, grid_ring_key<PR_RING_W>(s.pyr4, w4, h4, bx * 4 - PR_RING_OFF, by * 4 - PR_RING_OFF, sxy, sz, bx, by));
+            }
+            if (k < 0x7f800000u) {
+                k = min(k, grid_ring_key<PR_RING_W>(s.grid, (int)s.gw, (int)s.gh, bx * 4 - PR_RING_OFF, by * 4 - PR_RING_OFF, sxy, sz, bx, by));
+                const float bk = __uint_as_float(k) * 1.00002f + 1e-30f;     // the landing cell's exact distance is below this (see ring_key)
+                if (bk < best) best = bk;
+                return;
+            }
+        }
+    }
     {   // the 3 x 3 blocks of 64 x 64 pixels around the query's own projection first: a hypothesis within a few centimetres / degrees of the
         // scene pose has its neighbour there; only a query that finds nothing there looks at all blocks
         float u, v;

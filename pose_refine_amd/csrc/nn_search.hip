@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256, PR_BOUND_WAVES) void nn_bound_kernel(IcpBatch 
             const bool tried = (e.x & 0x40000000u) != 0u, settle = (e.x & 0x80000000u) != 0u;
             bst = __uint_as_float(e.y);
             const pr_vec3 q = ld_off<pr_vec3>(cl, j * 12u);
-            grid_pyramid_bound(scene, q.x, q.y, q.z, bst); ++n_pyramid;
+            grid_pyramid_bound(scene, q.x, q.y, q.z, bst, b.iter >= 1u); ++n_pyramid;
             uint32_t w = kNoPrev; float bsq = 0.0f, osq = 0.0f;
             // (a query whose largest window held nothing within its reach, or a tie, cannot be settled by the window after a descent either)
             const bool done = !tried && bst < accept && grid_search(scene, q.x, q.y, q.z, bst, w, &n_cells, &bsq, &osq, settle);

@@ -48,6 +48,12 @@
 #ifndef PR_RING_ROWS
 #define PR_RING_ROWS 2                                          // rows of a 6 x 6 ring of the descent in flight at a time (1, 2, 3, 6 measured: not latency-bound)
 #endif
+#ifndef PR_DESCENT_LATE
+#define PR_DESCENT_LATE 1                                       // the descent's first ring from pass 1 on: 0 = as in pass 0 (5 x 5 blocks of 16 x 16 pixels), 1 = 3 x 3 such blocks, 2 = none (straight to 5 x 5 blocks of 4 x 4 pixels)
+#endif
+#ifndef PR_RING16_W
+#define PR_RING16_W 5                                           // cells per side of the first ring (16 x 16-pixel blocks around the query's own projection)
+#endif
 #ifndef PR_RING_STAGED
 #define PR_RING_STAGED 1                                        // 1: a ring's rows are loaded PR_RING_ROWS at a time (72 VGPRs: seven wavefronts per SIMD); 0: all at once (101 VGPRs: four)
 #endif
