@@ -434,6 +434,7 @@ __device__ __forceinline__ void grid_pyramid_bound(const SceneNNDev &s, float sx
             }
             if (k < 0x7f800000u) {
                 k = min(k, grid_ring_key<PR_RING_W>(s.grid, (int)s.gw, (int)s.gh, bx * 4 - PR_RING_OFF, by * 4 - PR_RING_OFF, sxy, sz, bx, by));
+                // (a further ring of pixels centred on the landing pixel: walk pass 0 1195 -> 1146 us, bound pass 0 275 -> 355 us -- not kept)
                 const float bk = __uint_as_float(k) * 1.00002f + 1e-30f;     // the landing cell's exact distance is below this (see ring_key)
                 if (bk < best) best = bk;
                 return;
