@@ -420,6 +420,9 @@ __global__ __launch_bounds__(256, PR_WIDE_WAVES) void nn_tree_wide_kernel(IcpBat
     constexpr uint32_t kPer = 8u / kLanes, kTasks = 64u / kLanes;
     constexpr uint32_t kLeafPer = PR_WIDE_LEAF_PER;               // points of a leaf per lane and round
     __shared__ uint2 s_taskq[4][kTaskQCap + kTaskLCap];                          // per wavefront: node-task queue, leaf-task queue behind it; {reference, bound bits (low 6 bits cleared: rounded DOWN) | query slot}
+    // (Round 5, VERDICT r04 item 1b: the per-query records as six arrays of words instead of 16-byte records -- a step's 32 slots then hit 32 different
+    // banks -- left SQ_LDS_BANK_CONFLICT where it was, 5.13e7 against 5.16e7 cycles in pass 0, with a quarter more LDS instructions and 1 % less
+    // throughput: the conflicts are not in these gathers but in the stores to the task queues and the atomics on best / second / tied.)
     __shared__ float4 s_q[4][64];                                                // query point | bound (float bits, lowered with atomicMin)
     __shared__ uint2 s_qq[4][64];                                                // the query in whole units of the wide records' frame: ux | uy << 16, uz | uz << 16
     __shared__ uint32_t s_second[4][64], s_tied[4][64], s_ovf[4][64], s_root[4][64];
