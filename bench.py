@@ -61,7 +61,7 @@ PMC_DRAM_SOURCE = "committed: profiles/r05/pmc_proj_p1024_onebatch_*.md + kernel
 # wavefront's resident cycles with one of its VALU instructions in flight (six wavefronts share a SIMD), and 4 x SQ_ACTIVE_INST_VALU over
 # (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs) = the share of the chip's VALU issue slots the kernel fills
 NN_WALK_VALU_ACTIVE_FRAC = 0.21
-NN_WALK_VALU_ISSUE_FRAC = 0.79
+NN_WALK_VALU_ISSUE_FRAC = 0.75
 NN_WALK_HBM_BYTES_PER_POINT = 4.6                                  # profiles/r05/pmc_nn_*.md: the walk reads queue entries + cloud points, writes winners
 PMC_TRAFFIC_SOURCE = {"proj": "profiles/r05/pmc_proj_FETCH_SIZE.md + pmc_proj_WRITE_SIZE.md + sq_proj_SQ_INSTS_VALU*.md (icp_pass_kernel<SceneProjPacked>)",
                       "nn": "profiles/r05/pmc_nn_FETCH_SIZE.md + pmc_nn_WRITE_SIZE.md (search 37.1 + bound 11.2 + task walk 4.6 + winners pass 17.9 B/point)"}
@@ -708,6 +708,7 @@ def run_rank(args, group, local_dev, share_device, launcher_note, comm_ready, co
                      "launch_us_spread": ({"min": float(lus[0]), "median": float(np.median(lus)), "max": float(lus[-1]), "n": int(len(lus))} if lus is not None else None),
                      "algorithmic_bytes_per_launch": bytes_per_launch, "points_per_launch": pts_per_launch,
                      "sampled_in": job.sampled_in,
+                     "share_device_note": ("ranks share ONE device (test mode): the sampled launches run beside the other ranks' work, so avg_launch_us / frac of this line say nothing about the kernel" if share_device else None),
                      "timing": ("HIP events on the library stream around every launch (--sequential: synchronous single-group steps)" if args.sequential else
                                 f"HIP events on the library stream around every launch of {n_samples} step ({job.sampled_in}); "
                                 "the sampled step stays an asynchronous batch but its loop runs as one pose group and only once the other slot's batch is complete (option profile = 3), so the launch has the chip to itself")},
@@ -881,11 +882,11 @@ def kdtree_extra(args, api, model, poses, scene_depth, W, H, proj, K, steps=20):
                 "avg_launch_us": 1e3 * part_ms[k] / n_pass, "share_of_step": part_ms[k] / step_ms if step_ms > 0 else None,
                 "per_kernel_ms_per_step": {n: float(v) for n, v in zip(names, part_ms)}, "passes": int(n_pass), "one_group_step_ms": step_ms,
                 "first_passes_us": [float(v) for v in pass_us[:4]],
-                "bound": "valu issue (pass 0: 0.79 of the chip's VALU issue slots, 568 M wave-instructions for 5.4 M tree searches; a wavefront has a VALU instruction in flight 21 % of its resident cycles, six share a SIMD; HBM ~ 0)",
+                "bound": "valu issue (pass 0: 0.75 of the chip's VALU issue slots, 539 M wave-instructions for 5.4 M tree searches; a wavefront has a VALU instruction in flight 21 % of its resident cycles, six share a SIMD; HBM ~ 0)",
                 "frac": NN_WALK_VALU_ISSUE_FRAC, "frac_of": "VALU issue slots of the chip in pass 0 (the binding resource by the SQ counters; committed pass, see valu_active_frac_source)",
                 "valu_issue_frac": NN_WALK_VALU_ISSUE_FRAC,
                 "valu_active_frac": NN_WALK_VALU_ACTIVE_FRAC,
-                "valu_active_frac_source": "committed: profiles/r05/sq_nn_pass0.txt (nn_tree_wide_kernel, pass 0 of a 256-hypothesis batch: SQ_ACTIVE_INST_VALU 5.68e8, SQ_WAVE_CYCLES 2.69e9, GRBM_GUI_ACTIVE 2.24e7 over 8 XCDs)",
+                "valu_active_frac_source": "committed: profiles/r05/sq_nn_pass0.txt (nn_tree_wide_kernel, pass 0 of a 256-hypothesis batch: SQ_ACTIVE_INST_VALU 5.39e8, SQ_WAVE_CYCLES 2.6e9, GRBM_GUI_ACTIVE 2.2e7 over 8 XCDs)",
                 # HBM side of the task walk alone: committed counter bytes per cloud point x this batch's points over this run's launch time
                 "hbm_GBps": (NN_WALK_HBM_BYTES_PER_POINT * pts / walk_s / 1e9) if walk_s > 0 else None,
                 "hbm_frac": (NN_WALK_HBM_BYTES_PER_POINT * pts / walk_s / HBM_PEAK) if walk_s > 0 else None,
