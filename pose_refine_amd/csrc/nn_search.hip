@@ -706,6 +706,7 @@ hipError_t launch_nn_search(const IcpBatch &b, const SceneNNDev &sc, uint32_t n_
 {
     if (n_poses == 0 || max_points == 0) return hipSuccess;
     if (!sc.rec32 || (sc.stack_depth != 16 && sc.stack_depth != 24) || !b.nn_prev || !b.nn_slack || !b.nn_queue || !b.nn_queue2 || !b.nn_qcount) return hipErrorInvalidValue;
+    if (max_points >= (1u << 30)) return hipErrorInvalidValue;        // nn_bound_kernel keeps two flags in the top bits of a point's index (a cloud of 2^30 points is 12 GiB)
     if (run == 0) run = 1;
     if (run > 8) run = 8;
     const uint32_t per_block = kBlockThreads * run;
