@@ -372,3 +372,51 @@ def test_host_solve_batches_run_on_the_slots_helper_threads(gpu, model, scenario
         assert api.refine_wait(0)[0].tobytes() == ref_a[0].tobytes()
     finally:
         api.set_option("host_worker", 1); api.set_option("solve", api.SOLVE_DEVICE if False else api.SOLVE_HOST)
+
+
+def test_pr_free_on_another_thread_while_helper_threads_come_and_go(gpu, model, scenario, gscenes):
+    """a slot's helper thread registers / unregisters its private context while its caller holds the caller's context mutex
+    and waits for it; pr_free on a third thread used to hold the registry's mutex while it locked every context of the device -- a three-way
+    wait that never ended.  Here one thread keeps allocating and freeing device buffers while this thread starts host-solve batches on fresh
+    helper threads over and over (pr_shutdown retires them: the next submit creates new ones).  A hang fails the test through its timeout."""
+    poses = synth.hypotheses(16, seed=77)
+    crit = api.ICPConvergenceCriteria(0.0, 0.0, 3)
+    args = (W, H, scenario["proj"], scenario["K"], gscenes["proj"], crit)
+    api.set_option("solve", api.SOLVE_HOST)
+    stop = threading.Event()
+    errors = []
+
+    def churn():
+        try:
+            api.set_device(0)
+            while not stop.is_set():
+                v = api.DeviceVector(4096, np.float32)
+                del v                                              # pr_free: walks every context of the device
+        except Exception as e:                                     # noqa: BLE001
+            errors.append(repr(e))
+    t = threading.Thread(target=churn)
+    t.start()
+    done = threading.Event()
+
+    def work():
+        try:
+            ref = None
+            for _ in range(12):
+                api.refine_submit(0, model, poses, *args)          # first submit after a shutdown: the slot's helper thread and its private context are created
+                api.refine_submit(1, model, poses, *args)
+                a = api.refine_wait(0); b = api.refine_wait(1)
+                assert a[0].tobytes() == b[0].tobytes()
+                ref = ref or a[0].tobytes()
+                assert a[0].tobytes() == ref
+                api.shutdown(); api.init(0); api.set_option("solve", api.SOLVE_HOST)     # retires the helper threads (join under the context mutex)
+            done.set()
+        except Exception as e:                                     # noqa: BLE001
+            errors.append(repr(e)); done.set()
+    w = threading.Thread(target=work)
+    w.start()
+    finished = done.wait(timeout=120)
+    stop.set()
+    t.join(timeout=30); w.join(timeout=30)
+    api.init(0); api.set_option("solve", api.SOLVE_HOST)
+    assert finished and not t.is_alive() and not w.is_alive(), "deadlock between pr_free, a slot's helper thread and its caller"
+    assert not errors, errors
