@@ -413,11 +413,11 @@ __device__ __forceinline__ void grid_pyramid_bound(const SceneNNDev &s, float sx
     const int w4 = ((int)s.gw + 3) / 4, h4 = ((int)s.gh + 3) / 4, w16 = (w4 + 3) / 4, h16 = (h4 + 3) / 4, w64 = (w16 + 3) / 4, h64 = (h16 + 3) / 4;
     float dmin = FLT_MAX, dall;
     int bx = 0, by = 0;
-    // Round 5: the descent starts AT THE QUERY'S OWN PROJECTION -- a 5 x 5 ring of 16 x 16-pixel blocks centred on it (`late`, from pass 1 on, where
-    // the cloud is within millimetres of the surface: PR_DESCENT_LATE) -- instead of choosing one of the 3 x 3 blocks of 64 x 64 pixels around it
-    // first: nine cells fewer, and a BETTER landing (the chosen 64-block's children did not always hold the neighbour of a query near the block's
-    // edge): same box, bound 1.58 -> 1.54 ms and walk 2.94 -> 2.79 ms per group-step, configs[2] 50.9 -> 53.0 k poses/s.  A ring that holds no scene
-    // point at all (the query projects far off the object) falls through to the blocks of 64 x 64 pixels below.
+    // Round 5: the descent starts AT THE QUERY'S OWN PROJECTION -- a ring of 5 x 5 blocks of 16 x 16 pixels centred on it (3 x 3 when `late`: from
+    // pass 1 on the cloud is within millimetres of the surface, PR_DESCENT_LATE) -- instead of choosing one of the 3 x 3 blocks of 64 x 64 pixels
+    // around it first: 9 to 25 cells fewer, and a BETTER landing (the chosen 64-block's children did not always hold the neighbour of a query near
+    // the block's edge): same box, bound 1.58 -> 1.46 ms and walk 2.94 -> 2.80 ms per group-step, configs[2] 50.9 -> 53.2 k poses/s.  A ring that
+    // holds no scene point at all (the query projects far off the object) falls through to the blocks of 64 x 64 pixels below.
     if (w16 >= PR_RING16_W && h16 >= PR_RING16_W && w16 >= PR_RING_W && h16 >= PR_RING_W) {
         float u, v;
         grid_project(s, sx, sy, sz, u, v);
@@ -485,7 +485,7 @@ __device__ __forceinline__ void grid_pyramid_bound(const SceneNNDev &s, float sx
 // scanned without one: the radius it covers (`rc`, the formula of `settle`) takes the bound's place, and whatever minimum the scan finds below
 // rc^2 is the global one (every closer point projects into the window) -- exact under the same uniqueness rule, without the 84-cell descent
 // through the representative points that would otherwise have to tighten the bound first.  When nothing lies within rc the call fails and the
-// query takes the usual way (descent, tree); `*full_min` then carries the nearest point the window did hold (a valid bound), if any.
+// query takes the usual way (descent, tree); `*best_sq` then carries the nearest point the window did hold (a valid bound), if any.
 __device__ __forceinline__ bool grid_search(const SceneNNDev &s, float sx, float sy, float sz, float bound, uint32_t &winner, uint32_t *cells = nullptr,
                                             float *best_sq = nullptr, float *other_sq = nullptr, bool settle = false, bool full = false)
 {
