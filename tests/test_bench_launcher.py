@@ -145,3 +145,25 @@ def test_bench_force_comm_runs_the_rccl_gather_with_a_world_of_one():
     for key in ("step_ms_spread", "host_cpu_ms_per_step", "roofline"):
         assert key in d
     assert d["roofline"]["frac"] <= 1.0 and d["roofline"]["frac_end_to_end"] > 0
+
+
+def test_committed_bench_lines_keep_the_contract():
+    """The round's committed bench lines (profiles/r05/, written by tools/gpu_round.sh on the GPU box): the contract's keys, a `roofline.frac` that
+    is a fraction (the binding resource, never above 1), the §8d score next to it, `cpu_baseline` on the one-rank line."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r05", "bench_*.json")))
+    assert len(files) >= 10
+    for f in files:
+        d = json.loads(open(f).read().strip().splitlines()[-1])
+        for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+            assert key in d, (f, key)
+        assert d["unit"] == "poses/s" and d["dtype"] == "f32" and d["vs_baseline"] is None and "workload" in d["config"]
+        r = d["roofline"]
+        for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "frac_algorithmic", "frac_end_to_end"):
+            assert key in r, (f, key)
+        assert 0.0 <= r["frac"] <= 1.0, (f, r["frac"])
+        assert abs(d["value"] * d["ms_per_step"] * 1e-3 - d["config"]["global_batch"]) < 1e-3 * d["config"]["global_batch"]      # value = hypotheses of a step / its time
+    head = json.loads(open(os.path.join(ROOT, "profiles", "r05", "bench_p256_proj_steps20.json")).read())
+    assert head["n_gpus"] == 1 and head["steps"] == 20 and head["warmup"] == 5
+    assert head["cpu_baseline"]["kind"] == "port" and head["cpu_baseline"]["cores"] >= 1 and "sample" in head["cpu_baseline"]
+    assert {"projective", "kdtree"} <= set(head["default_criteria"]) and "north_star_solve_on_host" in head["config"]
