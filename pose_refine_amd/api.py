@@ -381,8 +381,9 @@ class Scene_projective:
             raise ValueError(f"scene depth holds {scene_depth_dev.size()} values, expected {width} x {height}: pass width / height of the image")
         self.width, self.height, self.max_dist_diff = width, height, max_dist_diff
         self.K = _f32(scene_K, -1)
-        self.pcd_buffer = DeviceVector(width * height * 3, np.float32)
-        self.normal_buffer = DeviceVector(width * height * 3, np.float32)
+        if self.pcd_buffer is None or self.pcd_buffer.size() != width * height * 3:        # a scene object that is re-initialised frame after frame keeps its arrays
+            self.pcd_buffer = DeviceVector(width * height * 3, np.float32)
+            self.normal_buffer = DeviceVector(width * height * 3, np.float32)
         check(_lib.load().pr_scene_proj_prepare_dev(scene_depth_dev.data(), int(scene_depth_dev.dtype == np.int32), ptr(self.K),
                                                     width, height, self.pcd_buffer.data(), self.normal_buffer.data()))
         return self
@@ -453,9 +454,10 @@ class Scene_nn:
         px = width * height
         if scene_depth_dev.size() != px:
             raise ValueError(f"scene depth holds {scene_depth_dev.size()} values, expected {width} x {height}")
-        self.pcd_buffer = DeviceVector(px * 3, np.float32)
-        self.normal_buffer = DeviceVector(px * 3, np.float32)
-        self.nodes = DeviceVector(2 * px + 1, KDNODE)
+        if self.pcd_buffer is None or self.pcd_buffer.size() != px * 3 or self.nodes is None or self.nodes.size() != 2 * px + 1:    # (kept across re-initialisations)
+            self.pcd_buffer = DeviceVector(px * 3, np.float32)
+            self.normal_buffer = DeviceVector(px * 3, np.float32)
+            self.nodes = DeviceVector(2 * px + 1, KDNODE)
         npts, nnodes = C.c_uint32(), C.c_uint32()
         check(_lib.load().pr_scene_nn_prepare_dev(scene_depth_dev.data(), int(scene_depth_dev.dtype == np.int32), ptr(k), width, height, max_leaf,
                                                   self.pcd_buffer.data(), self.normal_buffer.data(), self.nodes.data(), 2 * px + 1,

@@ -169,33 +169,35 @@ __device__ __forceinline__ bool wide_quant_box(const float4 lo4, const float4 hi
     u[0] = q[0] | (q[1] << 16); u[1] = q[2] | (q[3] << 16); u[2] = q[4] | (q[5] << 16);
     return ok;
 }
-// One workgroup builds the wide nodes level by level (a scene is prepared once; 6 287 binary nodes give 5 levels).  Per level:
-// (A) every wide node opens its binary root into a frontier of up to eight descendants -- repeatedly the internal frontier node
-// with the longest box diagonal -- and counts the internal ones, (B) an exclusive scan of those counts numbers the next level's
-// wide nodes (deterministic: a wide node's index does not depend on timing), (C) the records are written.  `wq[k]` = binary root
-// of wide node k, `cnt[k]` = scan scratch.  A tree whose links are out of order (child index <= parent index) clears info[8].
-constexpr uint32_t kWideBuildThreads = 1024;
-__global__ __launch_bounds__(kWideBuildThreads) void nn_wide_build_kernel(const int4 *__restrict__ topo, const float4 *__restrict__ bmin,
-                                                                           const float4 *__restrict__ bmax, uint32_t n_nodes, uint4 *__restrict__ wide,
-                                                                           uint32_t cap_wide, uint32_t *__restrict__ wq, uint32_t *__restrict__ cnt,
-                                                                           uint32_t n_points, uint32_t *__restrict__ info)
+// The wide nodes are built level by level, two launches per level over all wide nodes of the level (round 5: ONE workgroup looping over the
+// levels took 1.1 ms for a frame-filling scene's 61 k binary nodes; the scene is prepared once per frame when the scene changes per frame):
+// (A) `open`: every wide node opens its binary root into a frontier of up to eight descendants -- repeatedly the internal frontier node
+// with the longest box diagonal -- and counts the internal ones (also summed per chunk of 1 024 wide nodes), (B + C) `number`: an exclusive
+// scan of those counts numbers the next level's wide nodes (deterministic: a wide node's index does not depend on timing) and the records'
+// references are rewritten; then (D) `layout`, once the last level is through.  `wq[k]` = binary root of wide node k, `cnt[k]` = its count.
+// The level's range lives in a control record double-buffered by level parity ({begin, end, bad}; level 0 is {0, 1, frame unusable}); a tree
+// whose links are out of order (child index <= parent index) or that does not fit sets `bad`, and info[8] stays 0.  The host launches eight
+// levels and the layout kernel before its one synchronisation; info[8] = 2 tells it that the tree is deeper (it launches eight more).
+constexpr uint32_t kWideChunk = 1024;
+struct WideLevel { uint32_t begin, end, bad, pad; };
+__device__ __forceinline__ WideLevel wide_level_state(const WideLevel *__restrict__ ctrl, uint32_t level, const uint32_t *__restrict__ info)
 {
-    __shared__ uint32_t part[kWideBuildThreads];
-    __shared__ uint32_t s_bad;
-    const uint32_t tid = threadIdx.x;
-    if (tid == 0) { wq[0] = 0u; s_bad = (info[1] == 1u && info[20] == 1u) ? 0u : 1u; }
-    __syncthreads();
-    uint32_t begin = 0, end = 1;
-    for (int level = 0; level < 64 && begin < end; ++level) {
-        // s_bad is read into a register BETWEEN two barriers (the one that ended the previous level and this one): stage (A) below sets it,
-        // and a thread still evaluating the loop condition while a faster one is already in (A) would leave the loop alone -- a divergent barrier
-        const bool bad_so_far = s_bad != 0u;
-        __syncthreads();
-        if (bad_so_far) break;
-        // (A) frontiers; the words of the record hold binary node ids for now
-        for (uint32_t k = begin + tid; k < end; k += kWideBuildThreads) {
+    if (level == 0u) return WideLevel{ 0u, 1u, (info[1] == 1u && info[20] == 1u) ? 0u : 1u, 0u };
+    return ctrl[level & 1u];
+}
+__global__ __launch_bounds__(256) void nn_wide_open_kernel(const int4 *__restrict__ topo, const float4 *__restrict__ bmin, const float4 *__restrict__ bmax, uint32_t n_nodes,
+                                                           uint4 *__restrict__ wide, const uint32_t *__restrict__ wq, uint32_t *__restrict__ cnt, const WideLevel *__restrict__ ctrl,
+                                                           uint32_t *__restrict__ bad_flag, uint32_t *__restrict__ chunk_sum /* this level's */, uint32_t level, uint32_t n_points, const uint32_t *__restrict__ info)
+{
+    const WideLevel st = wide_level_state(ctrl, level, info);
+    if (st.bad || st.begin >= st.end) return;
+    bool bad = false;
+    for (uint32_t k0 = st.begin + blockIdx.x * 256; k0 < st.end; k0 += gridDim.x * 256) {     // (workgroup-uniform trip count: the wavefront folds its counts below)
+        const uint32_t k = k0 + threadIdx.x;
+        uint32_t internal = 0;
+        if (k < st.end) {
             uint32_t fr[8]; float fsz[8]; int nf = 1;
-            fr[0] = wq[k];
+            fr[0] = level == 0u ? 0u : wq[k];
             auto size_of = [&](uint32_t n) -> float {              // -1 for a leaf (never opened)
                 if (topo[n].z < 0) return -1.0f;
                 const float4 a = bmin[n], b = bmax[n];
@@ -208,88 +210,135 @@ __global__ __launch_bounds__(kWideBuildThreads) void nn_wide_build_kernel(const 
                 if (pick < 0) break;
                 const uint32_t n = fr[pick];
                 const int4 t = topo[n];
-                if (!((uint32_t)t.y < n_nodes && (uint32_t)t.z < n_nodes && (uint32_t)t.y > n && (uint32_t)t.z > n)) { s_bad = 1u; fsz[pick] = -1.0f; continue; }
+                if (!((uint32_t)t.y < n_nodes && (uint32_t)t.z < n_nodes && (uint32_t)t.y > n && (uint32_t)t.z > n)) { bad = true; fsz[pick] = -1.0f; continue; }
                 fr[pick] = (uint32_t)t.y; fsz[pick] = size_of((uint32_t)t.y);
                 fr[nf] = (uint32_t)t.z;   fsz[nf] = size_of((uint32_t)t.z);
                 ++nf;
             }
-            uint32_t internal = 0;
-            for (int c = 0; c < 8; ++c) {                            // slot c = {box, reference}; internal children carry their BINARY id until (C)
+            for (int c = 0; c < 8; ++c) {                            // slot c = {box, reference}; internal children carry their BINARY id until they are numbered
                 uint32_t u[3] = { 0u, 0u, 0u }, ref = kWideEmpty;
                 if (c < nf) {
                     const uint32_t n = fr[c];
                     const int4 t = topo[n];
-                    if (!wide_quant_box(bmin[n], bmax[n], info, u)) s_bad = 1u;
+                    if (!wide_quant_box(bmin[n], bmax[n], info, u)) bad = true;
                     if (t.z < 0) {
                         const int lo = t.x, hi = t.y;
                         if (lo >= 0 && hi > lo && (uint32_t)(hi - lo) <= kWideMaxLeafPoints && (uint32_t)lo <= kWideFirstMask && (uint32_t)hi <= n_points)
                             ref = kWideLeaf | ((uint32_t)(hi - lo) << 27) | (uint32_t)lo;
-                        else if (hi != lo) s_bad = 1u;               // (an empty leaf stays an empty slot)
-                    } else { ref = n; ++internal; if (n >= 0x7fffffffu) s_bad = 1u; }
+                        else if (hi != lo) bad = true;               // (an empty leaf stays an empty slot)
+                    } else { ref = n; ++internal; if (n >= 0x7fffffffu) bad = true; }
                 }
                 wide[(size_t)k * 8 + c] = make_uint4(u[0], u[1], u[2], ref);
             }
             cnt[k] = internal;
         }
-        __syncthreads();
-        // (B) exclusive scan of cnt[begin, end): contiguous chunk per thread, Hillis-Steele over the chunk sums
-        const uint32_t span = end - begin, chunk = (span + kWideBuildThreads - 1) / kWideBuildThreads;
-        const uint32_t c0 = begin + tid * chunk, c1 = (c0 + chunk < end) ? c0 + chunk : end;
-        uint32_t sum = 0;
-        for (uint32_t k = c0; k < c1 && k >= begin; ++k) sum += cnt[k];
-        part[tid] = sum;
-        __syncthreads();
-        for (uint32_t off = 1; off < kWideBuildThreads; off <<= 1) {
-            const uint32_t v = (tid >= off) ? part[tid - off] : 0u;
-            __syncthreads();
-            part[tid] += v;
-            __syncthreads();
+        // one addition per wavefront and chunk (64 consecutive wide nodes: one chunk, at a boundary two)
+        uint32_t chunk = (k - st.begin) / kWideChunk, left = internal;
+        for (;;) {
+            const unsigned long long todo = __ballot(left != 0u);
+            if (!todo) break;
+            const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)chunk, (int)__builtin_ctzll(todo));
+            uint32_t mine = (left != 0u && chunk == c) ? left : 0u;
+            if (chunk == c) left = 0u;
+            for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off);
+            if ((threadIdx.x & 63u) == 0u) atomicAdd(&chunk_sum[c], mine);
         }
-        const uint32_t total = part[kWideBuildThreads - 1];
-        uint32_t run = part[tid] - sum;                              // exclusive prefix of this thread's chunk
-        for (uint32_t k = c0; k < c1 && k >= begin; ++k) { const uint32_t v = cnt[k]; cnt[k] = run; run += v; }
-        if (tid == 0 && (size_t)end + total > (size_t)cap_wide) s_bad = 1u;
+    }
+    if (bad) *bad_flag = 1u;
+}
+__global__ __launch_bounds__(1024) void nn_wide_number_kernel(uint4 *__restrict__ wide, uint32_t cap_wide, uint32_t *__restrict__ wq, const uint32_t *__restrict__ cnt,
+                                                              const WideLevel *__restrict__ ctrl, WideLevel *__restrict__ ctrl_next, const uint32_t *__restrict__ bad_flag,
+                                                              const uint32_t *__restrict__ sums, uint32_t *__restrict__ sums_next, uint32_t level, const uint32_t *__restrict__ info)
+{
+    __shared__ uint32_t s_a[16], s_b[16];
+    const WideLevel st = wide_level_state(ctrl, level, info);
+    const bool bad = st.bad || *bad_flag != 0u;
+    if (bad || st.begin >= st.end) { if (blockIdx.x == 0 && threadIdx.x == 0) *ctrl_next = WideLevel{ st.begin, st.end, bad ? 1u : 0u, 0u }; return; }
+    const uint32_t span = st.end - st.begin, n_chunk = (span + kWideChunk - 1u) / kWideChunk, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    for (uint32_t chunk = blockIdx.x; chunk < n_chunk; chunk += gridDim.x) {
+        uint32_t before = 0u, all = 0u;
+        for (uint32_t i = threadIdx.x; i < n_chunk; i += 1024) { const uint32_t c = sums[i]; all += c; if (i < chunk) before += c; }
+        for (int off = 32; off > 0; off >>= 1) { before += __shfl_xor(before, off); all += __shfl_xor(all, off); }
         __syncthreads();
-        if (s_bad) break;
-        // (C) number the internal children: wide node k's go to end + cnt[k] ...
-        for (uint32_t k = begin + tid; k < end; k += kWideBuildThreads) {
-            uint32_t next = end + cnt[k];
+        if (lane == 0u) { s_a[wave] = before; s_b[wave] = all; }
+        __syncthreads();
+        before = 0u; all = 0u;
+        for (uint32_t w = 0; w < 16; ++w) { before += s_a[w]; all += s_b[w]; }
+        __syncthreads();
+        const uint32_t k = st.begin + chunk * kWideChunk + threadIdx.x;
+        const uint32_t mine = k < st.end ? cnt[k] : 0u;
+        uint32_t incl = mine;
+#pragma unroll
+        for (uint32_t off = 1; off < 64; off <<= 1) { const uint32_t v = __shfl_up(incl, off); if (lane >= off) incl += v; }
+        if (lane == 63u) s_a[wave] = incl;
+        __syncthreads();
+        uint32_t excl = incl - mine;
+        for (uint32_t w = 0; w < wave; ++w) excl += s_a[w];
+        const bool fits = (size_t)st.end + all <= (size_t)cap_wide;
+        if (k < st.end && fits) {                                    // number the internal children: wide node k's go to end + (counts before k) ...
+            uint32_t next = st.end + before + excl;
             for (int c = 0; c < 8; ++c) {
                 uint4 r = wide[(size_t)k * 8 + c];
                 if (r.w != kWideEmpty && !(r.w & kWideLeaf)) { wq[next] = r.w; r.w = next; ++next; wide[(size_t)k * 8 + c] = r; }
             }
         }
-        __syncthreads();
-        begin = end; end = end + total;
-    }
-    __syncthreads();
-    const bool ok = !(s_bad || begin < end);
-    // (D) the layout the task walk reads (kWidePaired): a wide node is two 64-byte halves, one per lane of a task; a half holds its four
-    // slots as two PAIRS -- per pair six words {lo.x, lo.y, lo.z, hi.x, hi.y, hi.z}, each word = first slot | second slot << 16, so that
-    // one packed 16-bit instruction works on both boxes -- followed by the four references.
-    if (ok)
-        for (uint32_t k = tid; k < end; k += kWideBuildThreads) {
-            uint4 sl[8];
-            for (int c = 0; c < 8; ++c) sl[c] = wide[(size_t)k * 8 + c];
-            for (int h = 0; h < 2; ++h) {
-                uint32_t w[16];
-                for (int pr = 0; pr < 2; ++pr) {
-                    const uint4 A = sl[4 * h + 2 * pr], B = sl[4 * h + 2 * pr + 1];
-                    // a slot: x = lo.x | lo.y << 16, y = lo.z | hi.x << 16, z = hi.y | hi.z << 16
-                    const uint32_t a6[6] = { A.x & 0xffffu, A.x >> 16, A.y & 0xffffu, A.y >> 16, A.z & 0xffffu, A.z >> 16 };
-                    const uint32_t b6[6] = { B.x & 0xffffu, B.x >> 16, B.y & 0xffffu, B.y >> 16, B.z & 0xffffu, B.z >> 16 };
-                    for (int f = 0; f < 6; ++f) w[6 * pr + f] = a6[f] | (b6[f] << 16);
-                }
-                for (int c = 0; c < 4; ++c) w[12 + c] = sl[4 * h + c].w;
-                for (int v = 0; v < 4; ++v) wide[(size_t)k * 8 + 4 * h + v] = make_uint4(w[4 * v], w[4 * v + 1], w[4 * v + 2], w[4 * v + 3]);
-            }
+        if (chunk == 0u) {
+            if (threadIdx.x == 0) *ctrl_next = WideLevel{ st.end, fits ? st.end + all : st.end, fits ? 0u : 1u, 0u };
+            for (uint32_t i = threadIdx.x; i < (all + kWideChunk - 1u) / kWideChunk; i += 1024) sums_next[i] = 0u;       // the next level's chunk sums
         }
-    if (tid == 0) { info[8] = ok ? 1u : 0u; info[9] = end; }
+    }
+}
+// (D) the layout the task walk reads (kWidePaired): a wide node is two 64-byte halves, one per lane of a task; a half holds its four
+// slots as two PAIRS -- per pair six words {lo.x, lo.y, lo.z, hi.x, hi.y, hi.z}, each word = first slot | second slot << 16, so that
+// one packed 16-bit instruction works on both boxes -- followed by the four references.
+__global__ __launch_bounds__(256) void nn_wide_layout_kernel(uint4 *__restrict__ wide, const WideLevel *__restrict__ ctrl, uint32_t levels, uint32_t *__restrict__ info)
+{
+    const WideLevel st = wide_level_state(ctrl, levels, info);     // (levels >= 1: the record the last `number` launch wrote)
+    const bool done = st.begin >= st.end, ok = !st.bad && done;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { info[8] = ok ? 1u : ((!st.bad && !done) ? 2u : 0u); info[9] = st.end; }
+    if (!ok) return;
+    for (uint32_t k = blockIdx.x * 256 + threadIdx.x; k < st.end; k += gridDim.x * 256) {
+        uint4 sl[8];
+        for (int c = 0; c < 8; ++c) sl[c] = wide[(size_t)k * 8 + c];
+        for (int h = 0; h < 2; ++h) {
+            uint32_t w[16];
+            for (int pr = 0; pr < 2; ++pr) {
+                const uint4 A = sl[4 * h + 2 * pr], B = sl[4 * h + 2 * pr + 1];
+                // a slot: x = lo.x | lo.y << 16, y = lo.z | hi.x << 16, z = hi.y | hi.z << 16
+                const uint32_t a6[6] = { A.x & 0xffffu, A.x >> 16, A.y & 0xffffu, A.y >> 16, A.z & 0xffffu, A.z >> 16 };
+                const uint32_t b6[6] = { B.x & 0xffffu, B.x >> 16, B.y & 0xffffu, B.y >> 16, B.z & 0xffffu, B.z >> 16 };
+                for (int f = 0; f < 6; ++f) w[6 * pr + f] = a6[f] | (b6[f] << 16);
+            }
+            for (int c = 0; c < 4; ++c) w[12 + c] = sl[4 * h + c].w;
+            for (int v = 0; v < 4; ++v) wide[(size_t)k * 8 + 4 * h + v] = make_uint4(w[4 * v], w[4 * v + 1], w[4 * v + 2], w[4 * v + 3]);
+        }
+    }
+}
+
+// wide levels [first, first + count), then the layout; scratch = nn_wide_scratch_words(n_nodes) words
+hipError_t launch_nn_wide_levels(const int4 *topo, const float4 *bmin, const float4 *bmax, uint32_t n_nodes, uint32_t n_points, uint4 *wide, uint32_t *scratch,
+                                 uint32_t *info, uint32_t first, uint32_t count, hipStream_t s)
+{
+    const uint32_t cap = (uint32_t)nn_wide_capacity(n_nodes), chunks = cap / kWideChunk + 2u;
+    uint32_t *wq = scratch, *cnt = scratch + cap, *sums = cnt + cap, *bad_flag = sums + 2u * chunks;
+    WideLevel *ctrl = reinterpret_cast<WideLevel *>(bad_flag + 4);
+    if (first == 0u) {
+        const hipError_t e = hipMemsetAsync(sums, 0, (2u * chunks + 4u + 8u) * sizeof(uint32_t), s);      // chunk sums, flag, control records
+        if (e != hipSuccess) return e;
+    }
+    const uint32_t open_groups = std::min<uint32_t>((cap + 255u) / 256u, 1024u), number_groups = std::min<uint32_t>(chunks, 128u);
+    for (uint32_t level = first; level < first + count; ++level) {
+        uint32_t *mine = sums + (size_t)(level & 1u) * chunks, *other = sums + (size_t)((level + 1u) & 1u) * chunks;
+        hipLaunchKernelGGL(nn_wide_open_kernel, dim3(open_groups), dim3(256), 0, s, topo, bmin, bmax, n_nodes, wide, wq, cnt, ctrl, bad_flag, mine, level, n_points, info);
+        hipLaunchKernelGGL(nn_wide_number_kernel, dim3(number_groups), dim3(1024), 0, s, wide, cap, wq, cnt, ctrl, ctrl + ((level + 1u) & 1u), bad_flag, mine, other, level, info);
+    }
+    hipLaunchKernelGGL(nn_wide_layout_kernel, dim3(open_groups), dim3(256), 0, s, wide, ctrl, first + count, info);
+    return hipGetLastError();
 }
 
 hipError_t launch_build_nn_accel(const pr_kdnode *nodes, uint32_t n_nodes, const pr_vec3 *pcd, uint32_t n_points,
                                  int4 *topo, float4 *bmin, float4 *bmax, float4 *pts, float4 *rec, uint4 *rec32, uint2 *desc, uint32_t *info, hipStream_t s,
-                                 uint4 *wide, uint32_t *wide_scratch, float wide_margin)
+                                 float wide_margin)
 {
     const uint32_t m = (n_nodes > n_points) ? n_nodes : n_points;
     if (m == 0) return hipSuccess;
@@ -299,10 +348,6 @@ hipError_t launch_build_nn_accel(const pr_kdnode *nodes, uint32_t n_nodes, const
     hipLaunchKernelGGL(nn_records_kernel, dim3((n_nodes + 255) / 256), dim3(256), 0, s, topo, bmin, bmax, n_nodes, rec, info);
     hipLaunchKernelGGL(nn_frame_kernel, dim3(1), dim3(64), 0, s, bmin, bmax, info, wide_margin);
     hipLaunchKernelGGL(nn_records32_kernel, dim3((n_nodes + 255) / 256), dim3(256), 0, s, topo, bmin, bmax, n_nodes, rec32, desc, info);
-    if (wide && wide_scratch) {
-        const uint32_t cap = (uint32_t)nn_wide_capacity(n_nodes);
-        hipLaunchKernelGGL(nn_wide_build_kernel, dim3(1), dim3(kWideBuildThreads), 0, s, topo, bmin, bmax, n_nodes, wide, cap, wide_scratch, wide_scratch + cap, n_points, info);
-    }
     return hipGetLastError();
 }
 

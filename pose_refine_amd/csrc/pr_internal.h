@@ -200,10 +200,23 @@ hipError_t launch_icp_finalize_solve(const float *partial, PoseMeta *meta, uint3
                                      uint32_t n_poses, hipStream_t s);
 hipError_t launch_pack_results(const DevIcpState *st, pr_result *out, uint32_t n_poses, hipStream_t s);
 
-hipError_t launch_kd_init(pr_kdnode *nodes, uint32_t cap, int *idx, uint32_t n, uint32_t *ctrl, hipStream_t s);
-hipError_t launch_kd_level(pr_kdnode *nodes, uint32_t *ctrl, int max_leaf, int *child_of, uint32_t cap, uint32_t level_nodes,
-                           const pr_vec3 *pcd, int *idx, int *scratch, bool plan_only, hipStream_t s);
-hipError_t launch_kd_permute(const pr_vec3 *pcd, const pr_vec3 *nrm, const int *idx, uint32_t n, pr_vec3 *pcd_out, pr_vec3 *nrm_out, hipStream_t s);
+// kd_build.hip: the level-order build's workspace (one allocation, carved by kd_work_bytes) and its launches
+struct KdLevelNode { int left, right, child, axis; float cut; int pad0, pad1, pad2; };   // a node of the level being split: position range, first child's id (-1: a leaf), axis, cut
+struct KdCtrl { uint32_t lo, hi, next, done, levels, error, pad0, pad1; };               // nodes [lo, hi) = the level, their children [hi, next); levels = scatter passes done
+struct KdWork {
+    void *base = nullptr;
+    KdCtrl *ctrl[2] = { nullptr, nullptr };                                            // by level parity: a level's launches read [level & 1], its plan writes the other
+    int *idx[2] = { nullptr, nullptr }, *owner[2] = { nullptr, nullptr };                // permutation and each position's node (index within its level), double-buffered
+    KdLevelNode *lv[2] = { nullptr, nullptr };
+    unsigned long long *bbkeys = nullptr, *lrkeys = nullptr;
+    uint32_t *left_total = nullptr, *tile_agg = nullptr, *chunk_cnt = nullptr;
+    unsigned long long *root_part = nullptr;
+    uint32_t max_level = 0;
+};
+size_t kd_work_bytes(uint32_t n, uint32_t cap, KdWork *w);           // bytes needed; with w->base set, also fills in the pointers
+hipError_t launch_kd_init(const KdWork &w, pr_kdnode *nodes, uint32_t cap, const pr_vec3 *pcd, uint32_t n, int max_leaf, hipStream_t s);
+hipError_t launch_kd_level(const KdWork &w, pr_kdnode *nodes, uint32_t cap, const pr_vec3 *pcd, uint32_t n, int max_leaf, uint32_t level, hipStream_t s);
+hipError_t launch_kd_permute(const KdWork &w, uint32_t levels_launched, const pr_vec3 *pcd, const pr_vec3 *nrm, uint32_t n, pr_vec3 *pcd_out, pr_vec3 *nrm_out, hipStream_t s);
 template <typename T>
 hipError_t launch_nn_gather(const T *depth, uint32_t W, uint32_t H, float fx, float fy, float cx, float cy, const pr_vec3 *normal_full,
                             uint32_t *row_count, uint32_t *row_off, uint32_t *count, pr_vec3 *pcd, pr_vec3 *nrm, bool emit, hipStream_t s);
@@ -217,12 +230,15 @@ hipError_t launch_pack_proj_scene(const pr_vec3 *pcd, const pr_vec3 *normal, flo
                                   uint32_t width, uint32_t height, float fx, float fy, float cx, float cy, uint32_t tl_x, uint32_t tl_y,
                                   uint32_t *exact, hipStream_t s);
 // info[0] = tree depth, info[1] = 1 when the 32-byte records are valid, info[2..7] = qmin[3], qscale[3] (float bits)
-// info[8] = 1 when the wide records are valid, info[9] = number of wide nodes; wide: nn_wide_capacity(n_nodes) lines of 128 bytes,
-// wide_scratch: 2 * nn_wide_capacity(n_nodes) words (both may be null: no wide records are built)
+// wide records (nn_wide_build: launch_nn_wide_levels): info[8] = 1 when they are valid, 2 when the tree has more wide levels than were launched,
+// info[9] = number of wide nodes; wide: nn_wide_capacity(n_nodes) lines of 128 bytes, scratch: nn_wide_scratch_words(n_nodes) words
 inline size_t nn_wide_capacity(uint32_t n_nodes) { return (size_t)n_nodes / 2 + 2; }
+inline size_t nn_wide_scratch_words(uint32_t n_nodes) { const size_t cap = nn_wide_capacity(n_nodes); return 2 * cap + 2 * (cap / 1024 + 2) + 4 + 8; }
 hipError_t launch_build_nn_accel(const pr_kdnode *nodes, uint32_t n_nodes, const pr_vec3 *pcd, uint32_t n_points,
                                  int4 *topo, float4 *bmin, float4 *bmax, float4 *pts, float4 *rec, uint4 *rec32, uint2 *desc, uint32_t *info, hipStream_t s,
-                                 uint4 *wide = nullptr, uint32_t *wide_scratch = nullptr, float wide_margin = 0.0f);   // wide_margin: how far beyond the root box the wide records' frame reaches (the acceptance radius)
+                                 float wide_margin = 0.0f);   // wide_margin: how far beyond the root box the wide records' frame reaches (the acceptance radius)
+hipError_t launch_nn_wide_levels(const int4 *topo, const float4 *bmin, const float4 *bmax, uint32_t n_nodes, uint32_t n_points, uint4 *wide, uint32_t *scratch,
+                                 uint32_t *info, uint32_t first, uint32_t count, hipStream_t s);
 
 }  // namespace prk
 

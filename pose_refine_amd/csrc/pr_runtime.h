@@ -252,7 +252,7 @@ struct Ctx {
     const void *mesh_key = nullptr; size_t mesh_n = 0;   // triangle buffer aabb_host belongs to
     uint32_t cloud_hint = 0;          // largest cloud of the latest finished asynchronous batch: sizes the next batch's grid
     // workspaces
-    DevBuf aabb, aabb_keys, bbox, poses, depth, row_count, row_off, counts, cloud, meta, partial, sums, topo, bmin, bmax, pts, nnrec, nnrec32, nndesc, nnwide, nnwq, nn_prev, nndepth, dstate, dresults, arrive, conv16, conv8, kd_idx, kd_scratch, kd_child, kd_ctrl, kd_tmp, nn_full;
+    DevBuf aabb, aabb_keys, bbox, poses, depth, row_count, row_off, counts, cloud, meta, partial, sums, topo, bmin, bmax, pts, nnrec, nnrec32, nndesc, nnwide, nnwq, nn_prev, nndepth, dstate, dresults, arrive, conv16, conv8, kd_scratch, kd_tmp, nn_full;
     PinBuf h_sums, h_meta, h_counts, h_results, h_dstate;
     PackedCache packed;              // synchronous paths (the asynchronous slots keep their own)
     struct { const void *pcd = nullptr, *normal = nullptr, *nodes = nullptr; uint32_t n_points = 0, n_nodes = 0; uint64_t gen = 0; bool valid = false;

@@ -111,15 +111,21 @@ int make_scene(int kind, const void *scene, bool want_packed, SceneSel &out, Pac
             PR_TRY(g->nndesc.ensure((size_t)s->n_nodes * sizeof(uint2)));
             // wide records: one 128-byte line per wide node
             PR_TRY(g->nnwide.ensure(prk::nn_wide_capacity(s->n_nodes) * 128));
-            PR_TRY(g->nnwq.ensure(prk::nn_wide_capacity(s->n_nodes) * 2 * sizeof(uint32_t)));
+            PR_TRY(g->nnwq.ensure(prk::nn_wide_scratch_words(s->n_nodes) * sizeof(uint32_t)));
             HIP_TRY(prk::launch_build_nn_accel(s->nodes, s->n_nodes, s->pcd, s->n_points, g->topo.as<int4>(), g->bmin.as<float4>(),
                                                g->bmax.as<float4>(), g->pts.as<float4>(), g->nnrec.as<float4>(), g->nnrec32.as<uint4>(),
-                                               g->nndesc.as<uint2>(), g->nndepth.as<uint32_t>(), g->stream,
-                                               g->nnwide.as<uint4>(), g->nnwq.as<uint32_t>(), s->max_dist_diff * 1.01f));
+                                               g->nndesc.as<uint2>(), g->nndepth.as<uint32_t>(), g->stream, s->max_dist_diff * 1.01f));
             HIP_TRY(prk::launch_scene_fingerprint(s->pcd, (size_t)s->n_points * sizeof(pr_vec3), s->nodes, (size_t)s->n_nodes * sizeof(pr_kdnode), s->normal,
                                                   (size_t)s->n_points * sizeof(pr_vec3), g->nndepth.as<uint32_t>() + 12, nullptr, false, g->stream));
-            HIP_TRY(hipMemcpyAsync(nc.info, g->nndepth.p, sizeof nc.info, hipMemcpyDeviceToHost, g->stream));
-            HIP_TRY(hipStreamSynchronize(g->stream));
+            // the wide records, eight levels per synchronisation (8^8 wide nodes: deeper only for a lopsided tree)
+            for (uint32_t level = 0; ; level += 8) {
+                HIP_TRY(prk::launch_nn_wide_levels(g->topo.as<int4>(), g->bmin.as<float4>(), g->bmax.as<float4>(), s->n_nodes, s->n_points, g->nnwide.as<uint4>(),
+                                                   g->nnwq.as<uint32_t>(), g->nndepth.as<uint32_t>(), level, 8, g->stream));
+                HIP_TRY(hipMemcpyAsync(nc.info, g->nndepth.p, sizeof nc.info, hipMemcpyDeviceToHost, g->stream));
+                HIP_TRY(hipStreamSynchronize(g->stream));
+                if (nc.info[8] != 2u) break;
+                if (level + 8 >= 64) { nc.info[8] = 0u; break; }    // (as before: more than 64 wide levels -> the binary records)
+            }
             nc.pcd = s->pcd; nc.normal = s->normal; nc.nodes = s->nodes; nc.n_points = s->n_points; nc.n_nodes = s->n_nodes; nc.gen = gen; nc.valid = true;
             nc.frame_margin = s->max_dist_diff * 1.01f;
         }
@@ -176,34 +182,35 @@ int make_scene(int kind, const void *scene, bool want_packed, SceneSel &out, Pac
     return PR_ERR_INVALID;
 }
 
-// KDTree_cpu::build_tree on the device: level loop driven from the host (one 16-byte read-back per level)
+// KDTree_cpu::build_tree on the device (kd_build.hip): three launches per level over all points; the host reads the 32-byte control record back
+// after twelve levels and then every four (launches past the last level return at once)
 int kd_build_dev(pr_vec3 *pcd, pr_vec3 *nrm, uint32_t n, int max_leaf, pr_kdnode *nodes, size_t cap, uint32_t *n_nodes)
 {
     if (n == 0 || cap == 0) { set_error("kd-tree build: no points"); return PR_ERR_INVALID; }
+    if (n >= 0x7fffffffu) { set_error("kd-tree build: %u points are more than the node records' int ranges hold", n); return PR_ERR_INVALID; }
     const uint32_t cap32 = (uint32_t)std::min<size_t>(cap, 0x7fffffff);
-    PR_TRY(g->kd_idx.ensure(sizeof(int) * n));
-    PR_TRY(g->kd_scratch.ensure(sizeof(int) * n));
-    PR_TRY(g->kd_child.ensure(sizeof(int) * cap32));
-    PR_TRY(g->kd_ctrl.ensure(sizeof(uint32_t) * 4));
+    prk::KdWork w;
+    PR_TRY(g->kd_scratch.ensure(prk::kd_work_bytes(n, cap32, nullptr)));
+    w.base = g->kd_scratch.p;
+    prk::kd_work_bytes(n, cap32, &w);
     PR_TRY(g->kd_tmp.ensure(sizeof(pr_vec3) * 2 * (size_t)n));
-    HIP_TRY(prk::launch_kd_init(nodes, cap32, g->kd_idx.as<int>(), n, g->kd_ctrl.as<uint32_t>(), g->stream));
-    uint32_t ctrl[4] = { 0, 1, 1, 1 };
-    for (int level = 0; level < 4096; ++level) {
-        HIP_TRY(prk::launch_kd_level(nodes, g->kd_ctrl.as<uint32_t>(), max_leaf, g->kd_child.as<int>(), cap32, 0, pcd, g->kd_idx.as<int>(),
-                                     g->kd_scratch.as<int>(), /*plan_only=*/true, g->stream));
-        HIP_TRY(hipMemcpyAsync(ctrl, g->kd_ctrl.p, sizeof ctrl, hipMemcpyDeviceToHost, g->stream));
+    HIP_TRY(prk::launch_kd_init(w, nodes, cap32, pcd, n, max_leaf, g->stream));
+    prk::KdCtrl ctrl{};
+    uint32_t level = 0;
+    for (uint32_t until = 12; ; until += 4) {
+        for (; level < until; ++level) HIP_TRY(prk::launch_kd_level(w, nodes, cap32, pcd, n, max_leaf, level, g->stream));
+        HIP_TRY(hipMemcpyAsync(&ctrl, w.ctrl[level & 1u], sizeof ctrl, hipMemcpyDeviceToHost, g->stream));
         HIP_TRY(hipStreamSynchronize(g->stream));
-        if (ctrl[3] > cap32) { set_error("kd-tree build: node capacity %u too small", cap32); return PR_ERR_NOMEM; }
-        if (ctrl[3] == ctrl[2]) break;                             // no node of this level split: done (pcd_scene.cpp:166-168)
-        HIP_TRY(prk::launch_kd_level(nodes, g->kd_ctrl.as<uint32_t>(), max_leaf, g->kd_child.as<int>(), cap32, ctrl[1] - ctrl[0], pcd,
-                                     g->kd_idx.as<int>(), g->kd_scratch.as<int>(), /*plan_only=*/false, g->stream));
+        if (ctrl.error) { set_error("kd-tree build: node capacity %u too small", cap32); return PR_ERR_NOMEM; }
+        if (ctrl.done) break;
+        if (level >= 4096) { set_error("kd-tree build: more than 4096 levels (max_leaf %d)", max_leaf); return PR_ERR_INVALID; }
     }
     pr_vec3 *tp = g->kd_tmp.as<pr_vec3>(), *tn = tp + n;
-    HIP_TRY(prk::launch_kd_permute(pcd, nrm, g->kd_idx.as<int>(), n, tp, tn, g->stream));
+    HIP_TRY(prk::launch_kd_permute(w, level, pcd, nrm, n, tp, tn, g->stream));
     HIP_TRY(hipMemcpyAsync(pcd, tp, sizeof(pr_vec3) * n, hipMemcpyDeviceToDevice, g->stream));
     HIP_TRY(hipMemcpyAsync(nrm, tn, sizeof(pr_vec3) * n, hipMemcpyDeviceToDevice, g->stream));
     HIP_TRY(hipStreamSynchronize(g->stream));
-    if (n_nodes) *n_nodes = ctrl[2];
+    if (n_nodes) *n_nodes = ctrl.next;
     return PR_OK;
 }
 

@@ -108,6 +108,9 @@
 #ifndef PR_WIDE_LEAF_PER
 #define PR_WIDE_LEAF_PER 5                                      // points of a leaf a lane tests per round: 2 x 5 = the reference's max_leaf in ONE round (the records allow 15-point leaves: two)
 #endif
+#ifndef PR_KD_PER
+#define PR_KD_PER 4                                             // kd-tree build: consecutive positions per thread of the per-level passes (tile = 256 x this)
+#endif
 #ifndef PR_WIDE_QCAP
 #define PR_WIDE_QCAP 288                                        // entries of a wavefront's node-task queue
 #endif

@@ -77,6 +77,62 @@ def test_device_kdtree_build_random_points_with_ties(gpu, max_leaf, n):
     assert np.array_equal(dp.to_host(), op.reshape(-1)) and np.array_equal(dn.to_host(), on.reshape(-1))
 
 
+@pytest.mark.parametrize("kind,n,max_leaf", [("grid", 40000, 10), ("zeros", 30000, 10), ("fine", 20000, 1), ("fine", 70000, 2), ("planes", 50000, 10)])
+def test_device_kdtree_build_whole_levels_at_a_time(gpu, kind, n, max_leaf):
+    """The level-order build's passes over whole levels (kd_build.hip): point sets that span dozens of tiles -- a coarse grid (every cut is hit by
+    hundreds of points: the alternating tie rule across tile borders), coordinates that are zeros of BOTH signs (the stored extremes keep the sign of the
+    first occurrence), leaves of one or two points (more nodes of a level inside a tile than its key table holds: the straight-to-memory path), and
+    depth-quantised planes -- against the oracle's build_tree: same nodes, bit for bit, same permutation."""
+    import ctypes as C
+    from pose_refine_amd import _lib
+    rng = np.random.default_rng(n + max_leaf)
+    if kind == "grid": pts = np.round(rng.normal(size=(n, 3)) * 3.0, 0).astype(np.float32) / 8
+    elif kind == "zeros":
+        pts = rng.normal(size=(n, 3)).astype(np.float32)
+        z = rng.random((n, 3)) < 0.4
+        pts[z] = np.where(rng.random(int(z.sum())) < 0.5, np.float32(0.0), np.float32(-0.0))
+    elif kind == "fine": pts = rng.normal(size=(n, 3)).astype(np.float32)
+    else:
+        u, v = rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)
+        z = np.round((1.0 + 0.1 * u + 0.05 * v) * 1000.0) / 1000.0
+        pts = np.stack([u * z, v * z, z], 1).astype(np.float32)
+    nrm = rng.normal(size=(n, 3)).astype(np.float32)
+    op, on = pts.copy(), nrm.copy()
+    onodes = np.zeros(2 * n + 1, O.KDNODE)
+    ocnt = O.lib().po_kd_build(op.reshape(-1), on.reshape(-1), n, max_leaf, onodes.ctypes.data, len(onodes))
+    assert ocnt > 0
+    dp, dn = api.DeviceVector.from_host(pts.reshape(-1)), api.DeviceVector.from_host(nrm.reshape(-1))
+    dnodes = api.DeviceVector(2 * n + 1, _lib.KDNODE); dcnt = C.c_uint32()
+    _lib.check(_lib.load().pr_kdtree_build_dev(dp.data(), dn.data(), n, max_leaf, dnodes.data(), 2 * n + 1, C.byref(dcnt)))
+    assert dcnt.value == ocnt
+    assert dnodes.to_host()[:ocnt].tobytes() == onodes[:ocnt].tobytes()
+    assert dp.to_host().tobytes() == op.tobytes() and dn.to_host().tobytes() == on.tobytes()          # (bytes: -0.0 and 0.0 are different points here)
+    # a node array that is too small is an error, as in the reference's restatement (po_kd_build returns 0), not a truncated tree
+    small = api.DeviceVector(ocnt - 2, _lib.KDNODE)
+    dp2, dn2 = api.DeviceVector.from_host(pts.reshape(-1)), api.DeviceVector.from_host(nrm.reshape(-1))
+    assert _lib.load().pr_kdtree_build_dev(dp2.data(), dn2.data(), n, max_leaf, small.data(), ocnt - 2, C.byref(dcnt)) != 0
+    assert O.lib().po_kd_build(pts.copy().reshape(-1), nrm.copy().reshape(-1), n, max_leaf, np.zeros(ocnt - 2, O.KDNODE).ctypes.data, ocnt - 2) == 0
+
+
+def test_device_nn_scene_of_a_frame_filling_image(gpu):
+    """640 x 480 valid pixels (a curved wall behind nothing): gather, normals, the 300-tile build and the wide records derived from it, against the oracle."""
+    W, H = 640, 480
+    yy, xx = np.mgrid[0:H, 0:W]
+    depth = (900 + 0.05 * xx + 0.03 * yy + 3.0 * np.sin(xx / 17.0) * np.cos(yy / 23.0)).astype(np.int32)
+    K = synth.K_TEST
+    dev = api.Scene_nn().init_Scene_nn_device(api.DeviceVector.from_host(depth.reshape(-1)), K, W, H)
+    ref = O.NNScene(depth, K)
+    npt, nn = len(ref.pcd), len(ref.nodes)
+    assert (dev._n_points, dev._n_nodes) == (npt, nn) == (W * H, nn)
+    assert np.array_equal(dev.pcd_buffer.to_host()[:3 * npt].reshape(-1, 3), ref.pcd) and np.array_equal(dev.normal_buffer.to_host()[:3 * npt].reshape(-1, 3), ref.normal)
+    assert dev.nodes.to_host()[:nn].tobytes() == ref.nodes.tobytes()
+    # and a search against it: a cloud of the wall's own points pushed 4 mm towards the camera
+    cloud = (ref.pcd[::37] * np.float32(0.996)).astype(np.float32)
+    got = api.ICP_Point2Plane(api.DeviceVector.from_host(cloud.reshape(-1)), dev, api.ICPConvergenceCriteria(0.0, 0.0, 3))
+    want, _, _, _ = O.icp(cloud, ref, (0.0, 0.0, 3), O.SUM_CANONICAL, api.get_option("points_per_block"))
+    assert got.fitness_ == float(want["fitness"]) and np.allclose(got.transformation_.reshape(-1), want["T"], rtol=0, atol=TOL_T)
+
+
 # ---- cropped projective scene: pcd2dep / dep2pcd with tl_x, tl_y (common.h:47-73) ------------------------------------------
 @pytest.mark.device_solve
 def test_cropped_scene_lookup_with_offsets(gpu, model, scenario, gscenes):
