@@ -26,9 +26,21 @@ __global__ __launch_bounds__(256) void nn_accel_kernel(const pr_kdnode *__restri
         bmin[i] = make_float4(lo[0], lo[1], lo[2], 0.0f);
         bmax[i] = make_float4(hi[0], hi[1], hi[2], 0.0f);
     } else {
+        // .w of the two box records: the "size" (squared box diagonal; -1: a leaf) of child1 / child2 -- what nn_wide_open_kernel orders its frontier by,
+        // so that opening a node is ONE round of loads keyed by the node (it was the node's links, then the children's links and boxes)
+        float csz[2] = { -1.0f, -1.0f };
+        const int ch[2] = { nd.child1, nd.child2 };
+        for (int c = 0; c < 2; ++c)
+            if ((uint32_t)ch[c] < n_nodes) {
+                const pr_kdnode k = nodes[ch[c]];
+                if (!(k.child1 < 0 || k.child2 < 0)) {
+                    const float dx = k.bbox[1] - k.bbox[0], dy = k.bbox[3] - k.bbox[2], dz = k.bbox[5] - k.bbox[4];
+                    csz[c] = dx * dx + dy * dy + dz * dz;
+                }
+            }
         topo[i] = make_int4(__float_as_int(nd.split_v), nd.child1, nd.child2, pw);
-        bmin[i] = make_float4(nd.bbox[0], nd.bbox[2], nd.bbox[4], 0.0f);
-        bmax[i] = make_float4(nd.bbox[1], nd.bbox[3], nd.bbox[5], 0.0f);
+        bmin[i] = make_float4(nd.bbox[0], nd.bbox[2], nd.bbox[4], csz[0]);
+        bmax[i] = make_float4(nd.bbox[1], nd.bbox[3], nd.bbox[5], csz[1]);
     }
 }
 
@@ -191,49 +203,59 @@ __global__ __launch_bounds__(256) void nn_wide_open_kernel(const int4 *__restric
 {
     const WideLevel st = wide_level_state(ctrl, level, info);
     if (st.bad || st.begin >= st.end) return;
+    // EIGHT LANES per wide node, one per slot of its frontier: (node, size) live in registers, the pick is a reduction over the eight, and the
+    // boxes of the eight slots are quantised side by side (one thread per wide node kept the frontier in scratch memory -- a dynamically
+    // indexed array -- and worked through the slots one after the other: 32 us for the single wide node of level 0)
+    const uint32_t lane = threadIdx.x & 63u, g = lane & 7u, gbase = lane & ~7u;
     bool bad = false;
-    for (uint32_t k0 = st.begin + blockIdx.x * 256; k0 < st.end; k0 += gridDim.x * 256) {     // (workgroup-uniform trip count: the wavefront folds its counts below)
-        const uint32_t k = k0 + threadIdx.x;
-        uint32_t internal = 0;
-        if (k < st.end) {
-            uint32_t fr[8]; float fsz[8]; int nf = 1;
-            fr[0] = level == 0u ? 0u : wq[k];
-            auto size_of = [&](uint32_t n) -> float {              // -1 for a leaf (never opened)
-                if (topo[n].z < 0) return -1.0f;
-                const float4 a = bmin[n], b = bmax[n];
-                return (b.x - a.x) * (b.x - a.x) + (b.y - a.y) * (b.y - a.y) + (b.z - a.z) * (b.z - a.z);
-            };
-            fsz[0] = (topo[fr[0]].z < 0) ? -1.0f : FLT_MAX;        // the root of a wide node is always opened (unless the whole tree is one leaf)
-            while (nf < 8) {
-                int pick = -1;
-                for (int i = 0; i < nf; ++i) if (fsz[i] >= 0.0f && (pick < 0 || fsz[i] > fsz[pick])) pick = i;
-                if (pick < 0) break;
-                const uint32_t n = fr[pick];
-                const int4 t = topo[n];
-                if (!((uint32_t)t.y < n_nodes && (uint32_t)t.z < n_nodes && (uint32_t)t.y > n && (uint32_t)t.z > n)) { bad = true; fsz[pick] = -1.0f; continue; }
-                fr[pick] = (uint32_t)t.y; fsz[pick] = size_of((uint32_t)t.y);
-                fr[nf] = (uint32_t)t.z;   fsz[nf] = size_of((uint32_t)t.z);
-                ++nf;
-            }
-            for (int c = 0; c < 8; ++c) {                            // slot c = {box, reference}; internal children carry their BINARY id until they are numbered
-                uint32_t u[3] = { 0u, 0u, 0u }, ref = kWideEmpty;
-                if (c < nf) {
-                    const uint32_t n = fr[c];
-                    const int4 t = topo[n];
-                    if (!wide_quant_box(bmin[n], bmax[n], info, u)) bad = true;
-                    if (t.z < 0) {
-                        const int lo = t.x, hi = t.y;
-                        if (lo >= 0 && hi > lo && (uint32_t)(hi - lo) <= kWideMaxLeafPoints && (uint32_t)lo <= kWideFirstMask && (uint32_t)hi <= n_points)
-                            ref = kWideLeaf | ((uint32_t)(hi - lo) << 27) | (uint32_t)lo;
-                        else if (hi != lo) bad = true;               // (an empty leaf stays an empty slot)
-                    } else { ref = n; ++internal; if (n >= 0x7fffffffu) bad = true; }
-                }
-                wide[(size_t)k * 8 + c] = make_uint4(u[0], u[1], u[2], ref);
-            }
-            cnt[k] = internal;
+    for (uint32_t k0 = st.begin + blockIdx.x * 32u; k0 < st.end; k0 += gridDim.x * 32u) {       // (workgroup-uniform trip count)
+        const uint32_t k = k0 + threadIdx.x / 8u;
+        const bool live = k < st.end;
+        uint32_t node = 0u; float size = -1.0f; uint32_t nf = live ? 1u : 8u;
+        if (live && g == 0u) {
+            node = level == 0u ? 0u : wq[k];
+            size = (topo[node].z < 0) ? -1.0f : FLT_MAX;           // the root of a wide node is always opened (unless the whole tree is one leaf)
         }
-        // one addition per wavefront and chunk (64 consecutive wide nodes: one chunk, at a boundary two)
-        uint32_t chunk = (k - st.begin) / kWideChunk, left = internal;
+        for (;;) {
+            // the first of the largest sizes among the slots in use ("fsz[i] > fsz[pick]": strictly larger replaces)
+            float best = (g < nf && size >= 0.0f) ? size : -1.0f; uint32_t arg = g;
+#pragma unroll
+            for (int off = 1; off < 8; off <<= 1) {
+                const float b2 = __shfl_xor(best, off); const uint32_t a2 = __shfl_xor(arg, off);
+                if (b2 > best || (b2 == best && a2 < arg)) { best = b2; arg = a2; }
+            }
+            const bool going = nf < 8u && best >= 0.0f;
+            if (!__any(going)) break;
+            int4 t = make_int4(0, 0, 0, 0); float s1 = -1.0f, s2 = -1.0f; uint32_t okl = 1u;
+            if (going && g == arg) {
+                t = topo[node]; s1 = bmin[node].w; s2 = bmax[node].w;          // the children's sizes (nn_accel_kernel): -1 for a leaf (never opened)
+                okl = ((uint32_t)t.y < n_nodes && (uint32_t)t.z < n_nodes && (uint32_t)t.y > node && (uint32_t)t.z > node) ? 1u : 0u;
+                if (!okl) { bad = true; size = -1.0f; } else { node = (uint32_t)t.y; size = s1; }
+            }
+            const uint32_t src = gbase + arg;
+            const uint32_t ok_b = __shfl(okl, src), c2 = (uint32_t)__shfl(t.z, src); const float sz2 = __shfl(s2, src);
+            if (going && ok_b) { if (g == nf) { node = c2; size = sz2; } ++nf; }
+        }
+        uint32_t internal = 0u;
+        if (live) {                                                   // slot g = {box, reference}; internal children carry their BINARY id until they are numbered
+            uint32_t u[3] = { 0u, 0u, 0u }, ref = kWideEmpty;
+            if (g < nf) {
+                const int4 t = topo[node];
+                if (!wide_quant_box(bmin[node], bmax[node], info, u)) bad = true;
+                if (t.z < 0) {
+                    const int lo = t.x, hi = t.y;
+                    if (lo >= 0 && hi > lo && (uint32_t)(hi - lo) <= kWideMaxLeafPoints && (uint32_t)lo <= kWideFirstMask && (uint32_t)hi <= n_points)
+                        ref = kWideLeaf | ((uint32_t)(hi - lo) << 27) | (uint32_t)lo;
+                    else if (hi != lo) bad = true;                   // (an empty leaf stays an empty slot)
+                } else { ref = node; internal = 1u; if (node >= 0x7fffffffu) bad = true; }
+            }
+            wide[(size_t)k * 8 + g] = make_uint4(u[0], u[1], u[2], ref);
+        }
+#pragma unroll
+        for (int off = 1; off < 8; off <<= 1) internal += __shfl_xor(internal, off);
+        if (live && g == 0u) cnt[k] = internal;
+        // one addition per wavefront and chunk (eight consecutive wide nodes: one chunk, at a boundary two)
+        uint32_t chunk = (k - st.begin) / kWideChunk, left = (live && g == 0u) ? internal : 0u;
         for (;;) {
             const unsigned long long todo = __ballot(left != 0u);
             if (!todo) break;
@@ -241,7 +263,7 @@ __global__ __launch_bounds__(256) void nn_wide_open_kernel(const int4 *__restric
             uint32_t mine = (left != 0u && chunk == c) ? left : 0u;
             if (chunk == c) left = 0u;
             for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off);
-            if ((threadIdx.x & 63u) == 0u) atomicAdd(&chunk_sum[c], mine);
+            if (lane == 0u) atomicAdd(&chunk_sum[c], mine);
         }
     }
     if (bad) *bad_flag = 1u;
@@ -326,7 +348,7 @@ hipError_t launch_nn_wide_levels(const int4 *topo, const float4 *bmin, const flo
         const hipError_t e = hipMemsetAsync(sums, 0, (2u * chunks + 4u + 8u) * sizeof(uint32_t), s);      // chunk sums, flag, control records
         if (e != hipSuccess) return e;
     }
-    const uint32_t open_groups = std::min<uint32_t>((cap + 255u) / 256u, 1024u), number_groups = std::min<uint32_t>(chunks, 128u);
+    const uint32_t open_groups = std::min<uint32_t>((cap + 31u) / 32u, 2048u), number_groups = std::min<uint32_t>(chunks, 128u);
     for (uint32_t level = first; level < first + count; ++level) {
         uint32_t *mine = sums + (size_t)(level & 1u) * chunks, *other = sums + (size_t)((level + 1u) & 1u) * chunks;
         hipLaunchKernelGGL(nn_wide_open_kernel, dim3(open_groups), dim3(256), 0, s, topo, bmin, bmax, n_nodes, wide, wq, cnt, ctrl, bad_flag, mine, level, n_points, info);
