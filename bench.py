@@ -747,6 +747,8 @@ def run_rank(args, group, local_dev, share_device, launcher_note, comm_ready, co
         out["config2_kdtree"] = kdtree_extra(args, api, model, job.poses, scene_depth, W, H, proj, K)
     if solo and not args.no_kdtree_extra and not args.sequential:
         out["default_criteria"] = default_criteria_extra(args, api, model, job.poses, scene_depth, W, H, proj, K)
+    if solo and not args.no_kdtree_extra and not args.sequential:
+        out["new_scene_per_frame"] = new_scene_extra(args, api, model, job.poses, scene_depth, W, H, proj, K)
     if solo and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, args.scene, model.tris, scene_depth, K, W, H)
         if "config2_kdtree" in out:
@@ -930,6 +932,37 @@ def default_criteria_extra(args, api, model, poses, scene_depth, W, H, proj, K, 
         api.refine_wait((n - 1) & 1)
         dt = (time.perf_counter() - t0) / n
         out["projective" if kind == "proj" else "kdtree"] = {"value": len(poses) / dt, "unit": "poses/s", "ms_per_step": 1e3 * dt, "steps": n}
+    return out
+
+
+def new_scene_extra(args, api, model, poses, scene_depth, W, H, proj, K, frames=8):
+    """SURVEY 8f rank 1 (the reference's README names scene preparation -- normals and the kd-tree build, both on the CPU there -- as what is left
+    when the scene changes per frame): a frame = a NEW depth image already in HBM -> scene preparation on the device -> one batch of the headline's
+    hypotheses refined against it, synchronously; next to it the same call against an unchanged scene.  Nothing is cached across frames (every frame's
+    image differs in a pixel); the scene object keeps its arrays.  tools/scene_frame_time.py splits the figures further."""
+    crit = api.ICPConvergenceCriteria(0.0, 0.0, args.iters)
+    out = {"note": "ms per frame: device scene preparation from a depth image in HBM + one synchronous batch of the headline's hypotheses; `steady_ms`: the same call, scene unchanged",
+           "hypotheses": int(len(poses))}
+    for kind in ("proj", "nn"):
+        scene = api.Scene_projective() if kind == "proj" else api.Scene_nn()
+        prep_ms, frame_ms, steady_ms = [], [], []
+        for f in range(frames + 2):
+            d = np.ascontiguousarray(scene_depth.astype(np.int32))
+            d[f % H, f % W] = 0 if d[f % H, f % W] else 905
+            dev = api.DeviceVector.from_host(d.reshape(-1))
+            api.sync(); t0 = time.perf_counter()
+            if kind == "proj": scene.init_Scene_projective_device(dev, K, W, H)
+            else: scene.init_Scene_nn_device(dev, K, W, H)
+            api.sync(); t1 = time.perf_counter()
+            api.refine_batch(model, poses, W, H, proj, K, scene, crit)
+            api.sync(); t2 = time.perf_counter()
+            api.refine_batch(model, poses, W, H, proj, K, scene, crit)
+            api.sync(); t3 = time.perf_counter()
+            if f >= 2:
+                prep_ms.append(1e3 * (t1 - t0)); frame_ms.append(1e3 * (t2 - t0)); steady_ms.append(1e3 * (t3 - t2))
+        out["projective" if kind == "proj" else "kdtree"] = {"frame_ms": float(np.median(frame_ms)), "of_which_preparation_ms": float(np.median(prep_ms)),
+                                                             "steady_ms": float(np.median(steady_ms)), "frames": frames,
+                                                             "poses_per_s_with_a_new_scene_every_batch": float(len(poses) / (1e-3 * np.median(frame_ms)))}
     return out
 
 
