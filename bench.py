@@ -940,6 +940,7 @@ def new_scene_extra(args, api, model, poses, scene_depth, W, H, proj, K, frames=
     when the scene changes per frame): a frame = a NEW depth image already in HBM -> scene preparation on the device -> one batch of the headline's
     hypotheses refined against it, synchronously; next to it the same call against an unchanged scene.  Nothing is cached across frames (every frame's
     image differs in a pixel); the scene object keeps its arrays.  tools/scene_frame_time.py splits the figures further."""
+    import numpy as np
     crit = api.ICPConvergenceCriteria(0.0, 0.0, args.iters)
     out = {"note": "ms per frame: device scene preparation from a depth image in HBM + one synchronous batch of the headline's hypotheses; `steady_ms`: the same call, scene unchanged",
            "hypotheses": int(len(poses))}
