@@ -407,10 +407,11 @@ __global__ __launch_bounds__(256) void kd_permute_kernel(const pr_vec3 *__restri
     pcd_out[i] = pcd[idx[i]]; nrm_out[i] = nrm[idx[i]];
 }
 
-size_t kd_work_bytes(uint32_t n, uint32_t cap, KdWork *w)
+size_t kd_work_bytes(uint32_t n, uint32_t cap, int max_leaf, KdWork *w)
 {
     const size_t n8 = ((size_t)n + 7) & ~(size_t)7, tiles = ((size_t)n + kKdTile - 1) / kKdTile, parts = ((size_t)n + 255) / 256;
-    const uint32_t max_level = (uint32_t)std::min<size_t>(cap, 2 * (size_t)n + 2);
+    // nodes of one level: the children of disjoint nodes that hold more than max_leaf points each (max_leaf < 1 -- every point a node that splits -- twice as many)
+    const uint32_t max_level = (uint32_t)std::min<size_t>(cap, (max_leaf >= 1 ? (size_t)n : 2 * (size_t)n) + 2);
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t at = off; off += (bytes + 255) & ~(size_t)255; return at; };
     const size_t o_ctrl = take(2 * sizeof(KdCtrl)), o_idx0 = take(4 * n8), o_idx1 = take(4 * n8), o_own0 = take(4 * n8), o_own1 = take(4 * n8),

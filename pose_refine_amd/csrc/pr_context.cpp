@@ -30,9 +30,10 @@ void ctx_teardown(Ctx *c)        // c->mu held (or c unreachable); the calling t
     hipStreamSynchronize(c->stream);
     for (Slot &sl : c->slots) slot_release(sl);
     for (DevBuf *b : { &c->aabb, &c->aabb_keys, &c->bbox, &c->poses, &c->depth, &c->row_count, &c->row_off, &c->counts, &c->cloud, &c->meta, &c->partial,
-                       &c->sums, &c->packed.rec, &c->topo, &c->bmin, &c->bmax, &c->pts, &c->nnrec, &c->nnrec32, &c->nndesc, &c->nnwide, &c->nnwq, &c->nn_prev, &c->nndepth, &c->dstate, &c->dresults, &c->arrive, &c->conv16, &c->conv8, &c->kd_scratch, &c->kd_tmp, &c->nn_full, &c->gather_tmp, &c->nn_cells, &c->nn_grid, &c->nn_counters }) b->release();
+                       &c->sums, &c->packed.rec, &c->nn_prev, &c->dstate, &c->dresults, &c->arrive, &c->conv16, &c->conv8, &c->kd_scratch, &c->kd_tmp, &c->nn_full, &c->gather_tmp, &c->nn_counters }) b->release();
+    for (NNDerived &d : c->nn_sets) d.release();
     for (PinBuf *b : { &c->h_sums, &c->h_meta, &c->h_counts, &c->h_results, &c->h_dstate }) b->release();
-    c->packed = PackedCache(); c->nn_cache.valid = false;
+    c->packed = PackedCache();
     for (auto &gr : c->graphs) destroy_graph(gr);
     c->graphs.clear();
     for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);

@@ -213,7 +213,7 @@ struct KdWork {
     unsigned long long *root_part = nullptr;
     uint32_t max_level = 0;
 };
-size_t kd_work_bytes(uint32_t n, uint32_t cap, KdWork *w);           // bytes needed; with w->base set, also fills in the pointers
+size_t kd_work_bytes(uint32_t n, uint32_t cap, int max_leaf, KdWork *w);           // bytes needed; with w->base set, also fills in the pointers
 hipError_t launch_kd_init(const KdWork &w, pr_kdnode *nodes, uint32_t cap, const pr_vec3 *pcd, uint32_t n, int max_leaf, hipStream_t s);
 hipError_t launch_kd_level(const KdWork &w, pr_kdnode *nodes, uint32_t cap, const pr_vec3 *pcd, uint32_t n, int max_leaf, uint32_t level, hipStream_t s);
 hipError_t launch_kd_permute(const KdWork &w, uint32_t levels_launched, const pr_vec3 *pcd, const pr_vec3 *nrm, uint32_t n, pr_vec3 *pcd_out, pr_vec3 *nrm_out, hipStream_t s);

@@ -310,7 +310,8 @@ int refine_wait(int slot)
         // (or a scene array no longer has the content its cached form was derived from: same cure)
         drain_all_slots();
         for (Slot &o : g->slots) o.packed.valid = false;
-        g->packed.valid = false; g->nn_cache.valid = false; g->nn_cache.grid_valid = false;
+        g->packed.valid = false;
+        for (NNDerived &d : g->nn_sets) { d.valid = false; d.grid_valid = false; }
         const Resubmit &r = sl.again;
         const void *scene = (r.scene_kind == PR_SCENE_NN) ? static_cast<const void *>(&r.sn) : static_cast<const void *>(&r.sp);
         return refine_impl(r.tris, r.n_tris, sl.h_in.as<pr_mat4>(), sl.P, r.W, r.H, &r.proj, r.K, r.scene_kind, scene, r.crit, r.roi,
@@ -486,6 +487,7 @@ int refine_submit_async(Slot &sl, const pr_triangle *tris_dev, size_t n_tris, ui
     if (scene_stream != sl.stream)
         for (Slot &o : g->slots) if (&o != &sl && o.pending && !o.delivered && o.timed && o.progress_valid) HIP_TRY(hipStreamWaitEvent(scene_stream, o.progress, 0));
     PR_TRY(make_scene(scene_kind, scene, /*want_packed=*/true, sc, &sl.packed, scene_stream, scene_kind == PR_SCENE_NN ? &cam : nullptr, /*verify_now=*/false));
+    sl.nn_set = (scene_kind == PR_SCENE_NN) ? sc.nn_set : -1;        // (what make_scene must not rebuild under this batch while it is in flight)
 
     PR_TRY(ensure_model_box(tris_dev, n_tris));                 // once per triangle buffer ...
     const size_t res_off = ((size_t)P * 4 + 63) & ~(size_t)63;
@@ -517,7 +519,7 @@ int refine_submit_async(Slot &sl, const pr_triangle *tris_dev, size_t n_tris, ui
                 chk.fa = reinterpret_cast<const uint32_t *>(sn->pcd); chk.na = (size_t)sn->n_points * sizeof(pr_vec3) / 4;
                 chk.fb = reinterpret_cast<const uint32_t *>(sn->nodes); chk.nb = (size_t)sn->n_nodes * sizeof(pr_kdnode) / 4;
                 chk.fc = reinterpret_cast<const uint32_t *>(sn->normal); chk.nc = (size_t)sn->n_points * sizeof(pr_vec3) / 4;
-                chk.fp_expected = g->nndepth.as<uint32_t>() + 12;
+                chk.fp_expected = g->nn_sets[sc.nn_set].nndepth.as<uint32_t>() + 12;
             } else if (sl.packed.valid) {
                 const pr_scene_proj *sp = static_cast<const pr_scene_proj *>(scene);
                 const size_t n = (size_t)sp->width * sp->height;

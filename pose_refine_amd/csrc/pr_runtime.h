@@ -205,6 +205,7 @@ struct Slot {
     hipEvent_t fork = nullptr, join[3] = { nullptr, nullptr, nullptr }, done = nullptr, scene_ready = nullptr, progress = nullptr;
     bool progress_valid = false;
     bool pending = false, delivered = false;
+    int nn_set = -1;                 // the set of derived kd-tree records the batch in flight reads (Ctx::nn_sets), -1: none
     uint32_t P = 0;
     pr_result *user_results_host = nullptr;
     uint32_t *user_sizes = nullptr;
@@ -236,6 +237,16 @@ inline void destroy_graph(CachedGraph &c)
     c = CachedGraph();
 }
 
+constexpr int kNNSets = 2;
+struct NNDerived {
+    DevBuf topo, bmin, bmax, pts, nnrec, nnrec32, nndesc, nnwide, nnwq, nndepth, nn_cells, nn_grid;
+    const void *pcd = nullptr, *normal = nullptr, *nodes = nullptr; uint32_t n_points = 0, n_nodes = 0; uint64_t gen = 0; bool valid = false;
+    uint32_t info[24] = { 0 };
+    float frame_margin = 0.0f;                                   // the acceptance radius (x 1.01) the wide records' frame was built for: a larger radius rebuilds
+    bool grid_valid = false, grid_usable = false; uint32_t gw = 0, gh = 0; float gk[4] = { 0, 0, 0, 0 };
+    uint64_t used = 0;                                           // Ctx::nn_clock of the latest call that chose this set
+    void release() { for (DevBuf *b : { &topo, &bmin, &bmax, &pts, &nnrec, &nnrec32, &nndesc, &nnwide, &nnwq, &nndepth, &nn_cells, &nn_grid }) b->release(); valid = false; grid_valid = false; }
+};
 struct Ctx {
     std::mutex mu;                   // one call at a time per context; contexts of different devices / threads run side by side
     std::atomic<int> pins{ 0 };      // pr_free holds a private context alive through this while it drains it WITHOUT g_private_mu (private_unregister_and_wait)
@@ -252,14 +263,15 @@ struct Ctx {
     const void *mesh_key = nullptr; size_t mesh_n = 0;   // triangle buffer aabb_host belongs to
     uint32_t cloud_hint = 0;          // largest cloud of the latest finished asynchronous batch: sizes the next batch's grid
     // workspaces
-    DevBuf aabb, aabb_keys, bbox, poses, depth, row_count, row_off, counts, cloud, meta, partial, sums, topo, bmin, bmax, pts, nnrec, nnrec32, nndesc, nnwide, nnwq, nn_prev, nndepth, dstate, dresults, arrive, conv16, conv8, kd_scratch, kd_tmp, nn_full;
+    DevBuf aabb, aabb_keys, bbox, poses, depth, row_count, row_off, counts, cloud, meta, partial, sums, nn_prev, dstate, dresults, arrive, conv16, conv8, kd_scratch, kd_tmp, nn_full;
     PinBuf h_sums, h_meta, h_counts, h_results, h_dstate;
     PackedCache packed;              // synchronous paths (the asynchronous slots keep their own)
-    struct { const void *pcd = nullptr, *normal = nullptr, *nodes = nullptr; uint32_t n_points = 0, n_nodes = 0; uint64_t gen = 0; bool valid = false;
-             uint32_t info[24] = { 0 };
-             float frame_margin = 0.0f;                             // the acceptance radius (x 1.01) the wide records' frame was built for: a larger radius rebuilds
-             bool grid_valid = false, grid_usable = false; uint32_t gw = 0, gh = 0; float gk[4] = { 0, 0, 0, 0 }; } nn_cache;   // kd traversal records (topo ... nndesc) + pixel grid of the latest kd-tree scene
-    DevBuf nn_cells, nn_grid, nn_counters;
+    // kd-tree scenes: what the library derives from a scene (traversal records, wide records, pixel grid) -- kNNSets sets, so that with a NEW scene per
+    // frame the batch of one asynchronous slot keeps the set it runs on while the next frame's records are derived into the other (round 5: one set
+    // meant draining both slots before every new scene)
+    NNDerived nn_sets[kNNSets];
+    uint64_t nn_clock = 0;
+    DevBuf nn_counters;
     // profiling
     std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
     struct Span { size_t e0, e1; int kind; };
@@ -399,6 +411,7 @@ struct SceneSel {
     prk::SceneNNDev nn{};
     uint32_t nn_split = 0;           // kd-tree scene: search kernel + winners pass instead of the fused search pass
     uint32_t nn_max_points = 0;      // largest cloud of the batch (grid of the search kernel)
+    int nn_set = -1;                 // kd-tree scene: which of Ctx::nn_sets the records are in
 };
 constexpr uint32_t kCounterPasses = 64;
 // camera of the hypotheses (fused paths): lets a kd-tree scene be indexed by pixel as well

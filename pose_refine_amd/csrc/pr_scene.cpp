@@ -84,44 +84,63 @@ int make_scene(int kind, const void *scene, bool want_packed, SceneSel &out, Pac
     if (kind == PR_SCENE_NN) {
         const pr_scene_nn *s = static_cast<const pr_scene_nn *>(scene);
         if (!s || !s->pcd || !s->normal || !s->nodes || s->n_nodes == 0 || s->n_points == 0) { set_error("invalid pr_scene_nn"); return PR_ERR_INVALID; }
-        auto &nc = g->nn_cache;
-        const bool same = nc.valid && nc.pcd == s->pcd && nc.normal == s->normal && nc.nodes == s->nodes && nc.n_points == s->n_points && nc.n_nodes == s->n_nodes &&
-                          s->max_dist_diff * 1.01f <= nc.frame_margin;     // (a smaller radius keeps its pruning inside the larger frame; a larger one would lose it outside the old)
-        bool hit = same && opt.scene_cache && !g_writes.written_since(nc.gen, s->pcd, (size_t)s->n_points * sizeof(pr_vec3)) &&
-                   !g_writes.written_since(nc.gen, s->nodes, (size_t)s->n_nodes * sizeof(pr_kdnode));
+        // which of the sets of derived records: one that holds this scene and is still good, else a victim -- a stale set of the same arrays, an
+        // empty one, the least recently used one that no batch in flight reads; only when every set is being read does a slot have to drain first
+        auto matches = [&](const NNDerived &d) {
+            return d.valid && d.pcd == s->pcd && d.normal == s->normal && d.nodes == s->nodes && d.n_points == s->n_points && d.n_nodes == s->n_nodes &&
+                   s->max_dist_diff * 1.01f <= d.frame_margin;       // (a smaller radius keeps its pruning inside the larger frame; a larger one would lose it outside the old)
+        };
+        auto in_flight = [&](int set) { for (Slot &o : g->slots) if (o.pending && !o.delivered && o.nn_set == set) return true; return false; };
+        auto drain_readers = [&](int set) { for (Slot &o : g->slots) if (o.pending && !o.delivered && o.nn_set == set) slot_drain(o); };
+        int pick = -1;
+        bool hit = false;
+        for (int i = 0; i < kNNSets && pick < 0; ++i) {
+            const NNDerived &d = g->nn_sets[i];
+            if (matches(d) && opt.scene_cache && !g_writes.written_since(d.gen, s->pcd, (size_t)s->n_points * sizeof(pr_vec3)) &&
+                !g_writes.written_since(d.gen, s->nodes, (size_t)s->n_nodes * sizeof(pr_kdnode))) { pick = i; hit = true; }
+        }
         if (hit && verify_now) {
             bool stale = false;
             PR_TRY(fingerprint_differs(s->pcd, (size_t)s->n_points * sizeof(pr_vec3), s->nodes, (size_t)s->n_nodes * sizeof(pr_kdnode), s->normal,
-                                       (size_t)s->n_points * sizeof(pr_vec3), g->nndepth.as<uint32_t>() + 12, g->stream, stale));
+                                       (size_t)s->n_points * sizeof(pr_vec3), g->nn_sets[pick].nndepth.as<uint32_t>() + 12, g->stream, stale));
             hit = !stale;
         }
+        if (!hit) {
+            if (pick < 0) for (int i = 0; i < kNNSets && pick < 0; ++i) { const NNDerived &d = g->nn_sets[i]; if (d.valid && d.pcd == s->pcd && d.nodes == s->nodes) pick = i; }   // this scene's arrays, rewritten
+            if (pick < 0) for (int i = 0; i < kNNSets && pick < 0; ++i) if (!g->nn_sets[i].valid) pick = i;
+            if (pick < 0) { for (int i = 0; i < kNNSets; ++i) if (!in_flight(i) && (pick < 0 || g->nn_sets[i].used < g->nn_sets[pick].used)) pick = i; }
+            if (pick < 0) { pick = 0; for (int i = 1; i < kNNSets; ++i) if (g->nn_sets[i].used < g->nn_sets[pick].used) pick = i; }
+        }
+        NNDerived &nc = g->nn_sets[pick];
+        nc.used = ++g->nn_clock;
+        out.nn_set = pick;
         if (hit) {
             nc.gen = g_writes.now();                                // (the normals are read through the caller's pointer, never copied)
         } else {
-            drain_all_slots();                                      // the records below are shared by both slots' batches
+            drain_readers(pick);                                    // (a batch in flight that reads this very set: it finishes first)
             nc.valid = false; nc.grid_valid = false;
             const uint64_t gen = g_writes.now();
-            PR_TRY(g->topo.ensure((size_t)s->n_nodes * sizeof(int4)));
-            PR_TRY(g->bmin.ensure((size_t)s->n_nodes * sizeof(float4)));
-            PR_TRY(g->bmax.ensure((size_t)s->n_nodes * sizeof(float4)));
-            PR_TRY(g->pts.ensure(((size_t)s->n_points + 16u) * sizeof(float4)));   // + 16: a leaf task of the walk reads its ten slots whatever the leaf holds (nn_tree_wide_kernel)
-            PR_TRY(g->nnrec.ensure((size_t)s->n_nodes * 4 * sizeof(float4)));
-            PR_TRY(g->nndepth.ensure(24 * sizeof(uint32_t)));      // [0] depth [1] rec32 valid [2..7] rec32 frame [8] wide valid [9] wide nodes [12] fingerprint [16..19] wide frame
-            PR_TRY(g->nnrec32.ensure((size_t)s->n_nodes * 2 * sizeof(uint4)));
-            PR_TRY(g->nndesc.ensure((size_t)s->n_nodes * sizeof(uint2)));
+            PR_TRY(nc.topo.ensure((size_t)s->n_nodes * sizeof(int4)));
+            PR_TRY(nc.bmin.ensure((size_t)s->n_nodes * sizeof(float4)));
+            PR_TRY(nc.bmax.ensure((size_t)s->n_nodes * sizeof(float4)));
+            PR_TRY(nc.pts.ensure(((size_t)s->n_points + 16u) * sizeof(float4)));   // + 16: a leaf task of the walk reads its ten slots whatever the leaf holds (nn_tree_wide_kernel)
+            PR_TRY(nc.nnrec.ensure((size_t)s->n_nodes * 4 * sizeof(float4)));
+            PR_TRY(nc.nndepth.ensure(24 * sizeof(uint32_t)));      // [0] depth [1] rec32 valid [2..7] rec32 frame [8] wide valid [9] wide nodes [12] fingerprint [16..19] wide frame
+            PR_TRY(nc.nnrec32.ensure((size_t)s->n_nodes * 2 * sizeof(uint4)));
+            PR_TRY(nc.nndesc.ensure((size_t)s->n_nodes * sizeof(uint2)));
             // wide records: one 128-byte line per wide node
-            PR_TRY(g->nnwide.ensure(prk::nn_wide_capacity(s->n_nodes) * 128));
-            PR_TRY(g->nnwq.ensure(prk::nn_wide_scratch_words(s->n_nodes) * sizeof(uint32_t)));
-            HIP_TRY(prk::launch_build_nn_accel(s->nodes, s->n_nodes, s->pcd, s->n_points, g->topo.as<int4>(), g->bmin.as<float4>(),
-                                               g->bmax.as<float4>(), g->pts.as<float4>(), g->nnrec.as<float4>(), g->nnrec32.as<uint4>(),
-                                               g->nndesc.as<uint2>(), g->nndepth.as<uint32_t>(), g->stream, s->max_dist_diff * 1.01f));
+            PR_TRY(nc.nnwide.ensure(prk::nn_wide_capacity(s->n_nodes) * 128));
+            PR_TRY(nc.nnwq.ensure(prk::nn_wide_scratch_words(s->n_nodes) * sizeof(uint32_t)));
+            HIP_TRY(prk::launch_build_nn_accel(s->nodes, s->n_nodes, s->pcd, s->n_points, nc.topo.as<int4>(), nc.bmin.as<float4>(),
+                                               nc.bmax.as<float4>(), nc.pts.as<float4>(), nc.nnrec.as<float4>(), nc.nnrec32.as<uint4>(),
+                                               nc.nndesc.as<uint2>(), nc.nndepth.as<uint32_t>(), g->stream, s->max_dist_diff * 1.01f));
             HIP_TRY(prk::launch_scene_fingerprint(s->pcd, (size_t)s->n_points * sizeof(pr_vec3), s->nodes, (size_t)s->n_nodes * sizeof(pr_kdnode), s->normal,
-                                                  (size_t)s->n_points * sizeof(pr_vec3), g->nndepth.as<uint32_t>() + 12, nullptr, false, g->stream));
+                                                  (size_t)s->n_points * sizeof(pr_vec3), nc.nndepth.as<uint32_t>() + 12, nullptr, false, g->stream));
             // the wide records, eight levels per synchronisation (8^8 wide nodes: deeper only for a lopsided tree)
             for (uint32_t level = 0; ; level += 8) {
-                HIP_TRY(prk::launch_nn_wide_levels(g->topo.as<int4>(), g->bmin.as<float4>(), g->bmax.as<float4>(), s->n_nodes, s->n_points, g->nnwide.as<uint4>(),
-                                                   g->nnwq.as<uint32_t>(), g->nndepth.as<uint32_t>(), level, 8, g->stream));
-                HIP_TRY(hipMemcpyAsync(nc.info, g->nndepth.p, sizeof nc.info, hipMemcpyDeviceToHost, g->stream));
+                HIP_TRY(prk::launch_nn_wide_levels(nc.topo.as<int4>(), nc.bmin.as<float4>(), nc.bmax.as<float4>(), s->n_nodes, s->n_points, nc.nnwide.as<uint4>(),
+                                                   nc.nnwq.as<uint32_t>(), nc.nndepth.as<uint32_t>(), level, 8, g->stream));
+                HIP_TRY(hipMemcpyAsync(nc.info, nc.nndepth.p, sizeof nc.info, hipMemcpyDeviceToHost, g->stream));
                 HIP_TRY(hipStreamSynchronize(g->stream));
                 if (nc.info[8] != 2u) break;
                 if (level + 8 >= 64) { nc.info[8] = 0u; break; }    // (as before: more than 64 wide levels -> the binary records)
@@ -139,13 +158,13 @@ int make_scene(int kind, const void *scene, bool want_packed, SceneSel &out, Pac
         uint32_t stack = 0;
         if (opt.nn_stack) stack = (depth <= 16) ? 16u : ((depth <= 24) ? 24u : 0u);
         if (stack) lds = std::min<uint32_t>({ (uint32_t)std::max(0, opt.nn_lds_records), s->n_nodes, (65536u - stack * 2048u) / 64u });   // stacks + records <= 64 KiB
-        out.nn = prk::SceneNNDev{ s->max_dist_diff, g->topo.as<int4>(), g->bmin.as<float4>(), g->bmax.as<float4>(), g->pts.as<float4>(),
-                                  s->pcd, s->normal, s->n_nodes, lds, g->nnrec.as<float4>(), stack, nullptr, { 0, 0, 0 }, { 0, 0, 0 }, g->nndesc.as<uint2>() };
+        out.nn = prk::SceneNNDev{ s->max_dist_diff, nc.topo.as<int4>(), nc.bmin.as<float4>(), nc.bmax.as<float4>(), nc.pts.as<float4>(),
+                                  s->pcd, s->normal, s->n_nodes, lds, nc.nnrec.as<float4>(), stack, nullptr, { 0, 0, 0 }, { 0, 0, 0 }, nc.nndesc.as<uint2>() };
         if (stack && opt.nn_compact && info[1] == 1u) {
-            out.nn.rec32 = g->nnrec32.as<uint4>();
+            out.nn.rec32 = nc.nnrec32.as<uint4>();
             for (int a = 0; a < 3; ++a) { std::memcpy(&out.nn.qmin[a], &info[2 + a], 4); std::memcpy(&out.nn.qscale[a], &info[5 + a], 4); }
             if (opt.nn_wide && info[8] == 1u && info[9] > 0u) {
-                out.nn.wide = g->nnwide.as<uint4>(); out.nn.n_wide = info[9];
+                out.nn.wide = nc.nnwide.as<uint4>(); out.nn.n_wide = info[9];
                 for (int a = 0; a < 3; ++a) std::memcpy(&out.nn.wmin[a], &info[16 + a], 4);
                 std::memcpy(&out.nn.wscale, &info[19], 4);
             }
@@ -158,20 +177,20 @@ int make_scene(int kind, const void *scene, bool want_packed, SceneSel &out, Pac
         if (cam && opt.nn_grid && out.nn.rec32 && (size_t)cam->w * cam->h <= ((size_t)1 << 24)) {
             const float gk[4] = { cam->fx, cam->fy, cam->cx, cam->cy };
             if (!(nc.grid_valid && nc.gw == cam->w && nc.gh == cam->h && std::memcmp(nc.gk, gk, sizeof gk) == 0)) {
-                drain_all_slots();
+                drain_readers(pick);
                 const size_t cells = (size_t)cam->w * cam->h;
-                PR_TRY(g->nn_cells.ensure(cells * sizeof(int32_t) + 16));
-                PR_TRY(g->nn_grid.ensure(prk::nn_grid_cells(cam->w, cam->h) * sizeof(float4)));
-                uint32_t *flag = reinterpret_cast<uint32_t *>(g->nn_cells.as<int32_t>() + cells);
-                HIP_TRY(prk::launch_build_nn_grid(s->pcd, s->n_points, cam->w, cam->h, gk[0], gk[1], gk[2], gk[3], g->nn_cells.as<int32_t>(),
-                                                  g->nn_grid.as<float4>(), flag, g->stream));
+                PR_TRY(nc.nn_cells.ensure(cells * sizeof(int32_t) + 16));
+                PR_TRY(nc.nn_grid.ensure(prk::nn_grid_cells(cam->w, cam->h) * sizeof(float4)));
+                uint32_t *flag = reinterpret_cast<uint32_t *>(nc.nn_cells.as<int32_t>() + cells);
+                HIP_TRY(prk::launch_build_nn_grid(s->pcd, s->n_points, cam->w, cam->h, gk[0], gk[1], gk[2], gk[3], nc.nn_cells.as<int32_t>(),
+                                                  nc.nn_grid.as<float4>(), flag, g->stream));
                 uint32_t usable = 0;
                 HIP_TRY(hipMemcpyAsync(&usable, flag, sizeof usable, hipMemcpyDeviceToHost, g->stream));
                 HIP_TRY(hipStreamSynchronize(g->stream));
                 nc.grid_valid = true; nc.grid_usable = usable != 0; nc.gw = cam->w; nc.gh = cam->h; std::memcpy(nc.gk, gk, sizeof gk);
             }
             if (nc.grid_usable) {
-                out.nn.grid = g->nn_grid.as<float4>(); out.nn.gw = cam->w; out.nn.gh = cam->h; out.nn.gfx = gk[0]; out.nn.gfy = gk[1]; out.nn.gcx = gk[2]; out.nn.gcy = gk[3];
+                out.nn.grid = nc.nn_grid.as<float4>(); out.nn.gw = cam->w; out.nn.gh = cam->h; out.nn.gfx = gk[0]; out.nn.gfy = gk[1]; out.nn.gcx = gk[2]; out.nn.gcy = gk[3];
                 const size_t w4 = (cam->w + 3) / 4, h4 = (cam->h + 3) / 4, w16 = (w4 + 3) / 4, h16 = (h4 + 3) / 4;
                 out.nn.pyr4 = out.nn.grid + (size_t)cam->w * cam->h; out.nn.pyr16 = out.nn.pyr4 + w4 * h4; out.nn.pyr64 = out.nn.pyr16 + w16 * h16;
             }
@@ -190,9 +209,9 @@ int kd_build_dev(pr_vec3 *pcd, pr_vec3 *nrm, uint32_t n, int max_leaf, pr_kdnode
     if (n >= 0x7fffffffu) { set_error("kd-tree build: %u points are more than the node records' int ranges hold", n); return PR_ERR_INVALID; }
     const uint32_t cap32 = (uint32_t)std::min<size_t>(cap, 0x7fffffff);
     prk::KdWork w;
-    PR_TRY(g->kd_scratch.ensure(prk::kd_work_bytes(n, cap32, nullptr)));
+    PR_TRY(g->kd_scratch.ensure(prk::kd_work_bytes(n, cap32, max_leaf, nullptr)));
     w.base = g->kd_scratch.p;
-    prk::kd_work_bytes(n, cap32, &w);
+    prk::kd_work_bytes(n, cap32, max_leaf, &w);
     PR_TRY(g->kd_tmp.ensure(sizeof(pr_vec3) * 2 * (size_t)n));
     HIP_TRY(prk::launch_kd_init(w, nodes, cap32, pcd, n, max_leaf, g->stream));
     prk::KdCtrl ctrl{};
