@@ -129,3 +129,46 @@ def test_kdtree_scene_rewritten_behind_the_librarys_back_is_noticed_by_a_bare_ic
     raw_d2d(a.nodes.data(), b.nodes.data(), len(a.nodes_host) * 52)
     got = run(a)
     assert np.array_equal(got.transformation_, want_b.transformation_) and got.fitness_ == want_b.fitness_
+
+
+@pytest.mark.device_solve
+def test_kdtree_scenes_that_change_every_frame_keep_both_slots_running(gpu, model, scenario):
+    """a NEW kd-tree scene per frame, frames pipelined through the two slots.  The library keeps two sets of derived records
+    (pr_runtime.h NNDerived): the set a batch in flight reads is never rebuilt under it -- three scenes in rotation (every frame finds neither set
+    holding its scene while the other slot still reads one of them), then ONE scene object re-initialised on the device frame after frame while the
+    previous frame's batch runs on a second object.  Every frame's records equal the synchronous call's against the same scene (which
+    test_golden_full_gpu / test_kdtree_search_gpu hold to the oracle), bit for bit."""
+    K, proj = scenario["K"], scenario["proj"]
+    poses = synth.hypotheses(48)
+    crit = api.ICPConvergenceCriteria(0.0, 0.0, 6)
+    base = scenario["depth"][1].astype(np.int32)
+    depths = []
+    for i in range(3):
+        d = base.copy()
+        d[d > 0] += 3 * i                                            # the same surface 0 / 3 / 6 mm further away: different trees, different answers
+        d[(40 * i) % H::7, ::5] = 0
+        depths.append(d)
+    scenes = [api.Scene_nn().init_Scene_nn_device(api.DeviceVector.from_host(d.reshape(-1)), K, W, H) for d in depths]
+    want = [api.refine_batch(model, poses, W, H, proj, K, s, crit) for s in scenes]
+    assert want[0][0].tobytes() != want[1][0].tobytes() != want[2][0].tobytes()
+    repeated_before = api.stats()[0]
+    # (1) three scenes in rotation over two slots
+    for k in range(9):
+        api.refine_submit(k & 1, model, poses, W, H, proj, K, scenes[k % 3], crit)
+        if k:
+            res, sizes = api.refine_wait((k - 1) & 1)
+            assert res.tobytes() == want[(k - 1) % 3][0].tobytes() and np.array_equal(sizes, want[(k - 1) % 3][1])
+    res, sizes = api.refine_wait(0)
+    assert res.tobytes() == want[8 % 3][0].tobytes()
+    # (2) two scene objects re-initialised in turn from images on the device, each while the other one's batch is in flight
+    devs = [api.DeviceVector.from_host(d.reshape(-1)) for d in depths]
+    objs = [api.Scene_nn(), api.Scene_nn()]
+    for k in range(8):
+        objs[k & 1].init_Scene_nn_device(devs[k % 3], K, W, H)      # (slot k & 1 delivered its previous batch two frames ago: its scene object is free)
+        api.refine_submit(k & 1, model, poses, W, H, proj, K, objs[k & 1], crit)
+        if k:
+            res, sizes = api.refine_wait((k - 1) & 1)
+            assert res.tobytes() == want[(k - 1) % 3][0].tobytes() and np.array_equal(sizes, want[(k - 1) % 3][1])
+    res, _ = api.refine_wait(1)
+    assert res.tobytes() == want[7 % 3][0].tobytes()
+    assert api.stats()[0] == repeated_before                        # (no batch had to be run again by the stale-cache safety net)
