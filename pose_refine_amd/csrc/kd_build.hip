@@ -389,7 +389,7 @@ __global__ __launch_bounds__(1024) void kd_plan_kernel(const KdCtrl *__restrict_
             KdCtrl o = now;
             o.lo = hi; o.hi = next; o.next = after;
             if (!first) o.levels = now.levels + 1u;
-            if (after > cap || n_child > max_level) { o.error = 1u; o.done = 1u; }
+            if (after > cap || n_child > max_level || after - next > max_level) { o.error = 1u; o.done = 1u; }       // (the next level's arrays hold max_level nodes)
             else if (after == next) o.done = 1u;                     // no node of this level splits: done (pcd_scene.cpp:166-168)
             *ctrl_next = o;
         }

@@ -341,8 +341,8 @@ __global__ __launch_bounds__(256) void nn_wide_layout_kernel(uint4 *__restrict__
 hipError_t launch_nn_wide_levels(const int4 *topo, const float4 *bmin, const float4 *bmax, uint32_t n_nodes, uint32_t n_points, uint4 *wide, uint32_t *scratch,
                                  uint32_t *info, uint32_t first, uint32_t count, hipStream_t s)
 {
-    const uint32_t cap = (uint32_t)nn_wide_capacity(n_nodes), chunks = cap / kWideChunk + 2u;
-    uint32_t *wq = scratch, *cnt = scratch + cap, *sums = cnt + cap, *bad_flag = sums + 2u * chunks;
+    const uint32_t cap = (uint32_t)nn_wide_capacity(n_nodes), chunks = (cap / kWideChunk + 3u) & ~1u;
+    uint32_t *wq = scratch, *cnt = scratch + cap, *sums = scratch + ((2u * cap + 3u) & ~3u), *bad_flag = sums + 2u * chunks;      // (the control records 16-byte aligned: chunks is even)
     WideLevel *ctrl = reinterpret_cast<WideLevel *>(bad_flag + 4);
     if (first == 0u) {
         const hipError_t e = hipMemsetAsync(sums, 0, (2u * chunks + 4u + 8u) * sizeof(uint32_t), s);      // chunk sums, flag, control records

@@ -233,7 +233,7 @@ hipError_t launch_pack_proj_scene(const pr_vec3 *pcd, const pr_vec3 *normal, flo
 // wide records (nn_wide_build: launch_nn_wide_levels): info[8] = 1 when they are valid, 2 when the tree has more wide levels than were launched,
 // info[9] = number of wide nodes; wide: nn_wide_capacity(n_nodes) lines of 128 bytes, scratch: nn_wide_scratch_words(n_nodes) words
 inline size_t nn_wide_capacity(uint32_t n_nodes) { return (size_t)n_nodes / 2 + 2; }
-inline size_t nn_wide_scratch_words(uint32_t n_nodes) { const size_t cap = nn_wide_capacity(n_nodes); return 2 * cap + 2 * (cap / 1024 + 2) + 4 + 8; }
+inline size_t nn_wide_scratch_words(uint32_t n_nodes) { const size_t cap = nn_wide_capacity(n_nodes); return 2 * cap + 4 + 2 * (cap / 1024 + 4) + 4 + 8; }   // wq, cnt, chunk sums x 2, flag, control records x 2
 hipError_t launch_build_nn_accel(const pr_kdnode *nodes, uint32_t n_nodes, const pr_vec3 *pcd, uint32_t n_points,
                                  int4 *topo, float4 *bmin, float4 *bmax, float4 *pts, float4 *rec, uint4 *rec32, uint2 *desc, uint32_t *info, hipStream_t s,
                                  float wide_margin = 0.0f);   // wide_margin: how far beyond the root box the wide records' frame reaches (the acceptance radius)
