@@ -65,7 +65,7 @@ PR_BENCH_FORCE_COMM=1 timeout 300 python bench.py --steps 20 --warmup 5 2>/dev/n
 timeout 300 python tools/scene_frame_time.py 2>/dev/null | grep "valid pixels" > $OUT/scene_frame_time.txt
 timeout 300 python tools/frames_pipe.py 2>/dev/null | grep "frame" >> $OUT/scene_frame_time.txt; cat $OUT/scene_frame_time.txt
 REPS=4 rocprofv3 --kernel-trace --stats -d $OUT/stats5 -o sf -- python tools/scene_frame_time.py > /dev/null 2>&1
-summ $OUT/stats5/sf_results.db | grep -E "kernel|---|kd_|nn_wide|nn_accel|nn_records|nn_frame|nn_grid|nn_gather|scene_proj_prepare|pack_proj|fingerprint" > $OUT/kernel_stats_scene_preparation.md; rm -rf $OUT/stats5
+summ $OUT/stats5/sf_results.db | grep -E "^# |^\| kernel|---|kd_|nn_wide|nn_accel|nn_records|nn_frame|nn_grid|nn_gather|scene_proj_prepare|pack_proj|fingerprint" > $OUT/kernel_stats_scene_preparation.md; rm -rf $OUT/stats5
 # C++ host: shard driver
 g++ -std=c++14 -O2 -pthread -Iinclude tests/cpp/shard_test.cpp -o tests/cpp/shard_test -Lpose_refine_amd/lib -lpose_refine_hip -Wl,-rpath,$PWD/pose_refine_amd/lib && ./tests/cpp/shard_test tests/golden/ 4096 2>&1 | tail -1 > $OUT/shard_test_4096.json; cat $OUT/shard_test_4096.json
 python -c "from pose_refine_amd import api; print('visible devices:', api.device_count())" >> $OUT/shard_test_4096.json 2>/dev/null
