@@ -11,6 +11,8 @@ from pose_refine_amd import api, synth
 
 W, H = 640, 480
 api.init(0); api.set_option("solve", 1)
+for kv in filter(None, os.environ.get("PR_OPTS", "").split(",")):
+    k_, v_ = kv.split("="); api.set_option(k_, int(v_))
 model = api.Model(os.path.join(ROOT, "tests/golden/obj_06.ply"))
 K = synth.K_TEST; proj = api.compute_proj(K, W, H)
 obj = api.render_host(model, synth.scene_pose()[None], W, H, proj)[0].astype(np.int32)
