@@ -114,12 +114,13 @@ def test_device_kdtree_build_whole_levels_at_a_time(gpu, kind, n, max_leaf):
     assert O.lib().po_kd_build(pts.copy().reshape(-1), nrm.copy().reshape(-1), n, max_leaf, np.zeros(ocnt - 2, O.KDNODE).ctypes.data, ocnt - 2) == 0
 
 
-def test_device_nn_scene_of_a_frame_filling_image(gpu):
-    """640 x 480 valid pixels (a curved wall behind nothing): gather, normals, the 300-tile build and the wide records derived from it, against the oracle."""
-    W, H = 640, 480
+@pytest.mark.parametrize("W,H", [(640, 480), (1280, 720)])
+def test_device_nn_scene_of_a_frame_filling_image(gpu, W, H):
+    """Every pixel valid (a curved wall behind nothing), 640 x 480 and BASELINE configs[4]'s 1280 x 720: gather, normals, the 300 / 900-tile build and the wide
+    records derived from it, against the oracle."""
     yy, xx = np.mgrid[0:H, 0:W]
     depth = (900 + 0.05 * xx + 0.03 * yy + 3.0 * np.sin(xx / 17.0) * np.cos(yy / 23.0)).astype(np.int32)
-    K = synth.K_TEST
+    K = synth.K_TEST if W == 640 else np.array([W * 0.9, 0, W / 2, 0, W * 0.9, H / 2, 0, 0, 1], np.float32)
     dev = api.Scene_nn().init_Scene_nn_device(api.DeviceVector.from_host(depth.reshape(-1)), K, W, H)
     ref = O.NNScene(depth, K)
     npt, nn = len(ref.pcd), len(ref.nodes)
@@ -127,7 +128,7 @@ def test_device_nn_scene_of_a_frame_filling_image(gpu):
     assert np.array_equal(dev.pcd_buffer.to_host()[:3 * npt].reshape(-1, 3), ref.pcd) and np.array_equal(dev.normal_buffer.to_host()[:3 * npt].reshape(-1, 3), ref.normal)
     assert dev.nodes.to_host()[:nn].tobytes() == ref.nodes.tobytes()
     # and a search against it: a cloud of the wall's own points pushed 4 mm towards the camera
-    cloud = (ref.pcd[::37] * np.float32(0.996)).astype(np.float32)
+    cloud = (ref.pcd[::37 if W == 640 else 151] * np.float32(0.996)).astype(np.float32)
     got = api.ICP_Point2Plane(api.DeviceVector.from_host(cloud.reshape(-1)), dev, api.ICPConvergenceCriteria(0.0, 0.0, 3))
     want, _, _, _ = O.icp(cloud, ref, (0.0, 0.0, 3), O.SUM_CANONICAL, api.get_option("points_per_block"))
     assert got.fitness_ == float(want["fitness"]) and np.allclose(got.transformation_.reshape(-1), want["T"], rtol=0, atol=TOL_T)
