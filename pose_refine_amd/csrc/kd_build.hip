@@ -77,33 +77,35 @@ __global__ __launch_bounds__(1024) void kd_root_kernel(pr_kdnode *__restrict__ n
 }
 
 // what a position of the permutation is to its node in this level
-struct KdPos { int id, o; bool split, head, lt, tie; float v; };
-struct KdTileIn { KdPos p[kKdPer]; KdLevelNode nd[kKdPer]; };
+// (arrays of scalars, filled through plain assignments: as an array of records copied with a conditional expression the whole set lived in scratch memory, 196 bytes per lane)
+struct KdTileIn { int id[kKdPer], o[kKdPer], left[kKdPer], right[kKdPer], child[kKdPer]; bool split[kKdPer], head[kKdPer], lt[kKdPer], tie[kKdPer]; float v[kKdPer]; };
 __device__ __forceinline__ void kd_classify(const KdLevelNode *__restrict__ lv, const pr_vec3 *__restrict__ pcd, const int *__restrict__ idx,
                                             const int *__restrict__ owner, uint32_t n, uint32_t k0, KdTileIn &t)
 {
-    int id4[kKdPer], o4[kKdPer];
     if (k0 + kKdPer - 1u < n) {
 #pragma unroll
         for (uint32_t q = 0; q < kKdPer; q += 4) {
             const int4 a = *reinterpret_cast<const int4 *>(idx + k0 + q), b = *reinterpret_cast<const int4 *>(owner + k0 + q);
-            id4[q] = a.x; id4[q + 1] = a.y; id4[q + 2] = a.z; id4[q + 3] = a.w; o4[q] = b.x; o4[q + 1] = b.y; o4[q + 2] = b.z; o4[q + 3] = b.w;
+            t.id[q] = a.x; t.id[q + 1] = a.y; t.id[q + 2] = a.z; t.id[q + 3] = a.w; t.o[q] = b.x; t.o[q + 1] = b.y; t.o[q + 2] = b.z; t.o[q + 3] = b.w;
         }
     } else {
 #pragma unroll
-        for (uint32_t j = 0; j < kKdPer; ++j) { id4[j] = 0; o4[j] = -1; if (k0 + j < n) { id4[j] = idx[k0 + j]; o4[j] = owner[k0 + j]; } }
+        for (uint32_t j = 0; j < kKdPer; ++j) { const bool in = k0 + j < n; t.id[j] = in ? idx[k0 + j] : 0; t.o[j] = in ? owner[k0 + j] : -1; }
     }
+    int axis = 0; float cut = 0.0f;
 #pragma unroll
     for (uint32_t j = 0; j < kKdPer; ++j) {
-        KdPos &p = t.p[j];
-        p.id = id4[j]; p.o = o4[j]; p.split = p.head = p.lt = p.tie = false; p.v = 0.0f;
-        if (p.o < 0) continue;
-        t.nd[j] = (j > 0 && o4[j] == o4[j - 1]) ? t.nd[j - 1] : lv[p.o];
-        if (t.nd[j].child < 0) continue;
-        p.split = true;
-        p.v = axis_coord(pcd[p.id], t.nd[j].axis);
-        p.lt = p.v < t.nd[j].cut; p.tie = p.v == t.nd[j].cut;
-        p.head = (int)(k0 + j) == t.nd[j].left;
+        const bool owned = t.o[j] >= 0;
+        if (j == 0 || t.o[j] != t.o[j - 1]) {                         // (consecutive positions of one node: one record)
+            int4 r = make_int4(0, 0, -1, 0); float c = 0.0f;
+            if (owned) { r = *reinterpret_cast<const int4 *>(&lv[t.o[j]]); c = lv[t.o[j]].cut; }       // left, right, child, axis | cut
+            t.left[j] = r.x; t.right[j] = r.y; t.child[j] = r.z; axis = r.w; cut = c;
+        } else { t.left[j] = t.left[j - 1]; t.right[j] = t.right[j - 1]; t.child[j] = t.child[j - 1]; }
+        t.split[j] = owned && t.child[j] >= 0;
+        const float v = t.split[j] ? axis_coord(pcd[t.id[j]], axis) : 0.0f;
+        t.v[j] = v;
+        t.lt[j] = t.split[j] && v < cut; t.tie[j] = t.split[j] && v == cut;
+        t.head[j] = t.split[j] && (int)(k0 + j) == t.left[j];
     }
 }
 // segmented sums over the tile, in position order: (h, a) = (a node starts in the span, packed counts since the last start -- below the cut in
@@ -135,7 +137,7 @@ __global__ __launch_bounds__(256) void kd_tile_count_kernel(const KdCtrl *__rest
     kd_classify(lv, pcd, idx, owner, n, blockIdx.x * kKdTile + kKdPer * threadIdx.x, t);
     uint32_t h = 0u, a = 0u;
 #pragma unroll
-    for (uint32_t j = 0; j < kKdPer; ++j) { if (t.p[j].head) { h = 1u; a = 0u; } a += (t.p[j].lt ? 1u : 0u) + (t.p[j].tie ? 0x10000u : 0u); }
+    for (uint32_t j = 0; j < kKdPer; ++j) { if (t.head[j]) { h = 1u; a = 0u; } a += (t.lt[j] ? 1u : 0u) + (t.tie[j] ? 0x10000u : 0u); }
     kd_seg_wave_scan(h, a);
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     if (lane == 63u) { s_h[wave] = h; s_a[wave] = a; }
@@ -210,9 +212,9 @@ __global__ __launch_bounds__(256) void kd_tile_scatter_kernel(const KdCtrl *__re
     int o_min = 0x7fffffff;                                         // the level's nodes are numbered in position order: the first splitting one of the tile has the smallest number
 #pragma unroll
     for (uint32_t j = 0; j < kKdPer; ++j) {
-        if (t.p[j].head) { h = 1u; a = 0u; }
-        a += (t.p[j].lt ? 1u : 0u) + (t.p[j].tie ? 0x10000u : 0u);
-        if (t.p[j].split && t.p[j].o < o_min) o_min = t.p[j].o;
+        if (t.head[j]) { h = 1u; a = 0u; }
+        a += (t.lt[j] ? 1u : 0u) + (t.tie[j] ? 0x10000u : 0u);
+        if (t.split[j] && t.o[j] < o_min) o_min = t.o[j];
     }
     kd_seg_wave_scan(h, a);
     for (int off = 32; off > 0; off >>= 1) { const int o2 = __shfl_xor(o_min, off); o_min = o2 < o_min ? o2 : o_min; }
@@ -236,27 +238,26 @@ __global__ __launch_bounds__(256) void kd_tile_scatter_kernel(const KdCtrl *__re
     uint32_t run_h = xh, run = xa;
 #pragma unroll
     for (uint32_t j = 0; j < kKdPer; ++j) {
-        const KdPos &p = t.p[j];
         const uint32_t k = k0 + j;
         if (k >= n) break;
-        if (!p.split) { idx_out[k] = p.id; owner_out[k] = -1; continue; }
-        const KdLevelNode &nd = t.nd[j];
-        if (p.head) { run_h = 1u; run = 0u; }
+        const int id = t.id[j], o = t.o[j], n_left = t.left[j], n_right = t.right[j];
+        if (!t.split[j]) { idx_out[k] = id; owner_out[k] = -1; continue; }
+        if (t.head[j]) { run_h = 1u; run = 0u; }
         const uint32_t lt_before = (run & 0xffffu) + (run_h ? 0u : carry_lt), tie_before = (run >> 16) + (run_h ? 0u : carry_tie);
-        run += (p.lt ? 1u : 0u) + (p.tie ? 0x10000u : 0u);
+        run += (t.lt[j] ? 1u : 0u) + (t.tie[j] ? 0x10000u : 0u);
         // pcd_scene.cpp:113-133: the switch starts on and flips at every point on the cut BEFORE the test -- the k-th such point goes left iff k is even
-        const bool goes_left = p.lt || (p.tie && ((tie_before + 1u) & 1u) == 0u);
-        const uint32_t left_before = lt_before + (tie_before >> 1), right_before = (k - (uint32_t)nd.left) - left_before;
-        const uint32_t dest = goes_left ? (uint32_t)nd.left + left_before : (uint32_t)nd.right - 1u - right_before;
-        const uint32_t side = goes_left ? 0u : 1u, child0 = (uint32_t)nd.child - first_child;
-        idx_out[dest] = p.id; owner_out[dest] = (int)(child0 + side);
-        if ((int)k == nd.right - 1) left_total[p.o] = left_before + (goes_left ? 1u : 0u);
-        if (p.o != o_cur) {
+        const bool goes_left = t.lt[j] || (t.tie[j] && ((tie_before + 1u) & 1u) == 0u);
+        const uint32_t left_before = lt_before + (tie_before >> 1), right_before = (k - (uint32_t)n_left) - left_before;
+        const uint32_t dest = goes_left ? (uint32_t)n_left + left_before : (uint32_t)n_right - 1u - right_before;
+        const uint32_t side = goes_left ? 0u : 1u, child0 = (uint32_t)t.child[j] - first_child;
+        idx_out[dest] = id; owner_out[dest] = (int)(child0 + side);
+        if ((int)k == n_right - 1) left_total[o] = left_before + (goes_left ? 1u : 0u);
+        if (o != o_cur) {
             if (o_cur >= 0) { kd_keys_flush(keys, o_cur, o_base, child_cur, s_table, bbkeys, lrkeys); kd_keys_clear(keys); }
-            o_cur = p.o; child_cur = child0;
+            o_cur = o; child_cur = child0;
         }
-        const pr_vec3 pt = pcd[p.id];
-        const unsigned long long lr = goes_left ? kd_key_max(p.v, k) : kd_key_min(p.v, k);     // "below" / "above" of the reference's loop, in the OLD order
+        const pr_vec3 pt = pcd[id];
+        const unsigned long long lr = goes_left ? kd_key_max(t.v[j], k) : kd_key_min(t.v[j], k);     // "below" / "above" of the reference's loop, in the OLD order
         keys.lr[0] = min_u64(keys.lr[0], goes_left ? lr : kKdNoKey); keys.lr[1] = min_u64(keys.lr[1], goes_left ? kKdNoKey : lr);
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(256) void kd_tile_scatter_kernel(const KdCtrl *__re
     {
         // every lane of the wavefront on the same node (all wavefronts of the upper levels): fold across the lanes first
         const int o_first = __builtin_amdgcn_readfirstlane(o_cur);
-        const bool same = o_cur == o_first && o_cur >= 0 && t.p[0].o == o_cur;      // (the lane never changed node: its keys are all of o_cur)
+        const bool same = o_cur == o_first && o_cur >= 0 && t.o[0] == o_cur;      // (the lane never changed node: its keys are all of o_cur)
         if (__all(same)) {
 #pragma unroll
             for (int c = 0; c < 2; ++c) { keys.lr[c] = wave_min_u64(keys.lr[c]); for (int q = 0; q < 6; ++q) keys.bb[c][q] = wave_min_u64(keys.bb[c][q]); }
