@@ -22,14 +22,26 @@ struct Scene_projective {
                                  "pr_scene_proj_prepare");
         pcd_ptr = pcd_buffer.data(); normal_ptr = normal_buffer.data();
     }
-    // depth_scene.cu:3-20: CPU preparation + two uploads
+    // depth_scene.cu:3-20 = CPU preparation + two uploads (7.4 MB).  Here the depth image goes up (1.2 MB) and back-projection + normals run as one kernel:
+    // the same arrays, bit for bit (tests/test_scene_prep_gpu.py).  -DPOSE_REFINE_CPU_SCENE_PREP keeps the reference's route.
     void init_Scene_projective_cuda(cv::Mat &scene_depth, Mat3x3f &scene_K, device_vector_holder<Vec3f> &pcd_buffer,
                                     device_vector_holder<Vec3f> &normal_buffer, size_t width_ = 640, size_t height_ = 480, float max_dist_diff_ = 0.1f)
     {
+#ifdef POSE_REFINE_CPU_SCENE_PREP
         std::vector<Vec3f> p, n;
         init_Scene_projective_cpu(scene_depth, scene_K, p, n, width_, height_, max_dist_diff_);
         pcd_buffer.upload(p); normal_buffer.upload(n);
         pcd_ptr = pcd_buffer.data(); normal_ptr = normal_buffer.data();
+#else
+        assert(scene_depth.type() == CV_16U || scene_depth.type() == CV_32S);
+        const bool is32 = scene_depth.type() == CV_32S;
+        const size_t px = width_ * height_;                          // (the reference reads rows < height_, cols < width_ of the image it is given)
+        assert((size_t)scene_depth.cols == width_ && (size_t)scene_depth.rows >= height_);
+        device_vector_holder<unsigned char> depth_dev(px * (is32 ? 4 : 2));
+        pose_refine_detail::must(pr_memcpy_h2d(depth_dev.data(), scene_depth.data, px * (is32 ? 4 : 2)), "pr_memcpy_h2d");
+        if (is32) init_Scene_projective_device(reinterpret_cast<int32_t *>(depth_dev.data()), scene_K, pcd_buffer, normal_buffer, width_, height_, max_dist_diff_);
+        else init_Scene_projective_device(reinterpret_cast<uint16_t *>(depth_dev.data()), scene_K, pcd_buffer, normal_buffer, width_, height_, max_dist_diff_);
+#endif
     }
     // the same initialisation with the depth image already on the device (T = int32_t or uint16_t);
     // back-projection and normals run as one kernel, bit-identical to the CPU preparation.

@@ -53,12 +53,27 @@ public:
         remember_camera(scene_K, scene_depth.cols, scene_depth.rows);
         pcd_ptr = kdtree.pcd_buffer.data(); normal_ptr = kdtree.normal_buffer.data(); node_ptr = kdtree.nodes.data();
     }
-    void init_Scene_nn_cuda(cv::Mat &scene_depth, Mat3x3f &scene_K, KDTree_cuda &kdtree)   // pcd_scene.cu:3-20
+    // pcd_scene.cu:3-20 prepares the scene on the CPU (init_Scene_nn_cpu) and uploads three arrays -- the step the reference's README names as what is
+    // left on the CPU.  Here the depth image goes up once and normals, gather and the level-order build run on the device: the SAME arrays, bit for bit
+    // (tests/test_scene_prep_gpu.py), in about a millisecond instead of tens.  -DPOSE_REFINE_CPU_SCENE_PREP keeps the reference's route.
+    void init_Scene_nn_cuda(cv::Mat &scene_depth, Mat3x3f &scene_K, KDTree_cuda &kdtree)
     {
+#ifdef POSE_REFINE_CPU_SCENE_PREP
         KDTree_cpu cpu;
         init_Scene_nn_cpu(scene_depth, scene_K, cpu);
         kdtree.pcd_buffer.upload(cpu.pcd_buffer); kdtree.normal_buffer.upload(cpu.normal_buffer); kdtree.nodes.upload(cpu.nodes);
         pcd_ptr = kdtree.pcd_buffer.data(); normal_ptr = kdtree.normal_buffer.data(); node_ptr = kdtree.nodes.data();
+#else
+        assert(scene_depth.type() == CV_16U || scene_depth.type() == CV_32S);
+        const bool is32 = scene_depth.type() == CV_32S;
+        const size_t px = (size_t)scene_depth.rows * scene_depth.cols;
+        device_vector_holder<unsigned char> depth_dev(px * (is32 ? 4 : 2));
+        pose_refine_detail::must(pr_memcpy_h2d(depth_dev.data(), scene_depth.data, px * (is32 ? 4 : 2)), "pr_memcpy_h2d");
+        if (is32) init_Scene_nn_device(reinterpret_cast<int32_t *>(depth_dev.data()), scene_K, scene_depth.cols, scene_depth.rows, kdtree);
+        else init_Scene_nn_device(reinterpret_cast<uint16_t *>(depth_dev.data()), scene_K, scene_depth.cols, scene_depth.rows, kdtree);
+        // (the arrays are allocated for a frame full of valid pixels; their sizes say what they hold, as the reference's uploads do)
+        kdtree.pcd_buffer.__size = n_points; kdtree.normal_buffer.__size = n_points; kdtree.nodes.__size = n_nodes;
+#endif
     }
     // normals, valid-pixel gather and the level-order kd-tree build on the device (bit-identical tree)
     template <class T>
