@@ -448,7 +448,10 @@ hipError_t launch_kd_init(const KdWork &w, pr_kdnode *nodes, uint32_t cap, const
 hipError_t launch_kd_level(const KdWork &w, pr_kdnode *nodes, uint32_t cap, const pr_vec3 *pcd, uint32_t n, int max_leaf, uint32_t level, hipStream_t s)
 {
     const uint32_t a = level & 1u, b = a ^ 1u, tiles = (n + kKdTile - 1) / kKdTile;
-    const uint32_t node_groups = std::min<uint32_t>((w.max_level + 255u) / 256u, 512u), chunk_groups = std::min<uint32_t>(w.max_level / kKdChunk + 1u, 128u);
+    // (level l holds at most 2^l nodes and twice as many children: the upper levels' finish and plan launches are one workgroup each -- under load a launch waits
+    //  for wave slots for every workgroup it brings, whether it has work or not)
+    const uint32_t level_nodes = level < 20u ? std::min<uint32_t>(1u << level, w.max_level) : w.max_level, level_children = std::min<uint32_t>(2u * level_nodes, w.max_level);
+    const uint32_t node_groups = std::min<uint32_t>((level_nodes + 255u) / 256u, 512u), chunk_groups = std::min<uint32_t>(level_children / kKdChunk + 1u, 128u);
     hipLaunchKernelGGL(kd_tile_count_kernel, dim3(tiles), dim3(256), 0, s, w.ctrl[a], w.lv[a], pcd, w.idx[a], w.owner[a], n, w.tile_agg, w.bbkeys, w.lrkeys, w.chunk_cnt);
     hipLaunchKernelGGL(kd_tile_scatter_kernel, dim3(tiles), dim3(256), 0, s, w.ctrl[a], w.lv[a], pcd, w.idx[a], w.owner[a], n, w.tile_agg, w.idx[b], w.owner[b],
                        w.left_total, w.bbkeys, w.lrkeys);

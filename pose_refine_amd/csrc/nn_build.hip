@@ -350,9 +350,12 @@ hipError_t launch_nn_wide_levels(const int4 *topo, const float4 *bmin, const flo
     }
     const uint32_t open_groups = std::min<uint32_t>((cap + 31u) / 32u, 2048u), number_groups = std::min<uint32_t>(chunks, 128u);
     for (uint32_t level = first; level < first + count; ++level) {
+        // (wide level l holds at most 8^l nodes: the first levels' launches bring one workgroup, not 2 048 that find nothing to do)
+        const uint32_t level_nodes = level < 8u ? std::min<uint32_t>(1u << (3u * level), cap) : cap;
+        const uint32_t og = std::min<uint32_t>((level_nodes + 31u) / 32u, open_groups), ng = std::min<uint32_t>(level_nodes / kWideChunk + 1u, number_groups);
         uint32_t *mine = sums + (size_t)(level & 1u) * chunks, *other = sums + (size_t)((level + 1u) & 1u) * chunks;
-        hipLaunchKernelGGL(nn_wide_open_kernel, dim3(open_groups), dim3(256), 0, s, topo, bmin, bmax, n_nodes, wide, wq, cnt, ctrl, bad_flag, mine, level, n_points, info);
-        hipLaunchKernelGGL(nn_wide_number_kernel, dim3(number_groups), dim3(1024), 0, s, wide, cap, wq, cnt, ctrl, ctrl + ((level + 1u) & 1u), bad_flag, mine, other, level, info);
+        hipLaunchKernelGGL(nn_wide_open_kernel, dim3(og), dim3(256), 0, s, topo, bmin, bmax, n_nodes, wide, wq, cnt, ctrl, bad_flag, mine, level, n_points, info);
+        hipLaunchKernelGGL(nn_wide_number_kernel, dim3(ng), dim3(1024), 0, s, wide, cap, wq, cnt, ctrl, ctrl + ((level + 1u) & 1u), bad_flag, mine, other, level, info);
     }
     hipLaunchKernelGGL(nn_wide_layout_kernel, dim3(open_groups), dim3(256), 0, s, wide, ctrl, first + count, info);
     return hipGetLastError();
