@@ -5,8 +5,8 @@ workspaces, changing grid hints, sub-batches, empty clouds) and every batch is c
     [PR_STRESS_TIMED=1] [PR_STRESS_SOLVE=host] python tools/stress_async.py [jobs] [kd-tree fraction]
     (PR_STRESS_TIMED: every third batch is a timed one, profile 3; PR_STRESS_SOLVE=host: the 6x6 solve on the host -- submitted batches run on the slots' helper threads)
 
-With a kd-tree fraction > 0 some jobs run against one of TWO kd-tree scenes: the search records and the pixel grid are shared by
-both slots and hold one scene at a time, so alternating scenes forces rebuilds while the other slot has a batch in flight."""
+With a kd-tree fraction > 0 some jobs run against one of THREE kd-tree scenes: a context holds two sets of derived records (search records, pixel
+grid), so three scenes in random order force rebuilds -- also of a set the other slot's batch is reading, which then has to finish first."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -20,7 +20,9 @@ scene = api.Scene_projective().init_Scene_projective_cuda(sd, K)
 nn_frac = float(sys.argv[2]) if len(sys.argv) > 2 else 0.0
 other = synth.scene_pose().copy(); other.reshape(4, 4)[0, 3] += 15.0; other.reshape(4, 4)[2, 3] += 25.0
 sd2 = api.render_host(model, other[None], W, H, proj)[0]
-nn_scenes = [api.Scene_nn().init_Scene_nn_cuda(sd, K), api.Scene_nn().init_Scene_nn_cuda(sd2, K)] if nn_frac > 0 else []
+third = synth.scene_pose().copy(); third.reshape(4, 4)[1, 3] -= 12.0; third.reshape(4, 4)[2, 3] -= 20.0
+sd3 = api.render_host(model, third[None], W, H, proj)[0]
+nn_scenes = [api.Scene_nn().init_Scene_nn_cuda(d, K) for d in (sd, sd2, sd3)] if nn_frac > 0 else []
 rng = np.random.default_rng(7)
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 jobs = []
@@ -33,7 +35,7 @@ for i in range(N):
     if P > 2 and rng.random() < 0.3:
         poses.reshape(-1, 4, 4)[1, 0, 3] += 1e6
     crit = api.ICPConvergenceCriteria(0.0, 0.0, int(rng.choice([0, 3, 20]))) if rng.random() < 0.7 else api.ICPConvergenceCriteria(1e-5, 1e-5, 30)
-    jobs.append((poses, crit, nn_scenes[int(rng.integers(2))] if use_nn else scene))
+    jobs.append((poses, crit, nn_scenes[int(rng.integers(3))] if use_nn else scene))
 api.set_option("sub_batch", 256)
 api.set_option("profile", 1)                                   # timed calls take the synchronous path
 refs = [api.refine_batch(model, p, W, H, proj, K, sc, c) for p, c, sc in jobs]
