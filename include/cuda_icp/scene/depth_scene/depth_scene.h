@@ -2,6 +2,7 @@
 // {width, height, max_dist_diff, K, pcd_ptr, normal_ptr} over user-owned buffers.  72 bytes, same
 // field order as the reference, bit-compatible with pr_scene_proj of the C ABI.
 #pragma once
+#include <iostream>
 #include "../common.h"
 
 struct Scene_projective {
@@ -36,7 +37,10 @@ struct Scene_projective {
         assert(scene_depth.type() == CV_16U || scene_depth.type() == CV_32S);
         const bool is32 = scene_depth.type() == CV_32S;
         const size_t px = width_ * height_;                          // (the reference reads rows < height_, cols < width_ of the image it is given)
-        assert((size_t)scene_depth.cols == width_ && (size_t)scene_depth.rows >= height_);
+        if ((size_t)scene_depth.cols != width_ || (size_t)scene_depth.rows < height_) {      // (the reference indexes the image with the width it is told and trusts the caller)
+            std::cerr << "init_Scene_projective_cuda: the depth image is " << scene_depth.cols << " x " << scene_depth.rows << ", not " << width_ << " x " << height_ << ": pass width / height of the image" << std::endl;
+            std::exit(1);
+        }
         device_vector_holder<unsigned char> depth_dev(px * (is32 ? 4 : 2));
         pose_refine_detail::must(pr_memcpy_h2d(depth_dev.data(), scene_depth.data, px * (is32 ? 4 : 2)), "pr_memcpy_h2d");
         if (is32) init_Scene_projective_device(reinterpret_cast<int32_t *>(depth_dev.data()), scene_K, pcd_buffer, normal_buffer, width_, height_, max_dist_diff_);
