@@ -206,3 +206,54 @@ def test_misused_entry_points_return_codes_and_leave_no_trace(gpu):
     assert lib.pr_malloc(C.byref(q), 1024) == 0 and lib.pr_free(q) == 0 and lib.pr_free(q) != 0 and lib.pr_free(None) == 0
     assert lib.pr_fill_i32(d.data(), 64, 9) == 0 and int(d.to_host()[0]) == 9
     assert lib.pr_set_option(None, 1) == -3 and lib.pr_set_option(b"nonsense", 1) == -3 and lib.pr_refine_wait(7) == -3 and lib.pr_refine_wait(-1) == -3
+
+
+@pytest.mark.device_solve
+@pytest.mark.parametrize("kind", ["proj", "nn"])
+def test_scenes_prepared_by_a_helper_thread_while_batches_run(gpu, model, scenario, kind):
+    """The per-frame pattern of tools/frames_pipe.py: a helper thread with a private context prepares the NEXT frames' scenes on the device (its own stream and
+    build workspace) while the caller's two slots refine against the scenes it handed over before.  What the helper writes is seen by the caller's context
+    (the write log is the library's, not a context's: the caller's cached records of a re-used scene object are stale the moment it is re-initialised)."""
+    import queue
+    K, proj = scenario["K"], scenario["proj"]
+    poses = synth.hypotheses(40)
+    crit = api.ICPConvergenceCriteria(0.0, 0.0, 5)
+    base = scenario["depth"][1].astype(np.int32)
+    depths = []
+    for i in range(3):
+        d = base.copy(); d[d > 0] += 2 * i; d[(30 * i) % H::9, ::4] = 0
+        depths.append(d)
+    def make(obj, dev):
+        return obj.init_Scene_projective_device(dev, K, W, H) if kind == "proj" else obj.init_Scene_nn_device(dev, K, W, H)
+    devs = [api.DeviceVector.from_host(d.reshape(-1)) for d in depths]
+    new = (lambda: api.Scene_projective()) if kind == "proj" else (lambda: api.Scene_nn())
+    want = [api.refine_batch(model, poses, W, H, proj, K, make(new(), dv), crit) for dv in devs]
+    objs = [new() for _ in range(4)]
+    ready, free, errors = queue.Queue(), queue.Queue(), []
+    for i in range(4): free.put(i)
+    N = 14
+    def producer():
+        try:
+            api.thread_context(True)
+            for k in range(N):
+                i = free.get()
+                make(objs[i], devs[k % 3])
+                ready.put(i)
+            api.thread_context(False)
+        except Exception as e:                                       # noqa: BLE001 -- reported by the main thread
+            errors.append(e); ready.put(-1)
+    th = threading.Thread(target=producer); th.start()
+    held = {}
+    for k in range(N):
+        i = ready.get()
+        assert i >= 0, errors
+        api.refine_submit(k & 1, model, poses, W, H, proj, K, objs[i], crit)
+        held[k] = i
+        if k:
+            res, sizes = api.refine_wait((k - 1) & 1)
+            assert res.tobytes() == want[(k - 1) % 3][0].tobytes() and np.array_equal(sizes, want[(k - 1) % 3][1])
+            free.put(held.pop(k - 1))
+    res, _ = api.refine_wait((N - 1) & 1)
+    assert res.tobytes() == want[(N - 1) % 3][0].tobytes()
+    th.join()
+    assert not errors
