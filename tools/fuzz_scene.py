@@ -14,7 +14,7 @@ seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 t0 = time.time(); n = 0; bad = 0
 while time.time() - t0 < budget:
     rng = np.random.default_rng(seed)
-    W, H = int(rng.integers(12, 400)), int(rng.integers(12, 300))
+    W, H = (int(rng.integers(300, 1400)), int(rng.integers(200, 800))) if os.environ.get("PR_FUZZ_BIG") else (int(rng.integers(12, 400)), int(rng.integers(12, 300)))   # PR_FUZZ_BIG: up to a million pixels (hundreds of tiles per level of the device build)
     K = np.array([rng.uniform(0.6, 1.5) * W, 0, W / 2 + rng.uniform(-5, 5), 0, rng.uniform(0.6, 1.5) * W, H / 2 + rng.uniform(-5, 5), 0, 0, 1], np.float32)
     yy, xx = np.mgrid[0:H, 0:W]
     d = np.zeros((H, W), np.float64)
