@@ -34,17 +34,11 @@ struct Scene_projective {
         pcd_buffer.upload(p); normal_buffer.upload(n);
         pcd_ptr = pcd_buffer.data(); normal_ptr = normal_buffer.data();
 #else
-        assert(scene_depth.type() == CV_16U || scene_depth.type() == CV_32S);
-        const bool is32 = scene_depth.type() == CV_32S;
-        const size_t px = width_ * height_;                          // (the reference reads rows < height_, cols < width_ of the image it is given)
-        if ((size_t)scene_depth.cols != width_ || (size_t)scene_depth.rows < height_) {      // (the reference indexes the image with the width it is told and trusts the caller)
-            std::cerr << "init_Scene_projective_cuda: the depth image is " << scene_depth.cols << " x " << scene_depth.rows << ", not " << width_ << " x " << height_ << ": pass width / height of the image" << std::endl;
-            std::exit(1);
-        }
-        device_vector_holder<unsigned char> depth_dev(px * (is32 ? 4 : 2));
-        pose_refine_detail::must(pr_memcpy_h2d(depth_dev.data(), scene_depth.data, px * (is32 ? 4 : 2)), "pr_memcpy_h2d");
-        if (is32) init_Scene_projective_device(reinterpret_cast<int32_t *>(depth_dev.data()), scene_K, pcd_buffer, normal_buffer, width_, height_, max_dist_diff_);
-        else init_Scene_projective_device(reinterpret_cast<uint16_t *>(depth_dev.data()), scene_K, pcd_buffer, normal_buffer, width_, height_, max_dist_diff_);
+        bool is32 = false;
+        device_vector_holder<unsigned char> depth_dev;
+        pose_refine_detail::upload_depth(scene_depth, width_, height_, depth_dev, is32);      // type / size checked at run time; pitched or wider images row by row
+        if (is32) init_Scene_projective_device(reinterpret_cast<int32_t *>(depth_dev.__gpu_memory), scene_K, pcd_buffer, normal_buffer, width_, height_, max_dist_diff_);
+        else init_Scene_projective_device(reinterpret_cast<uint16_t *>(depth_dev.__gpu_memory), scene_K, pcd_buffer, normal_buffer, width_, height_, max_dist_diff_);
 #endif
     }
     // the same initialisation with the depth image already on the device (T = int32_t or uint16_t);

@@ -64,13 +64,11 @@ public:
         kdtree.pcd_buffer.upload(cpu.pcd_buffer); kdtree.normal_buffer.upload(cpu.normal_buffer); kdtree.nodes.upload(cpu.nodes);
         pcd_ptr = kdtree.pcd_buffer.data(); normal_ptr = kdtree.normal_buffer.data(); node_ptr = kdtree.nodes.data();
 #else
-        assert(scene_depth.type() == CV_16U || scene_depth.type() == CV_32S);
-        const bool is32 = scene_depth.type() == CV_32S;
-        const size_t px = (size_t)scene_depth.rows * scene_depth.cols;
-        device_vector_holder<unsigned char> depth_dev(px * (is32 ? 4 : 2));
-        pose_refine_detail::must(pr_memcpy_h2d(depth_dev.data(), scene_depth.data, px * (is32 ? 4 : 2)), "pr_memcpy_h2d");
-        if (is32) init_Scene_nn_device(reinterpret_cast<int32_t *>(depth_dev.data()), scene_K, scene_depth.cols, scene_depth.rows, kdtree);
-        else init_Scene_nn_device(reinterpret_cast<uint16_t *>(depth_dev.data()), scene_K, scene_depth.cols, scene_depth.rows, kdtree);
+        bool is32 = false;
+        device_vector_holder<unsigned char> depth_dev;
+        pose_refine_detail::upload_depth(scene_depth, (size_t)scene_depth.cols, (size_t)scene_depth.rows, depth_dev, is32);     // (a pitched Mat row by row)
+        if (is32) init_Scene_nn_device(reinterpret_cast<int32_t *>(depth_dev.__gpu_memory), scene_K, scene_depth.cols, scene_depth.rows, kdtree);
+        else init_Scene_nn_device(reinterpret_cast<uint16_t *>(depth_dev.__gpu_memory), scene_K, scene_depth.cols, scene_depth.rows, kdtree);
         // (the arrays are allocated for a frame full of valid pixels; their sizes say what they hold, as the reference's uploads do)
         kdtree.pcd_buffer.__size = n_points; kdtree.normal_buffer.__size = n_points; kdtree.nodes.__size = n_nodes;
 #endif

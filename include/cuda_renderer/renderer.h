@@ -71,20 +71,31 @@ public:
     device_vector_holder &operator=(device_vector_holder &&o) noexcept
     { if (this != &o) { __free(); __gpu_memory = o.__gpu_memory; __size = o.__size; valid = o.valid; o.__gpu_memory = nullptr; o.__size = 0; o.valid = false; } return *this; }
     ~device_vector_holder() { __free(); }
-    T *data() { return __gpu_memory; }
-    T *begin() { return __gpu_memory; }
-    T *end() { return __gpu_memory + __size; }
+    // A non-const accessor hands out a pointer the caller may WRITE through (thrust::copy(..., begin_thr()), a kernel of its own), and the
+    // library caches forms derived from scene arrays by address: every such hand-out is announced (pr_invalidate: a host-side generation
+    // bump), the const overloads are for reading.  A pointer that is kept and written through LATER is caught by the full-array fingerprint
+    // every synchronous ICP / refine call compares (pose_refine.h "Caches"): the reference reads the arrays at every call.
+    T *data() { touched(); return __gpu_memory; }
+    T *begin() { touched(); return __gpu_memory; }
+    T *end() { touched(); return __gpu_memory + __size; }
+    const T *data() const { return __gpu_memory; }
+    const T *begin() const { return __gpu_memory; }
+    const T *end() const { return __gpu_memory + __size; }
     size_t size() const { return __size; }
 #ifdef POSE_REFINE_HAVE_THRUST
-    thrust::device_ptr<T> data_thr() { return thrust::device_ptr<T>(__gpu_memory); }
-    thrust::device_ptr<T> begin_thr() { return thrust::device_ptr<T>(__gpu_memory); }
-    thrust::device_ptr<T> end_thr() { return thrust::device_ptr<T>(__gpu_memory + __size); }
+    thrust::device_ptr<T> data_thr() { touched(); return thrust::device_ptr<T>(__gpu_memory); }
+    thrust::device_ptr<T> begin_thr() { touched(); return thrust::device_ptr<T>(__gpu_memory); }
+    thrust::device_ptr<T> end_thr() { touched(); return thrust::device_ptr<T>(__gpu_memory + __size); }
+    thrust::device_ptr<const T> data_thr() const { return thrust::device_ptr<const T>(__gpu_memory); }
+    thrust::device_ptr<const T> begin_thr() const { return thrust::device_ptr<const T>(__gpu_memory); }
+    thrust::device_ptr<const T> end_thr() const { return thrust::device_ptr<const T>(__gpu_memory + __size); }
 #endif
     void __malloc(size_t n) { if (valid) __free(); void *p = nullptr; if (pr_malloc(&p, n * sizeof(T)) != PR_OK) { std::cerr << pr_last_error() << std::endl; std::exit(1); } __gpu_memory = static_cast<T *>(p); __size = n; valid = true; }
     void __free() { if (valid) { pr_free(__gpu_memory); valid = false; __size = 0; __gpu_memory = nullptr; } }
     void upload(const std::vector<T> &h) { if (__size != h.size()) __malloc(h.size()); if (!h.empty()) pr_memcpy_h2d(__gpu_memory, h.data(), h.size() * sizeof(T)); }
     std::vector<T> download() const { std::vector<T> h(__size); if (__size) pr_memcpy_d2h(h.data(), __gpu_memory, __size * sizeof(T)); return h; }
 private:
+    void touched() { if (valid && __size) pr_invalidate(__gpu_memory, __size * sizeof(T)); }
     void fill(T init)
     {
         if (sizeof(T) == 4) { int32_t bits; std::memcpy(&bits, &init, 4); if (pr_fill_i32(reinterpret_cast<int32_t *>(__gpu_memory), __size, bits) != PR_OK) { std::cerr << pr_last_error() << std::endl; std::exit(1); } }
@@ -110,7 +121,7 @@ inline device_vector_holder<int> render_cuda_keep_in_gpu(device_vector_holder<Mo
                                                          size_t width, size_t height, const Model::mat4x4 &proj_mat, const Model::ROI roi = { 0, 0, 0, 0 })
 {
     device_vector_holder<int> out(poses.size() * detail::out_pixels(width, height, roi));
-    detail::must(pr_render(reinterpret_cast<const pr_triangle *>(tris.data()), tris.size(), reinterpret_cast<const pr_mat4 *>(poses.data()), poses.size(),
+    detail::must(pr_render(reinterpret_cast<const pr_triangle *>(tris.__gpu_memory), tris.size(), reinterpret_cast<const pr_mat4 *>(poses.data()), poses.size(),
                            width, height, reinterpret_cast<const pr_mat4 *>(&proj_mat), detail::roi(roi), out.data()));
     return out;
 }
@@ -124,7 +135,7 @@ inline std::vector<int32_t> render_cuda(device_vector_holder<Model::Triangle> &t
                                         size_t width, size_t height, const Model::mat4x4 &proj_mat, const Model::ROI roi = { 0, 0, 0, 0 })
 {
     std::vector<int32_t> out(poses.size() * detail::out_pixels(width, height, roi));
-    detail::must(pr_render_to_host(reinterpret_cast<const pr_triangle *>(tris.data()), tris.size(), reinterpret_cast<const pr_mat4 *>(poses.data()), poses.size(),
+    detail::must(pr_render_to_host(reinterpret_cast<const pr_triangle *>(tris.__gpu_memory), tris.size(), reinterpret_cast<const pr_mat4 *>(poses.data()), poses.size(),
                                    width, height, reinterpret_cast<const pr_mat4 *>(&proj_mat), detail::roi(roi), out.data()));
     return out;
 }

@@ -26,10 +26,12 @@ class Mat {
 public:
     int rows = 0, cols = 0;
     unsigned char *data = nullptr;
+    size_t step = 0;                                               // bytes per row (always dense here; cv::Mat::step converts to size_t the same way)
     Mat() {}
-    Mat(int r, int c, int type) : rows(r), cols(c), type_(type), own_(new std::vector<unsigned char>((size_t)r * c * elem(type), 0))
+    Mat(int r, int c, int type) : rows(r), cols(c), step((size_t)c * elem(type)), type_(type), own_(new std::vector<unsigned char>((size_t)r * c * elem(type), 0))
     { data = own_->data(); }
-    Mat(int r, int c, int type, void *ext) : rows(r), cols(c), data(static_cast<unsigned char *>(ext)), type_(type) {}
+    Mat(int r, int c, int type, void *ext) : rows(r), cols(c), data(static_cast<unsigned char *>(ext)), step((size_t)c * elem(type)), type_(type) {}
+    bool isContinuous() const { return true; }
     int type() const { return type_; }
     bool empty() const { return data == nullptr || rows == 0 || cols == 0; }
     size_t elemSize() const { return elem(type_); }

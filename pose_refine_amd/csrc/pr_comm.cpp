@@ -131,7 +131,7 @@ int pr_gather_results(const pr_result *send_dev, uint32_t n_local, uint32_t n_to
     if ((n_local && !send_dev) || (rank == root && n_total && !recv_dev)) { set_error("pr_gather_results: null buffer"); return PR_ERR_INVALID; }
     if (!g->comm) {                                               // no communicator: a single-rank job gathers by copying
         if (n_local && recv_dev != send_dev) HIP_TRY(hipMemcpyAsync(recv_dev, send_dev, sizeof(pr_result) * n_local, hipMemcpyDeviceToDevice, g->stream));
-        if (n_local) g_writes.note(recv_dev, sizeof(pr_result) * n_local);
+        if (n_local) note_write(recv_dev, sizeof(pr_result) * n_local);
         return PR_OK;
     }
     std::pair<hipEvent_t, hipEvent_t> *ev = nullptr;                // option "profile": the exchange's own time on the stream it runs on
@@ -148,7 +148,7 @@ int pr_gather_results(const pr_result *send_dev, uint32_t n_local, uint32_t n_to
             pr_shard_range(n_total, (uint32_t)r, (uint32_t)world, &f, &c);
             if (c) NCCL_TRY(g_rccl.Recv(recv_dev + f, (size_t)c * sizeof(pr_result), ncclChar, r, g->comm, g->stream));
         }
-        g_writes.note(recv_dev, sizeof(pr_result) * n_total);
+        note_write(recv_dev, sizeof(pr_result) * n_total);
     }
     NCCL_TRY(g_rccl.GroupEnd());
     if (ev) HIP_TRY(hipEventRecord(ev->second, g->stream));

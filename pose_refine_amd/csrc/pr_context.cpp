@@ -176,24 +176,32 @@ int pr_free(void *dev_ptr)
     // capture -- and its streams are waited for, one context at a time.  (hipDeviceSynchronize would do it in one call, but it breaks
     // a graph capture another thread has open.)
     {
-        std::vector<Ctx *> others;
-        { std::lock_guard<std::mutex> lk(g_reg_mu); for (Ctx *c : g_shared) if (c && c != self && c->device == self->device) others.push_back(c); }
-        const size_t n_shared = others.size();
-        {   // private contexts: pinned under the list's mutex, drained without it (pr_runtime.h "context registry")
-            std::lock_guard<std::mutex> plk(g_private_mu);
-            for (Ctx *c : g_private) if (c != self && c->device == self->device) { c->pins.fetch_add(1, std::memory_order_acq_rel); others.push_back(c); }
-        }
-        for (size_t i = 0; i < others.size(); ++i) {
-            Ctx *c = others[i];
+        auto drain_locked = [](Ctx *c) {
+            std::lock_guard<std::mutex> lk(c->mu);
+            if (!c->ready) return;
+            if (c->stream) (void)hipStreamSynchronize(c->stream);
+            for (hipStream_t sd : c->side) if (sd) (void)hipStreamSynchronize(sd);
+            for (Slot &sl : c->slots) slot_drain(sl);
+        };
+        std::vector<Ctx *> shared;
+        { std::lock_guard<std::mutex> lk(g_reg_mu); for (Ctx *c : g_shared) if (c && c != self && c->device == self->device) shared.push_back(c); }
+        for (Ctx *c : shared) drain_locked(c);                       // (shared contexts are never deleted)
+        // private contexts: pinned ONE AT A TIME, just before its mutex is taken, and unpinned before the next is looked at -- this thread never
+        // holds a pin on one context while it blocks on another's mutex (with all of them pinned up front, a thread tearing its
+        // context down joins a slot's helper thread, whose exit spins until ITS context is unpinned, while this thread waits for the first one's
+        // mutex: a three-way wait).  A context is unregistered before it is torn down, so one that is found here is alive until the pin goes.
+        std::vector<Ctx *> seen;
+        for (;;) {
+            Ctx *c = nullptr;
             {
-                std::lock_guard<std::mutex> lk(c->mu);
-                if (c->ready) {
-                    if (c->stream) (void)hipStreamSynchronize(c->stream);
-                    for (hipStream_t sd : c->side) if (sd) (void)hipStreamSynchronize(sd);
-                    for (Slot &sl : c->slots) slot_drain(sl);
-                }
+                std::lock_guard<std::mutex> plk(g_private_mu);
+                for (Ctx *p : g_private)
+                    if (p != self && p->device == self->device && std::find(seen.begin(), seen.end(), p) == seen.end()) { c = p; c->pins.fetch_add(1, std::memory_order_acq_rel); break; }
             }
-            if (i >= n_shared) c->pins.fetch_sub(1, std::memory_order_acq_rel);
+            if (!c) break;
+            seen.push_back(c);
+            drain_locked(c);
+            c->pins.fetch_sub(1, std::memory_order_acq_rel);
         }
     }
     HIP_TRY(hipFree(dev_ptr));
@@ -205,7 +213,7 @@ static int copy_sync(void *dst, const void *src, size_t bytes, hipMemcpyKind kin
     PR_ENTER();
     if (bytes == 0) return PR_OK;
     if (kind != hipMemcpyDeviceToHost) {
-        g_writes.note(dst, bytes);
+        note_write(dst, bytes);
         if (g->mesh_key && reinterpret_cast<uintptr_t>(dst) < reinterpret_cast<uintptr_t>(g->mesh_key) + g->mesh_n * sizeof(pr_triangle) &&
             reinterpret_cast<uintptr_t>(g->mesh_key) < reinterpret_cast<uintptr_t>(dst) + bytes) { g->mesh_key = nullptr; g->aabb_host_valid = false; }
     }
@@ -224,7 +232,7 @@ int pr_fill_i32(int32_t *dev_dst, size_t count, int32_t value)
 {
     PR_ENTER();
     if (!dev_dst && count) { set_error("pr_fill_i32: null destination"); return PR_ERR_INVALID; }
-    g_writes.note(dev_dst, count * sizeof(int32_t));
+    note_write(dev_dst, count * sizeof(int32_t));
     HIP_TRY(prk::launch_fill_i32(dev_dst, count, value, g->stream));
     HIP_TRY(hipStreamSynchronize(g->stream));
     return PR_OK;

@@ -372,7 +372,7 @@ int pr_debug_contrib29(pr_vec3 *cloud_dev, uint32_t n_points, int scene_kind, co
     else e = prk::launch_contrib29_proj_aos(cloud_dev, n_points, update16, sc.aos, out.as<float>(), g->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(contrib_host, out.p, sizeof(float) * 29 * (size_t)n_points, hipMemcpyDeviceToHost, g->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
-    g_writes.note(cloud_dev, sizeof(pr_vec3) * (size_t)n_points);
+    note_write(cloud_dev, sizeof(pr_vec3) * (size_t)n_points);
     out.release();
     if (e != hipSuccess) { (void)hipGetLastError(); set_error("pr_debug_contrib29: %s", hipGetErrorString(e)); return PR_ERR_HIP; }
     return PR_OK;

@@ -226,6 +226,7 @@ hipError_t launch_raw2depth_mask(const int32_t *raw, size_t n, uint16_t *depth16
 // sampled hash of up to three arrays (null = absent): check = false stores it in *expected, check = true sets *flag = 1 if it differs
 hipError_t launch_scene_fingerprint(const void *a, size_t a_bytes, const void *b, size_t b_bytes, const void *c, size_t c_bytes,
                                     uint32_t *expected, uint32_t *flag, bool check, hipStream_t s);
+hipError_t launch_scene_fingerprint_full(const void *a, size_t a_bytes, const void *b, size_t b_bytes, const void *c, size_t c_bytes, uint32_t *sum, hipStream_t s);
 hipError_t launch_pack_proj_scene(const pr_vec3 *pcd, const pr_vec3 *normal, float4 *rec, size_t n, float *colf, float *rowf,
                                   uint32_t width, uint32_t height, float fx, float fy, float cx, float cy, uint32_t tl_x, uint32_t tl_y,
                                   uint32_t *exact, hipStream_t s);

@@ -202,6 +202,25 @@ void drain_all_slots()
 {
     for (Slot &o : g->slots) if (o.pending && !o.delivered) slot_drain(o);
 }
+void drain_slots_reading(const void *p, size_t bytes)
+{
+    if (!p || bytes == 0) return;
+    const uintptr_t lo = reinterpret_cast<uintptr_t>(p), hi = lo + bytes;
+    auto hit = [&](const void *a, size_t ab) { const uintptr_t s = reinterpret_cast<uintptr_t>(a); return a && ab && s < hi && lo < s + ab; };
+    for (Slot &sl : g->slots) {
+        if (!sl.pending || sl.delivered) continue;
+        const Resubmit &r = (sl.worker_job && sl.worker) ? sl.worker->in : sl.again;     // (a helper thread's job is posted and read under g->mu by this thread only)
+        bool reads = hit(r.tris, r.n_tris * sizeof(pr_triangle)) || hit(r.results_dev, (size_t)sl.P * sizeof(pr_result));
+        if (r.scene_kind == PR_SCENE_NN)
+            reads = reads || hit(r.sn.pcd, (size_t)r.sn.n_points * sizeof(pr_vec3)) || hit(r.sn.normal, (size_t)r.sn.n_points * sizeof(pr_vec3)) ||
+                    hit(r.sn.nodes, (size_t)r.sn.n_nodes * sizeof(pr_kdnode));
+        else {
+            const size_t n = (size_t)r.sp.view.width * r.sp.view.height;
+            reads = reads || hit(r.sp.view.pcd, n * sizeof(pr_vec3)) || hit(r.sp.view.normal, n * sizeof(pr_vec3));
+        }
+        if (reads) slot_drain(sl);
+    }
+}
 void slot_release(Slot &sl)
 {
     slot_drain(sl);
@@ -734,7 +753,7 @@ int pr_render(const pr_triangle *tris_dev, size_t n_tris, const pr_mat4 *poses_h
               const pr_mat4 *proj, pr_roi roi, int32_t *depth_dev_out)
 {
     PR_ENTER();
-    if (depth_dev_out) g_writes.note(depth_dev_out, sizeof(int32_t) * n_poses * ((roi.width > 0 && roi.height > 0) ? (size_t)roi.width * roi.height : width * height));
+    if (depth_dev_out) note_write(depth_dev_out, sizeof(int32_t) * n_poses * ((roi.width > 0 && roi.height > 0) ? (size_t)roi.width * roi.height : width * height));
     PR_TRY(render_impl(tris_dev, n_tris, poses_host, n_poses, width, height, proj, roi, depth_dev_out, true));
     HIP_TRY(hipStreamSynchronize(g->stream));            // renderer.cu:295 cudaDeviceSynchronize
     drain_spans();

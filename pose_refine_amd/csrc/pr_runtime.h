@@ -428,6 +428,11 @@ int ensure_stream(hipStream_t &st, hipEvent_t *ev = nullptr);
 int icp_drive(pr_vec3 *cloud_base, const uint32_t *start_h, const uint32_t *count_h, uint32_t P, const SceneSel &sc_in,
               pr_criteria crit, pr_result *results_host, pr_result *results_dev);
 void drain_all_slots();
+// a write through the library into caller-owned device memory: logged for the caches (WriteLog) and ordered BEHIND every batch of this context that is still
+// in flight and reads the range as part of its scene, mesh or result block (a scene object re-initialised per frame keeps its arrays, so the
+// next frame's preparation would otherwise overwrite them under the previous frame's batch).  Call with g->mu held.
+void drain_slots_reading(const void *p, size_t bytes);
+inline void note_write(const void *p, size_t bytes) { g_writes.note(p, bytes); drain_slots_reading(p, bytes); }
 void slot_release(Slot &sl);
 void slot_drain(Slot &sl);
 void comm_teardown(Ctx *c);

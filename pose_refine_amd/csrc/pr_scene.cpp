@@ -6,16 +6,18 @@ namespace prr {
 // Packed copy of a projective scene in `pc`: reused while the caller's arrays are unchanged as far as the library can tell
 // (option scene_cache, WriteLog above), rebuilt otherwise.  A rebuild also learns (one 4-byte read-back) whether the pcd array
 // is exactly what dep2pcd produces -- only then may the packed form stand in for it.
-// Synchronous callers (pr_icp_*, the synchronous fused path) check a cache hit on the spot: the sampled fingerprint of the source arrays
-// against the one stored with the cache (`slot[0]`), `slot[1]` receives the verdict.  ~15 us; the asynchronous path checks on its idle stream.
+// Synchronous callers (pr_icp_*, the synchronous fused path -- everything the C++ adapters of the reference's API reach) check a cache hit on the
+// spot, and since round 6 against a fingerprint of EVERY word of the source arrays (`slot[2]`, taken when the cache was built; `slot[3]` is this
+// call's): the reference reads the caller's arrays at every call (depth_scene.h:29-48), so an in-place edit through a pointer the adapters handed
+// out must be seen even when nobody announced it.  ~20 us per call; the asynchronous path compares the 4096-word SAMPLE
+// (`slot[0]`, verdict in `slot[1]`) inside its raster launch and documents pr_invalidate for edits the sample cannot see.
 int fingerprint_differs(const void *a, size_t ab, const void *b, size_t bb, const void *c, size_t cb, uint32_t *slot, hipStream_t st, bool &differs)
 {
-    HIP_TRY(hipMemsetAsync(slot + 1, 0, sizeof(uint32_t), st));
-    HIP_TRY(prk::launch_scene_fingerprint(a, ab, b, bb, c, cb, slot, slot + 1, true, st));
-    uint32_t flag = 0;
-    HIP_TRY(hipMemcpyAsync(&flag, slot + 1, sizeof flag, hipMemcpyDeviceToHost, st));
+    HIP_TRY(prk::launch_scene_fingerprint_full(a, ab, b, bb, c, cb, slot + 3, st));
+    uint32_t v[2] = { 0, 1 };
+    HIP_TRY(hipMemcpyAsync(v, slot + 2, sizeof v, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    differs = flag != 0u;
+    differs = v[0] != v[1];
     return PR_OK;
 }
 int ensure_packed(PackedCache &pc, const pr_scene_proj &s, uint32_t tl_x, uint32_t tl_y, hipStream_t st, bool verify_now)
@@ -44,6 +46,7 @@ int ensure_packed(PackedCache &pc, const pr_scene_proj &s, uint32_t tl_x, uint32
     HIP_TRY(prk::launch_pack_proj_scene(s.pcd, s.normal, pc.rec.as<float4>(), n, colf, rowf, (uint32_t)s.width, (uint32_t)s.height,
                                         k[0], k[1], k[2], k[3], tl_x, tl_y, exact_dev, st));
     HIP_TRY(prk::launch_scene_fingerprint(s.pcd, n * sizeof(pr_vec3), s.normal, n * sizeof(pr_vec3), nullptr, 0, exact_dev + 1, nullptr, false, st));
+    HIP_TRY(prk::launch_scene_fingerprint_full(s.pcd, n * sizeof(pr_vec3), s.normal, n * sizeof(pr_vec3), nullptr, 0, exact_dev + 3, st));
     uint32_t exact = 0;
     HIP_TRY(hipMemcpyAsync(&exact, exact_dev, sizeof exact, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -125,7 +128,7 @@ int make_scene(int kind, const void *scene, bool want_packed, SceneSel &out, Pac
             PR_TRY(nc.bmax.ensure((size_t)s->n_nodes * sizeof(float4)));
             PR_TRY(nc.pts.ensure(((size_t)s->n_points + 16u) * sizeof(float4)));   // + 16: a leaf task of the walk reads its ten slots whatever the leaf holds (nn_tree_wide_kernel)
             PR_TRY(nc.nnrec.ensure((size_t)s->n_nodes * 4 * sizeof(float4)));
-            PR_TRY(nc.nndepth.ensure(24 * sizeof(uint32_t)));      // [0] depth [1] rec32 valid [2..7] rec32 frame [8] wide valid [9] wide nodes [12] fingerprint [16..19] wide frame
+            PR_TRY(nc.nndepth.ensure(24 * sizeof(uint32_t)));      // [0] depth [1] rec32 valid [2..7] rec32 frame [8] wide valid [9] wide nodes [12] sampled fingerprint [13] its verdict [14] full fingerprint [15] a call's full fingerprint [16..19] wide frame
             PR_TRY(nc.nnrec32.ensure((size_t)s->n_nodes * 2 * sizeof(uint4)));
             PR_TRY(nc.nndesc.ensure((size_t)s->n_nodes * sizeof(uint2)));
             // wide records: one 128-byte line per wide node
@@ -136,6 +139,8 @@ int make_scene(int kind, const void *scene, bool want_packed, SceneSel &out, Pac
                                                nc.nndesc.as<uint2>(), nc.nndepth.as<uint32_t>(), g->stream, s->max_dist_diff * 1.01f));
             HIP_TRY(prk::launch_scene_fingerprint(s->pcd, (size_t)s->n_points * sizeof(pr_vec3), s->nodes, (size_t)s->n_nodes * sizeof(pr_kdnode), s->normal,
                                                   (size_t)s->n_points * sizeof(pr_vec3), nc.nndepth.as<uint32_t>() + 12, nullptr, false, g->stream));
+            HIP_TRY(prk::launch_scene_fingerprint_full(s->pcd, (size_t)s->n_points * sizeof(pr_vec3), s->nodes, (size_t)s->n_nodes * sizeof(pr_kdnode), s->normal,
+                                                       (size_t)s->n_points * sizeof(pr_vec3), nc.nndepth.as<uint32_t>() + 14, g->stream));
             // the wide records, eight levels per synchronisation (8^8 wide nodes: deeper only for a lopsided tree)
             for (uint32_t level = 0; ; level += 8) {
                 HIP_TRY(prk::launch_nn_wide_levels(nc.topo.as<int4>(), nc.bmin.as<float4>(), nc.bmax.as<float4>(), s->n_nodes, s->n_points, nc.nnwide.as<uint4>(),
@@ -268,7 +273,7 @@ int pr_scene_proj_prepare_dev(const void *depth_dev, int depth_is_i32, const flo
 {
     PR_ENTER();
     if (!depth_dev || !K || !pcd_dev_out || !normal_dev_out || width == 0 || height == 0) { set_error("pr_scene_proj_prepare_dev: bad arguments"); return PR_ERR_INVALID; }
-    g_writes.note(pcd_dev_out, width * height * sizeof(pr_vec3)); g_writes.note(normal_dev_out, width * height * sizeof(pr_vec3));
+    note_write(pcd_dev_out, width * height * sizeof(pr_vec3)); note_write(normal_dev_out, width * height * sizeof(pr_vec3));
     if (depth_is_i32) HIP_TRY(prk::launch_scene_proj_prepare<int32_t>(static_cast<const int32_t *>(depth_dev), (uint32_t)width, (uint32_t)height, K[0], K[4], K[2], K[5], pcd_dev_out, normal_dev_out, g->stream));
     else HIP_TRY(prk::launch_scene_proj_prepare<uint16_t>(static_cast<const uint16_t *>(depth_dev), (uint32_t)width, (uint32_t)height, K[0], K[4], K[2], K[5], pcd_dev_out, normal_dev_out, g->stream));
     HIP_TRY(hipStreamSynchronize(g->stream));
@@ -279,7 +284,7 @@ int pr_kdtree_build_dev(pr_vec3 *pcd_dev, pr_vec3 *normal_dev, size_t n_points, 
 {
     PR_ENTER();
     if (!pcd_dev || !normal_dev || !nodes_dev_out) { set_error("pr_kdtree_build_dev: bad arguments"); return PR_ERR_INVALID; }
-    g_writes.note(pcd_dev, n_points * sizeof(pr_vec3)); g_writes.note(normal_dev, n_points * sizeof(pr_vec3)); g_writes.note(nodes_dev_out, cap_nodes * sizeof(pr_kdnode));
+    note_write(pcd_dev, n_points * sizeof(pr_vec3)); note_write(normal_dev, n_points * sizeof(pr_vec3)); note_write(nodes_dev_out, cap_nodes * sizeof(pr_kdnode));
     return kd_build_dev(pcd_dev, normal_dev, (uint32_t)n_points, max_leaf, nodes_dev_out, cap_nodes, n_nodes);
 }
 
@@ -289,7 +294,7 @@ int pr_scene_nn_prepare_dev(const void *depth_dev, int depth_is_i32, const float
 {
     PR_ENTER();
     if (!depth_dev || !K || !pcd_dev_out || !normal_dev_out || !nodes_dev_out || width <= 0 || height <= 0) { set_error("pr_scene_nn_prepare_dev: bad arguments"); return PR_ERR_INVALID; }
-    g_writes.note(pcd_dev_out, (size_t)width * height * sizeof(pr_vec3)); g_writes.note(normal_dev_out, (size_t)width * height * sizeof(pr_vec3)); g_writes.note(nodes_dev_out, cap_nodes * sizeof(pr_kdnode));
+    note_write(pcd_dev_out, (size_t)width * height * sizeof(pr_vec3)); note_write(normal_dev_out, (size_t)width * height * sizeof(pr_vec3)); note_write(nodes_dev_out, cap_nodes * sizeof(pr_kdnode));
     if (depth_is_i32) return scene_nn_prepare_dev_t<int32_t>(static_cast<const int32_t *>(depth_dev), K, (uint32_t)width, (uint32_t)height, max_leaf,
                                                              pcd_dev_out, normal_dev_out, nodes_dev_out, cap_nodes, n_points, n_nodes);
     return scene_nn_prepare_dev_t<uint16_t>(static_cast<const uint16_t *>(depth_dev), K, (uint32_t)width, (uint32_t)height, max_leaf,
@@ -319,7 +324,7 @@ int pr_scene_proj_crop_dev(const pr_vec3 *pcd_full_dev, const pr_vec3 *normal_fu
     if (!pcd_full_dev || !normal_full_dev || !pcd_out_dev || !normal_out_dev || window.width <= 0 || window.height <= 0 || window.x < 0 || window.y < 0 ||
         (size_t)window.x + (size_t)window.width > width || (size_t)window.y + (size_t)window.height > height) { set_error("pr_scene_proj_crop_dev: bad arguments"); return PR_ERR_INVALID; }
     const size_t cw = (size_t)window.width, ch = (size_t)window.height;
-    g_writes.note(pcd_out_dev, cw * ch * sizeof(pr_vec3)); g_writes.note(normal_out_dev, cw * ch * sizeof(pr_vec3));
+    note_write(pcd_out_dev, cw * ch * sizeof(pr_vec3)); note_write(normal_out_dev, cw * ch * sizeof(pr_vec3));
     const size_t off = (size_t)window.y * width + (size_t)window.x;
     HIP_TRY(hipMemcpy2DAsync(pcd_out_dev, cw * sizeof(pr_vec3), pcd_full_dev + off, width * sizeof(pr_vec3), cw * sizeof(pr_vec3), ch, hipMemcpyDeviceToDevice, g->stream));
     HIP_TRY(hipMemcpy2DAsync(normal_out_dev, cw * sizeof(pr_vec3), normal_full_dev + off, width * sizeof(pr_vec3), cw * sizeof(pr_vec3), ch, hipMemcpyDeviceToDevice, g->stream));

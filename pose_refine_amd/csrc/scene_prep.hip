@@ -165,6 +165,41 @@ hipError_t launch_scene_fingerprint(const void *a, size_t a_bytes, const void *b
     return hipGetLastError();
 }
 
+// The same hash over EVERY word of the arrays (order-free sum over workgroups, atomicAdd into *sum, which the caller zeroes): what the
+// synchronous entry points -- the ones the C++ adapters of the reference's API call -- compare on a cache hit, so that an in-place edit of
+// any word of a scene array is seen although the caller never announced it (the reference reads the arrays at every call,
+// depth_scene.h:29-48).  7.4 MB of a 640 x 480 projective scene: ~5 us.
+__global__ __launch_bounds__(256) void scene_fingerprint_full_kernel(const uint32_t *__restrict__ a, unsigned long long na, const uint32_t *__restrict__ b,
+                                                                     unsigned long long nb, const uint32_t *__restrict__ c, unsigned long long nc,
+                                                                     uint32_t *__restrict__ sum)
+{
+    __shared__ uint32_t part[4];
+    const uint32_t *arr[3] = { a, b, c };
+    const unsigned long long len[3] = { na, nb, nc };
+    uint32_t h = 0;
+    const unsigned long long stride = (unsigned long long)gridDim.x * 256ull;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (!arr[k]) continue;
+        for (unsigned long long i = (unsigned long long)blockIdx.x * 256ull + threadIdx.x; i < len[k]; i += stride)
+            h += (arr[k][i] ^ (uint32_t)i) * 2654435761u + (uint32_t)k + (uint32_t)(i >> 32);
+    }
+    for (int off = 32; off > 0; off >>= 1) h += __shfl_xor(h, off);
+    if ((threadIdx.x & 63u) == 0u) part[threadIdx.x >> 6] = h;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(sum, part[0] + part[1] + part[2] + part[3]);
+}
+hipError_t launch_scene_fingerprint_full(const void *a, size_t a_bytes, const void *b, size_t b_bytes, const void *c, size_t c_bytes, uint32_t *sum, hipStream_t s)
+{
+    const size_t words = a_bytes / 4 + b_bytes / 4 + c_bytes / 4;
+    const uint32_t grid = (uint32_t)std::max<size_t>(1, std::min<size_t>(1024, (words + 256 * 16 - 1) / (256 * 16)));
+    hipError_t e = hipMemsetAsync(sum, 0, sizeof(uint32_t), s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(scene_fingerprint_full_kernel, dim3(grid), dim3(256), 0, s, static_cast<const uint32_t *>(a), (unsigned long long)(a_bytes / 4),
+                       static_cast<const uint32_t *>(b), (unsigned long long)(b_bytes / 4), static_cast<const uint32_t *>(c), (unsigned long long)(c_bytes / 4), sum);
+    return hipGetLastError();
+}
+
 template <typename T>
 hipError_t launch_nn_gather(const T *depth, uint32_t W, uint32_t H, float fx, float fy, float cx, float cy, const pr_vec3 *normal_full,
                             uint32_t *row_count, uint32_t *row_off, uint32_t *count, pr_vec3 *pcd, pr_vec3 *nrm, bool emit, hipStream_t s)

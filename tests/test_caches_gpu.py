@@ -172,3 +172,85 @@ def test_kdtree_scenes_that_change_every_frame_keep_both_slots_running(gpu, mode
     res, _ = api.refine_wait(1)
     assert res.tobytes() == want[7 % 3][0].tobytes()
     assert api.stats()[0] == repeated_before                        # (no batch had to be run again by the stale-cache safety net)
+
+
+@pytest.mark.device_solve
+@pytest.mark.parametrize("kind", ["proj", "nn"])
+def test_one_scene_object_reinitialised_under_its_own_batch_in_flight(gpu, model, scenario, kind):
+    """a scene object keeps its arrays across re-initialisation, so `submit k; init scene k+1 on the SAME object; wait k` has the
+    preparation of frame k+1 write the arrays batch k is still reading.  The library orders such a write behind the batches of the context that
+    read the range (drain_slots_reading, pr_runtime.h) -- the reference reads the caller's arrays at every call (depth_scene.h:29-48) and its
+    uploads are synchronous, so a caller written against it may do exactly this.  Every frame's records equal the synchronous call's."""
+    K, proj = scenario["K"], scenario["proj"]
+    poses = synth.hypotheses(64)
+    crit = api.ICPConvergenceCriteria(0.0, 0.0, 8)
+    base = scenario["depth"][1].astype(np.int32)
+    depths = []
+    for i in range(3):
+        d = base.copy()
+        d[d > 0] += 4 * i
+        d[(30 * i) % H::9, ::4] = 0
+        depths.append(d)
+    devs = [api.DeviceVector.from_host(d.reshape(-1)) for d in depths]
+    make = (lambda s, dv: s.init_Scene_projective_device(dv, K, W, H)) if kind == "proj" else (lambda s, dv: s.init_Scene_nn_device(dv, K, W, H))
+    want = [api.refine_batch(model, poses, W, H, proj, K, make(api.Scene_projective() if kind == "proj" else api.Scene_nn(), dv), crit) for dv in devs]
+    assert want[0][0].tobytes() != want[1][0].tobytes() != want[2][0].tobytes()
+    one = api.Scene_projective() if kind == "proj" else api.Scene_nn()
+    make(one, devs[0])
+    for k in range(7):
+        api.refine_submit(k & 1, model, poses, W, H, proj, K, one, crit)
+        make(one, devs[(k + 1) % 3])                                 # the next frame's scene into the SAME arrays, batch k in flight
+        if k:
+            res, sizes = api.refine_wait((k - 1) & 1)
+            assert res.tobytes() == want[(k - 1) % 3][0].tobytes() and np.array_equal(sizes, want[(k - 1) % 3][1]), k
+    res, _ = api.refine_wait(0)
+    assert res.tobytes() == want[6 % 3][0].tobytes()
+
+
+def sampled_words(n_words):
+    """The word positions fingerprint_lane (csrc/pr_device.h) looks at in an array of n_words 32-bit words: one per stripe of n / 4096."""
+    stripe = n_words // 4096
+    assert stripe > 0
+    s = np.arange(4096, dtype=np.uint64)
+    h = (s * np.uint64(2654435761) + np.uint64(0x9E3779B9)) & np.uint64(0xFFFFFFFF)
+    return (s * np.uint64(stripe) + ((h * np.uint64(stripe)) >> np.uint64(32))).astype(np.int64)
+
+
+@pytest.mark.parametrize("solve", [api.SOLVE_HOST, api.SOLVE_DEVICE])
+def test_in_place_edit_that_the_sampled_fingerprint_cannot_see_is_noticed_by_a_synchronous_call(gpu, model, scenario, solve):
+    """the reference reads the caller's scene arrays at every call (depth_scene.h:29-48), and its device_vector_holder hands out
+    raw mutable pointers.  Here a scene's arrays are rewritten in place through raw copies (no pr_invalidate) with another frame's content in EVERY
+    word EXCEPT the 4096 the sampled fingerprint reads (those keep the old frame's values): the synchronous entry points -- what the C++ adapters
+    call -- compare a fingerprint of every word and must answer like the oracle on the edited arrays.  (The edited pcd is no longer what dep2pcd
+    produces for its depth, so this is also the route on which the caller's arrays are used as they are.)"""
+    K = scenario["K"]
+    api.set_option("solve", solve)
+    try:
+        a = api.Scene_projective().init_Scene_projective_cuda(scenario["depth"][1], K)
+        oa, ob = O.ProjScene(scenario["depth"][1], K), O.ProjScene(scenario["depth"][0], K)
+        cloud = scenario["cloud"]
+        crit = (0.0, 0.0, 8)
+        run = lambda: api.ICP_Point2Plane(api.DeviceVector.from_host(cloud.reshape(-1)), a, api.ICPConvergenceCriteria(*crit))
+        first = run()                                                  # builds the packed copy + both fingerprints
+        ref_a, _, _, _ = O.icp(cloud, oa, crit, O.SUM_CANONICAL, api.get_option("points_per_block"))
+        assert first.fitness_ == float(ref_a["fitness"])
+        keep = sampled_words(W * H * 3)
+        for arr_b, arr_a, dev in ((ob.pcd, oa.pcd, a.pcd_buffer), (ob.normal, oa.normal, a.normal_buffer)):
+            mixed = arr_b.reshape(-1).copy().view(np.uint32)
+            mixed[keep] = arr_a.reshape(-1).view(np.uint32)[keep]
+            raw_h2d(dev.data(), mixed)                                 # behind the library's back
+            arr_b.reshape(-1).view(np.uint32)[:] = mixed               # the oracle's scene `ob` now holds exactly the edited arrays
+        got = run()
+        ref, _, _, _ = O.icp(cloud, ob, crit, O.SUM_CANONICAL, api.get_option("points_per_block"))
+        assert float(ref["fitness"]) != float(ref_a["fitness"])
+        assert got.fitness_ == float(ref["fitness"])
+        assert got.inlier_rmse_ == pytest.approx(float(ref["inlier_rmse"]), rel=1e-6)
+        assert np.allclose(got.transformation_, ref["T"].reshape(4, 4), rtol=0, atol=TOL_T)
+        # the fused synchronous call as well
+        poses = synth.hypotheses(12)
+        res, sizes = api.refine_batch(model, poses, W, H, scenario["proj"], K, a, api.ICPConvergenceCriteria(0.0, 0.0, 4))
+        ores, osizes, _ = O.refine_batch(scenario["tris"], poses, W, H, O.compute_proj(K, W, H), K, ob, (0.0, 0.0, 4), O.SUM_CANONICAL, api.get_option("points_per_block"))
+        assert np.array_equal(sizes, osizes) and np.array_equal(res["fitness"], ores["fitness"])
+        assert np.allclose(res["T"], ores["T"], rtol=0, atol=TOL_T)
+    finally:
+        api.set_option("solve", api.SOLVE_HOST)
