@@ -554,14 +554,15 @@ def _slots() -> dict:
 
 def refine_submit(slot: int, tris, poses, width: int, height: int, proj, K, scene,
                   criteria: ICPConvergenceCriteria = ICPConvergenceCriteria(), results_dev: Optional[int] = None,
-                  roi: Sequence[int] = (0, 0, 0, 0)):
+                  roi: Sequence[int] = (0, 0, 0, 0), also_host: bool = False):
     """Asynchronous ``refine_batch``: enqueue the batch on ``slot`` (0 or 1) and return at once; ``refine_wait(slot)``
-    delivers what ``refine_batch`` returns.  With two slots, batch k+1 is enqueued while batch k runs."""
+    delivers what ``refine_batch`` returns.  With two slots, batch k+1 is enqueued while batch k runs.  ``results_dev``: the records go to
+    that device block (a sharded job's gather reads them there); ``also_host``: and to the host as well, like the reference's by-value return."""
     td = _tris_dev(tris)
     poses = _f32(poses, (-1, 16))
     pj, k = _f32(proj, -1), _f32(K, -1)
     sizes = np.zeros(len(poses), np.uint32)
-    res = np.zeros(len(poses), RESULT) if results_dev is None else None
+    res = np.zeros(len(poses), RESULT) if (results_dev is None or also_host) else None
     d = scene.desc()
     check(_lib.load().pr_refine_submit_roi(int(slot), td.data(), td.size() // 9, ptr(poses), len(poses), width, height, ptr(pj), ptr(k),
                                            scene.kind, C.addressof(d), criteria.c(), Roi(*roi), ptr(res) if res is not None else None,

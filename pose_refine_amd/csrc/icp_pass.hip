@@ -67,43 +67,7 @@ __global__ __launch_bounds__(256, PR_PASS_WAVES) void icp_pass_kernel(IcpBatch b
             vb_accumulate<Scene, kNN, kStack>(acc, cl, n, vb * ppb, b.steps, xf, M, scene, lds_topo, stk_node, stk_lb, nn_prev, xf);
             t = vb_reduce(acc, wsum);
         }
-        float *slot = b.partial + ((size_t)pose * b.nblk + vb) * kAccStride;
-        if (!b.fused) {
-            if (threadIdx.x < 29) slot[threadIdx.x] = t;
-            continue;
-        }
-        // Fused finalize + solve: partial sums cross workgroups (and XCDs) through memory with system-scope accesses on both
-        // sides; wave 0 drains its stores before the arrival atomic that publishes them.  The workgroup that delivers the last
-        // partial sum of the pose (it cannot have another block left) adds the partials in block order (same sequence as
-        // icp_finalize_solve_kernel) and runs the iteration logic.  PoseMeta / DevIcpState are only read again by the next
-        // launch, so plain accesses suffice for them.
-        if (threadIdx.x >= 64) continue;
-        if (threadIdx.x < 29) st_sys_f32(slot + threadIdx.x, t);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        uint32_t ticket = 0;
-        if (threadIdx.x == 0) ticket = atomicAdd(&b.arrive[pose], 1u);
-        ticket = __builtin_amdgcn_readfirstlane(ticket);
-        if (ticket + 1u != used) continue;
-        if (threadIdx.x == 0) st_sys_u32(&b.arrive[pose], 0u);
-        if (b.fused == 2u) {                                     // solve on the host: the sums of the hypothesis, straight into host memory
-            if (threadIdx.x < 29) st_sys_f32(b.sums_out + (size_t)pose * kAccStride + threadIdx.x, sum_partials_sys(b.partial, pose, b.nblk, used, threadIdx.x));
-            return;
-        }
-        DevIcpState s = b.st[pose];                              // uniform; in flight together with the partial sums
-        float total = 0.0f;
-        if (threadIdx.x < 29) total = sum_partials_sys(b.partial, pose, b.nblk, used, threadIdx.x);
-        float E[16];
-        const bool finished = pose_iteration_wave(total, n, s, b.crit, b.iter, E);
-        if (threadIdx.x != 0) return;
-        PoseMeta *wm = const_cast<PoseMeta *>(b.meta) + pose;
-        if (finished) { s.done = 1; wm->state = kSkip; }
-        else {
-#pragma unroll
-            for (int i = 0; i < 12; ++i) wm->xform[i] = E[i];
-            wm->state = kRunWithTransform;
-        }
-        b.st[pose] = s;
-        return;
+        if (pass_deliver(b, pose, vb, used, n, t)) return;
     }
 }
 

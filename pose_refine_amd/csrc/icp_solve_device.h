@@ -195,4 +195,53 @@ __device__ __forceinline__ bool pose_iteration_wave(float total, uint32_t n, Dev
     return false;
 }
 
+// The tail of a correspondence pass (icp_pass_kernel, nn_late_pass_kernel): thread `c` < 29 of the workgroup holds sum `c` of virtual block `vb`.
+// Not fused: the partial sums go to memory and a second launch adds them.  Fused finalize + solve: partial sums cross workgroups (and XCDs)
+// through memory with system-scope accesses on both sides; wave 0 drains its stores before the arrival atomic that publishes them.  The
+// workgroup that delivers the last partial sum of the hypothesis (it cannot have another block left) adds the partials in block order (same
+// sequence as icp_finalize_solve_kernel) and runs the iteration logic.  PoseMeta / DevIcpState are only read again by the next launch, so
+// plain accesses suffice for them.  Returns true in the lanes that are done with the kernel.
+__device__ __forceinline__ bool pass_deliver(const IcpBatch &b, uint32_t pose, uint32_t vb, uint32_t used, uint32_t n, float t)
+{
+    float *slot = b.partial + ((size_t)pose * b.nblk + vb) * kAccStride;
+    if (!b.fused) {
+        if (threadIdx.x < 29) slot[threadIdx.x] = t;
+        return false;
+    }
+    if (threadIdx.x >= 64) return false;
+    if (threadIdx.x < 29) st_sys_f32(slot + threadIdx.x, t);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    uint32_t ticket = 0;
+    if (threadIdx.x == 0) ticket = atomicAdd(&b.arrive[pose], 1u);
+    ticket = __builtin_amdgcn_readfirstlane(ticket);
+    if (ticket + 1u != used) return false;
+    if (threadIdx.x == 0) st_sys_u32(&b.arrive[pose], 0u);
+    if (b.fused == 2u) {                                         // solve on the host: the sums of the hypothesis, straight into host memory
+        if (threadIdx.x < 29) st_sys_f32(b.sums_out + (size_t)pose * kAccStride + threadIdx.x, sum_partials_sys(b.partial, pose, b.nblk, used, threadIdx.x));
+        // ... and behind them the word the host polls (round 6): the iteration's tag in word 31 of the hypothesis' row.  Both are write-through stores at
+        // system scope; the wavefront waits until its 29 sum stores have been acknowledged before it issues the tag, so the tag cannot overtake them
+        // on the way to host memory -- and the host may solve the hypothesis the moment it sees the tag, while the pass is still running for others
+        // (pr_icp.cpp, PR_SOLVE_HOST).  (NOT a release store: at system scope that is a write-back of the whole L2 per hypothesis -- measured: 82 k
+        // instead of 234 k poses/s.)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (threadIdx.x == 0) st_sys_u32(reinterpret_cast<uint32_t *>(b.sums_out + (size_t)pose * kAccStride) + 31, b.iter + 1u);
+        return true;
+    }
+    DevIcpState s = b.st[pose];                                  // uniform; in flight together with the partial sums
+    float total = 0.0f;
+    if (threadIdx.x < 29) total = sum_partials_sys(b.partial, pose, b.nblk, used, threadIdx.x);
+    float E[16];
+    const bool finished = pose_iteration_wave(total, n, s, b.crit, b.iter, E);
+    if (threadIdx.x != 0) return true;
+    PoseMeta *wm = const_cast<PoseMeta *>(b.meta) + pose;
+    if (finished) { s.done = 1; wm->state = kSkip; }
+    else {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) wm->xform[i] = E[i];
+        wm->state = kRunWithTransform;
+    }
+    b.st[pose] = s;
+    return true;
+}
+
 }  // namespace prk

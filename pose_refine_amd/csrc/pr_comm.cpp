@@ -25,7 +25,15 @@ int rccl_load()
     std::lock_guard<std::mutex> lk(g_reg_mu);
     if (g_rccl.lib) return PR_OK;
     void *h = nullptr;
-    for (const char *name : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" }) { h = dlopen(name, RTLD_NOW | RTLD_LOCAL); if (h) break; }
+    // PR_RCCL_LIBRARY=<path>: bind the nine entry points from that library instead.  Test use: tests/rccl_loopback (ranks of ONE process matched
+    // through a table, bytes moved by hipMemcpyAsync) lets the N > 1 branch of pr_gather_results run on a box with one GPU, where RCCL itself
+    // refuses two ranks on a device.  A path that cannot be opened is an error, never a silent fall-back to the real library.
+    const char *forced = std::getenv("PR_RCCL_LIBRARY");
+    if (forced && *forced) {
+        h = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+        if (!h) { set_error("PR_RCCL_LIBRARY=%s cannot be opened (%s)", forced, dlerror()); return PR_ERR_COMM; }
+    }
+    else for (const char *name : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" }) { h = dlopen(name, RTLD_NOW | RTLD_LOCAL); if (h) break; }
     if (!h) { set_error("cannot open librccl (%s)", dlerror()); return PR_ERR_COMM; }
     Rccl r; r.lib = h;
 #define PR_SYM(field, name) r.field = reinterpret_cast<decltype(r.field)>(dlsym(h, name)); if (!r.field) { set_error("librccl lacks %s", name); dlclose(h); return PR_ERR_COMM; }

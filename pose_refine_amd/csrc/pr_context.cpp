@@ -261,6 +261,7 @@ int pr_set_option(const char *name, int value)
     else if (n == "nn_run") opt.nn_run = std::min(256, std::max(1, value));
     else if (n == "nn_grid") opt.nn_grid = value ? 1 : 0;
     else if (n == "nn_count") opt.nn_count = value ? 1 : 0;
+    else if (n == "host_poll") opt.host_poll = value ? 1 : 0;
     else if (n == "graph") opt.use_graph = value ? 1 : 0;
     else if (n == "fused_solve") opt.fused_solve = value ? 1 : 0;
     else if (n == "sub_batch") opt.sub_batch = std::min(32768, std::max(32, value));    // (the hypothesis index is the y dimension of the launches)
@@ -295,6 +296,7 @@ int pr_get_option(const char *name, int *value)
     else if (n == "nn_run") *value = opt.nn_run;
     else if (n == "nn_grid") *value = opt.nn_grid;
     else if (n == "nn_count") *value = opt.nn_count;
+    else if (n == "host_poll") *value = opt.host_poll;
     else if (n == "raster_mode") *value = opt.raster_mode;
     else if (n == "eager_streams") *value = opt.eager_streams;
     else if (n == "graph") *value = opt.use_graph;

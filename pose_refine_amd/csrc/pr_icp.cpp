@@ -249,30 +249,71 @@ int icp_drive(pr_vec3 *cloud_base, const uint32_t *start_h, const uint32_t *coun
         }
         return PR_OK;
     };
-    // the host's part of an iteration for one group (its download has completed); returns how many of its hypotheses go on
-    auto solve_group = [&](uint32_t grp, uint32_t it) -> uint32_t {
-        uint32_t active = 0;
-        for (uint32_t i = group_begin(grp); i < group_begin(grp + 1); ++i) {
-            if (h_meta[i].state == prk::kSkip) continue;
-            const float *Ab = h_sums + (size_t)i * prk::kAccStride;
-            pr_result &r = res[i];
-            const float prev_fit = r.fitness, prev_rmse = r.inlier_rmse;
-            const float cnt = Ab[28], err = Ab[27];
-            if (cnt == 0) { h_meta[i].state = prk::kSkip; continue; }                        // icp.cu:183
-            r.fitness = cnt / (float)count_h[i];                                          // icp.cu:185
-            r.inlier_rmse = std::sqrt(err / cnt);                                         // icp.cu:186
-            if (it == (uint32_t)crit.max_iteration) { h_meta[i].state = prk::kSkip; continue; }   // icp.cu:189
-            if (std::fabs(r.fitness - prev_fit) < crit.relative_fitness &&
-                std::fabs(r.inlier_rmse - prev_rmse) < crit.relative_rmse) { h_meta[i].state = prk::kSkip; continue; }   // icp.cu:191-194
-            float A[36], bb[6], E[16];
-            for (int k = 0; k < 6; ++k) bb[k] = Ab[21 + k];
-            int sh = 0;
-            for (int y = 0; y < 6; ++y) for (int x = y; x < 6; ++x) { A[x + y * 6] = Ab[sh]; A[y + x * 6] = Ab[sh]; ++sh; }   // icp.cu:196-205
-            prh::solve_666(A, bb, E);
-            std::memcpy(h_meta[i].xform, E, sizeof(float) * 12);
-            prh::mat4_mul(E, r.T, r.T);                                                   // icp.cu:212
-            h_meta[i].state = prk::kRunWithTransform;
-            ++active;
+    // the host's part of an iteration for one hypothesis whose 29 sums have arrived (icp.cu:178-212); returns whether the hypothesis goes on
+    auto solve_one = [&](uint32_t i, uint32_t it) -> bool {
+        const float *Ab = h_sums + (size_t)i * prk::kAccStride;
+        pr_result &r = res[i];
+        const float prev_fit = r.fitness, prev_rmse = r.inlier_rmse;
+        const float cnt = Ab[28], err = Ab[27];
+        if (cnt == 0) { h_meta[i].state = prk::kSkip; return false; }                         // icp.cu:183
+        r.fitness = cnt / (float)count_h[i];                                              // icp.cu:185
+        r.inlier_rmse = std::sqrt(err / cnt);                                             // icp.cu:186
+        if (it == (uint32_t)crit.max_iteration) { h_meta[i].state = prk::kSkip; return false; }    // icp.cu:189
+        if (std::fabs(r.fitness - prev_fit) < crit.relative_fitness &&
+            std::fabs(r.inlier_rmse - prev_rmse) < crit.relative_rmse) { h_meta[i].state = prk::kSkip; return false; }   // icp.cu:191-194
+        float A[36], bb[6], E[16];
+        for (int k = 0; k < 6; ++k) bb[k] = Ab[21 + k];
+        int sh = 0;
+        for (int y = 0; y < 6; ++y) for (int x = y; x < 6; ++x) { A[x + y * 6] = Ab[sh]; A[y + x * 6] = Ab[sh]; ++sh; }   // icp.cu:196-205
+        prh::solve_666(A, bb, E);
+        std::memcpy(h_meta[i].xform, E, sizeof(float) * 12);
+        prh::mat4_mul(E, r.T, r.T);                                                       // icp.cu:212
+        h_meta[i].state = prk::kRunWithTransform;
+        return true;
+    };
+    // Round 6: with the sums stored straight into pinned memory (host_fused) the host does not wait for the STREAM any more but
+    // for the HYPOTHESES: the workgroup that stores a hypothesis' 29 totals stores the iteration's tag behind them (word 31 of the row, release order at
+    // system scope), this thread polls the tags of the group and solves every hypothesis the moment its sums are there -- while the pass is still
+    // running for the others.  What stays on the critical path of an iteration is the solve of the LAST hypothesis to arrive and the next launch,
+    // not a stream wake-up (10-20 us) followed by 128 solves (20-30 us).  The stream is still queried now and then: an error must not turn the poll
+    // into an endless loop.  Option blocking_wait (several ranks sharing few CPUs) keeps the sleeping wait.
+    const bool poll_tags = host_fused && !opt.blocking_wait && opt.host_poll;
+    if (poll_tags) for (uint32_t i = 0; i < P; ++i) reinterpret_cast<volatile uint32_t *>(h_sums + (size_t)i * prk::kAccStride)[31] = 0u;
+    std::vector<uint32_t> waiting;
+    waiting.reserve(P);
+    // returns how many hypotheses of the group go on; < 0: a HIP error
+    auto finish_group = [&](uint32_t grp, uint32_t it) -> int {
+        int active = 0;
+        if (!poll_tags) {
+            if (hipError_t e = hipStreamSynchronize(group_stream(grp)); e != hipSuccess) { set_error("HIP error: %s", hipGetErrorString(e)); return -1; }
+            for (uint32_t i = group_begin(grp); i < group_begin(grp + 1); ++i) if (h_meta[i].state != prk::kSkip && solve_one(i, it)) ++active;
+            return active;
+        }
+        waiting.clear();
+        for (uint32_t i = group_begin(grp); i < group_begin(grp + 1); ++i) if (h_meta[i].state != prk::kSkip) waiting.push_back(i);
+        const uint32_t tag = it + 1u;
+        uint32_t idle = 0;
+        bool drained = false;
+        while (!waiting.empty()) {
+            size_t kept = 0;
+            for (size_t k = 0; k < waiting.size(); ++k) {
+                const uint32_t i = waiting[k];
+                if (reinterpret_cast<volatile uint32_t *>(h_sums + (size_t)i * prk::kAccStride)[31] == tag) {
+                    std::atomic_thread_fence(std::memory_order_acquire);
+                    if (solve_one(i, it)) ++active;
+                } else waiting[kept++] = i;
+            }
+            if (kept == waiting.size()) {
+                if (drained) { set_error("PR_SOLVE_HOST: the pass of iteration %u finished without delivering the sums of %zu hypotheses", it, kept); return -1; }
+                if (++idle >= 4096u) {                               // every few hundred microseconds of fruitless polling: is the stream still alive?
+                    idle = 0;
+                    const hipError_t q = hipStreamQuery(group_stream(grp));
+                    if (q == hipSuccess) drained = true;           // (one more sweep: the tags were stored before the kernel ended)
+                    else if (q != hipErrorNotReady) { (void)hipGetLastError(); set_error("HIP error: %s", hipGetErrorString(q)); return -1; }
+                }
+                __builtin_ia32_pause();
+            } else idle = 0;
+            waiting.resize(kept);
         }
         return active;
     };
@@ -285,12 +326,14 @@ int icp_drive(pr_vec3 *cloud_base, const uint32_t *start_h, const uint32_t *coun
     for (uint32_t it = 0; it <= (uint32_t)crit.max_iteration && rc_loop == PR_OK && (live[0] || live[1] || live[2] || live[3]); ++it) {
         for (uint32_t grp = 0; grp < n_groups && rc_loop == PR_OK; ++grp) {
             if (!live[grp]) continue;
-            if (hipError_t e = hipStreamSynchronize(group_stream(grp)); e != hipSuccess) { set_error("HIP error: %s", hipGetErrorString(e)); rc_loop = PR_ERR_HIP; break; }
-            live[grp] = solve_group(grp, it) > 0;
+            const int active = finish_group(grp, it);
+            if (active < 0) { rc_loop = PR_ERR_HIP; break; }
+            live[grp] = active > 0;
             if (live[grp]) rc_loop = enqueue_group(grp, it + 1);                          // it + 1 <= max_iteration: the last iteration leaves nobody active
         }
     }
     for (uint32_t k = 1; k < n_groups; ++k) (void)hipStreamSynchronize(g->side[k - 1]);  // nothing of this call is left on a side stream, error or not
+    if (poll_tags) (void)hipStreamSynchronize(g->stream);         // (the tags arrive before the last pass has formally ended: nothing of this call runs on after it returns)
     if (rc_loop != PR_OK) { (void)hipStreamSynchronize(g->stream); drain_spans(); return rc_loop; }
     if (results_host) std::memcpy(results_host, res, sizeof(pr_result) * P);
     if (results_dev) {

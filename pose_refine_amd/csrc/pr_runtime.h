@@ -137,6 +137,7 @@ struct Options {
     int nn_run = 8;                  // 256-point chunks a workgroup of the search kernel walks (1..8).  Since the window scans left that kernel (round 4) it is a light
                                      // streaming pass and fewer, longer workgroups are a little better: 38.9 k (2) against 39.3 k (8) poses/s over five runs each
     int nn_grid = 1;                 // fused path: pixel grid of the scene points (seeds + window search); 0 = tree only
+    int host_poll = 1;               // PR_SOLVE_HOST with the sums stored straight into pinned memory: 1 = the host polls per-hypothesis tags and solves each hypothesis as its sums arrive; 0 = it waits for the stream, then solves the group (rounds 2-5)
     int nn_count = 0;                // instrumented runs: the search kernel counts its work per pass (pr_nn_counters)
     int start_overlap = -1;          // asynchronous path, a batch submitted while the other slot is idle: the pass after which the next batch's render may start.
                                      // -1 = the per-batch rule of a running pipeline.  Rounds 2-3 released the next render at pass 0 here; with the roofline

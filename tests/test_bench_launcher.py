@@ -135,6 +135,20 @@ def test_bench_starts_eight_ranks_by_itself(launcher):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("extra, when, gathers", [([], "job", 1), (["--global-poses", "509"], "step", 6)])
+def test_bench_eight_rank_threads_gather_through_the_c_abi_over_the_loopback_library(extra, when, gathers):
+    """`bench.py --gpus 8 --launcher threads` with gather_mode = cabi on a one-GPU box -- the eight rank threads (private contexts
+    on device 0) form a communicator of the loop-back stand-in (PR_RCCL_LIBRARY, tests/rccl_loopback) and the job's gather runs through
+    pr_gather_results' N > 1 branch: even shards as the job's single exchange, uneven shards (509 over 8) as one exchange per step."""
+    from test_gather_loopback_gpu import build_loopback
+    d = _run_bench(["--launcher", "threads", "--poses", "64"] + extra, {"PR_RCCL_LIBRARY": build_loopback()}, gpus=8)
+    assert d["n_gpus"] == 8 and d["launcher"]["kind"] == "threads"
+    assert d["gather"].startswith("pr_gather_results") and "loop-back" in d["gather"], d["gather"]
+    assert d["gather_note"] is None and d["gather_when"] == when and d["gathers_in_timed_region"] == gathers
+    assert d["value"] > 1000
+
+
+@pytest.mark.gpu
 def test_bench_force_comm_runs_the_rccl_gather_with_a_world_of_one():
     """PR_BENCH_FORCE_COMM=1: the whole N > 1 machinery with ONE rank -- torch's process group on the RCCL backend and the library's own
     dlopened RCCL communicator (pr_comm_init_rank, pr_gather_results) in one process, on every round's GPU box."""

@@ -214,3 +214,4 @@ def test_large_kdtree_scenes(gpu, W, H):
     model = api.Model(tris=tris)
     res, sizes = api.refine_batch(model, poses, W, H, proj, K, scene, api.ICPConvergenceCriteria(*crit))
     assert [int(s) for s in sizes] == [int((x > 0).sum()) for x in ref] and res["fitness"][0] == 1.0
+

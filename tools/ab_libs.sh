@@ -19,7 +19,7 @@ for round in 1 2; do for v in "$@"; do
 import sqlite3, sys, glob
 c = sqlite3.connect(glob.glob(sys.argv[1].replace("t/t_results.db", "t/**/t_results.db"), recursive=True)[0] if not __import__("os").path.exists(sys.argv[1]) else sys.argv[1])
 rows = list(c.execute("select name, start, (end-start)/1000.0 from kernels order by start"))
-for key in ("nn_search", "nn_bound", "nn_tree", "icp_pass", "raster_kernel"):
+for key in ("nn_search", "nn_bound", "nn_tree", "icp_pass", "nn_late", "raster_kernel"):
     v = [r[2] for r in rows if key in r[0]]
     if v: print("%-13s us:" % key, " ".join(f"{x:.0f}" for x in v[-21:]), " sum %.2f ms" % (sum(v[-21:]) / 1e3))
 PY

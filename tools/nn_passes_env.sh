@@ -9,10 +9,10 @@ for envs in "$@"; do
   python - $OUT/e_$i/t_results.db "$envs" <<'PY'
 import sqlite3, sys
 c = sqlite3.connect(sys.argv[1])
-rows = list(c.execute("select name, start, (end-start)/1000.0 from kernels where name like '%nn_search%' or name like '%nn_tree%' or name like '%nn_bound%' or name like '%icp_pass%' order by start"))
+rows = list(c.execute("select name, start, (end-start)/1000.0 from kernels where name like '%nn_search%' or name like '%nn_tree%' or name like '%nn_bound%' or name like '%icp_pass%' or name like '%nn_late%' order by start"))
 n = 21
 print("==", sys.argv[2])
-for key in ("nn_search", "nn_bound", "nn_tree", "icp_pass"):
+for key in ("nn_search", "nn_bound", "nn_tree", "icp_pass", "nn_late"):
     v = [r[2] for r in rows if key in r[0]]
     if v: print("%-9s us:" % key, " ".join(f"{x:.0f}" for x in v[-n:]), " sum %.2f ms" % (sum(v[-n:]) / 1e3))
 PY
