@@ -218,13 +218,15 @@ __device__ __forceinline__ bool pass_deliver(const IcpBatch &b, uint32_t pose, u
     if (threadIdx.x == 0) st_sys_u32(&b.arrive[pose], 0u);
     if (b.fused == 2u) {                                         // solve on the host: the sums of the hypothesis, straight into host memory
         if (threadIdx.x < 29) st_sys_f32(b.sums_out + (size_t)pose * kAccStride + threadIdx.x, sum_partials_sys(b.partial, pose, b.nblk, used, threadIdx.x));
-        // ... and behind them the word the host polls (round 6): the iteration's tag in word 31 of the hypothesis' row.  Both are write-through stores at
-        // system scope; the wavefront waits until its 29 sum stores have been acknowledged before it issues the tag, so the tag cannot overtake them
-        // on the way to host memory -- and the host may solve the hypothesis the moment it sees the tag, while the pass is still running for others
-        // (pr_icp.cpp, PR_SOLVE_HOST).  (NOT a release store: at system scope that is a write-back of the whole L2 per hypothesis -- measured: 82 k
-        // instead of 234 k poses/s.)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (threadIdx.x == 0) st_sys_u32(reinterpret_cast<uint32_t *>(b.sums_out + (size_t)pose * kAccStride) + 31, b.iter + 1u);
+        // ... and, when the host polls (round 6, option host_poll), the group's count: the wavefront waits until its 29 sum stores have been acknowledged,
+        // then counts its hypothesis in; the one that completes the pose group re-arms the counter and stores the iteration's tag into pinned host
+        // memory -- behind every hypothesis' sums (each was acknowledged before its count).  The host then solves the group while the launch is still
+        // winding down (the end-of-kernel write-back of the clouds it moved), instead of waiting for the stream.  Plain write-through stores: a release
+        // at system scope would write the whole L2 back per hypothesis (measured: 82 k instead of 234 k poses/s).
+        if (b.grp_flag) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (threadIdx.x == 0 && atomicAdd(b.grp_count, 1u) + 1u == b.grp_expected) { st_sys_u32(b.grp_count, 0u); st_sys_u32(b.grp_flag, b.iter + 1u); }
+        }
         return true;
     }
     DevIcpState s = b.st[pose];                                  // uniform; in flight together with the partial sums

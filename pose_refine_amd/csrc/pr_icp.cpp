@@ -50,7 +50,7 @@ int icp_drive(pr_vec3 *cloud_base, const uint32_t *start_h, const uint32_t *coun
     PR_TRY(g->partial.ensure(sizeof(float) * prk::kAccStride * (size_t)std::max(1u, nblk) * P));
     PR_TRY(g->sums.ensure(sizeof(float) * prk::kAccStride * P));
     PR_TRY(g->h_meta.ensure(sizeof(prk::PoseMeta) * P));
-    PR_TRY(g->h_sums.ensure(sizeof(float) * prk::kAccStride * P));
+    PR_TRY(g->h_sums.ensure(sizeof(float) * prk::kAccStride * P + 64));        // (+ the pose groups' flags, PR_SOLVE_HOST with host_poll)
     PR_TRY(g->h_results.ensure(sizeof(pr_result) * P));
 
     prk::IcpBatch b{};
@@ -207,7 +207,7 @@ int icp_drive(pr_vec3 *cloud_base, const uint32_t *start_h, const uint32_t *coun
     const uint32_t host_sample_it = (uint32_t)(((host_tick / (uint64_t)std::max(1, opt.sample_period)) * 5 + 1) % (uint64_t)(crit.max_iteration + 1));
     const uint32_t n_groups = (opt.profile == 1 || opt.profile == 3 || host_sample_call) ? 1u : std::max(1u, std::min({ pose_groups_for(sc.kind), 4u, P / 32u }));
     auto group_begin = [&](uint32_t grp) { return (uint32_t)(((uint64_t)P * grp) / n_groups); };
-    if (opt.fused_solve) { PR_TRY(g->arrive.ensure(sizeof(uint32_t) * P)); HIP_TRY(hipMemsetAsync(g->arrive.p, 0, sizeof(uint32_t) * P, g->stream)); }
+    if (opt.fused_solve) { PR_TRY(g->arrive.ensure(sizeof(uint32_t) * (P + 4))); HIP_TRY(hipMemsetAsync(g->arrive.p, 0, sizeof(uint32_t) * (P + 4), g->stream)); }   // (+ one counter per pose group)
     if (n_groups > 1) {
         for (uint32_t k = 1; k < n_groups; ++k) PR_TRY(ensure_stream(g->side[k - 1], &g->ev_join[k - 1]));
         HIP_TRY(hipEventRecord(g->ev_fork, g->stream));               // the groups start behind the render / cloud work of this call
@@ -220,7 +220,7 @@ int icp_drive(pr_vec3 *cloud_base, const uint32_t *start_h, const uint32_t *coun
     const bool host_fused = opt.fused_solve != 0;
     float *sums_dev = nullptr;
     if (host_fused) {
-        PR_TRY(g->arrive.ensure(sizeof(uint32_t) * P));
+        PR_TRY(g->arrive.ensure(sizeof(uint32_t) * (P + 4)));
         HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&sums_dev), h_sums, 0));
     }
     // Projective scenes also read the per-hypothesis state (64 bytes: cloud span, pending update) from the pinned host array instead
@@ -228,6 +228,12 @@ int icp_drive(pr_vec3 *cloud_base, const uint32_t *start_h, const uint32_t *coun
     // batch.  The four kernels of a kd-tree pass have ten times the workgroups; there the copy is cheaper (8.3 against 8.8 ms).
     const prk::PoseMeta *meta_dev = nullptr;
     if (host_fused && sc.kind != PR_SCENE_NN) HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(const_cast<prk::PoseMeta **>(&meta_dev)), h_meta, 0));
+    // Round 6: the host waits for a pose group's FLAG in pinned memory (stored by the workgroup that delivers the group's last
+    // hypothesis) instead of for the stream -- it solves while the launch winds down.  Option blocking_wait (several ranks sharing few CPUs) and
+    // host_poll = 0 keep the stream wait.
+    const bool poll_flag = host_fused && !opt.blocking_wait && opt.host_poll;
+    volatile uint32_t *h_flags = reinterpret_cast<volatile uint32_t *>(h_sums + (size_t)P * prk::kAccStride);
+    if (poll_flag) for (int k = 0; k < 4; ++k) h_flags[k] = 0u;
     // one iteration of one group goes onto its stream: state upload, pass, block sums -> pose sums, download
     auto enqueue_group = [&](uint32_t grp, uint32_t it) -> int {
         const uint32_t p0 = group_begin(grp), np = group_begin(grp + 1) - p0;
@@ -238,6 +244,12 @@ int icp_drive(pr_vec3 *cloud_base, const uint32_t *start_h, const uint32_t *coun
         bb.meta += p0; bb.partial += (size_t)p0 * nblk * prk::kAccStride; if (bb.nn_qcount) bb.nn_qcount += prk::kQCountStride * (size_t)p0;
         bb.iter = it;
         if (host_fused) { bb.fused = 2; bb.arrive = g->arrive.as<uint32_t>() + p0; bb.sums_out = sums_dev + (size_t)p0 * prk::kAccStride; }
+        if (poll_flag) {                                             // the group's count and flag (see pass_deliver): how many hypotheses will deliver
+            uint32_t expected = 0;
+            for (uint32_t i = p0; i < p0 + np; ++i) expected += (h_meta[i].state != prk::kSkip) ? 1u : 0u;
+            bb.grp_count = g->arrive.as<uint32_t>() + P + grp; bb.grp_expected = expected;
+            bb.grp_flag = reinterpret_cast<uint32_t *>(sums_dev + (size_t)P * prk::kAccStride) + grp;
+        }
         if (opt.profile == 1 || opt.profile == 3 || (host_sample_call && it == host_sample_it)) {
             SpanGuard sp(kSpanIcp); HIP_TRY(launch_pass(bb, sc, np, st));
             for (uint32_t i = p0; i < p0 + np; ++i) if (h_meta[i].state != prk::kSkip) { g->icp_points += count_h[i]; g->icp_bytes += (uint64_t)count_h[i] * (it == 0 ? 36u : 48u); }
@@ -271,50 +283,28 @@ int icp_drive(pr_vec3 *cloud_base, const uint32_t *start_h, const uint32_t *coun
         h_meta[i].state = prk::kRunWithTransform;
         return true;
     };
-    // Round 6: with the sums stored straight into pinned memory (host_fused) the host does not wait for the STREAM any more but
-    // for the HYPOTHESES: the workgroup that stores a hypothesis' 29 totals stores the iteration's tag behind them (word 31 of the row, release order at
-    // system scope), this thread polls the tags of the group and solves every hypothesis the moment its sums are there -- while the pass is still
-    // running for the others.  What stays on the critical path of an iteration is the solve of the LAST hypothesis to arrive and the next launch,
-    // not a stream wake-up (10-20 us) followed by 128 solves (20-30 us).  The stream is still queried now and then: an error must not turn the poll
-    // into an endless loop.  Option blocking_wait (several ranks sharing few CPUs) keeps the sleeping wait.
-    const bool poll_tags = host_fused && !opt.blocking_wait && opt.host_poll;
-    if (poll_tags) for (uint32_t i = 0; i < P; ++i) reinterpret_cast<volatile uint32_t *>(h_sums + (size_t)i * prk::kAccStride)[31] = 0u;
-    std::vector<uint32_t> waiting;
-    waiting.reserve(P);
     // returns how many hypotheses of the group go on; < 0: a HIP error
     auto finish_group = [&](uint32_t grp, uint32_t it) -> int {
-        int active = 0;
-        if (!poll_tags) {
+        if (!poll_flag) {
             if (hipError_t e = hipStreamSynchronize(group_stream(grp)); e != hipSuccess) { set_error("HIP error: %s", hipGetErrorString(e)); return -1; }
-            for (uint32_t i = group_begin(grp); i < group_begin(grp + 1); ++i) if (h_meta[i].state != prk::kSkip && solve_one(i, it)) ++active;
-            return active;
-        }
-        waiting.clear();
-        for (uint32_t i = group_begin(grp); i < group_begin(grp + 1); ++i) if (h_meta[i].state != prk::kSkip) waiting.push_back(i);
-        const uint32_t tag = it + 1u;
-        uint32_t idle = 0;
-        bool drained = false;
-        while (!waiting.empty()) {
-            size_t kept = 0;
-            for (size_t k = 0; k < waiting.size(); ++k) {
-                const uint32_t i = waiting[k];
-                if (reinterpret_cast<volatile uint32_t *>(h_sums + (size_t)i * prk::kAccStride)[31] == tag) {
-                    std::atomic_thread_fence(std::memory_order_acquire);
-                    if (solve_one(i, it)) ++active;
-                } else waiting[kept++] = i;
-            }
-            if (kept == waiting.size()) {
-                if (drained) { set_error("PR_SOLVE_HOST: the pass of iteration %u finished without delivering the sums of %zu hypotheses", it, kept); return -1; }
-                if (++idle >= 4096u) {                               // every few hundred microseconds of fruitless polling: is the stream still alive?
+        } else {
+            const uint32_t tag = it + 1u;
+            uint32_t idle = 0;
+            bool drained = false;
+            while (h_flags[grp] != tag) {
+                if (drained) { set_error("PR_SOLVE_HOST: the pass of iteration %u ended without completing its pose group", it); return -1; }
+                if (++idle >= 20000u) {                              // every few hundred microseconds of fruitless polling: is the stream still alive?
                     idle = 0;
                     const hipError_t q = hipStreamQuery(group_stream(grp));
-                    if (q == hipSuccess) drained = true;           // (one more sweep: the tags were stored before the kernel ended)
+                    if (q == hipSuccess) drained = true;           // (one more look: the flag was stored before the kernel ended)
                     else if (q != hipErrorNotReady) { (void)hipGetLastError(); set_error("HIP error: %s", hipGetErrorString(q)); return -1; }
                 }
                 __builtin_ia32_pause();
-            } else idle = 0;
-            waiting.resize(kept);
+            }
+            std::atomic_thread_fence(std::memory_order_acquire);
         }
+        int active = 0;
+        for (uint32_t i = group_begin(grp); i < group_begin(grp + 1); ++i) if (h_meta[i].state != prk::kSkip && solve_one(i, it)) ++active;
         return active;
     };
     bool live[4] = { false, false, false, false };
@@ -333,7 +323,7 @@ int icp_drive(pr_vec3 *cloud_base, const uint32_t *start_h, const uint32_t *coun
         }
     }
     for (uint32_t k = 1; k < n_groups; ++k) (void)hipStreamSynchronize(g->side[k - 1]);  // nothing of this call is left on a side stream, error or not
-    if (poll_tags) (void)hipStreamSynchronize(g->stream);         // (the tags arrive before the last pass has formally ended: nothing of this call runs on after it returns)
+    if (poll_flag) (void)hipStreamSynchronize(g->stream);         // (a flag arrives before its pass has formally ended: nothing of this call runs on after it returns)
     if (rc_loop != PR_OK) { (void)hipStreamSynchronize(g->stream); drain_spans(); return rc_loop; }
     if (results_host) std::memcpy(results_host, res, sizeof(pr_result) * P);
     if (results_dev) {

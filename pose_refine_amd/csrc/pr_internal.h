@@ -50,6 +50,9 @@ struct IcpBatch {
     uint32_t        fused;      // 0 = separate icp_finalize[_solve] launch; 1 = finalize + solve in the pass; 2 = finalize in the pass, the 29 sums of a
                                 // hypothesis go to sums_out (PR_SOLVE_HOST: pinned host memory, read by the host after the stream has drained)
     float          *sums_out;   // fused == 2: [P][kAccStride], same pose indexing as `meta`
+    uint32_t       *grp_count;  // fused == 2, optional: device counter of the hypotheses of this launch's pose GROUP that have delivered their sums; the one that makes it
+    uint32_t        grp_expected;   // grp_expected re-zeroes it and stores iter + 1 into *grp_flag (pinned host memory): the host polls that one word instead of waiting for the stream
+    uint32_t       *grp_flag;
     uint32_t        iter;       // iteration index of this pass (icp.cu:178 loop variable)
     DevIcpState    *st;         // [P]
     uint32_t       *arrive;     // [P] zero before the first pass; the solving workgroup re-zeroes its entry

@@ -373,6 +373,16 @@ int refine_impl(const pr_triangle *tris_dev, size_t n_tris, const pr_mat4 *poses
 void slot_worker_main(SlotWorker *w)
 {
     bool ready = bind_shared(w->device) == PR_OK && pr_thread_context(1) == PR_OK;
+    // the streams this thread's batches will run on -- its context's own and the first side stream (two pose groups) -- are created NOW, while the thread
+    // that starts the helpers waits: the helpers of a context's slots are started one after the other (slot_worker_post), so their four streams get four
+    // consecutive hardware queues = four different pipes of the command processor.  Created lazily by whichever helper came first, two of them could share a
+    // pipe: the host-solve pipeline then ran at 208 k instead of 240-254 k poses/s, in about one process out of three (round 6, same box).
+    if (ready) {
+        std::lock_guard<std::mutex> ck(g->mu);
+        ready = require_ctx() == PR_OK && ensure_stream(g->side[0], &g->ev_join[0]) == PR_OK;
+    }
+    { std::lock_guard<std::mutex> lk(w->mu); w->started = true; }
+    w->cv.notify_all();
     for (;;) {
         std::unique_lock<std::mutex> lk(w->mu);
         w->cv.wait(lk, [&] { return w->has_job || w->quit; });
@@ -408,10 +418,16 @@ int slot_worker_post(Slot &sl, const pr_triangle *tris_dev, size_t n_tris, const
     if (scene_kind != PR_SCENE_NN && scene_kind != PR_SCENE_PROJ && scene_kind != PR_SCENE_PROJ_CROP) { set_error("unknown scene kind %d", scene_kind); return PR_ERR_INVALID; }
     if (!scene) { set_error("pr_refine_submit: null scene"); return PR_ERR_INVALID; }
     if (!sl.worker) {
-        sl.worker.reset(new SlotWorker());
-        sl.worker->device = g->device; sl.worker->alive = true;
-        try { sl.worker->th = std::thread(slot_worker_main, sl.worker.get()); }
-        catch (...) { sl.worker.reset(); set_error("pr_refine_submit: cannot start the slot's helper thread"); return PR_ERR_NOMEM; }
+        // the helpers of ALL slots of this context, one after the other, each with its streams made before the next one starts (see slot_worker_main)
+        for (Slot &o : g->slots) {
+            if (o.worker) continue;
+            o.worker.reset(new SlotWorker());
+            o.worker->device = g->device; o.worker->alive = true;
+            try { o.worker->th = std::thread(slot_worker_main, o.worker.get()); }
+            catch (...) { o.worker.reset(); if (&o == &sl) { set_error("pr_refine_submit: cannot start the slot's helper thread"); return PR_ERR_NOMEM; } continue; }
+            std::unique_lock<std::mutex> lk(o.worker->mu);
+            o.worker->cv.wait(lk, [&] { return o.worker->started; });
+        }
     }
     SlotWorker &w = *sl.worker;
     {

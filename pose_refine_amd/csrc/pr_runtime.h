@@ -184,7 +184,7 @@ struct SlotWorker {
     std::thread th;
     std::mutex mu;
     std::condition_variable cv;
-    bool has_job = false, done = false, quit = false, alive = false;
+    bool has_job = false, done = false, quit = false, alive = false, started = false;
     int device = 0;
     // the job: every input by value (the caller's arrays of poses may go away after pr_refine_submit returns)
     Resubmit in;
