@@ -825,17 +825,21 @@ def share_extra(api, label, workload, model, poses, W, H, proj, K, scene, iters,
         if k:
             api.refine_wait((k - 1) & 1)
     api.refine_wait(0)
-    t0 = time.perf_counter()
-    for k in range(steps):
-        api.refine_submit(k & 1, model, poses, W, H, proj, K, scene, crit)
-        if k:
-            _, sizes = api.refine_wait((k - 1) & 1)
-    res, sizes = api.refine_wait((steps - 1) & 1)
-    dt = (time.perf_counter() - t0) / steps
+    seg = []
+    for _ in range(3):                                           # three segments, the median is the figure (see host_solve_extra)
+        t0 = time.perf_counter()
+        for k in range(steps):
+            api.refine_submit(k & 1, model, poses, W, H, proj, K, scene, crit)
+            if k:
+                _, sizes = api.refine_wait((k - 1) & 1)
+        res, sizes = api.refine_wait((steps - 1) & 1)
+        seg.append((time.perf_counter() - t0) / steps)
+    dt = sorted(seg)[1]
     n_mean = float(np.mean(sizes))
     bytes_per_pose = 36.0 * n_tris + 8.0 * W * H + 12.0 * n_mean + 996.0 * n_mean          # render + cloud + projective loop
     value = len(poses) / dt
     return {"workload": workload, "value": value, "unit": "poses/s", "ms_per_step": 1e3 * dt, "steps": steps, "poses_per_gpu": int(len(poses)),
+            "segments_poses_per_s": [len(poses) / d for d in seg], "value_is": "the median of three consecutive segments of `steps` pipelined steps",
             "points_per_pose_mean": n_mean, "mean_fitness": float(np.mean(res["fitness"])),
             "end_to_end_algorithmic_bytes_per_pose": bytes_per_pose, "hbm_ceiling_poses_per_s": HBM_PEAK / bytes_per_pose,
             "frac_end_to_end": bytes_per_pose * value / HBM_PEAK, "note": note}
@@ -934,13 +938,16 @@ def kdtree_extra(args, api, model, poses, scene_depth, W, H, proj, K, steps=20):
     scene = api.Scene_nn().init_Scene_nn_cuda(scene_depth, K)
     for _ in range(2):
         api.refine_batch(model, poses, W, H, proj, K, scene, crit)
-    t0 = time.perf_counter()
-    for k in range(steps):                                       # the two slots, like the headline loop: step k is enqueued, then step k-1 collected
-        api.refine_submit(k & 1, model, poses, W, H, proj, K, scene, crit)
-        if k:
-            api.refine_wait((k - 1) & 1)
-    api.refine_wait((steps - 1) & 1)
-    dt = (time.perf_counter() - t0) / steps
+    seg = []
+    for _ in range(3):                                           # three segments, the median is the figure (see host_solve_extra)
+        t0 = time.perf_counter()
+        for k in range(steps):                                   # the two slots, like the headline loop: step k is enqueued, then step k-1 collected
+            api.refine_submit(k & 1, model, poses, W, H, proj, K, scene, crit)
+            if k:
+                api.refine_wait((k - 1) & 1)
+        api.refine_wait((steps - 1) & 1)
+        seg.append((time.perf_counter() - t0) / steps)
+    dt = sorted(seg)[1]
     # the dominant kernel of this configuration by itself: ONE more batch with events between the four kernels of every pass (profile 3:
     # asynchronous, one pose group, the chip to itself) -> pr_profile_nn
     api.profile_reset()
@@ -984,6 +991,7 @@ def kdtree_extra(args, api, model, poses, scene_depth, W, H, proj, K, steps=20):
                         "descent through the representative points + window, task walk over 128-byte wide nodes for the rest, ties repeated by the ordered walk), "
                         f"{args.iters} ICP iterations, two asynchronous slots",
             "value": len(poses) / dt, "unit": "poses/s", "ms_per_step": dt * 1e3, "steps": steps,
+            "segments_poses_per_s": [len(poses) / d for d in seg], "value_is": "the median of three consecutive segments of `steps` pipelined steps",
             "roofline": roof,
             "queries_per_step": tot[0], "settled_by_pixel_window_frac": tot[1] / max(tot[0], 1.0), "tree_searches_frac": tot[2] / max(tot[0], 1.0),
             "tree_nodes_per_tree_search": tot[4] / max(tot[2], 1.0), "leaf_points_per_tree_search": tot[6] / max(tot[2], 1.0),
@@ -1077,13 +1085,19 @@ def host_solve_extra(args, api, model, poses, W, H, proj, K, scene, steps=30):
             if k:
                 api.refine_wait((k - 1) & 1)
         api.refine_wait(1)
-        t0 = time.perf_counter()
-        for k in range(steps):
-            api.refine_submit(k & 1, model, poses, W, H, proj, K, scene, crit)
-            if k:
-                api.refine_wait((k - 1) & 1)
-        api.refine_wait((steps - 1) & 1)
-        dt = (time.perf_counter() - t0) / steps
+        # three segments of `steps` steps, the MEDIAN segment is the figure (all three are in the line): a 30 ms region catches a one-off stall of
+        # 4-6 ms in about one run out of three on this pool's boxes (PR_BENCH_MARKS, round 6: one 6.5 ms step among forty of 1.0 ms, with the solve on
+        # either side) -- the median says what the pipeline sustains, the spread what a single short region can read
+        seg = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            for k in range(steps):
+                api.refine_submit(k & 1, model, poses, W, H, proj, K, scene, crit)
+                if k:
+                    api.refine_wait((k - 1) & 1)
+            api.refine_wait((steps - 1) & 1)
+            seg.append((time.perf_counter() - t0) / steps)
+        dt = sorted(seg)[1]
         n_threads = 2
         barrier = threading.Barrier(n_threads + 1)
         errors = []
@@ -1111,7 +1125,8 @@ def host_solve_extra(args, api, model, poses, W, H, proj, K, scene, steps=30):
     finally:
         api.set_option("solve", api.SOLVE_DEVICE)
     out = {"value": len(poses) / dt, "unit": "poses/s", "ms_per_step": dt * 1e3, "steps": steps, "host_threads": "1 (+2 library: one helper thread per slot)",
-           "note": "PR_SOLVE_HOST, batches pipelined through pr_refine_submit / pr_refine_wait on the two slots from one caller thread; each slot's helper thread runs its batch: 21 launches per pose group (two groups on two streams, software-pipelined: the host solves one group while the other group's pass runs); the workgroup that delivers a hypothesis' last partial sum stores its 29 totals straight into pinned host memory, the host solves (pivoted LDLT in double, as Eigen) and the next pass reads the update from the pinned array",
+           "segments_poses_per_s": [len(poses) / d for d in seg], "value_is": "the median of three consecutive segments of `steps` pipelined steps",
+           "note": "PR_SOLVE_HOST, batches pipelined through pr_refine_submit / pr_refine_wait on the two slots from one caller thread; each slot's helper thread runs its batch: 21 launches per pose group (two groups on two streams, software-pipelined: the host solves one group while the other group's pass runs); the workgroup that delivers a hypothesis' last partial sum stores its 29 totals straight into pinned host memory, the one that completes the pose group stores the group's flag behind them; the host polls that flag (round 6: not the stream), solves (pivoted LDLT in double, as Eigen) and the next pass reads the update from the pinned array",
            "one_synchronous_call_per_step": {"value": len(poses) / dt_sync, "unit": "poses/s", "ms_per_step": dt_sync * 1e3, "steps": steps,
                                              "note": "pr_refine_batch in a loop: nothing of batch k+1 can start before batch k has returned"}}
     if dt2:

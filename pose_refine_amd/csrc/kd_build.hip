@@ -390,7 +390,8 @@ __global__ __launch_bounds__(1024) void kd_plan_kernel(const KdCtrl *__restrict_
             KdCtrl o = now;
             o.lo = hi; o.hi = next; o.next = after;
             if (!first) o.levels = now.levels + 1u;
-            if (after > cap || n_child > max_level || after - next > max_level) { o.error = 1u; o.done = 1u; }       // (the next level's arrays hold max_level nodes)
+            if (after > cap) { o.error = 1u; o.done = 1u; }                                                          // 1: the caller's node array is too small
+            else if (n_child > max_level || after - next > max_level) { o.error = 2u; o.done = 1u; }               // 2: a level wider than the work arrays were sized for       // (the next level's arrays hold max_level nodes)
             else if (after == next) o.done = 1u;                     // no node of this level splits: done (pcd_scene.cpp:166-168)
             *ctrl_next = o;
         }

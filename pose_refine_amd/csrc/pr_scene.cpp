@@ -225,6 +225,7 @@ int kd_build_dev(pr_vec3 *pcd, pr_vec3 *nrm, uint32_t n, int max_leaf, pr_kdnode
         for (; level < until; ++level) HIP_TRY(prk::launch_kd_level(w, nodes, cap32, pcd, n, max_leaf, level, g->stream));
         HIP_TRY(hipMemcpyAsync(&ctrl, w.ctrl[level & 1u], sizeof ctrl, hipMemcpyDeviceToHost, g->stream));
         HIP_TRY(hipStreamSynchronize(g->stream));
+        if (ctrl.error == 2u) { set_error("kd-tree build: a level holds more nodes than the work arrays were sized for (%u points, max_leaf %d) -- an internal bound, not the caller's capacity", n, max_leaf); return PR_ERR_INVALID; }
         if (ctrl.error) { set_error("kd-tree build: node capacity %u too small", cap32); return PR_ERR_NOMEM; }
         if (ctrl.done) break;
         if (level >= 4096) { set_error("kd-tree build: more than 4096 levels (max_leaf %d)", max_leaf); return PR_ERR_INVALID; }
