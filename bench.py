@@ -74,8 +74,8 @@ NN_WALK_VALU_ISSUE_FRAC = 0.75 * 6.144e11 / VALU_PEAK              # r05's 0.75 
 # wavefront's resident cycles spent waiting for an instruction's operands (SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES)
 PROJ_PASS_WAIT_FRAC = 0.31
 NN_WALK_HBM_BYTES_PER_POINT = 4.6                                  # profiles/r05/pmc_nn_*.md: the walk reads queue entries + cloud points, writes winners
-PMC_TRAFFIC_SOURCE = {"proj": "profiles/r05/pmc_proj_FETCH_SIZE.md + pmc_proj_WRITE_SIZE.md + sq_proj_SQ_INSTS_VALU*.md (icp_pass_kernel<SceneProjPacked>)",
-                      "nn": "profiles/r05/pmc_nn_FETCH_SIZE.md + pmc_nn_WRITE_SIZE.md (search 37.1 + bound 11.2 + task walk 4.6 + winners pass 17.9 B/point)"}
+PMC_TRAFFIC_SOURCE = {"proj": "profiles/r06/pmc_proj_FETCH_SIZE.md + pmc_proj_WRITE_SIZE.md + sq_proj_SQ_INSTS_VALU*.md (icp_pass_kernel<SceneProjPacked>)",
+                      "nn": "profiles/r06/pmc_nn_FETCH_SIZE.md + pmc_nn_WRITE_SIZE.md (search 37.1 + bound 11.2 + task walk 4.6 + winners pass 17.9 B/point)"}
 
 
 def effective_cpus():
@@ -795,7 +795,7 @@ def run_rank(args, group, local_dev, share_device, launcher_note, comm_ready, co
 # sha256 (first 16 hex digits) of the sources of icp_pass_kernel<SceneProjPacked> at the time the committed SQ / PMC constants above were measured:
 # when the kernel's sources change, the line says that the VALU figures are stale instead of presenting them as measured
 PMC_PROFILED_SOURCES = ("icp_pass.hip", "icp_accumulate.h", "proj_query.h", "icp_solve_device.h", "pr_tuning.h")
-PMC_PROFILED_HASH = "caf9920e76199470"
+PMC_PROFILED_HASH = "e5b8646c2f4d590e"
 
 
 def pmc_sources_hash():

@@ -32,10 +32,13 @@
  * pr_fill_i32, pr_free, pr_render, the *_prepare_dev / *_build_dev / *_crop_dev functions); a caller that rewrites a scene
  * array by other means (its own kernels, raw hipMemcpy) MUST announce it with pr_invalidate(ptr, bytes) before the next ICP /
  * refine call, or switch the caches off with pr_set_option("scene_cache", 0).
- * As a safety net every call that finds a cached form also compares a sampled fingerprint of the scene arrays (4096 words of each, spread over
- * the array) with the one taken when the cache was built -- asynchronous batches on an idle stream (a mismatch repeats the batch with fresh
- * caches), synchronous calls on the spot (~15 us) -- so a frame replaced as a whole is noticed even without pr_invalidate; an edit confined to
- * words the sample does not look at is not.
+ * Behind that (round 6): every SYNCHRONOUS call that finds a cached form (pr_icp_*, pr_refine_batch*: what the C++ adapters of the reference's API
+ * reach) compares a fingerprint of EVERY word of the scene arrays with the one taken when the cache was built (~20 us) and rebuilds on a mismatch --
+ * an in-place edit through any pointer is seen without pr_invalidate, as with the reference, which reads the arrays at every call
+ * (depth_scene.h:29-48).  Asynchronous batches (pr_refine_submit) compare a SAMPLE of 4096 words per array inside their raster launch (a mismatch
+ * repeats the batch with fresh caches, pr_stats): a frame replaced as a whole is noticed, an edit confined to words the sample does not look at
+ * needs pr_invalidate.  A write THROUGH this library into a range that a batch still in flight on the calling context reads (its scene arrays, its
+ * mesh, its result block) waits for that batch first: a scene object may be re-initialised while its previous frame's batch is running.
  */
 #ifndef POSE_REFINE_H
 #define POSE_REFINE_H

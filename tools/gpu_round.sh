@@ -10,6 +10,8 @@ summ() { python tools/rocpd_summary.py "$1"; }
 rocprofv3 --kernel-trace --stats -d $OUT/cov -o t -- python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" | tail -3 > $OUT/pytest_gpu.txt; cat $OUT/pytest_gpu.txt
 python tools/kernel_coverage.py $OUT/cov > $OUT/kernel_coverage.md; tail -1 $OUT/kernel_coverage.md; rm -rf $OUT/cov
 python __graft_entry__.py --smoke 2>&1 | tail -2 > $OUT/smoke.txt; cat $OUT/smoke.txt
+# VALU issue calibration: wave-instructions per second by instruction class -> bench.py's VALU_PEAK
+mkdir -p tools/scratch; hipcc --offload-arch=gfx950 -O3 tools/valu_peak.hip -o tools/scratch/valu_peak 2>/dev/null && tools/scratch/valu_peak > $OUT/valu_peak.md 2>&1; tail -2 $OUT/valu_peak.md
 $B 2>/dev/null | tail -1 > $OUT/bench_p256_proj.json
 $B --steps 20 --warmup 5 2>/dev/null | tail -1 > $OUT/bench_p256_proj_steps20.json
 $B --steps 40 --warmup 5 --solve host --no-cpu-baseline --no-kdtree-extra 2>/dev/null | tail -1 > $OUT/bench_p256_proj_hostsolve.json
@@ -59,8 +61,15 @@ PR_BENCH_SHARE_DEVICE=1 timeout 600 python bench.py --gpus 2 --steps 40 --warmup
 # EIGHT ranks on the one GPU: the driver's SCALE job on this box's 16-CPU cgroup, both launchers; per-rank host CPU over the timed region is in the line
 PR_BENCH_SHARE_DEVICE=1 timeout 900 python bench.py --gpus 8 --steps 20 --warmup 5 2>/dev/null | tail -1 > $OUT/bench_8ranks_share_device_processes.json
 PR_BENCH_SHARE_DEVICE=1 timeout 900 python bench.py --gpus 8 --steps 20 --warmup 5 --launcher threads 2>/dev/null | tail -1 > $OUT/bench_8ranks_share_device_threads.json
+# eight rank THREADS on the one GPU gathering through pr_gather_results' N > 1 branch over the loop-back stand-in for librccl (tests/rccl_loopback)
+hipcc -shared -fPIC -O2 tests/rccl_loopback/loopback_rccl.cpp -o tests/rccl_loopback/librccl_loopback.so 2>/dev/null
+PR_BENCH_SHARE_DEVICE=1 PR_RCCL_LIBRARY=$PWD/tests/rccl_loopback/librccl_loopback.so timeout 900 python bench.py --gpus 8 --steps 20 --warmup 5 --launcher threads 2>/dev/null | tail -1 > $OUT/bench_8ranks_loopback_gather_threads.json
+PR_RCCL_LIBRARY=$PWD/tests/rccl_loopback/librccl_loopback.so timeout 300 python tests/rccl_loopback/run_gather.py 8 2>/dev/null | tail -1 > $OUT/gather_loopback_8ranks.json; cut -c1-300 $OUT/gather_loopback_8ranks.json
 # the whole N > 1 machinery with a world of one: torch's RCCL process group and the library's own dlopened RCCL in one process
 PR_BENCH_FORCE_COMM=1 timeout 300 python bench.py --steps 20 --warmup 5 2>/dev/null | tail -1 > $OUT/bench_force_comm_world1.json
+# the host-solve pipeline over time from its first step (round 6: one flag per pose group polled by the helper threads), and the device-solve one
+for m in host host device; do timeout 300 python tools/host_warm_probe.py $m 2>/dev/null | tail -1; done > $OUT/pipeline_rate_over_time.txt
+for hp in 0 1 0 1 0 1; do timeout 200 python bench.py --steps 40 --warmup 5 --solve host --no-cpu-baseline --no-kdtree-extra --no-live-pmc --opt host_poll=$hp 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('host_poll $hp: %.0f poses/s, largest step %.2f ms, closing fence %.2f ms' % (d['value'], d['step_ms_spread']['max'], d['step_ms_spread']['closing_fence_ms']))"; done > $OUT/host_poll_ab.txt; cat $OUT/host_poll_ab.txt
 # a new scene per frame -- what it costs next to a batch, and frames pipelined through the two slots
 timeout 300 python tools/scene_frame_time.py 2>/dev/null | grep "valid pixels" > $OUT/scene_frame_time.txt
 timeout 300 python tools/frames_pipe.py 2>/dev/null | grep "frame" >> $OUT/scene_frame_time.txt; cat $OUT/scene_frame_time.txt
