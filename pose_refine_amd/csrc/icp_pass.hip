@@ -151,6 +151,13 @@ __global__ void stage_words_kernel(const uint4 *__restrict__ src, uint4 *__restr
     if (i < n16) dst[i] = src[i];
 }
 
+// the same in 8-byte words, for records whose total is no multiple of 16 (72-byte results): never a byte beyond the destination
+__global__ void stage_words64_kernel(const uint2 *__restrict__ src, uint2 *__restrict__ dst, uint32_t n8)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n8) dst[i] = src[i];
+}
+
 template <class Scene, bool kNN, int kStack = 0>
 static hipError_t launch_pass(const IcpBatch &b, const Scene &sc, uint32_t n_poses, size_t lds_bytes, hipStream_t s)
 {
@@ -214,6 +221,26 @@ hipError_t launch_stage_words(const void *src_host_mapped, void *dst, size_t byt
     const uint32_t n16 = (uint32_t)((bytes + 15) / 16);
     if (n16 == 0) return hipSuccess;
     hipLaunchKernelGGL(stage_words_kernel, dim3((n16 + 255) / 256), dim3(256), 0, s, static_cast<const uint4 *>(src_host_mapped), static_cast<uint4 *>(dst), n16);
+    return hipGetLastError();
+}
+// 4-byte words, either direction (device -> pinned host too: small read-backs without a copy command)
+__global__ void copy_words32_kernel(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+hipError_t launch_copy_words32(const void *src, void *dst, uint32_t n_words, hipStream_t s)
+{
+    if (n_words == 0) return hipSuccess;
+    hipLaunchKernelGGL(copy_words32_kernel, dim3((n_words + 255) / 256), dim3(256), 0, s, static_cast<const uint32_t *>(src), static_cast<uint32_t *>(dst), n_words);
+    return hipGetLastError();
+}
+hipError_t launch_stage_words64(const void *src_host_mapped, void *dst, size_t bytes, hipStream_t s)
+{
+    if (bytes % 8) return hipErrorInvalidValue;
+    const uint32_t n8 = (uint32_t)(bytes / 8);
+    if (n8 == 0) return hipSuccess;
+    hipLaunchKernelGGL(stage_words64_kernel, dim3((n8 + 255) / 256), dim3(256), 0, s, static_cast<const uint2 *>(src_host_mapped), static_cast<uint2 *>(dst), n8);
     return hipGetLastError();
 }
 hipError_t launch_pack_results(const DevIcpState *st, pr_result *out, uint32_t n_poses, hipStream_t s)

@@ -13,6 +13,45 @@ void set_error(const char *fmt, ...)
 
 namespace prr {
 
+static std::mutex &g_reg_mu_trace() { static std::mutex m; return m; }
+
+// ---- PR_TRACE: a ring of (thread, tag, nanoseconds), written to the named file at exit ---------------------------------------------
+namespace {
+struct TraceRec { uint64_t ns; const char *tag; uint32_t tid; };
+constexpr size_t kTraceCap = 1u << 18;
+TraceRec *g_trace = nullptr;
+std::atomic<uint64_t> g_trace_n{ 0 };
+std::atomic<int> g_trace_state{ 0 };                              // 0 unknown, 1 off, 2 on
+std::string g_trace_path;
+void trace_dump()
+{
+    FILE *f = std::fopen(g_trace_path.c_str(), "w");
+    if (!f) return;
+    const uint64_t n = std::min<uint64_t>(g_trace_n.load(), kTraceCap);
+    for (uint64_t i = 0; i < n; ++i) std::fprintf(f, "%llu %u %s\n", (unsigned long long)g_trace[i].ns, g_trace[i].tid, g_trace[i].tag);
+    std::fclose(f);
+}
+}  // namespace
+void trace_mark(const char *tag)
+{
+    int st = g_trace_state.load(std::memory_order_acquire);
+    if (st == 1) return;
+    if (st == 0) {
+        std::lock_guard<std::mutex> lk(g_reg_mu_trace());
+        st = g_trace_state.load();
+        if (st == 0) {
+            const char *p = std::getenv("PR_TRACE");
+            if (p && *p) { g_trace_path = p; g_trace = new TraceRec[kTraceCap]; std::atexit(trace_dump); st = 2; } else st = 1;
+            g_trace_state.store(st, std::memory_order_release);
+        }
+        if (st == 1) return;
+    }
+    timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
+    static thread_local uint32_t tid = (uint32_t)std::hash<std::thread::id>()(std::this_thread::get_id());
+    const uint64_t i = g_trace_n.fetch_add(1);
+    if (i < kTraceCap) g_trace[i] = TraceRec{ (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec, tag, tid };
+}
+
 WriteLog g_writes;
 Options opt;
 std::mutex g_reg_mu;
@@ -32,7 +71,7 @@ void ctx_teardown(Ctx *c)        // c->mu held (or c unreachable); the calling t
     for (DevBuf *b : { &c->aabb, &c->aabb_keys, &c->bbox, &c->poses, &c->depth, &c->row_count, &c->row_off, &c->counts, &c->cloud, &c->meta, &c->partial,
                        &c->sums, &c->packed.rec, &c->nn_prev, &c->dstate, &c->dresults, &c->arrive, &c->conv16, &c->conv8, &c->kd_scratch, &c->kd_tmp, &c->nn_full, &c->gather_tmp, &c->nn_counters }) b->release();
     for (NNDerived &d : c->nn_sets) d.release();
-    for (PinBuf *b : { &c->h_sums, &c->h_meta, &c->h_counts, &c->h_results, &c->h_dstate }) b->release();
+    for (PinBuf *b : { &c->h_sums, &c->h_meta, &c->h_counts, &c->h_results, &c->h_dstate, &c->h_poses, &c->h_flags }) b->release();
     c->packed = PackedCache();
     for (auto &gr : c->graphs) destroy_graph(gr);
     c->graphs.clear();

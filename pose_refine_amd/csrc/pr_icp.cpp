@@ -109,8 +109,13 @@ int icp_drive(pr_vec3 *cloud_base, const uint32_t *start_h, const uint32_t *coun
         const uint32_t n_groups = timed_call ? 1u : std::max(1u, std::min({ pose_groups_for(sc.kind), 4u, P / 32u }));
         // the fixed sequence: state upload, (max_iteration+1) x [correspondence pass, finalize+solve], result pack
         auto enqueue_all = [&](std::vector<hipEvent_t> *, bool host_checks) -> int {
-            HIP_TRY(hipMemcpyAsync(g->dstate.p, init, sizeof(prk::DevIcpState) * P, hipMemcpyHostToDevice, g->stream));
-            HIP_TRY(hipMemcpyAsync(g->meta.p, h_meta, sizeof(prk::PoseMeta) * P, hipMemcpyHostToDevice, g->stream));
+            // start state and per-hypothesis records: PULLED from the pinned arrays by a kernel, results pushed into the pinned array by one -- no copy
+            // command on a per-call path (round 6: the runtime's copy-engine path is where one-off multi-millisecond stalls came from, see below)
+            void *init_dev = nullptr, *meta_host_dev = nullptr;
+            HIP_TRY(hipHostGetDevicePointer(&init_dev, init, 0));
+            HIP_TRY(hipHostGetDevicePointer(&meta_host_dev, h_meta, 0));
+            HIP_TRY(prk::launch_stage_words(init_dev, g->dstate.p, sizeof(prk::DevIcpState) * P, g->stream));
+            HIP_TRY(prk::launch_stage_words(meta_host_dev, g->meta.p, sizeof(prk::PoseMeta) * P, g->stream));
             if (fused) HIP_TRY(hipMemsetAsync(g->arrive.p, 0, sizeof(uint32_t) * P, g->stream));
             // Two pose groups on two streams: while the (latency-bound, one wavefront per pose) finalize+solve
             // of one group runs, the correspondence pass of the other group keeps the chip busy.
@@ -152,7 +157,11 @@ int icp_drive(pr_vec3 *cloud_base, const uint32_t *start_h, const uint32_t *coun
             for (uint32_t k = 1; k < n_groups; ++k) { HIP_TRY(hipEventRecord(g->ev_join[k - 1], g->side[k - 1])); HIP_TRY(hipStreamWaitEvent(g->stream, g->ev_join[k - 1], 0)); }
             HIP_TRY(prk::launch_pack_results(g->dstate.as<prk::DevIcpState>(), dres, P, g->stream));
             // results go to the pinned staging buffer (a pageable destination is not capturable)
-            if (results_host) HIP_TRY(hipMemcpyAsync(res, dres, sizeof(pr_result) * P, hipMemcpyDeviceToHost, g->stream));
+            if (results_host) {
+                void *res_dev = nullptr;
+                HIP_TRY(hipHostGetDevicePointer(&res_dev, res, 0));
+                HIP_TRY(prk::launch_stage_words64(dres, res_dev, sizeof(pr_result) * P, g->stream));
+            }
             return PR_OK;
         };
 
@@ -324,10 +333,16 @@ int icp_drive(pr_vec3 *cloud_base, const uint32_t *start_h, const uint32_t *coun
     }
     for (uint32_t k = 1; k < n_groups; ++k) (void)hipStreamSynchronize(g->side[k - 1]);  // nothing of this call is left on a side stream, error or not
     if (poll_flag) (void)hipStreamSynchronize(g->stream);         // (a flag arrives before its pass has formally ended: nothing of this call runs on after it returns)
+    trace_mark("icp_drive: host loop done");
     if (rc_loop != PR_OK) { (void)hipStreamSynchronize(g->stream); drain_spans(); return rc_loop; }
     if (results_host) std::memcpy(results_host, res, sizeof(pr_result) * P);
     if (results_dev) {
-        HIP_TRY(hipMemcpyAsync(results_dev, res, sizeof(pr_result) * P, hipMemcpyHostToDevice, g->stream));
+        // the records are PULLED from the pinned array by a kernel, not pushed by a copy command: round 6 traced the one-off stall of the host-solve
+        // pipeline (one step of 6.5-8.7 ms among forty of 1.0 ms, PR_TRACE) to this 18 KB hipMemcpyAsync -- some batches into a helper thread's life
+        // the runtime spends milliseconds inside it, on both helpers at once (its copy-engine path; the kernels around it take microseconds)
+        void *res_dev = nullptr;
+        HIP_TRY(hipHostGetDevicePointer(&res_dev, res, 0));
+        HIP_TRY(prk::launch_stage_words64(res_dev, results_dev, sizeof(pr_result) * P, g->stream));
         HIP_TRY(hipStreamSynchronize(g->stream));
     }
     drain_spans();

@@ -173,6 +173,8 @@ hipError_t launch_render_boxes(const pr_triangle *tris, uint32_t n_tris, const p
 hipError_t launch_pack_export(const DevIcpState *st, pr_result *out, const uint32_t *counts, uint32_t *host_counts, pr_result *host_results,
                               uint32_t n, hipStream_t s);
 hipError_t launch_stage_words(const void *src_host_mapped, void *dst, size_t bytes, hipStream_t s);
+hipError_t launch_stage_words64(const void *src_host_mapped, void *dst, size_t bytes, hipStream_t s);
+hipError_t launch_copy_words32(const void *src, void *dst, uint32_t n_words, hipStream_t s);   // either direction (pinned host memory through its device pointer)   // 8-byte words: exact for 72-byte records
 // meta[i].start = exclusive scan of counts[0..i) rounded up to kCloudAlign points each (the packed layout of a batch's clouds)
 hipError_t launch_d2c_pack_starts(const uint32_t *counts, uint32_t n, PoseMeta *meta, hipStream_t s);
 hipError_t launch_emit_box(const int32_t *depth, uint32_t n_poses, uint32_t width, uint32_t height, const int4 *bbox, float fx, float fy,

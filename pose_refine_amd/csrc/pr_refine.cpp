@@ -26,7 +26,13 @@ int render_impl(const pr_triangle *tris_dev, size_t n_tris, const pr_mat4 *poses
     if (P == 0) return PR_OK;
     PR_TRY(g->poses.ensure(sizeof(pr_mat4) * P));
     SpanGuard sp(kSpanRender);
-    HIP_TRY(hipMemcpyAsync(g->poses.p, poses_host, sizeof(pr_mat4) * P, hipMemcpyHostToDevice, g->stream));
+    {   // poses through the pinned staging array, pulled by a kernel (no copy command from the caller's pageable array: see refine_impl)
+        PR_TRY(g->h_poses.ensure(sizeof(pr_mat4) * P));
+        std::memcpy(g->h_poses.p, poses_host, sizeof(pr_mat4) * P);
+        void *hp = nullptr;
+        HIP_TRY(hipHostGetDevicePointer(&hp, g->h_poses.p, 0));
+        HIP_TRY(prk::launch_stage_words(hp, g->poses.p, sizeof(pr_mat4) * P, g->stream));
+    }
     HIP_TRY(prk::launch_fill_i32(depth_dev, P * rw * rh, INT32_MAX, g->stream));
     HIP_TRY(prk::launch_raster(tris_dev, (uint32_t)n_tris, g->poses.as<pr_mat4>(), (uint32_t)P, depth_dev, (uint32_t)W, (uint32_t)H,
                                *proj, roi, (uint32_t)rw, (uint32_t)rh, g->stream));
@@ -46,8 +52,7 @@ int depth2cloud_impl(const T *depth_dev, uint32_t W, uint32_t H, const float K[9
     HIP_TRY(prk::launch_depth2cloud<T>(depth_dev, 1, 0, W, H, stride, tl_x, tl_y, K[0], K[4], K[2], K[5], false, g->row_count.as<uint32_t>(),
                                        g->row_off.as<uint32_t>(), g->counts.as<uint32_t>(), nullptr, 0, false, g->stream));
     uint32_t n = 0;
-    HIP_TRY(hipMemcpyAsync(&n, g->counts.p, sizeof n, hipMemcpyDeviceToHost, g->stream));
-    HIP_TRY(hipStreamSynchronize(g->stream));
+    PR_TRY(read_back_words(g->counts.p, &n, 1, g->stream));
     pr_vec3 *cloud = nullptr;
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&cloud), sizeof(pr_vec3) * std::max(1u, n)));
     if (n > 0) {
@@ -80,7 +85,9 @@ int refine_impl(const pr_triangle *tris_dev, size_t n_tris, const pr_mat4 *poses
     SceneSel sc;
     std::memset(static_cast<void *>(&sc), 0, sizeof sc);           // also zeroes padding: sc is part of the graph-cache key
     const Camera cam{ W, H, K[0], K[4], K[2], K[5] };
+    trace_mark("refine_impl: enter");
     PR_TRY(make_scene(scene_kind, scene, /*want_packed=*/true, sc, nullptr, nullptr, &cam));
+    trace_mark("refine_impl: scene ready");
     // bound the depth workspace to ~4 GiB per chunk (288 GB of HBM would allow far more; this keeps
     // first-touch cost and the 2^32 element index space comfortable)
     const size_t img = (size_t)W * H;
@@ -104,7 +111,15 @@ int refine_impl(const pr_triangle *tris_dev, size_t n_tris, const pr_mat4 *poses
         uint32_t *box_off = (prk::kBoxPack && opt.raster_mode != 1) ? reinterpret_cast<uint32_t *>(g->bbox.as<int4>() + np) : nullptr;
         {
             SpanGuard sp(kSpanRender);
-            HIP_TRY(hipMemcpyAsync(g->poses.p, poses_host + p0, sizeof(pr_mat4) * np, hipMemcpyHostToDevice, g->stream));
+            {   // the hypotheses' poses: through the context's pinned staging array, pulled by a kernel (as the asynchronous path stages its inputs) --
+                // a copy command from the caller's pageable array goes through the runtime's bounce buffers and its copy-engine path (see icp_drive's
+                // result block: that path is where the host-solve pipeline's one-off multi-millisecond stalls came from)
+                PR_TRY(g->h_poses.ensure(sizeof(pr_mat4) * np));
+                std::memcpy(g->h_poses.p, poses_host + p0, sizeof(pr_mat4) * np);
+                void *hp = nullptr;
+                HIP_TRY(hipHostGetDevicePointer(&hp, g->h_poses.p, 0));
+                HIP_TRY(prk::launch_stage_words(hp, g->poses.p, sizeof(pr_mat4) * np, g->stream));
+            }
             if (opt.raster_mode == 1)
                 HIP_TRY(prk::launch_render_bands(tris_dev, (uint32_t)n_tris, g->poses.as<pr_mat4>(), np, g->aabb.as<float>(), g->bbox.as<int4>(),
                                                  g->depth.as<int32_t>(), g->row_count.as<uint32_t>(), g->row_off.as<uint32_t>(),
@@ -114,8 +129,13 @@ int refine_impl(const pr_triangle *tris_dev, size_t n_tris, const pr_mat4 *poses
                                                  g->depth.as<int32_t>(), g->row_count.as<uint32_t>(), g->row_off.as<uint32_t>(),
                                                  g->counts.as<uint32_t>(), W, H, *proj, roi, g->stream, /*compute_boxes=*/true, nullptr, nullptr, nullptr, 0, box_off));
         }
-        HIP_TRY(hipMemcpyAsync(h_counts, g->counts.p, sizeof(uint32_t) * np, hipMemcpyDeviceToHost, g->stream));
+        {   // the cloud sizes come back through a kernel's stores into the pinned array, not through a copy command (see icp_drive's result block)
+            void *hc = nullptr;
+            HIP_TRY(hipHostGetDevicePointer(&hc, h_counts, 0));
+            HIP_TRY(prk::launch_copy_words32(g->counts.p, hc, np, g->stream));
+        }
         HIP_TRY(hipStreamSynchronize(g->stream));
+        trace_mark("refine_impl: render done, counts on host");
         uint32_t max_n = 0;
         for (uint32_t i = 0; i < np; ++i) max_n = std::max(max_n, h_counts[i]);
         // the clouds packed one behind the other, as in the asynchronous path (d2c_pack_starts_kernel; the host adds the same rounded sizes)
@@ -138,6 +158,7 @@ int refine_impl(const pr_triangle *tris_dev, size_t n_tris, const pr_mat4 *poses
                                          prk::kCloudAlign ? g->meta.as<prk::PoseMeta>() : nullptr, box_off));
         }
         if (sizes_host) std::memcpy(sizes_host + p0, count.data(), sizeof(uint32_t) * np);
+        trace_mark("refine_impl: clouds emitted, icp_drive next");
         PR_TRY(icp_drive(g->cloud.as<pr_vec3>(), start.data(), count.data(), np, sc, crit,
                          results_host ? results_host + p0 : nullptr, results_dev ? results_dev + p0 : nullptr));
     }
@@ -388,6 +409,7 @@ void slot_worker_main(SlotWorker *w)
         w->cv.wait(lk, [&] { return w->has_job || w->quit; });
         if (w->quit) break;
         lk.unlock();
+        trace_mark("worker: job taken");
         int rc = PR_ERR_HIP;
         if (!ready) set_error("the slot's helper thread could not create its context: %s", std::string(prh::g_err).c_str());
         else {
@@ -401,6 +423,7 @@ void slot_worker_main(SlotWorker *w)
                                  w->results_host, r.results_dev, w->sizes_host);
             }
         }
+        trace_mark("worker: job done");
         lk.lock();
         w->rc = rc; w->err = (rc == PR_OK) ? std::string() : prh::g_err;
         w->has_job = false; w->done = true;
@@ -676,6 +699,9 @@ int refine_submit_async(Slot &sl, const pr_triangle *tris_dev, size_t n_tris, ui
         size_t te = timed ? t_begin() : 0;
         // (the first render carries the batch's checks: the fingerprint's expected value belongs to the scene build, so the scene comes first --
         // an event that is complete when recorded unless a cache missed)
+        // (ADVICE r05 asked whether this wait costs a rebuilt scene its overlap with the render: it does not -- make_scene reads the rebuilt form's
+        // `exact` flag / tree depth back before it returns, so a rebuild has finished on the host's clock before the render is even enqueued; on a
+        // cache hit the event is complete when recorded)
         if (q0 == 0) HIP_TRY(hipStreamWaitEvent(st, sl.scene_ready, 0));
         HIP_TRY(prk::launch_render_boxes(tris_dev, (uint32_t)n_tris, d_poses + q0, nq, nullptr, d_box + q0, sl.depth.as<int32_t>(),
                                          sl.row_count.as<uint32_t>(), sl.row_off.as<uint32_t>(), sl.counts.as<uint32_t>() + q0, W, H, *proj, none, st,
@@ -841,8 +867,11 @@ int pr_refine_submit_roi(int slot, const pr_triangle *tris_dev, size_t n_tris, c
                          const pr_mat4 *proj, const float K[9], int scene_kind, const void *scene, pr_criteria crit, pr_roi roi,
                          pr_result *results_host, pr_result *results_dev, uint32_t *cloud_sizes_host)
 {
-    PR_ENTER();
-    return refine_submit(slot, tris_dev, n_tris, poses_host, n_poses, width, height, proj, K, scene_kind, scene, crit, roi, results_host, results_dev, cloud_sizes_host);
+    trace_mark("pr_refine_submit: enter");
+    int rc;
+    { PR_ENTER(); rc = refine_submit(slot, tris_dev, n_tris, poses_host, n_poses, width, height, proj, K, scene_kind, scene, crit, roi, results_host, results_dev, cloud_sizes_host); }
+    trace_mark("pr_refine_submit: exit");
+    return rc;
 }
 
 int pr_refine_submit(int slot, const pr_triangle *tris_dev, size_t n_tris, const pr_mat4 *poses_host, uint32_t n_poses, uint32_t width, uint32_t height,
@@ -854,8 +883,11 @@ int pr_refine_submit(int slot, const pr_triangle *tris_dev, size_t n_tris, const
 
 int pr_refine_wait(int slot)
 {
-    PR_ENTER();
-    return refine_wait(slot);
+    trace_mark("pr_refine_wait: enter");
+    int rc;
+    { PR_ENTER(); rc = refine_wait(slot); }
+    trace_mark("pr_refine_wait: exit");
+    return rc;
 }
 
 }  // extern "C"

@@ -36,6 +36,10 @@ namespace prr {
 
 using prh::set_error;
 
+// PR_TRACE=<file>: host-side time stamps of the batch path (who waits for whom when a step stalls), dumped at process exit.  Off: one load and a branch.
+void trace_mark(const char *tag);
+
+
 #define HIP_TRY(expr)                                                                           \
     do {                                                                                        \
         hipError_t e_ = (expr);                                                                 \
@@ -265,7 +269,7 @@ struct Ctx {
     uint32_t cloud_hint = 0;          // largest cloud of the latest finished asynchronous batch: sizes the next batch's grid
     // workspaces
     DevBuf aabb, aabb_keys, bbox, poses, depth, row_count, row_off, counts, cloud, meta, partial, sums, nn_prev, dstate, dresults, arrive, conv16, conv8, kd_scratch, kd_tmp, nn_full;
-    PinBuf h_sums, h_meta, h_counts, h_results, h_dstate;
+    PinBuf h_sums, h_meta, h_counts, h_results, h_dstate, h_poses, h_flags;
     PackedCache packed;              // synchronous paths (the asynchronous slots keep their own)
     // kd-tree scenes: what the library derives from a scene (traversal records, wide records, pixel grid) -- kNNSets sets, so that with a NEW scene per
     // frame the batch of one asynchronous slot keeps the set it runs on while the next frame's records are derived into the other (round 5: one set
@@ -399,6 +403,21 @@ inline void drain_spans()                   // call after the stream has been sy
     }
     g->spans.clear();
     g->ev_used = 0;
+}
+
+// A few words from device memory to the host WITHOUT a copy command: a kernel stores them into the context's pinned flag array, the stream is
+// waited for, the host copies them out.  Round 6: copy commands to pageable host memory go through the runtime's bounce buffers and its copy-engine
+// path -- tens of microseconds each, and the place where one-off multi-millisecond stalls came from (profiles/r06/README.md).  n_words <= 64.
+inline int read_back_words(const void *dev_src, void *host_dst, uint32_t n_words, hipStream_t st)
+{
+    if (n_words == 0 || n_words > 64) { set_error("read_back_words: 1..64 words"); return PR_ERR_INVALID; }
+    PR_TRY(g->h_flags.ensure(256));
+    void *vd = nullptr;
+    HIP_TRY(hipHostGetDevicePointer(&vd, g->h_flags.p, 0));
+    HIP_TRY(prk::launch_copy_words32(dev_src, vd, n_words, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    std::memcpy(host_dst, g->h_flags.p, sizeof(uint32_t) * n_words);
+    return PR_OK;
 }
 
 inline void identity16(float *T) { for (int i = 0; i < 16; ++i) T[i] = (i % 5 == 0) ? 1.0f : 0.0f; }

@@ -14,9 +14,9 @@ namespace prr {
 int fingerprint_differs(const void *a, size_t ab, const void *b, size_t bb, const void *c, size_t cb, uint32_t *slot, hipStream_t st, bool &differs)
 {
     HIP_TRY(prk::launch_scene_fingerprint_full(a, ab, b, bb, c, cb, slot + 3, st));
-    uint32_t v[2] = { 0, 1 };
-    HIP_TRY(hipMemcpyAsync(v, slot + 2, sizeof v, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    // both words come back through a kernel's stores into pinned memory (no copy command on the per-batch path: see icp_drive's result block)
+    uint32_t v[2] = { 0u, 1u };
+    PR_TRY(read_back_words(slot + 2, v, 2, st));
     differs = v[0] != v[1];
     return PR_OK;
 }
@@ -48,8 +48,7 @@ int ensure_packed(PackedCache &pc, const pr_scene_proj &s, uint32_t tl_x, uint32
     HIP_TRY(prk::launch_scene_fingerprint(s.pcd, n * sizeof(pr_vec3), s.normal, n * sizeof(pr_vec3), nullptr, 0, exact_dev + 1, nullptr, false, st));
     HIP_TRY(prk::launch_scene_fingerprint_full(s.pcd, n * sizeof(pr_vec3), s.normal, n * sizeof(pr_vec3), nullptr, 0, exact_dev + 3, st));
     uint32_t exact = 0;
-    HIP_TRY(hipMemcpyAsync(&exact, exact_dev, sizeof exact, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    PR_TRY(read_back_words(exact_dev, &exact, 1, st));
     pc.pcd = s.pcd; pc.normal = s.normal; pc.w = s.width; pc.h = s.height; std::memcpy(pc.k, k, sizeof k); pc.tl[0] = tl_x; pc.tl[1] = tl_y;
     pc.gen = gen; pc.exact = exact != 0; pc.valid = true;
     return PR_OK;
@@ -145,8 +144,7 @@ int make_scene(int kind, const void *scene, bool want_packed, SceneSel &out, Pac
             for (uint32_t level = 0; ; level += 8) {
                 HIP_TRY(prk::launch_nn_wide_levels(nc.topo.as<int4>(), nc.bmin.as<float4>(), nc.bmax.as<float4>(), s->n_nodes, s->n_points, nc.nnwide.as<uint4>(),
                                                    nc.nnwq.as<uint32_t>(), nc.nndepth.as<uint32_t>(), level, 8, g->stream));
-                HIP_TRY(hipMemcpyAsync(nc.info, nc.nndepth.p, sizeof nc.info, hipMemcpyDeviceToHost, g->stream));
-                HIP_TRY(hipStreamSynchronize(g->stream));
+                PR_TRY(read_back_words(nc.nndepth.p, nc.info, (uint32_t)(sizeof nc.info / sizeof(uint32_t)), g->stream));
                 if (nc.info[8] != 2u) break;
                 if (level + 8 >= 64) { nc.info[8] = 0u; break; }    // (as before: more than 64 wide levels -> the binary records)
             }
@@ -190,8 +188,7 @@ int make_scene(int kind, const void *scene, bool want_packed, SceneSel &out, Pac
                 HIP_TRY(prk::launch_build_nn_grid(s->pcd, s->n_points, cam->w, cam->h, gk[0], gk[1], gk[2], gk[3], nc.nn_cells.as<int32_t>(),
                                                   nc.nn_grid.as<float4>(), flag, g->stream));
                 uint32_t usable = 0;
-                HIP_TRY(hipMemcpyAsync(&usable, flag, sizeof usable, hipMemcpyDeviceToHost, g->stream));
-                HIP_TRY(hipStreamSynchronize(g->stream));
+                PR_TRY(read_back_words(flag, &usable, 1, g->stream));
                 nc.grid_valid = true; nc.grid_usable = usable != 0; nc.gw = cam->w; nc.gh = cam->h; std::memcpy(nc.gk, gk, sizeof gk);
             }
             if (nc.grid_usable) {
@@ -223,8 +220,7 @@ int kd_build_dev(pr_vec3 *pcd, pr_vec3 *nrm, uint32_t n, int max_leaf, pr_kdnode
     uint32_t level = 0;
     for (uint32_t until = 12; ; until += 4) {
         for (; level < until; ++level) HIP_TRY(prk::launch_kd_level(w, nodes, cap32, pcd, n, max_leaf, level, g->stream));
-        HIP_TRY(hipMemcpyAsync(&ctrl, w.ctrl[level & 1u], sizeof ctrl, hipMemcpyDeviceToHost, g->stream));
-        HIP_TRY(hipStreamSynchronize(g->stream));
+        PR_TRY(read_back_words(w.ctrl[level & 1u], &ctrl, (uint32_t)(sizeof ctrl / sizeof(uint32_t)), g->stream));
         if (ctrl.error == 2u) { set_error("kd-tree build: a level holds more nodes than the work arrays were sized for (%u points, max_leaf %d) -- an internal bound, not the caller's capacity", n, max_leaf); return PR_ERR_INVALID; }
         if (ctrl.error) { set_error("kd-tree build: node capacity %u too small", cap32); return PR_ERR_NOMEM; }
         if (ctrl.done) break;
@@ -254,8 +250,7 @@ int scene_nn_prepare_dev_t(const T *depth, const float K[9], uint32_t W, uint32_
     HIP_TRY(prk::launch_nn_gather<T>(depth, W, H, K[0], K[4], K[2], K[5], full_nrm, g->row_count.as<uint32_t>(), g->row_off.as<uint32_t>(),
                                      g->counts.as<uint32_t>(), nullptr, nullptr, false, g->stream));
     uint32_t n = 0;
-    HIP_TRY(hipMemcpyAsync(&n, g->counts.p, sizeof n, hipMemcpyDeviceToHost, g->stream));
-    HIP_TRY(hipStreamSynchronize(g->stream));
+    PR_TRY(read_back_words(g->counts.p, &n, 1, g->stream));
     if (n_points) *n_points = n;
     if (n == 0) { if (n_nodes) *n_nodes = 0; return PR_OK; }
     HIP_TRY(prk::launch_nn_gather<T>(depth, W, H, K[0], K[4], K[2], K[5], full_nrm, g->row_count.as<uint32_t>(), g->row_off.as<uint32_t>(),

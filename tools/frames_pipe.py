@@ -6,6 +6,8 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
+import faulthandler, signal
+faulthandler.register(signal.SIGUSR1, all_threads=True)          # kill -USR1: where every thread is (a stuck run)
 from pose_refine_amd import api, synth
 W, H = 640, 480
 api.init(0); api.set_option("solve", 1)
@@ -75,15 +77,17 @@ for kind in ("proj", "nn"):
     # helper threads (private contexts: own stream and workspaces) prepare scenes ahead; the main thread only submits and waits
     import threading, queue
     for n_prod in (1, 2, 3):
-        n_obj = 2 + 2 * n_prod
+        n_obj = 3 * n_prod
         scenes4 = [api.Scene_projective() if kind == "proj" else api.Scene_nn() for _ in range(n_obj)]
         ready = [queue.Queue() for _ in range(n_prod)]
-        free = queue.Queue()
-        for i in range(n_obj): free.put(i)
+        # every producer has scene objects of its own (round 6: with ONE pool two quick producers could take every free object for frames that are not due
+        # yet and starve the one whose frame is -- the main thread then waits for ever; it showed once the preparation had lost its copy-command stalls)
+        free = [queue.Queue() for _ in range(n_prod)]
+        for i in range(n_obj): free[i % n_prod].put(i)
         def producer(pi):
             api.thread_context(True)
             for k in range(pi, N + 8, n_prod):
-                i = free.get()
+                i = free[pi].get()
                 s = scenes4[i]
                 if kind == "proj": s.init_Scene_projective_device(devs[k % len(devs)], K, W, H)
                 else: s.init_Scene_nn_device(devs[k % len(devs)], K, W, H)
@@ -100,7 +104,7 @@ for kind in ("proj", "nn"):
             held[k] = i
             if k:
                 api.refine_wait((k - 1) & 1)
-                free.put(held.pop(k - 1))
+                j = held.pop(k - 1); free[j % n_prod].put(j)
         api.refine_wait((N + 7) & 1)
         api.sync(); thr_ms = 1e3 * (time.perf_counter() - t0) / N
         for th in ths: th.join()
