@@ -61,19 +61,19 @@ BYTES_PER_POINT_PASS0, BYTES_PER_POINT_PASSK = 36.0, 48.0
 # L2s fetch from the fabric, Infinity-Cache hits included (guide, HBM section): the counter figure is FABRIC traffic, an upper bound of DRAM
 # traffic -- with <= 512 hypotheses per sub-batch the clouds are Infinity-Cache resident by design.
 PMC_TRAFFIC_BYTES_PER_POINT = {"proj": 25.1, "nn": 70.9}       # P = 1024 as ONE sub-batch (clouds spill the Infinity Cache): 23.9 B/point -- the same: it is the cloud read + write-back
-PMC_VALU_WAVE_INSTR_PER_POINT = {"proj": 2.085, "nn": None}
+PMC_VALU_WAVE_INSTR_PER_POINT = {"proj": 2.092, "nn": None}             # profiles/r06: 740 442 795 wave-instructions over 63 launches of 5 618 880 points
 # what DRAM carries when the clouds do NOT fit the Infinity Cache (1024 hypotheses as one sub-batch): committed fallback of the run's own passes
 PMC_DRAM_FRAC = {"proj": 0.52, "nn": None}
-PMC_DRAM_SOURCE = "committed: profiles/r05/pmc_proj_p1024_onebatch_*.md + kernel_stats_p1024_onebatch.md (23.8 B/point x 22.47 M points = 536 MB per 128.9 us launch = 4.16 TB/s)"
-# committed SQ counter passes of the kd-tree task walk, pass 0 (profiles/r05/sq_nn_pass0.txt): SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES = the share of a
+PMC_DRAM_SOURCE = "committed: profiles/r06/pmc_proj_p1024_onebatch_*.md + kernel_stats_p1024_onebatch.md (23.8 B/point x 22.47 M points = 536 MB per 128.9 us launch = 4.16 TB/s)"
+# committed SQ counter passes of the kd-tree task walk, pass 0 (profiles/r06/sq_nn_pass0.txt, unchanged from r05's): SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES = the share of a
 # wavefront's resident cycles with one of its VALU instructions in flight (six wavefronts share a SIMD), and 4 x SQ_ACTIVE_INST_VALU over
 # (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs) = the share of the chip's VALU issue slots the kernel fills
 NN_WALK_VALU_ACTIVE_FRAC = 0.21
 NN_WALK_VALU_ISSUE_FRAC = 0.75 * 6.144e11 / VALU_PEAK              # r05's 0.75 was against 6.14e11/s: 0.47 of the calibrated peak
-# committed SQ pass of the projective correspondence kernel (profiles/r05/sq_proj_SQ_ACTIVE_INST_VALU_SQ_WAVE_CYCLES_SQ_WAIT_INST_ANY.md): share of a
+# committed SQ pass of the projective correspondence kernel (profiles/r06/sq_proj_SQ_ACTIVE_INST_VALU_SQ_WAVE_CYCLES_SQ_WAIT_INST_ANY.md): share of a
 # wavefront's resident cycles spent waiting for an instruction's operands (SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES)
-PROJ_PASS_WAIT_FRAC = 0.31
-NN_WALK_HBM_BYTES_PER_POINT = 4.6                                  # profiles/r05/pmc_nn_*.md: the walk reads queue entries + cloud points, writes winners
+PROJ_PASS_WAIT_FRAC = 0.307
+NN_WALK_HBM_BYTES_PER_POINT = 4.6                                  # profiles/r06/pmc_nn_*.md (2 x 589 970 + 428 381 KB over 63 passes of 5.62 M points): the walk reads queue entries + cloud points, writes winners
 PMC_TRAFFIC_SOURCE = {"proj": "profiles/r06/pmc_proj_FETCH_SIZE.md + pmc_proj_WRITE_SIZE.md + sq_proj_SQ_INSTS_VALU*.md (icp_pass_kernel<SceneProjPacked>)",
                       "nn": "profiles/r06/pmc_nn_FETCH_SIZE.md + pmc_nn_WRITE_SIZE.md (search 37.1 + bound 11.2 + task walk 4.6 + winners pass 17.9 B/point)"}
 
@@ -669,7 +669,7 @@ def run_rank(args, group, local_dev, share_device, launcher_note, comm_ready, co
                                                        + ("are unchanged since that pass" if profiled_ok else "HAVE CHANGED since that pass: the figure is stale until the SQ pass is repeated"),
                    "valu_constants_stale": (not profiled_ok),
                    "dram_frac_counter": frac_dram, "dram_frac_counter_source": dram_note,
-                   "wait_frac": PROJ_PASS_WAIT_FRAC, "wait_frac_source": "committed: SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES of icp_pass_kernel<SceneProjPacked> (1.06e9 of 3.46e9)",
+                   "wait_frac": PROJ_PASS_WAIT_FRAC, "wait_frac_source": "committed: profiles/r06/sq_proj_SQ_ACTIVE_INST_VALU_SQ_WAVE_CYCLES_SQ_WAIT_INST_ANY.md, SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES of icp_pass_kernel<SceneProjPacked> (1.07e9 of 3.48e9)",
                    "note": "a lane keeps four scene gathers in flight; 16 wavefronts per CU; the kernel saturates neither VALU issue nor DRAM"}
     else:
         binding = {"verdict": "latency (cache-resident search: HBM carries only clouds and winners)", "valu_issue_frac_walk_pass0": NN_WALK_VALU_ISSUE_FRAC,
@@ -795,7 +795,7 @@ def run_rank(args, group, local_dev, share_device, launcher_note, comm_ready, co
 # sha256 (first 16 hex digits) of the sources of icp_pass_kernel<SceneProjPacked> at the time the committed SQ / PMC constants above were measured:
 # when the kernel's sources change, the line says that the VALU figures are stale instead of presenting them as measured
 PMC_PROFILED_SOURCES = ("icp_pass.hip", "icp_accumulate.h", "proj_query.h", "icp_solve_device.h", "pr_tuning.h")
-PMC_PROFILED_HASH = "e5b8646c2f4d590e"
+PMC_PROFILED_HASH = "731c5cbf49b0a38f"
 
 
 def pmc_sources_hash():
@@ -980,7 +980,7 @@ def kdtree_extra(args, api, model, poses, scene_depth, W, H, proj, K, steps=20):
                 "frac": NN_WALK_VALU_ISSUE_FRAC, "frac_of": "VALU issue slots of the chip in pass 0 (the binding resource by the SQ counters; committed pass, see valu_active_frac_source)",
                 "valu_issue_frac": NN_WALK_VALU_ISSUE_FRAC,
                 "valu_active_frac": NN_WALK_VALU_ACTIVE_FRAC,
-                "valu_active_frac_source": "committed: profiles/r05/sq_nn_pass0.txt (nn_tree_wide_kernel, pass 0 of a 256-hypothesis batch: SQ_ACTIVE_INST_VALU 5.39e8, SQ_WAVE_CYCLES 2.6e9, GRBM_GUI_ACTIVE 2.2e7 over 8 XCDs)",
+                "valu_active_frac_source": "committed: profiles/r06/sq_nn_pass0.txt (nn_tree_wide_kernel, pass 0 of a 256-hypothesis batch: SQ_ACTIVE_INST_VALU 5.39e8, SQ_WAVE_CYCLES 2.6e9, GRBM_GUI_ACTIVE 2.2e7 over 8 XCDs)",
                 # HBM side of the task walk alone: committed counter bytes per cloud point x this batch's points over this run's launch time
                 "hbm_GBps": (NN_WALK_HBM_BYTES_PER_POINT * pts / walk_s / 1e9) if walk_s > 0 else None,
                 "hbm_frac": (NN_WALK_HBM_BYTES_PER_POINT * pts / walk_s / HBM_PEAK) if walk_s > 0 else None,

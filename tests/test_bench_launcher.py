@@ -162,10 +162,11 @@ def test_bench_force_comm_runs_the_rccl_gather_with_a_world_of_one():
 
 
 def test_committed_bench_lines_keep_the_contract():
-    """The round's committed bench lines (profiles/r05/, written by tools/gpu_round.sh on the GPU box): the contract's keys, a `roofline.frac` that
-    is a fraction (the binding resource, never above 1), the §8d score next to it, `cpu_baseline` on the one-rank line."""
+    """The round's committed bench lines (profiles/r06/, written by tools/gpu_round.sh on the GPU box): the contract's keys; `roofline` as the contract
+    words it (bound "hbm", achieved = SURVEY 8d's algorithmic GB/s, peak 8000, frac = achieved / peak) with the counters' verdict in
+    `roofline.binding` against the CALIBRATED VALU peak; `cpu_baseline` on the one-rank line; the workloads VERDICT r05 missed in the N = 1 line."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r05", "bench_*.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r06", "bench_*.json")))
     assert len(files) >= 10
     for f in files:
         d = json.loads(open(f).read().strip().splitlines()[-1])
@@ -173,11 +174,22 @@ def test_committed_bench_lines_keep_the_contract():
             assert key in d, (f, key)
         assert d["unit"] == "poses/s" and d["dtype"] == "f32" and d["vs_baseline"] is None and "workload" in d["config"]
         r = d["roofline"]
-        for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "frac_algorithmic", "frac_end_to_end"):
+        for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "frac_algorithmic", "frac_end_to_end", "binding"):
             assert key in r, (f, key)
-        assert 0.0 <= r["frac"] <= 1.0, (f, r["frac"])
+        assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+        assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.0 < r["frac"] < 1.2, (f, r["frac"])      # (above 1 at 512+ hypotheses per batch: 8d charges more bytes than the packed scene moves)
+        assert r["binding"]["valu_peak_wave_instr_per_s"] == 0.977e12 and "valu_peak.md" in r["binding"]["valu_peak_source"]
         assert abs(d["value"] * d["ms_per_step"] * 1e-3 - d["config"]["global_batch"]) < 1e-3 * d["config"]["global_batch"]      # value = hypotheses of a step / its time
-    head = json.loads(open(os.path.join(ROOT, "profiles", "r05", "bench_p256_proj_steps20.json")).read())
+    head = json.loads(open(os.path.join(ROOT, "profiles", "r06", "bench_p256_proj_steps20.json")).read())
     assert head["n_gpus"] == 1 and head["steps"] == 20 and head["warmup"] == 5
+    assert head["roofline"]["binding"]["verdict"] == "latency" and 0.2 < head["roofline"]["binding"]["valu_issue_frac"] < 0.45
+    assert head["roofline"]["binding"]["valu_constants_stale"] is False
     assert head["cpu_baseline"]["kind"] == "port" and head["cpu_baseline"]["cores"] >= 1 and "sample" in head["cpu_baseline"]
     assert {"projective", "kdtree"} <= set(head["default_criteria"]) and "north_star_solve_on_host" in head["config"]
+    for key in ("config3_share_512", "config4_share_128", "config2_kdtree", "solve_on_host"):
+        assert len(head[key]["segments_poses_per_s"]) == 3 and head[key]["value"] > 0, key
+    assert head["config4_share_128"]["poses_per_gpu"] == 128 and head["config3_share_512"]["poses_per_gpu"] == 512
+    loop = json.loads(open(os.path.join(ROOT, "profiles", "r06", "bench_8ranks_loopback_gather_threads.json")).read())
+    assert loop["n_gpus"] == 8 and loop["gather"].startswith("pr_gather_results") and "loop-back" in loop["gather"]
+    g = json.loads(open(os.path.join(ROOT, "profiles", "r06", "gather_loopback_8ranks.json")).read())
+    assert g["world"] == 8 and all(c["ok"] for c in g["cases"]) and g["refine"]["bit_identical_to_unsharded"] and g["errors"] == []
