@@ -235,7 +235,8 @@ int icp_drive(pr_vec3 *cloud_base, const uint32_t *start_h, const uint32_t *coun
     // Projective scenes also read the per-hypothesis state (64 bytes: cloud span, pending update) from the pinned host array instead
     // of receiving it through a copy command: one uniform load per workgroup over the host link, 1.62 -> 1.54 ms per 256-hypothesis
     // batch.  The four kernels of a kd-tree pass have ten times the workgroups; there the copy is cheaper (8.3 against 8.8 ms).
-    const prk::PoseMeta *meta_dev = nullptr;
+    const prk::PoseMeta *meta_dev = nullptr, *h_meta_mapped = nullptr;          // h_meta as the device sees it
+    HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(const_cast<prk::PoseMeta **>(&h_meta_mapped)), h_meta, 0));
     if (host_fused && sc.kind != PR_SCENE_NN) HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(const_cast<prk::PoseMeta **>(&meta_dev)), h_meta, 0));
     // Round 6: the host waits for a pose group's FLAG in pinned memory (stored by the workgroup that delivers the group's last
     // hypothesis) instead of for the stream -- it solves while the launch winds down.  Option blocking_wait (several ranks sharing few CPUs) and
@@ -249,7 +250,7 @@ int icp_drive(pr_vec3 *cloud_base, const uint32_t *start_h, const uint32_t *coun
         hipStream_t st = group_stream(grp);
         prk::IcpBatch bb = b;
         if (meta_dev) bb.meta = meta_dev;                            // the pass reads the 64-byte state of its hypothesis from the pinned host array
-        else HIP_TRY(hipMemcpyAsync(g->meta.as<prk::PoseMeta>() + p0, h_meta + p0, sizeof(prk::PoseMeta) * np, hipMemcpyHostToDevice, st));
+        else HIP_TRY(prk::launch_stage_words(h_meta_mapped + p0, g->meta.as<prk::PoseMeta>() + p0, sizeof(prk::PoseMeta) * np, st));   // (pulled by a kernel: no copy command per iteration)
         bb.meta += p0; bb.partial += (size_t)p0 * nblk * prk::kAccStride; if (bb.nn_qcount) bb.nn_qcount += prk::kQCountStride * (size_t)p0;
         bb.iter = it;
         if (host_fused) { bb.fused = 2; bb.arrive = g->arrive.as<uint32_t>() + p0; bb.sums_out = sums_dev + (size_t)p0 * prk::kAccStride; }

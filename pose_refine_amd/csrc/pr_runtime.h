@@ -167,7 +167,7 @@ inline uint32_t pose_groups_for(int scene_kind) { (void)scene_kind; return opt.p
 
 // packed projective scene (one 16-byte record per pixel + the two back-projection tables) of the latest scene it was built for
 struct PackedCache {
-    DevBuf rec;                      // [n] float4, colf[w], rowf[h], exact flag (uint32), sampled fingerprint of the source arrays (uint32)
+    DevBuf rec;                      // [n] float4, colf[w], rowf[h], then five words: exact flag, sampled fingerprint of the source arrays, its verdict, full fingerprint, a call's full fingerprint
     const void *pcd = nullptr, *normal = nullptr;
     uint64_t w = 0, h = 0; float k[4] = { 0, 0, 0, 0 }; uint32_t tl[2] = { 0, 0 };
     uint64_t gen = 0;

@@ -39,7 +39,7 @@ int ensure_packed(PackedCache &pc, const pr_scene_proj &s, uint32_t tl_x, uint32
     pc.valid = false;
     const uint64_t gen = g_writes.now();
     const size_t tables = ((s.width + s.height) * sizeof(float) + 15) & ~(size_t)15;
-    PR_TRY(pc.rec.ensure(n * sizeof(float4) + tables + 16));
+    PR_TRY(pc.rec.ensure(n * sizeof(float4) + tables + 32));      // behind the tables: [0] exact flag [1] sampled fingerprint [2] its verdict (asynchronous check) [3] full fingerprint [4] a call's full fingerprint
     float *colf = reinterpret_cast<float *>(pc.rec.as<float4>() + n);
     float *rowf = colf + s.width;
     uint32_t *exact_dev = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(colf) + tables);
