@@ -224,6 +224,9 @@ __device__ __forceinline__ float vb_reduce(float (&acc)[29], float (*wsum)[kAccS
 {
     constexpr int kFirst = kScoreOnly ? 27 : 0;                  // score-only passes carry zeros in sums 0..26
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#if PR_PASS_TAIL_PRIO
+    __builtin_amdgcn_s_setprio(PR_PASS_TAIL_PRIO);               // a wavefront in its reduction tail goes first: its workgroup retires sooner and frees its slots
+#endif
     if constexpr (!kScoreOnly) {
         // Same balanced pairwise tree, but after every level the live partial sums of two registers are interleaved into one
         // (a level's results sit in the upper half of each 2^k-lane group; the lower half is free to carry another sum's

@@ -10,10 +10,13 @@
 
 // ---- correspondence pass (icp_pass.hip) --------------------------------------------------------------------------------------------
 #ifndef PR_PASS_WAVES
-#define PR_PASS_WAVES 1                                         // __launch_bounds__ minimum waves per SIMD of icp_pass_kernel: 4, 5, 6 waves ran within 2 % of each other; the compiler's own choice wins
+#define PR_PASS_WAVES 1                                         // __launch_bounds__ minimum waves per SIMD of icp_pass_kernel: 4, 5 waves run within 0.2 % of the compiler's own choice (round 6: 277.8 / 277.1 k against 278.0 / 277.5 k); 6 spills the accumulators: 162 k
 #endif
 #ifndef PR_PASS_PREFETCH
 #define PR_PASS_PREFETCH 0                                      // 1: the next 1024-point step's cloud points are loaded before this step's gathers are consumed (12 more VGPRs: 106, four waves per SIMD).  Same box: 262 k against 274 k poses/s -- not kept
+#endif
+#ifndef PR_PASS_TAIL_PRIO
+#define PR_PASS_TAIL_PRIO 0                                     // s_setprio of a wavefront that has entered the reduction tail of icp_pass_kernel (0: none).  Round 6, same box, 100 steps x 2: priority 3 278.3 / 278.3 k against 278.0 / 277.5 k poses/s -- inside the noise, not kept
 #endif
 #ifndef PR_GATHER_BATCH
 #define PR_GATHER_BATCH 4                                       // projective scene gathers issued back to back before the first is tested (all four points of a lane)
