@@ -1126,6 +1126,7 @@ def host_solve_extra(args, api, model, poses, W, H, proj, K, scene, steps=30):
         api.set_option("solve", api.SOLVE_DEVICE)
     out = {"value": len(poses) / dt, "unit": "poses/s", "ms_per_step": dt * 1e3, "steps": steps, "host_threads": "1 (+2 library: one helper thread per slot)",
            "segments_poses_per_s": [len(poses) / d for d in seg], "value_is": "the median of three consecutive segments of `steps` pipelined steps",
+           "group_flags_that_overtook_a_row": int(api.get_option("stat_flag_overtook")),     # (expected 0: the library then waits for the stream instead)
            "note": "PR_SOLVE_HOST, batches pipelined through pr_refine_submit / pr_refine_wait on the two slots from one caller thread; each slot's helper thread runs its batch: 21 launches per pose group (two groups on two streams, software-pipelined: the host solves one group while the other group's pass runs); the workgroup that delivers a hypothesis' last partial sum stores its 29 totals straight into pinned host memory, the one that completes the pose group stores the group's flag behind them; the host polls that flag (round 6: not the stream), solves (pivoted LDLT in double, as Eigen) and the next pass reads the update from the pinned array",
            "one_synchronous_call_per_step": {"value": len(poses) / dt_sync, "unit": "poses/s", "ms_per_step": dt_sync * 1e3, "steps": steps,
                                              "note": "pr_refine_batch in a loop: nothing of batch k+1 can start before batch k has returned"}}

@@ -223,8 +223,15 @@ __device__ __forceinline__ bool pass_deliver(const IcpBatch &b, uint32_t pose, u
         // memory -- behind every hypothesis' sums (each was acknowledged before its count).  The host then solves the group while the launch is still
         // winding down (the end-of-kernel write-back of the clouds it moved), instead of waiting for the stream.  Plain write-through stores: a release
         // at system scope would write the whole L2 back per hypothesis (measured: 82 k instead of 234 k poses/s).
+        // Each row also carries the tag (word 31), stored by the wavefront that stored the row's sums, after them: the host checks it when it has seen the
+        // group's flag -- a flag that overtook a row on the way to host memory (writes of different compute units, in principle re-orderable by the
+        // fabric) is noticed there and costs a stream wait, never a solve on stale sums.
         if (b.grp_flag) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if PR_HOST_ROW_TAG
+            if (threadIdx.x == 0) st_sys_u32(reinterpret_cast<uint32_t *>(b.sums_out + (size_t)pose * kAccStride) + 31, b.iter + 1u);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
             if (threadIdx.x == 0 && atomicAdd(b.grp_count, 1u) + 1u == b.grp_expected) { st_sys_u32(b.grp_count, 0u); st_sys_u32(b.grp_flag, b.iter + 1u); }
         }
         return true;

@@ -53,6 +53,7 @@ void trace_mark(const char *tag)
 }
 
 WriteLog g_writes;
+std::atomic<uint64_t> g_flag_overtook{ 0 };
 Options opt;
 std::mutex g_reg_mu;
 std::vector<Ctx *> g_shared;         // index = device ordinal
@@ -336,6 +337,7 @@ int pr_get_option(const char *name, int *value)
     else if (n == "nn_grid") *value = opt.nn_grid;
     else if (n == "nn_count") *value = opt.nn_count;
     else if (n == "host_poll") *value = opt.host_poll;
+    else if (n == "stat_flag_overtook") *value = (int)std::min<uint64_t>(g_flag_overtook.load(), 0x7fffffffull);   // read-only
     else if (n == "raster_mode") *value = opt.raster_mode;
     else if (n == "eager_streams") *value = opt.eager_streams;
     else if (n == "graph") *value = opt.use_graph;

@@ -243,7 +243,7 @@ int icp_drive(pr_vec3 *cloud_base, const uint32_t *start_h, const uint32_t *coun
     // host_poll = 0 keep the stream wait.
     const bool poll_flag = host_fused && !opt.blocking_wait && opt.host_poll;
     volatile uint32_t *h_flags = reinterpret_cast<volatile uint32_t *>(h_sums + (size_t)P * prk::kAccStride);
-    if (poll_flag) for (int k = 0; k < 4; ++k) h_flags[k] = 0u;
+    if (poll_flag) { for (int k = 0; k < 4; ++k) h_flags[k] = 0u; for (uint32_t i = 0; i < P; ++i) reinterpret_cast<volatile uint32_t *>(h_sums + (size_t)i * prk::kAccStride)[31] = 0u; }
     // one iteration of one group goes onto its stream: state upload, pass, block sums -> pose sums, download
     auto enqueue_group = [&](uint32_t grp, uint32_t it) -> int {
         const uint32_t p0 = group_begin(grp), np = group_begin(grp + 1) - p0;
@@ -310,6 +310,18 @@ int icp_drive(pr_vec3 *cloud_base, const uint32_t *start_h, const uint32_t *coun
                     else if (q != hipErrorNotReady) { (void)hipGetLastError(); set_error("HIP error: %s", hipGetErrorString(q)); return -1; }
                 }
                 __builtin_ia32_pause();
+            }
+            std::atomic_thread_fence(std::memory_order_acquire);
+            // every row that was due carries the iteration's tag behind its sums (pass_deliver): a row without it was overtaken by the flag -- wait for the
+            // stream (the end of the launch makes everything visible) instead of solving on stale sums
+            bool all_in = true;
+#if PR_HOST_ROW_TAG
+            for (uint32_t i = group_begin(grp); i < group_begin(grp + 1) && all_in; ++i)
+                if (h_meta[i].state != prk::kSkip && reinterpret_cast<volatile uint32_t *>(h_sums + (size_t)i * prk::kAccStride)[31] != tag) all_in = false;
+#endif
+            if (!all_in) {
+                g_flag_overtook.fetch_add(1);
+                if (hipError_t e = hipStreamSynchronize(group_stream(grp)); e != hipSuccess) { set_error("HIP error: %s", hipGetErrorString(e)); return -1; }
             }
             std::atomic_thread_fence(std::memory_order_acquire);
         }

@@ -119,6 +119,7 @@ struct WriteLog {
     }
 };
 extern WriteLog g_writes;
+extern std::atomic<uint64_t> g_flag_overtook;     // PR_SOLVE_HOST: group flags that reached the host before all of their rows (process-wide; expected 0; read-only option "stat_flag_overtook")
 
 // ---- process-wide options (pr_set_option): plain ints, shared by every context ---------------------
 constexpr int kSlots = PR_SLOTS;            // asynchronous slots per context (pr_tuning.h)

@@ -15,6 +15,9 @@
 #ifndef PR_PASS_PREFETCH
 #define PR_PASS_PREFETCH 0                                      // 1: the next 1024-point step's cloud points are loaded before this step's gathers are consumed (12 more VGPRs: 106, four waves per SIMD).  Same box: 262 k against 274 k poses/s -- not kept
 #endif
+#ifndef PR_HOST_ROW_TAG
+#define PR_HOST_ROW_TAG 1                                        // PR_SOLVE_HOST with group flags: every row also carries the iteration's tag behind its sums, checked by the host (a flag that overtook a row costs a stream wait, never a wrong solve)
+#endif
 #ifndef PR_PASS_TAIL_PRIO
 #define PR_PASS_TAIL_PRIO 0                                     // s_setprio of a wavefront that has entered the reduction tail of icp_pass_kernel (0: none).  Round 6, same box, 100 steps x 2: priority 3 278.3 / 278.3 k against 278.0 / 277.5 k poses/s -- inside the noise, not kept
 #endif

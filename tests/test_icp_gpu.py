@@ -228,3 +228,34 @@ def test_host_solve_sampled_call_times_one_pass(gpu, model, scenario, gscenes):
         api.set_option("profile", 0); api.set_option("sample_period", 32); api.set_option("solve", api.SOLVE_DEVICE)
     assert all(g[0].tobytes() == ref[0].tobytes() for g in got)
     assert prof["icp_launches"] == 2 and prof["icp_points"] == 2 * int(ref[1].sum()) and prof["icp_kernel_ms"] > 0
+
+
+@pytest.mark.parametrize("kind", ["proj", "nn"])
+def test_host_solve_flag_polling_equals_the_stream_wait(gpu, model, scenario, gscenes, kind):
+    """Round 6: with the solve on the host the helper polls ONE flag per pose group in pinned memory (stored by the workgroup that completes the group,
+    behind every hypothesis' sums) instead of waiting for the stream.  Records are identical with the polling on and off (option host_poll), through the
+    synchronous call and through the slots' helper threads, fixed and early-exit criteria; and no flag ever reached the host before one of its rows
+    (each row carries the iteration's tag behind its sums; the library would fall back to the stream wait and count it)."""
+    K, proj = scenario["K"], scenario["proj"]
+    poses = synth.hypotheses(150, seed=9)
+    poses[5] = poses[5].copy(); poses[5].reshape(4, 4)[0, 3] += 1.0e6          # an empty cloud: a hypothesis that never delivers
+    got = {}
+    try:
+        api.set_option("solve", api.SOLVE_HOST)
+        for poll in (1, 0):
+            api.set_option("host_poll", poll)
+            for crit in ((0.0, 0.0, 12), (1e-5, 1e-5, 30)):
+                c = api.ICPConvergenceCriteria(*crit)
+                sync = api.refine_batch(model, poses, W, H, proj, K, gscenes[kind], c)
+                for k in range(3):
+                    api.refine_submit(k & 1, model, poses, W, H, proj, K, gscenes[kind], c)
+                    if k:
+                        slot = api.refine_wait((k - 1) & 1)
+                        assert slot[0].tobytes() == sync[0].tobytes() and np.array_equal(slot[1], sync[1])
+                api.refine_wait(0)
+                got[(poll, crit)] = sync
+        for crit in ((0.0, 0.0, 12), (1e-5, 1e-5, 30)):
+            assert got[(1, crit)][0].tobytes() == got[(0, crit)][0].tobytes()
+        assert api.get_option("stat_flag_overtook") == 0
+    finally:
+        api.set_option("host_poll", 1); api.set_option("solve", api.SOLVE_HOST)
