@@ -976,7 +976,7 @@ def kdtree_extra(args, api, model, poses, scene_depth, W, H, proj, K, steps=20):
                 "avg_launch_us": 1e3 * part_ms[k] / n_pass, "share_of_step": part_ms[k] / step_ms if step_ms > 0 else None,
                 "per_kernel_ms_per_step": {n: float(v) for n, v in zip(names, part_ms)}, "passes": int(n_pass), "one_group_step_ms": step_ms,
                 "first_passes_us": [float(v) for v in pass_us[:4]],
-                "bound": "valu issue (pass 0: 0.75 of the chip's VALU issue slots, 539 M wave-instructions for 5.4 M tree searches; a wavefront has a VALU instruction in flight 21 % of its resident cycles, six share a SIMD; HBM ~ 0)",
+                "bound": "valu issue + latency (pass 0: 0.47 of the CALIBRATED VALU issue peak -- about 0.6 with its half-rate instructions counted double; rounds 4-5 wrote 0.75 against a peak 1.6x too low -- 539 M wave-instructions for 5.4 M tree searches; a wavefront has a VALU instruction in flight 21 % of its resident cycles, six share a SIMD; HBM ~ 0)",
                 "frac": NN_WALK_VALU_ISSUE_FRAC, "frac_of": "VALU issue slots of the chip in pass 0 (the binding resource by the SQ counters; committed pass, see valu_active_frac_source)",
                 "valu_issue_frac": NN_WALK_VALU_ISSUE_FRAC,
                 "valu_active_frac": NN_WALK_VALU_ACTIVE_FRAC,
