@@ -15,6 +15,9 @@
 #ifndef PR_PASS_PREFETCH
 #define PR_PASS_PREFETCH 0                                      // 1: the next 1024-point step's cloud points are loaded before this step's gathers are consumed (12 more VGPRs: 106, four waves per SIMD).  Same box: 262 k against 274 k poses/s -- not kept
 #endif
+// (Round 6, measured and not kept: the cloud points of a workgroup's steps 1 and 2 requested up front straight into LDS -- global_load_lds_dwordx3, 24 KB per workgroup, no registers in
+// flight -- so that a workgroup's chain loses two of its three dependent trips for cloud points: 103 VGPRs / four waves per SIMD, or 96 with a spill at five; a lone 256-hypothesis launch
+// 43.1 / 43.4 against 38.5 us, pipelined 256-258 k / 263-265 k against 275 k poses/s, same box, three rounds.  The LDS-DMA path lands 768-byte pieces slower than plain loads return.)
 #ifndef PR_HOST_ROW_TAG
 #define PR_HOST_ROW_TAG 1                                        // PR_SOLVE_HOST with group flags: every row also carries the iteration's tag behind its sums, checked by the host (a flag that overtook a row costs a stream wait, never a wrong solve)
 #endif
