@@ -795,7 +795,7 @@ def run_rank(args, group, local_dev, share_device, launcher_note, comm_ready, co
 # sha256 (first 16 hex digits) of the sources of icp_pass_kernel<SceneProjPacked> at the time the committed SQ / PMC constants above were measured:
 # when the kernel's sources change, the line says that the VALU figures are stale instead of presenting them as measured
 PMC_PROFILED_SOURCES = ("icp_pass.hip", "icp_accumulate.h", "proj_query.h", "icp_solve_device.h", "pr_tuning.h")
-PMC_PROFILED_HASH = "d7ac6139553db89c"
+PMC_PROFILED_HASH = "952a3677bb94811d"
 
 
 def pmc_sources_hash():

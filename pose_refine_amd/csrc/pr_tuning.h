@@ -18,6 +18,14 @@
 // (Round 6, measured and not kept: the cloud points of a workgroup's steps 1 and 2 requested up front straight into LDS -- global_load_lds_dwordx3, 24 KB per workgroup, no registers in
 // flight -- so that a workgroup's chain loses two of its three dependent trips for cloud points: 103 VGPRs / four waves per SIMD, or 96 with a spill at five; a lone 256-hypothesis launch
 // 43.1 / 43.4 against 38.5 us, pipelined 256-258 k / 263-265 k against 275 k poses/s, same box, three rounds.  The LDS-DMA path lands 768-byte pieces slower than plain loads return.)
+// (Round 6, what the cloud's write-back costs the projective pass and what deferring it returns -- measured, not kept.  TIMING ONLY, results wrong: the pass without its
+// stores runs 32.5 against 38.4 us per 256-hypothesis launch and the pipeline 315 k against 277 k poses/s -- the 12 bytes per point written back are a sixth of the launch.
+// Bit-identical form: the updates of a hypothesis kept in a ring of K records, the cloud stored on every K-th pass only, the passes between applying the updates since
+// the last store one after the other in registers (the reference's own operations, so every point is the same float): K = 2 / 3 / 4 / 5 -> 268-283 / 279-281 / 274 / 269 k
+// against 274-276 k for K = 1 in the same build and 277-279 k for the present code -- the chain's extra transforms (14 issue slots each) and scalar loads give back what
+// the stores saved: the kernel behaves as the SUM of its parts (a wavefront issues a VALU instruction every 4.75 cycles at best and two are rarely ready at once).
+// More wavefronts by force: 6 per SIMD with two gathers in flight per lane (8 spilled registers) 256-268 k, one gather 235-248 k, 7 per SIMD 217-241 k; two gathers at
+// five wavefronts 270-276 k.  Five wavefronts, four gathers, every pass writing back stays.)
 #ifndef PR_HOST_ROW_TAG
 #define PR_HOST_ROW_TAG 1                                        // PR_SOLVE_HOST with group flags: every row also carries the iteration's tag behind its sums, checked by the host (a flag that overtook a row costs a stream wait, never a wrong solve)
 #endif
