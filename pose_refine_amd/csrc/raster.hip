@@ -92,6 +92,17 @@ __device__ __forceinline__ bool tri_fragment(const float px[3], const float py[3
     alpha = 1.0f - beta - gamma;
     return !(alpha < -0.0f || beta < -0.0f || gamma < -0.0f || alpha > 1.0f || beta > 1.0f || gamma > 1.0f);
 }
+// the same test with the triangle's two edge vectors from vertex 0 formed once per triangle (e1 = p1 - p0, e2 = p2 - p0: the very subtractions area2 makes per
+// pixel, so every product and difference below is the same float as in tri_fragment)
+__device__ __forceinline__ bool tri_fragment_edges(float px0, float py0, float e1x, float e1y, float e2x, float e2y, float base_inv, int x, int y,
+                                                   float &alpha, float &beta, float &gamma)
+{
+    const float dx = (float)x - px0, dy = (float)y - py0;
+    beta  = 0.5f * (e2x * dy - dx * e2y) * base_inv;               // area2(p0, f, p2) * base_inv
+    gamma = 0.5f * (dx * e1y - e1x * dy) * base_inv;               // area2(p0, p1, f) * base_inv
+    alpha = 1.0f - beta - gamma;
+    return !(alpha < -0.0f || beta < -0.0f || gamma < -0.0f || alpha > 1.0f || beta > 1.0f || gamma > 1.0f);
+}
 __device__ __forceinline__ int fragment_depth(float alpha, float beta, float gamma, float w0, float w1, float w2)
 {
     const float az = alpha / w0, bz = beta / w1, gz = gamma / w2;
@@ -119,7 +130,7 @@ __device__ __forceinline__ void wave_raster(const TriSetup &t, int n, float (*w)
     const int excl = incl - n;
     const int total = __shfl(incl, 63);
 
-    w[0][lane] = t.px[0]; w[1][lane] = t.py[0]; w[2][lane] = t.px[1]; w[3][lane] = t.py[1]; w[4][lane] = t.px[2]; w[5][lane] = t.py[2];
+    w[0][lane] = t.px[0]; w[1][lane] = t.py[0]; w[2][lane] = t.px[1] - t.px[0]; w[3][lane] = t.py[1] - t.py[0]; w[4][lane] = t.px[2] - t.px[0]; w[5][lane] = t.py[2] - t.py[0];
     w[6][lane] = t.w3[0]; w[7][lane] = t.w3[1]; w[8][lane] = t.w3[2]; w[9][lane] = t.base_inv;
     w[10][lane] = __int_as_float(t.x0); w[11][lane] = __int_as_float(t.y0); w[12][lane] = __int_as_float(t.nx > 0 ? t.nx : 1);
     w[13][lane] = __int_as_float(excl);
@@ -128,14 +139,19 @@ __device__ __forceinline__ void wave_raster(const TriSetup &t, int n, float (*w)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
+    // The owner of candidate c = the last triangle whose run starts at or before c.  Round 6: instead of a six-step search over the scanned offsets (six
+    // dependent LDS reads per candidate), the triangles whose runs start inside the current window of 64 candidates mark their first slot with lane + 1
+    // and an inclusive maximum over the lanes (four row shifts + two row broadcasts, no LDS) carries each mark to the end of its run; a run that began in
+    // an earlier window arrives through `carry`, the owner of that window's last candidate.
+    uint32_t *mark = queue + 128;
+    int carry = 0;
     int qn = 0;                                                    // wave-uniform fill level, < 64 between iterations
     auto drain = [&](int first, int count) {
         if ((int)lane < count) {
             const uint32_t e = queue[first + lane];
             const int o = (int)(e >> 26), x = (int)((e >> 13) & 0x1fffu), y = (int)(e & 0x1fffu);
-            const float px[3] = { w[0][o], w[2][o], w[4][o] }, py[3] = { w[1][o], w[3][o], w[5][o] };
             float alpha, beta, gamma;
-            (void)tri_fragment(px, py, w[9][o], x, y, alpha, beta, gamma);
+            (void)tri_fragment_edges(w[0][o], w[1][o], w[2][o], w[3][o], w[4][o], w[5][o], w[9][o], x, y, alpha, beta, gamma);
             sink(x, y, fragment_depth(alpha, beta, gamma, w[6][o], w[7][o], w[8][o]));
         }
     };
@@ -143,10 +159,23 @@ __device__ __forceinline__ void wave_raster(const TriSetup &t, int n, float (*w)
         const int c = c0 + (int)lane;
         bool pass = false;
         uint32_t entry = 0;
+        mark[lane] = 0u;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (n > 0 && excl >= c0 && excl < c0 + 64) mark[excl - c0] = lane + 1u;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        int own = (int)mark[lane];
+        own = max(own, __builtin_amdgcn_update_dpp(0, own, 0x111, 0xf, 0xf, true));      // row_shr:1
+        own = max(own, __builtin_amdgcn_update_dpp(0, own, 0x112, 0xf, 0xf, true));      // row_shr:2
+        own = max(own, __builtin_amdgcn_update_dpp(0, own, 0x114, 0xf, 0xf, true));      // row_shr:4
+        own = max(own, __builtin_amdgcn_update_dpp(0, own, 0x118, 0xf, 0xf, true));      // row_shr:8
+        own = max(own, __builtin_amdgcn_update_dpp(0, own, 0x142, 0xa, 0xf, true));      // row_bcast15 -> rows 1, 3
+        own = max(own, __builtin_amdgcn_update_dpp(0, own, 0x143, 0xc, 0xf, true));      // row_bcast31 -> rows 2, 3
+        own = max(own, carry);
+        carry = __builtin_amdgcn_readlane(own, 63);                 // (only used when another window follows: lane 63 then held a real candidate)
         if (c < total) {
-            int o = 0;
-#pragma unroll
-            for (int s = 32; s > 0; s >>= 1) { if (__float_as_int(w[13][o + s]) <= c) o += s; }
+            const int o = own - 1;
             const int k = c - __float_as_int(w[13][o]);
             const int nx = __float_as_int(w[12][o]);
             // k / nx from the owner's reciprocal with a one-step correction; k, nx, q*nx < 2^24 (a frame has < 2^24 pixels),
@@ -156,9 +185,8 @@ __device__ __forceinline__ void wave_raster(const TriSetup &t, int n, float (*w)
             if ((int)__umul24((unsigned)(q + 1), (unsigned)nx) <= k) ++q;
             const int x = __float_as_int(w[10][o]) + (k - (int)__umul24((unsigned)q, (unsigned)nx));
             const int y = __float_as_int(w[11][o]) + q;
-            const float px[3] = { w[0][o], w[2][o], w[4][o] }, py[3] = { w[1][o], w[3][o], w[5][o] };
             float alpha, beta, gamma;
-            pass = tri_fragment(px, py, w[9][o], x, y, alpha, beta, gamma);
+            pass = tri_fragment_edges(w[0][o], w[1][o], w[2][o], w[3][o], w[4][o], w[5][o], w[9][o], x, y, alpha, beta, gamma);
             entry = ((uint32_t)o << 26) | ((uint32_t)x << 13) | (uint32_t)y;
         }
         const unsigned long long m = __ballot(pass);
@@ -231,7 +259,7 @@ __global__ __launch_bounds__(256) void raster_kernel(const pr_triangle *__restri
                                                      const uint32_t *__restrict__ box_off, BatchCheck chk)
 {
     __shared__ float sh[4][kSetupWords][64];
-    __shared__ uint32_t shq[4][128];
+    __shared__ uint32_t shq[4][192];                              // per wavefront: 128 words of fragment queue, 64 of run marks (wave_raster)
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t ti = blockIdx.x * 256 + threadIdx.x;
     float tv[9];
