@@ -122,10 +122,22 @@ __device__ __forceinline__ void vb_accumulate(float (&acc_out)[29], float *cl, u
                 p[3 * i + 1] = t.y;
                 p[3 * i + 2] = M[8] * x + M[9] * y + M[10] * z + M[11];
             }
+#if !PR_PASS_LATE_STORE
 #pragma unroll
             for (uint32_t i = 0; i < 4; ++i)
                 if (i < cnt) st_off<pr_vec3>(cl, point_of(j0, i) * 12u, pr_vec3{ p[3 * i], p[3 * i + 1], p[3 * i + 2] });
+#endif
         }
+        auto store_back = [&]() {
+#if PR_PASS_LATE_STORE
+            if (xf) {
+#pragma unroll
+                for (uint32_t i = 0; i < 4; ++i)
+                    if (i < cnt) st_off<pr_vec3>(cl, point_of(j0, i) * 12u, pr_vec3{ p[3 * i], p[3 * i + 1], p[3 * i + 2] });
+            }
+#endif
+        };
+        if constexpr (kNN) store_back();
         if constexpr (kNN && kStack == -1) {
             // winners of the search kernel: four indices, then the four (point, normal) pairs, all in flight before the first use
             uint32_t w[4];
@@ -176,6 +188,7 @@ __device__ __forceinline__ void vb_accumulate(float (&acc_out)[29], float *cl, u
                     const uint32_t i = i0 + k;
                     in_img[k] = gather_issue(scene, p[3 * i], p[3 * i + 1], p[3 * i + 2], i < cnt, gth[k]);
                 }
+                if (i0 == 0) store_back();                           // (PR_PASS_LATE_STORE: the moved points go out BEHIND the step's first gathers instead of ahead of them)
 #pragma unroll
                 for (uint32_t k = 0; k < PR_GATHER_BATCH; ++k) {
                     const uint32_t i = i0 + k;

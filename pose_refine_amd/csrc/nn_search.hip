@@ -65,6 +65,11 @@ __global__ __launch_bounds__(256) void nn_search_kernel(IcpBatch b, SceneNNDev s
         float best = accept;
         if (live) {
             pr_vec3 q = ld_off<pr_vec3>(cl, j * 12u);
+            // (round 6: the point's previous winner and slack are requested together with the point -- behind the write-back below they were two more
+            // dependent trips to memory per chunk: the compiler may not move a load across a store it cannot tell apart.  0.88 -> 0.84 ms over the 21 passes,
+            // configs[2] 53.9-54.1 k against 53.2-53.4 k poses/s.  Also fetching the NEXT chunk's three values ahead: 0.80 ms alone, 53.7 k pipelined -- not kept.)
+            const uint32_t prev = xf ? win[j] : kNoPrev;
+            const float slack_in = xf ? slk[j] : 0.0f;
             float x = q.x, y = q.y, z = q.z;
             bool still = false;                                  // has this point (nearly) kept the position its winner is from?
             float step_sq = 0.0f;
@@ -78,7 +83,6 @@ __global__ __launch_bounds__(256) void nn_search_kernel(IcpBatch b, SceneNNDev s
                 st_off<pr_vec3>(cl, j * 12u, pr_vec3{ x, y, z });
             }
             ++n_query;
-            const uint32_t prev = xf ? win[j] : kNoPrev;
             bool kept = false;
             if (prev != kNoPrev) {
                 // KEEP THE WINNER WITHOUT SEARCHING.  `slack` is a lower bound on the distance from this point to every scene point
@@ -89,7 +93,7 @@ __global__ __launch_bounds__(256) void nn_search_kernel(IcpBatch b, SceneNNDev s
                 // visiting order.
                 const pr_vec3 pw = ld_off<pr_vec3>(scene.pcd, prev * 12u);
                 const float d2 = (x - pw.x) * (x - pw.x) + (y - pw.y) * (y - pw.y) + (z - pw.z) * (z - pw.z);
-                const float slack = slk[j] - margin_sqrt(step_sq) * 1.000002f;
+                const float slack = slack_in - margin_sqrt(step_sq) * 1.000002f;
                 if (d2 < accept && margin_sqrt(d2) * 1.00001f < slack) { kept = true; slk[j] = slack; ++n_kept; }
                 else { const float bnd = d2 * 1.000001f + 1e-30f; if (bnd < best) best = bnd; }              // = nn_seed_bound
             }

@@ -26,6 +26,9 @@
 // the stores saved: the kernel behaves as the SUM of its parts (a wavefront issues a VALU instruction every 4.75 cycles at best and two are rarely ready at once).
 // More wavefronts by force: 6 per SIMD with two gathers in flight per lane (8 spilled registers) 256-268 k, one gather 235-248 k, 7 per SIMD 217-241 k; two gathers at
 // five wavefronts 270-276 k.  Five wavefronts, four gathers, every pass writing back stays.)
+#ifndef PR_PASS_LATE_STORE
+#define PR_PASS_LATE_STORE 1                                     // projective pass: a step's write-back is issued BEHIND its four gathers, not ahead of them (the stores no longer sit in front of the gathers in the wavefront's memory queue).  Round 6, same box, six alternating 100-step runs: 280.1 / 280.2 / 278.4 / 281.0 / 281.1 / 280.3 k against 275.2 / 276.7 / 276.0 / 278.5 / 278.2 / 278.1 k poses/s; behind the step's accumulation instead: 278.5-279.9 k; as non-temporal stores: 279.1-280.6 k
+#endif
 #ifndef PR_HOST_ROW_TAG
 #define PR_HOST_ROW_TAG 1                                        // PR_SOLVE_HOST with group flags: every row also carries the iteration's tag behind its sums, checked by the host (a flag that overtook a row costs a stream wait, never a wrong solve)
 #endif
