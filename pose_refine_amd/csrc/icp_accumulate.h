@@ -107,7 +107,7 @@ __device__ __forceinline__ void vb_accumulate(float (&acc_out)[29], float *cl, u
     };
     auto process_step = [&](float (&p)[12], uint32_t j0, uint32_t cnt) {
         if (cnt == 0) return;
-        if (xf) {                                                // icp.cu:142-153 transform_pcd_cuda, fused
+        if ((!kNN || kStack != -1) && xf) {                      // icp.cu:142-153 transform_pcd_cuda, fused (never in the winners pass: nn_search_kernel has moved the cloud -- said at compile time, so that no conditional store stands between the point loads and the winner loads)
             // rows 0 and 1 of the update side by side in packed instructions (same per-element operations, same order:
             // ((m0*x + m1*y) + m2*z) + m3), row 2 scalar
             const float2v Mx{ M[0], M[4] }, My{ M[1], M[5] }, Mz{ M[2], M[6] }, Mt{ M[3], M[7] };
@@ -130,7 +130,7 @@ __device__ __forceinline__ void vb_accumulate(float (&acc_out)[29], float *cl, u
         }
         auto store_back = [&]() {
 #if PR_PASS_LATE_STORE
-            if (xf) {
+            if ((!kNN || kStack != -1) && xf) {
 #pragma unroll
                 for (uint32_t i = 0; i < 4; ++i)
                     if (i < cnt) st_off<pr_vec3>(cl, point_of(j0, i) * 12u, pr_vec3{ p[3 * i], p[3 * i + 1], p[3 * i + 2] });
