@@ -61,10 +61,10 @@ BYTES_PER_POINT_PASS0, BYTES_PER_POINT_PASSK = 36.0, 48.0
 # L2s fetch from the fabric, Infinity-Cache hits included (guide, HBM section): the counter figure is FABRIC traffic, an upper bound of DRAM
 # traffic -- with <= 512 hypotheses per sub-batch the clouds are Infinity-Cache resident by design.
 PMC_TRAFFIC_BYTES_PER_POINT = {"proj": 25.1, "nn": 70.9}       # P = 1024 as ONE sub-batch (clouds spill the Infinity Cache): 23.9 B/point -- the same: it is the cloud read + write-back
-PMC_VALU_WAVE_INSTR_PER_POINT = {"proj": 2.092, "nn": None}             # profiles/r06: 740 442 795 wave-instructions over 63 launches of 5 618 880 points
+PMC_VALU_WAVE_INSTR_PER_POINT = {"proj": 2.077, "nn": None}             # profiles/r06: 735 215 064 wave-instructions over 63 launches of 5 618 880 points (740 442 795 before the write-back moved behind the gathers)
 # what DRAM carries when the clouds do NOT fit the Infinity Cache (1024 hypotheses as one sub-batch): committed fallback of the run's own passes
 PMC_DRAM_FRAC = {"proj": 0.52, "nn": None}
-PMC_DRAM_SOURCE = "committed: profiles/r06/pmc_proj_p1024_onebatch_*.md + kernel_stats_p1024_onebatch.md (23.8 B/point x 22.47 M points = 536 MB per 128.9 us launch = 4.16 TB/s)"
+PMC_DRAM_SOURCE = "committed: profiles/r06/pmc_proj_p1024_onebatch_*.md + kernel_stats_p1024_onebatch.md (23.8 B/point x 22.47 M points = 536 MB per 129.2 us launch = 4.15 TB/s)"
 # committed SQ counter passes of the kd-tree task walk, pass 0 (profiles/r06/sq_nn_pass0.txt, unchanged from r05's): SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES = the share of a
 # wavefront's resident cycles with one of its VALU instructions in flight (six wavefronts share a SIMD), and 4 x SQ_ACTIVE_INST_VALU over
 # (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs) = the share of the chip's VALU issue slots the kernel fills
@@ -72,7 +72,7 @@ NN_WALK_VALU_ACTIVE_FRAC = 0.21
 NN_WALK_VALU_ISSUE_FRAC = 0.75 * 6.144e11 / VALU_PEAK              # r05's 0.75 was against 6.14e11/s: 0.47 of the calibrated peak
 # committed SQ pass of the projective correspondence kernel (profiles/r06/sq_proj_SQ_ACTIVE_INST_VALU_SQ_WAVE_CYCLES_SQ_WAIT_INST_ANY.md): share of a
 # wavefront's resident cycles spent waiting for an instruction's operands (SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES)
-PROJ_PASS_WAIT_FRAC = 0.307
+PROJ_PASS_WAIT_FRAC = 0.317
 NN_WALK_HBM_BYTES_PER_POINT = 4.6                                  # profiles/r06/pmc_nn_*.md (2 x 589 970 + 428 381 KB over 63 passes of 5.62 M points): the walk reads queue entries + cloud points, writes winners
 PMC_TRAFFIC_SOURCE = {"proj": "profiles/r06/pmc_proj_FETCH_SIZE.md + pmc_proj_WRITE_SIZE.md + sq_proj_SQ_INSTS_VALU*.md (icp_pass_kernel<SceneProjPacked>)",
                       "nn": "profiles/r06/pmc_nn_FETCH_SIZE.md + pmc_nn_WRITE_SIZE.md (search 37.1 + bound 11.2 + task walk 4.6 + winners pass 17.9 B/point)"}
@@ -795,7 +795,7 @@ def run_rank(args, group, local_dev, share_device, launcher_note, comm_ready, co
 # sha256 (first 16 hex digits) of the sources of icp_pass_kernel<SceneProjPacked> at the time the committed SQ / PMC constants above were measured:
 # when the kernel's sources change, the line says that the VALU figures are stale instead of presenting them as measured
 PMC_PROFILED_SOURCES = ("icp_pass.hip", "icp_accumulate.h", "proj_query.h", "icp_solve_device.h", "pr_tuning.h")
-PMC_PROFILED_HASH = "952a3677bb94811d"
+PMC_PROFILED_HASH = "d39e369ab211c4d6"
 
 
 def pmc_sources_hash():
