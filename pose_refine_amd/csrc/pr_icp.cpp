@@ -74,7 +74,7 @@ int icp_drive(pr_vec3 *cloud_base, const uint32_t *start_h, const uint32_t *coun
         b.nn_queue = reinterpret_cast<uint2 *>(b.nn_prev + 2 * span);
         b.nn_queue2 = reinterpret_cast<uint2 *>(b.nn_prev + 4 * span);
         b.nn_qcount = b.nn_prev + 6 * span;
-        HIP_TRY(hipMemsetAsync(b.nn_qcount, 0, sizeof(uint32_t) * prk::kQCountStride * P, g->stream));
+        HIP_TRY(prk::launch_fill_i32(reinterpret_cast<int32_t *>(b.nn_qcount), (size_t)prk::kQCountStride * P, 0, g->stream));     // (a kernel, not a memset command: no runtime copy / fill path on a per-call path, see below)
     }
 
     prk::PoseMeta *h_meta = g->h_meta.as<prk::PoseMeta>();
@@ -116,7 +116,7 @@ int icp_drive(pr_vec3 *cloud_base, const uint32_t *start_h, const uint32_t *coun
             HIP_TRY(hipHostGetDevicePointer(&meta_host_dev, h_meta, 0));
             HIP_TRY(prk::launch_stage_words(init_dev, g->dstate.p, sizeof(prk::DevIcpState) * P, g->stream));
             HIP_TRY(prk::launch_stage_words(meta_host_dev, g->meta.p, sizeof(prk::PoseMeta) * P, g->stream));
-            if (fused) HIP_TRY(hipMemsetAsync(g->arrive.p, 0, sizeof(uint32_t) * P, g->stream));
+            if (fused) HIP_TRY(prk::launch_fill_i32(g->arrive.as<int32_t>(), P, 0, g->stream));
             // Two pose groups on two streams: while the (latency-bound, one wavefront per pose) finalize+solve
             // of one group runs, the correspondence pass of the other group keeps the chip busy.
             auto group_begin = [&](uint32_t grp) { return (uint32_t)(((uint64_t)P * grp) / n_groups); };
@@ -216,7 +216,7 @@ int icp_drive(pr_vec3 *cloud_base, const uint32_t *start_h, const uint32_t *coun
     const uint32_t host_sample_it = (uint32_t)(((host_tick / (uint64_t)std::max(1, opt.sample_period)) * 5 + 1) % (uint64_t)(crit.max_iteration + 1));
     const uint32_t n_groups = (opt.profile == 1 || opt.profile == 3 || host_sample_call) ? 1u : std::max(1u, std::min({ pose_groups_for(sc.kind), 4u, P / 32u }));
     auto group_begin = [&](uint32_t grp) { return (uint32_t)(((uint64_t)P * grp) / n_groups); };
-    if (opt.fused_solve) { PR_TRY(g->arrive.ensure(sizeof(uint32_t) * (P + 4))); HIP_TRY(hipMemsetAsync(g->arrive.p, 0, sizeof(uint32_t) * (P + 4), g->stream)); }   // (+ one counter per pose group)
+    if (opt.fused_solve) { PR_TRY(g->arrive.ensure(sizeof(uint32_t) * (P + 4))); HIP_TRY(prk::launch_fill_i32(g->arrive.as<int32_t>(), (size_t)P + 4, 0, g->stream)); }   // (+ one counter per pose group)
     if (n_groups > 1) {
         for (uint32_t k = 1; k < n_groups; ++k) PR_TRY(ensure_stream(g->side[k - 1], &g->ev_join[k - 1]));
         HIP_TRY(hipEventRecord(g->ev_fork, g->stream));               // the groups start behind the render / cloud work of this call

@@ -716,7 +716,7 @@ int refine_submit_async(Slot &sl, const pr_triangle *tris_dev, size_t n_tris, ui
         // the iteration loop: (max_iteration+1) x [pass (+ fused finalize/solve)], pose groups on the slot's side streams
         const uint32_t n_groups = timed ? 1u : std::max(1u, std::min({ pose_groups_for(scene_kind), 4u, nq / 32u }));
         auto group_begin = [&](uint32_t grp) { return (uint32_t)(((uint64_t)nq * grp) / n_groups); };
-        if (nn_prev) HIP_TRY(hipMemsetAsync(nn_prev + 6 * nn_span, 0, sizeof(uint32_t) * prk::kQCountStride * nq, st));
+        if (nn_prev) HIP_TRY(prk::launch_fill_i32(reinterpret_cast<int32_t *>(nn_prev + 6 * nn_span), (size_t)prk::kQCountStride * nq, 0, st));
         if (n_groups > 1) {
             for (uint32_t k = 1; k < n_groups; ++k) PR_TRY(ensure_stream(sl.side[k - 1], &sl.join[k - 1]));
             HIP_TRY(hipEventRecord(sl.fork, st));
