@@ -128,7 +128,7 @@ struct Options {
                                      // launches of different groups overlap, so timed calls fall back to one group
     int solve_mode = PR_SOLVE_HOST;
     int host_worker = 1;             // PR_SOLVE_HOST batches of pr_refine_submit run on the slot's helper thread (0: on the caller's thread, inside the call)
-    int steps = 3;                   // 1024-point steps per workgroup -> 3072 points per workgroup (9 workgroups per 26 k-point cloud: measured 3-5 % faster than 2048 / 4096)
+    int steps = 4;                   // 1024-point steps per workgroup -> 4096 points per workgroup.  Round 3 chose 3072 (3-5 % faster than 2048 / 4096 then); round 6, with the write-back issued behind the gathers: 286.5 / 287.3 k at 4096 against 280.6 / 281.4 k at 3072, 282 k at 5120, 277 k at 6144, 242-262 k at 8192 (100 steps, same box); 20 steps 273.6 against 271.6 k; kd-tree and host solve within noise
     int profile = 0;
     int sample_period = 32;          // profile 2: one timed (synchronous, single-group) call in this many
     int nn_lds_nodes = 1024;

@@ -198,6 +198,7 @@ def test_reduction_tree_and_grouping_options_at_their_extremes(gpu, model, scena
     poses = synth.hypotheses(33, seed=2)
     crit = (0.0, 0.0, 5)
     cl = O.depth2cloud(O.render(scenario["tris"], poses[32:33], W, H, scenario["proj"])[0], scenario["K"])
+    ppb_default = api.get_option("points_per_block")
     try:
         for ppb in (1024, 65536):
             api.set_option("points_per_block", ppb)
@@ -207,7 +208,7 @@ def test_reduction_tree_and_grouping_options_at_their_extremes(gpu, model, scena
                 res, sizes = api.refine_batch(model, poses, W, H, scenario["proj"], scenario["K"], gscenes["proj"], api.ICPConvergenceCriteria(*crit))
                 assert sizes[32] == len(cl) and res[32]["fitness"] == want["fitness"] and np.allclose(res[32]["T"], want["T"], rtol=0, atol=1e-4), (ppb, groups, sub)
     finally:
-        api.set_option("points_per_block", 3072); api.set_option("pose_groups", 0); api.set_option("sub_batch", 512)
+        api.set_option("points_per_block", ppb_default); api.set_option("pose_groups", 0); api.set_option("sub_batch", 512)
 
 
 @pytest.mark.device_solve
