@@ -281,7 +281,7 @@ int pr_gather_results(const pr_result *send_dev, uint32_t n_local, uint32_t n_to
 /* pr_set_option names (all int; defaults in brackets).  None of them changes a result bit, except "points_per_block", which
  * selects the reduction tree and therefore the last bits of the sums (DESIGN.md "canonical tree").
  *   "solve"            [PR_SOLVE_HOST] PR_SOLVE_HOST = reference-style host solve per iteration, PR_SOLVE_DEVICE = loop on the device
- *   "points_per_block" [4096]  points per workgroup of the correspondence pass (multiple of 1024)
+ *   "points_per_block" [3072]  points per workgroup of the correspondence pass (multiple of 1024)
  *   "fused_solve"      [1]     the workgroup that delivers a hypothesis' last partial sum finalizes in the tail of the pass kernel instead of
  *                              a second launch: device solve = finalize + 6x6 solve there; host solve = the 29 totals stored into pinned host memory
  *   "pose_groups"      [0]     streams the batch is split over (1..4; 0 = 2): device solve = one group's solve tail under another's pass;

@@ -128,7 +128,7 @@ struct Options {
                                      // launches of different groups overlap, so timed calls fall back to one group
     int solve_mode = PR_SOLVE_HOST;
     int host_worker = 1;             // PR_SOLVE_HOST batches of pr_refine_submit run on the slot's helper thread (0: on the caller's thread, inside the call)
-    int steps = 4;                   // 1024-point steps per workgroup -> 4096 points per workgroup.  Round 3 chose 3072 (3-5 % faster than 2048 / 4096 then); round 6, with the write-back issued behind the gathers: 286.5 / 287.3 k at 4096 against 280.6 / 281.4 k at 3072, 282 k at 5120, 277 k at 6144, 242-262 k at 8192 (100 steps, same box); 20 steps 273.6 against 271.6 k; kd-tree and host solve within noise
+    int steps = 3;                   // 1024-point steps per workgroup -> 3072 points per workgroup (round 3: 3-5 % faster than 2048 / 4096).  Round 6, with the write-back issued behind the gathers, option points_per_block = 4096 pipelines 2 % better (286.5 / 287.3 k against 280.6 / 281.4 k, 100 steps, same box; 273.6 against 271.6 k at 20 steps; 5120: 282 k, 6144: 277 k, 8192: 242-262 k; kd-tree and host solve within noise) but a LONE 256-hypothesis launch takes 39.6 instead of 37.7 us (six longer chains per hypothesis instead of eight): the default stays, the option is there (it selects another summation tree: a quarter of the bench's hypotheses end in a different basin, the oracle follows)
     int profile = 0;
     int sample_period = 32;          // profile 2: one timed (synchronous, single-group) call in this many
     int nn_lds_nodes = 1024;

@@ -30,7 +30,7 @@ import oracle_lib as O  # noqa: E402
 from pose_refine_amd import dist, synth  # noqa: E402
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
-PPB = 4096          # the library's default points_per_block (pr_runtime.h); the GPU test asserts the option still has this value
+PPB = 3072          # the library's default points_per_block (pr_runtime.h); the GPU test asserts the option still has this value
 FIXED = (0.0, 0.0, 20)
 DEFAULT = (1e-5, 1e-5, 30)
 
